@@ -1,0 +1,195 @@
+"""Deterministic synthetic controlled paths + host-side coefficient preparation.
+
+Everything here is numpy only and independent of torch's RNG so that this container, the GPU
+box and every rank of a multi-GPU run regenerate bit-identical inputs.
+
+Coefficient preparation follows the *semantics* of the reference's builders (it is the step
+immediately before the hot path) and is checked against them in
+``oracle/gen_golden.py``:
+
+* rectilinear prep      -- /root/reference/modules/torchcde/torchcde/interpolation_linear.py:85-128
+* forward fill          -- /root/reference/modules/torchcde/torchcde/misc.py:103-126
+* natural cubic coeffs  -- /root/reference/modules/torchcde/torchcde/interpolation_cubic.py:7-53
+                           (tridiagonal solve: misc.py:13-67)
+"""
+import math
+
+import numpy as np
+
+_U64 = np.uint64
+
+
+def _splitmix64(x):
+    """splitmix64 finaliser on a uint64 array (wrap-around arithmetic)."""
+    with np.errstate(over="ignore"):
+        z = x + _U64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> _U64(30))) * _U64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> _U64(27))) * _U64(0x94D049BB133111EB)
+        return z ^ (z >> _U64(31))
+
+
+def uniform01(seed, n, stream=0):
+    """n doubles in [0, 1), a pure function of (seed, stream, index)."""
+    with np.errstate(over="ignore"):
+        base = _splitmix64(np.array([seed], dtype=_U64) * _U64(0x2545F4914F6CDD1D)
+                           + _U64(stream) * _U64(0xD1342543DE82EF95))[0]
+        idx = np.arange(n, dtype=_U64) + base
+    return (_splitmix64(idx) >> _U64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def normal(seed, n, stream=0):
+    """n standard normals (Box-Muller in fp64)."""
+    u1 = uniform01(seed, n, stream=2 * stream)
+    u2 = uniform01(seed, n, stream=2 * stream + 1)
+    return np.sqrt(-2.0 * np.log1p(-u1)) * np.cos(2.0 * math.pi * u2)
+
+
+def linear_weights(seed, stream, fan_out, fan_in):
+    """(W [fan_out, fan_in], b [fan_out]) ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)), fp32 (torch Linear scale)."""
+    bound = 1.0 / math.sqrt(fan_in)
+    w = (uniform01(seed, fan_out * fan_in, stream=2 * stream) * 2.0 - 1.0) * bound
+    b = (uniform01(seed, fan_out, stream=2 * stream + 1) * 2.0 - 1.0) * bound
+    return w.reshape(fan_out, fan_in).astype(np.float32), b.astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------
+# coefficient preparation (host side, numpy)
+# ----------------------------------------------------------------------------------------------
+def forward_fill(x):
+    """Forward fill NaNs along axis -2 of x[..., length, channels]; leading NaNs are left in place."""
+    x = np.asarray(x)
+    mask = np.isnan(x)
+    if not mask.any():
+        return x
+    length = x.shape[-2]
+    idx = np.where(~mask, np.arange(length).reshape(-1, 1), 0)
+    idx = np.maximum.accumulate(idx, axis=-2)
+    return np.take_along_axis(x, idx, axis=-2)
+
+
+def rectilinear_prep(x, time_index):
+    """[..., L, C] -> [..., 2L-1, C]: forward fill, repeat every row twice, advance the time channel
+    by one slot, drop the last row.  Linear interpolation of the result is the rectilinear path."""
+    x = forward_fill(x)
+    rep = np.repeat(x, 2, axis=-2)
+    rep[..., :-1, time_index] = rep[..., 1:, time_index].copy()
+    return np.ascontiguousarray(rep[..., :-1, :])
+
+
+def natural_cubic_coeffs(x):
+    """Natural cubic spline through x[..., L, C] on the integer grid t = 0..L-1 (no missing values).
+
+    Returns [..., L-1, 4C] = a || b || 2c || 3d per piece, the layout NaturalCubicSpline consumes
+    (interpolation_cubic.py:189, 294-298).  fp32 arithmetic in the reference's operation order.
+    """
+    x = np.asarray(x, dtype=np.float32)
+    xt = np.swapaxes(x, -1, -2)  # [..., C, L]
+    length = xt.shape[-1]
+    f32 = np.float32
+    if length == 2:
+        a = xt[..., :1]
+        b = xt[..., 1:] - xt[..., :1]
+        two_c = np.zeros_like(a)
+        three_d = np.zeros_like(a)
+    else:
+        recip = np.ones(length - 1, dtype=f32)  # 1/(t[i+1]-t[i]) on the integer grid
+        recip_sq = recip * recip
+        three_diff = f32(3) * (xt[..., 1:] - xt[..., :-1])
+        six_diff = f32(2) * three_diff
+        scaled = three_diff * recip_sq
+        diag = np.empty(length, dtype=f32)
+        diag[:-1] = recip
+        diag[-1] = 0
+        diag[1:] += recip
+        diag *= f32(2)
+        rhs = np.empty_like(xt)
+        rhs[..., :-1] = scaled
+        rhs[..., -1] = 0
+        rhs[..., 1:] += scaled
+        # Thomas algorithm, upper = lower = recip
+        new_b = [rhs[..., 0]]
+        new_d = [np.broadcast_to(diag[0], rhs[..., 0].shape).astype(f32)]
+        for i in range(1, length):
+            w = recip[i - 1] / new_d[i - 1]
+            new_d.append((diag[i] - w * recip[i - 1]).astype(f32))
+            new_b.append((rhs[..., i] - w * new_b[i - 1]).astype(f32))
+        outs = [None] * length
+        outs[length - 1] = new_b[length - 1] / new_d[length - 1]
+        for i in range(length - 2, -1, -1):
+            outs[i] = (new_b[i] - recip[i] * outs[i + 1]) / new_d[i]
+        kd = np.stack(outs, axis=-1).astype(f32)
+        a = xt[..., :-1]
+        b = kd[..., :-1]
+        two_c = (six_diff * recip - f32(4) * kd[..., :-1] - f32(2) * kd[..., 1:]) * recip
+        three_d = (-six_diff * recip + f32(3) * (kd[..., :-1] + kd[..., 1:])) * recip_sq
+    parts = [np.swapaxes(p, -1, -2) for p in (a, b, two_c, three_d)]
+    return np.ascontiguousarray(np.concatenate(parts, axis=-1).astype(f32))
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic workloads (BASELINE.json configs)
+# ----------------------------------------------------------------------------------------------
+def synthetic_series(batch, length, channels, missing=0.0, seed=1234, batch_offset=0):
+    """Raw irregular series x[batch, length, channels+1] fp32: channel 0 is time i/length, the rest
+    are scaled random walks with a fraction ``missing`` of entries NaN (never in the first row).
+
+    ``batch_offset`` selects a slice of one global deterministic batch, so rank r of an N-GPU run
+    draws samples [r*B/N, (r+1)*B/N) of exactly the data a 1-GPU run would see.
+    """
+    n = length * channels
+    out = np.empty((batch, length, channels + 1), dtype=np.float32)
+    t = (np.arange(length, dtype=np.float64) / length).astype(np.float32)
+    for i in range(batch):
+        g = batch_offset + i
+        incr = normal(seed, n, stream=2 * g).reshape(length, channels)
+        walk = np.cumsum(incr, axis=0) / math.sqrt(length)
+        if missing > 0.0:
+            drop = uniform01(seed, n, stream=4 * g + 1_000_003).reshape(length, channels) < missing
+            drop[0, :] = False
+            walk = np.where(drop, np.nan, walk)
+        out[i, :, 0] = t
+        out[i, :, 1:] = walk.astype(np.float32)
+    return out
+
+
+def make_rectilinear_coeffs(batch, length, channels, missing=0.3, seed=1234, batch_offset=0):
+    """coeffs[batch, 2*length-1, channels+1] for the rectilinear configs (cfg2/3/5)."""
+    x = synthetic_series(batch, length, channels, missing=missing, seed=seed, batch_offset=batch_offset)
+    return rectilinear_prep(x, time_index=0)
+
+
+def make_linear_coeffs(batch, length, channels, seed=1234, batch_offset=0):
+    """coeffs[batch, length, channels+1] for plain linear interpolation (no missing values)."""
+    return synthetic_series(batch, length, channels, missing=0.0, seed=seed, batch_offset=batch_offset)
+
+
+def make_cubic_coeffs(batch, length, channels, seed=1234, batch_offset=0):
+    """coeffs[batch, length-1, 4*(channels+1)] natural cubic (cfg4)."""
+    x = synthetic_series(batch, length, channels, missing=0.0, seed=seed, batch_offset=batch_offset)
+    return natural_cubic_coeffs(x)
+
+
+def make_field_weights(hidden, hidden_hidden, in_channels, seed=0, layer_dims=None):
+    """Vector-field parameters as a dict of fp32 arrays.
+
+    Default architecture = the reference's OriginalVectorField (src/ncde/vector_fields/base.py:64-69,
+    97-101): W0[HH,H], W1[HH,HH] (shared by all inner layers), Wo[H*C,HH].  ``layer_dims`` gives a
+    general un-shared stack instead (toy CDEFunc, experiments/sim_bm_toy_example.py:10-30).
+    """
+    p = {}
+    if layer_dims is None:
+        p["W0"], p["b0"] = linear_weights(seed, 1, hidden_hidden, hidden)
+        p["W1"], p["b1"] = linear_weights(seed, 2, hidden_hidden, hidden_hidden)
+        p["Wo"], p["bo"] = linear_weights(seed, 3, hidden * in_channels, hidden_hidden)
+    else:
+        dims = [hidden] + list(layer_dims)
+        for i in range(len(layer_dims)):
+            p[f"W{i}"], p[f"b{i}"] = linear_weights(seed, 10 + i, dims[i + 1], dims[i])
+        p["Wo"], p["bo"] = linear_weights(seed, 3, hidden * in_channels, dims[-1])
+    return p
+
+
+def make_readin_weights(hidden, in_channels, out_dim, seed=0):
+    wi, bi = linear_weights(seed, 4, hidden, in_channels)
+    wf, bf = linear_weights(seed, 5, out_dim, hidden)
+    return {"Wi": wi, "bi": bi, "Wf": wf, "bf": bf}

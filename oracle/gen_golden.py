@@ -1,0 +1,290 @@
+"""Generate golden vectors by IMPORTING the reference (this container only) and pin the oracle to it.
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz, prints oracle-vs-reference errors
+
+The reference (pure Python, /root/reference) cannot travel to the GPU box, so its outputs on
+deterministic inputs are committed as small fixtures.  For every case this script also runs
+oracle/ncde_oracle.py on the same inputs and asserts agreement, which is what pins the oracle.
+``autots`` (un-vendored third party imported by src/ncde/attention.py:3) is stubbed with an empty
+module; nothing on the NeuralCDE/cdeint path touches it.
+"""
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path[:0] = [REF, os.path.join(REF, "modules", "torchdiffeq"), os.path.join(REF, "modules", "torchcde")]
+
+_stub = types.ModuleType("autots")
+_pre = types.ModuleType("autots.preprocessing")
+for _n in ("ForwardFill", "PadRaggedTensors", "SimplePipeline"):
+    setattr(_pre, _n, type(_n, (), {}))
+_stub.preprocessing = _pre
+sys.modules["autots"] = _stub
+sys.modules["autots.preprocessing"] = _pre
+
+import torchcde  # noqa: E402  (the reference's vendored copy)
+from src.ncde import NeuralCDE as RefNeuralCDE  # noqa: E402
+from src.ncde.vector_fields.base import OriginalVectorField as RefField  # noqa: E402
+
+import ncde_amd  # noqa: E402
+import ncde_oracle as orc  # noqa: E402
+
+data = ncde_amd.data
+GOLD = os.path.join(ROOT, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def relerr(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def grad_out_like(shape, seed):
+    n = int(np.prod(shape))
+    return (data.normal(seed, n, stream=77).reshape(shape) / np.sqrt(shape[1])).astype(np.float32)
+
+
+class ToyFunc(torch.nn.Module):
+    """Same architecture as the reference toy's CDEFunc (experiments/sim_bm_toy_example.py:10-30);
+    restated here because that script imports matplotlib/pandas at module import."""
+
+    def __init__(self, C, H, width):
+        super().__init__()
+        self.C, self.H = C, H
+        self.linear0 = torch.nn.Linear(H, H)
+        self.linear1 = torch.nn.Linear(H, width)
+        self.linear2 = torch.nn.Linear(width, C * H)
+
+    def forward(self, t, z):
+        z = self.linear0(z).relu()
+        z = self.linear1(z).relu()
+        z = self.linear2(z).tanh()
+        return z.view(z.size(0), self.H, self.C)
+
+
+def ref_field_original(p, C, H, HH, nl):
+    f = RefField(input_dim=C, hidden_dim=H, hidden_hidden_dim=HH, num_layers=nl)
+    with torch.no_grad():
+        f.net_to_hh[0].weight.copy_(torch.from_numpy(p["W0"]))
+        f.net_to_hh[0].bias.copy_(torch.from_numpy(p["b0"]))
+        if nl > 1:
+            f.net_to_hh[2].weight.copy_(torch.from_numpy(p["W1"]))
+            f.net_to_hh[2].bias.copy_(torch.from_numpy(p["b1"]))
+        f.tanh_output_layer[0].weight.copy_(torch.from_numpy(p["Wo"]))
+        f.tanh_output_layer[0].bias.copy_(torch.from_numpy(p["bo"]))
+    return f
+
+
+def ref_solve(coeffs, kind, func, z0, method, sequence, gout):
+    """Reference cdeint forward + adjoint backward.  Returns z_out, dz0, [param grads]."""
+    c = torch.from_numpy(coeffs)
+    X = torchcde.LinearInterpolation(c) if kind == "linear" else torchcde.NaturalCubicSpline(c)
+    z0 = torch.from_numpy(z0).clone().requires_grad_(True)
+    t = X.grid_points if sequence else X.interval
+    for p in func.parameters():
+        p.grad = None
+    out = torchcde.cdeint(X, func, z0, t, adjoint=True, method=method, options={"step_size": 1})
+    (out * torch.from_numpy(gout)).sum().backward()
+    return out.detach(), z0.grad.detach(), [p.grad.detach().clone() for p in func.parameters()]
+
+
+def run_case(name, coeffs, kind, p, field_kind, dims, z0, method, sequence, store_inputs, meta, tol=(2e-6, 2e-5)):
+    C, H = dims["C"], dims["H"]
+    if field_kind == "original":
+        func = ref_field_original(p, C, H, dims["HH"], dims["nl"])
+        ofield = orc.Field.original(p, H, C, dims["nl"])
+        names = ["W0", "b0"] + (["W1", "b1"] if dims["nl"] > 1 else []) + ["Wo", "bo"]
+    else:
+        func = ToyFunc(C, H, dims["width"])
+        with torch.no_grad():
+            for i, lin in enumerate((func.linear0, func.linear1)):
+                lin.weight.copy_(torch.from_numpy(p[f"W{i}"]))
+                lin.bias.copy_(torch.from_numpy(p[f"b{i}"]))
+            func.linear2.weight.copy_(torch.from_numpy(p["Wo"]))
+            func.linear2.bias.copy_(torch.from_numpy(p["bo"]))
+        ofield = orc.Field([(p["W0"], p["b0"]), (p["W1"], p["b1"])], p["Wo"], p["bo"], H, C)
+        names = ["W0", "b0", "W1", "b1", "Wo", "bo"]
+    n_out = (coeffs.shape[1] + (1 if kind == "cubic" else 0)) if sequence else 2
+    gout = grad_out_like((coeffs.shape[0], n_out, H), seed=meta.get("gseed", 5))
+    t0 = time.time()
+    z_ref, dz0_ref, gp_ref = ref_solve(coeffs, kind, func, z0, method, sequence, gout)
+    t_ref = time.time() - t0
+    ctl = orc.Control(coeffs, kind)
+    t0 = time.time()
+    z_or = orc.solve_forward(ctl, ofield, z0, method, sequence)
+    dz0_or, gp_or = orc.solve_adjoint(ctl, ofield, z_or, gout, method, sequence)
+    t_or = time.time() - t0
+    e_z = relerr(z_or, z_ref)
+    e_dz = relerr(dz0_or, dz0_ref)
+    e_p = [relerr(a, b) for a, b in zip(gp_or, gp_ref)]
+    print(f"{name:28s} ref {t_ref:6.2f}s oracle {t_or:6.2f}s | oracle-vs-ref: z {e_z:.2e} dz0 {e_dz:.2e} "
+          f"dtheta max {max(e_p):.2e}")
+    assert e_z <= tol[0] and e_dz <= tol[1] and max(e_p) <= tol[1], "oracle does not reproduce the reference"
+    rec = {"z_out": z_ref.numpy(), "dz0": dz0_ref.numpy(), "grad_out": gout}
+    for n, g in zip(names, gp_ref):
+        if g.numel() > 200_000:     # keep the fixture small: every 16th row + column sums
+            rec["d" + n + "__rows16"] = g.numpy()[::16].copy()
+            rec["d" + n + "__colsum"] = g.double().sum(0).float().numpy()
+        else:
+            rec["d" + n] = g.numpy()
+    if store_inputs:
+        rec["coeffs"] = coeffs
+        rec["z0"] = z0
+        for k, v in p.items():
+            rec["p_" + k] = v
+    meta = dict(meta, name=name, kind=kind, method=method, sequence=bool(sequence), field=field_kind, dims=dims,
+                param_names=names, oracle_vs_ref={"z": e_z, "dz0": e_dz, "dtheta": max(e_p)})
+    rec["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+    return meta
+
+
+def z0_from(coeffs0, rw):
+    return (coeffs0 @ rw["Wi"].T + rw["bi"]).astype(np.float32)
+
+
+def main():
+    report = []
+    # ---- G1: toy (cfg1): 3-point 1-D BM + time, rectilinear -> T=5, C=2, H=8, width 128 ---------
+    B, L, C, H = 64, 3, 2, 8
+    coeffs = data.make_rectilinear_coeffs(B, L, C - 1, missing=0.0, seed=11)
+    p = data.make_field_weights(H, None, C, seed=1, layer_dims=[H, 128])
+    rw = data.make_readin_weights(H, C, 1, seed=1)
+    z0 = z0_from(coeffs[:, 0], rw)
+    for method in ("rk4", "midpoint", "euler"):
+        report.append(run_case(f"g1_toy_{method}_seq", coeffs, "linear", p, "toy",
+                               {"C": C, "H": H, "width": 128}, z0, method, True, True,
+                               {"gen": "make_rectilinear_coeffs(64,3,1,missing=0,seed=11)"}))
+    # ---- G2: small rectilinear RK4, cfg2 dims -------------------------------------------------
+    B, L, C, H, HH, nl = 32, 25, 20, 32, 32, 3
+    coeffs = data.make_rectilinear_coeffs(B, L, C - 1, missing=0.3, seed=1234)
+    p = data.make_field_weights(H, HH, C, seed=0)
+    rw = data.make_readin_weights(H, C, 1, seed=0)
+    z0 = z0_from(coeffs[:, 0], rw)
+    dims = {"C": C, "H": H, "HH": HH, "nl": nl}
+    for seq in (False, True):
+        report.append(run_case(f"g2_rect_rk4_{'seq' if seq else 'final'}", coeffs, "linear", p, "original", dims,
+                               z0, "rk4", seq, True, {"gen": "make_rectilinear_coeffs(32,25,19,0.3,1234)"}))
+    report.append(run_case("g2_rect_midpoint_final", coeffs, "linear", p, "original", dims, z0, "midpoint", False,
+                           False, {"gen": "make_rectilinear_coeffs(32,25,19,0.3,1234)", "inputs_in": "g2_rect_rk4_final"}))
+    # ---- G3: natural cubic, cfg4 dims ----------------------------------------------------------
+    B, L, C, H, HH, nl = 16, 30, 4, 64, 64, 3
+    coeffs = data.make_cubic_coeffs(B, L, C - 1, seed=4321)
+    ref_coeffs = torchcde.natural_cubic_coeffs(torch.from_numpy(data.synthetic_series(B, L, C - 1, seed=4321)))
+    print("cubic coeff builder vs reference:", relerr(coeffs, ref_coeffs))
+    assert relerr(coeffs, ref_coeffs) < 1e-5
+    p = data.make_field_weights(H, HH, C, seed=2)
+    rw = data.make_readin_weights(H, C, 1, seed=2)
+    z0 = z0_from(coeffs[:, 0, :C], rw)
+    dims = {"C": C, "H": H, "HH": HH, "nl": nl}
+    for method, seq in (("midpoint", False), ("midpoint", True), ("rk4", False), ("rk4", True)):
+        report.append(run_case(f"g3_cubic_{method}_{'seq' if seq else 'final'}", coeffs, "cubic", p, "original",
+                               dims, z0, method, seq, method == "midpoint" and not seq,
+                               {"gen": "make_cubic_coeffs(16,30,3,seed=4321)", "inputs_in": "g3_cubic_midpoint_final"}))
+    # ---- G4: wide (cfg5 dims, tiny batch); weights regenerated from the seeded generator ---------
+    B, L, C, H, HH, nl = 4, 40, 80, 128, 128, 3
+    coeffs = data.make_rectilinear_coeffs(B, L, C - 1, missing=0.6, seed=99)
+    p = data.make_field_weights(H, HH, C, seed=3)
+    rw = data.make_readin_weights(H, C, 1, seed=3)
+    z0 = z0_from(coeffs[:, 0], rw)
+    report.append(run_case("g4_wide_rk4_final", coeffs, "linear", p, "original",
+                           {"C": C, "H": H, "HH": HH, "nl": nl}, z0, "rk4", False, False,
+                           {"gen": "make_rectilinear_coeffs(4,40,79,0.6,99); make_field_weights(128,128,80,seed=3); "
+                                   "make_readin_weights(128,80,1,seed=3)"}))
+    # ---- G6: edge cases -------------------------------------------------------------------------
+    B, L, C, H, HH = 8, 6, 5, 16, 24
+    coeffs = data.make_rectilinear_coeffs(B, L, C - 1, missing=0.3, seed=7)
+    for nl in (1, 4):
+        p = data.make_field_weights(H, HH, C, seed=4)
+        rw = data.make_readin_weights(H, C, 1, seed=4)
+        z0 = z0_from(coeffs[:, 0], rw)
+        report.append(run_case(f"g6_nl{nl}_rk4_seq", coeffs, "linear", p, "original",
+                               {"C": C, "H": H, "HH": HH, "nl": nl}, z0, "rk4", True, True,
+                               {"gen": "make_rectilinear_coeffs(8,6,4,0.3,7)"}))
+    c2 = np.ascontiguousarray(coeffs[:, :2])  # T = 2: a single step
+    report.append(run_case("g6_T2_rk4_final", c2, "linear", p, "original",
+                           {"C": C, "H": H, "HH": HH, "nl": 4}, z0, "rk4", False, True, {"gen": "first two knots"}))
+    lin = data.make_linear_coeffs(8, 9, C - 1, seed=8)
+    report.append(run_case("g6_linear_euler_seq", lin, "linear", p, "original",
+                           {"C": C, "H": H, "HH": HH, "nl": 4}, z0, "euler", True, True, {"gen": "make_linear_coeffs(8,9,4,8)"}))
+
+    # ---- G7: NeuralCDE module level (h0, static, readout, rectilinear filter) --------------------
+    torch.manual_seed(0)
+    B, L, C, H, HH, nl, OUT = 8, 7, 5, 16, 24, 3, 3
+    coeffs = data.make_rectilinear_coeffs(B, L, C - 1, missing=0.3, seed=21)
+    static = data.normal(5, B * 4, stream=3).reshape(B, 4).astype(np.float32)
+    rec = {"coeffs": coeffs, "static": static}
+    variants = {
+        "final": dict(return_sequences=False),
+        "seq_filtered": dict(return_sequences=True, interpolation="rectilinear"),
+        "seq_all": dict(return_sequences=True, interpolation="rectilinear", return_filtered_rectilinear=False),
+        "static": dict(return_sequences=False, static_dim=4),
+        "noinit": dict(return_sequences=False, use_initial=False),
+    }
+    sd_ref = None
+    for vname, kw in variants.items():
+        kw = dict(dict(interpolation="linear"), **kw)
+        model = RefNeuralCDE(C, H, OUT, hidden_hidden_dim=HH, num_layers=nl, adjoint=True, solver="rk4", **kw)
+        sd = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+        inp = torch.from_numpy(coeffs)
+        if kw.get("static_dim"):
+            inp = (torch.from_numpy(static), inp)
+        out = model(inp)
+        w = torch.from_numpy(grad_out_like((out.shape[0], int(np.prod(out.shape[1:]))), 9).reshape(out.shape))
+        (out * w).sum().backward()
+        rec[f"{vname}__out"] = out.detach().numpy()
+        rec[f"{vname}__w"] = w.numpy()
+        for k, v in sd.items():
+            rec[f"{vname}__sd__{k}"] = v
+        for k, prm in model.named_parameters():
+            rec[f"{vname}__grad__{k}"] = prm.grad.numpy()
+        rec[f"{vname}__nfe"] = np.array(model.nfe)
+        print(f"g7_module/{vname}: out {tuple(out.shape)} nfe {model.nfe}")
+    rec["meta"] = np.array(json.dumps({"variants": {k: dict(dict(interpolation="linear"), **v) for k, v in variants.items()},
+                                       "dims": {"C": C, "H": H, "HH": HH, "nl": nl, "OUT": OUT}}))
+    np.savez_compressed(os.path.join(GOLD, "g7_module.npz"), **rec)
+
+    # ---- G5: full-size cfg2 forward z_T (inputs regenerated by tests from the generator) ---------
+    if "--no-full" not in sys.argv:
+        B, L, C, H, HH, nl = 4096, 200, 20, 32, 32, 3
+        coeffs = data.make_rectilinear_coeffs(B, L, C - 1, missing=0.3, seed=1234)
+        p = data.make_field_weights(H, HH, C, seed=0)
+        rw = data.make_readin_weights(H, C, 1, seed=0)
+        z0 = z0_from(coeffs[:, 0], rw)
+        func = ref_field_original(p, C, H, HH, nl)
+        X = torchcde.LinearInterpolation(torch.from_numpy(coeffs))
+        t0 = time.time()
+        with torch.no_grad():
+            zT = torchcde.cdeint(X, func, torch.from_numpy(z0), X.interval, adjoint=False, method="rk4",
+                                 options={"step_size": 1})[:, -1]
+        t_ref = time.time() - t0
+        ofield = orc.Field.original(p, H, C, nl)
+        t0 = time.time()
+        z_or = orc.solve_forward(orc.Control(coeffs, "linear"), ofield, z0, "rk4", False)[:, -1]
+        t_or = time.time() - t0
+        e = relerr(z_or, zT)
+        print(f"g5_cfg2_full: reference {t_ref:.2f}s ({B * (2 * L - 2) / t_ref:.3e} sample-steps/s) "
+              f"oracle {t_or:.2f}s ({B * (2 * L - 2) / t_or:.3e}) oracle-vs-ref {e:.2e}")
+        assert e < 2e-6
+        np.savez_compressed(os.path.join(GOLD, "g5_cfg2_full.npz"), zT=zT.numpy(),
+                            meta=np.array(json.dumps({"gen": "make_rectilinear_coeffs(4096,200,19,0.3,1234); "
+                                                      "make_field_weights(32,32,20,seed=0); make_readin_weights(32,20,1,seed=0)",
+                                                      "ref_seconds": t_ref, "oracle_seconds": t_or, "threads": 8,
+                                                      "oracle_vs_ref": e})))
+        report.append({"name": "g5_cfg2_full", "ref_seconds": t_ref, "oracle_seconds": t_or, "oracle_vs_ref": e})
+    with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
+        json.dump(report, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

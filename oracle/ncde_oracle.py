@@ -1,0 +1,241 @@
+"""ORACLE (test infrastructure, NOT product code) -- CPU restatement of the reference hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package never does (it fails loudly when the HIP library is missing).
+
+This is a plain PyTorch-CPU fp32 restatement of the op sequence the reference executes for
+``torchcde.cdeint(X, func, z0, t, adjoint=True, method in {rk4, midpoint, euler}, options={'step_size': 1})``
+on the default integer knot grid.  No autograd is used: the adjoint sweep uses hand-written VJPs.
+
+PARITY PIN: this file is checked against the *imported reference itself* (vendored torchcde 0.2.0 /
+torchdiffeq 0.2.1 under /root/reference/modules) by ``oracle/gen_golden.py``, which also writes the
+golden vectors in tests/golden/*.npz that tests/test_oracle_golden.py re-checks on every run.
+
+Reference lines restated (relative to /root/reference):
+  * knot index / linear derivative    modules/torchcde/torchcde/interpolation_linear.py:195-198, 212-219, 231-234
+  * cubic derivative                   modules/torchcde/torchcde/interpolation_cubic.py:291-305, 315-322, 331-336
+  * f_theta (MLP, shared inner layer)  src/ncde/vector_fields/base.py:64-69, 83-92, 97-104
+  * contraction f(z) dX/dt             modules/torchcde/torchcde/solver.py:112-137
+  * fixed grid loop / output pick      modules/torchdiffeq/torchdiffeq/_impl/solvers.py:78-87, 94-119, 166-172
+  * Euler / midpoint / RK4 (3/8 rule)  modules/torchdiffeq/torchdiffeq/_impl/fixed_grid.py:6-29, rk_common.py:106-114
+  * time reversal                      modules/torchdiffeq/torchdiffeq/_impl/misc.py:152-159, 262-271
+  * adjoint sweep                      modules/torchdiffeq/torchdiffeq/_impl/adjoint.py:37-145
+"""
+import math
+
+import torch
+
+_ONE_THIRD = 1 / 3
+_TWO_THIRDS = 2 / 3
+
+
+def _f32(x):
+    return torch.tensor(float(x), dtype=torch.float32)
+
+
+class Field:
+    """MLP vector field f_theta: R^H -> R^{H x C}.
+
+    ``layers`` is a list of (W, b) applied as Linear+ReLU; the same (W, b) tensors may appear several
+    times (the reference's OriginalVectorField repeats ONE inner layer nl-1 times, base.py:66-68).
+    ``Wo [H*C, d_last], bo [H*C]`` is the final Linear followed by tanh; row index = h*C + c.
+    """
+
+    def __init__(self, layers, Wo, bo, hidden, channels):
+        self.layers = [(torch.as_tensor(w), torch.as_tensor(b)) for w, b in layers]
+        self.Wo = torch.as_tensor(Wo)
+        self.bo = torch.as_tensor(bo)
+        self.H = hidden
+        self.C = channels
+        assert self.Wo.shape[0] == hidden * channels
+
+    @staticmethod
+    def original(p, hidden, channels, num_layers):
+        """OriginalVectorField parameter dict {W0,b0,W1,b1,Wo,bo} -> Field (W1 shared nl-1 times)."""
+        t = {k: torch.as_tensor(v) for k, v in p.items()}
+        layers = [(t["W0"], t["b0"])]
+        layers += [(t["W1"], t["b1"])] * (num_layers - 1)
+        return Field(layers, t["Wo"], t["bo"], hidden, channels)
+
+    def unique_params(self):
+        """De-duplicated parameter tensors in first-use order (adjoint.py:176-183 / nn.Module.parameters())."""
+        seen, out = set(), []
+        for w, b in self.layers:
+            for p in (w, b):
+                if id(p) not in seen:
+                    seen.add(id(p))
+                    out.append(p)
+        out += [self.Wo, self.bo]
+        return out
+
+    # -- forward of f_theta(z) . dX -----------------------------------------------------------
+    def g(self, z, dx, save=False):
+        x = z
+        acts = [z]
+        for w, b in self.layers:
+            x = torch.relu(torch.addmm(b, x, w.t()))
+            acts.append(x)
+        m = torch.tanh(torch.addmm(self.bo, x, self.Wo.t())).view(-1, self.H, self.C)
+        out = (m @ dx.unsqueeze(-1)).squeeze(-1)
+        if save:
+            return out, (acts, m)
+        return out
+
+    # -- VJP of g wrt (z, params) for cotangent c [B, H] ----------------------------------------
+    def g_vjp(self, saved, dx, c):
+        acts, m = saved
+        dm = c.unsqueeze(-1) * dx.unsqueeze(-2)                      # [B,H,C]
+        dp = (dm * (1 - m * m)).reshape(-1, self.H * self.C)          # tanh'
+        grads = {}
+
+        def acc(p, v):
+            if id(p) in grads:
+                grads[id(p)] = grads[id(p)] + v
+            else:
+                grads[id(p)] = v
+
+        acc(self.bo, dp.sum(0))
+        acc(self.Wo, dp.t() @ acts[-1])
+        dxl = dp @ self.Wo
+        for li in range(len(self.layers) - 1, -1, -1):
+            w, b = self.layers[li]
+            dpre = dxl * (acts[li + 1] > 0).to(dxl.dtype)
+            acc(b, dpre.sum(0))
+            acc(w, dpre.t() @ acts[li])
+            dxl = dpre @ w
+        return dxl, [grads[id(p)] for p in self.unique_params()]
+
+
+class Control:
+    """Control path on the default integer knot grid. kind in {'linear', 'cubic'} ('rectilinear' data
+    uses 'linear' evaluation, src/ncde/ncde.py:12-15)."""
+
+    def __init__(self, coeffs, kind):
+        self.kind = kind
+        coeffs = torch.as_tensor(coeffs)
+        self.coeffs = coeffs
+        if kind == "linear":
+            self.n_pieces = coeffs.shape[-2] - 1
+            # (c[1:]-c[:-1]) / (t[1:]-t[:-1]) with unit knot spacing (interpolation_linear.py:198)
+            t = torch.linspace(0, coeffs.shape[-2] - 1, coeffs.shape[-2], dtype=coeffs.dtype)
+            self.derivs = (coeffs[..., 1:, :] - coeffs[..., :-1, :]) / (t[1:] - t[:-1]).unsqueeze(-1)
+            self.channels = coeffs.shape[-1]
+        elif kind == "cubic":
+            self.n_pieces = coeffs.shape[-2]
+            ch = coeffs.shape[-1] // 4
+            self.channels = ch
+            self.a, self.b = coeffs[..., :ch], coeffs[..., ch:2 * ch]
+            self.two_c, self.three_d = coeffs[..., 2 * ch:3 * ch], coeffs[..., 3 * ch:]
+        else:
+            raise ValueError(kind)
+        self.n_knots = self.n_pieces + 1
+
+    def x0(self):
+        return self.coeffs[..., 0, :] if self.kind == "linear" else self.a[..., 0, :]
+
+    def piece(self, t):
+        """bucketize(t, knots, right=False) - 1, clamped: the LEFT piece at an exact knot."""
+        tv = float(t)
+        idx = int(math.ceil(tv)) - 1
+        return max(0, min(idx, self.n_pieces - 1))
+
+    def derivative(self, t):
+        idx = self.piece(t)
+        if self.kind == "linear":
+            return self.derivs[..., idx, :]
+        frac = t - _f32(idx)
+        inner = self.two_c[..., idx, :] + self.three_d[..., idx, :] * frac
+        return self.b[..., idx, :] + inner * frac
+
+
+def stage_plan(method):
+    if method not in ("rk4", "midpoint", "euler"):
+        raise ValueError('Invalid method "{}"'.format(method))
+    return method
+
+
+def _step(fn, method, t0, dt, t1, y0):
+    """One fixed step on a tuple state.  fn(t, state) -> tuple of derivatives."""
+    if method == "euler":
+        f0 = fn(t0, y0)
+        return tuple(y + dt * f for y, f in zip(y0, f0))
+    if method == "midpoint":
+        half_dt = 0.5 * dt
+        f0 = fn(t0, y0)
+        ymid = tuple(y + f * half_dt for y, f in zip(y0, f0))
+        fm = fn(t0 + half_dt, ymid)
+        return tuple(y + dt * f for y, f in zip(y0, fm))
+    # rk4 = torchdiffeq's rk4_alt_step_func (3/8 rule)
+    k1 = fn(t0, y0)
+    k2 = fn(t0 + dt * _ONE_THIRD, tuple(y + dt * a * _ONE_THIRD for y, a in zip(y0, k1)))
+    k3 = fn(t0 + dt * _TWO_THIRDS, tuple(y + dt * (b - a * _ONE_THIRD) for y, a, b in zip(y0, k1, k2)))
+    k4 = fn(t1, tuple(y + dt * (a - b + c) for y, a, b, c in zip(y0, k1, k2, k3)))
+    return tuple(y + (a + 3 * (b + c) + d) * dt * 0.125 for y, a, b, c, d in zip(y0, k1, k2, k3, k4))
+
+
+def solve_forward(control, field, z0, method="rk4", sequence=False, nfe=None):
+    """z at t = [0, T-1] (sequence=False -> [B,2,H]) or at every knot (sequence=True -> [B,T,H])."""
+    stage_plan(method)
+    z0 = torch.as_tensor(z0)
+    T = control.n_knots
+
+    def fn(t, state):
+        if nfe is not None:
+            nfe[0] += 1
+        return (field.g(state[0], control.derivative(t)),)
+
+    ys = [z0]
+    y = (z0,)
+    for n in range(T - 1):
+        t0, t1 = _f32(n), _f32(n + 1)
+        y = _step(fn, method, t0, t1 - t0, t1, y)
+        if sequence:
+            ys.append(y[0])
+    if not sequence:
+        ys.append(y[0])
+    return torch.stack(ys, dim=1)
+
+
+def solve_adjoint(control, field, z_out, grad_out, method="rk4", sequence=False, nfe=None):
+    """Continuous-adjoint reverse sweep of adjoint.py:37-145.
+
+    z_out / grad_out: [B, n_out, H] with n_out = 2 (interval) or T (every knot).
+    Returns (dL/dz0 [B,H], [dL/dparam ...] in Field.unique_params() order).
+    """
+    stage_plan(method)
+    z_out = torch.as_tensor(z_out)
+    grad_out = torch.as_tensor(grad_out)
+    T = control.n_knots
+    params = field.unique_params()
+
+    def fn(s, state):
+        # _ReverseFunc: -base(-s, .)   (misc.py:152-159); base = augmented_dynamics with cotangent -a
+        if nfe is not None:
+            nfe[0] += 1
+        y, a = state[0], state[1]
+        t = -s
+        dx = control.derivative(t)
+        f, saved = field.g(y, dx, save=True)
+        vjp_y, vjp_p = field.g_vjp(saved, dx, -a)
+        return (-f, -vjp_y) + tuple(-v for v in vjp_p)
+
+    y = z_out[:, -1]
+    a = grad_out[:, -1].clone()
+    g = tuple(torch.zeros_like(p) for p in params)
+
+    def sweep(n_hi, n_lo, y, a, g):
+        state = (y, a) + g
+        for n in range(n_hi, n_lo, -1):          # reverse step n -> n-1, in negated time s: -n -> -(n-1)
+            s0, s1 = _f32(-n), _f32(-(n - 1))
+            state = _step(fn, method, s0, s1 - s0, s1, state)
+        return state[0], state[1], tuple(state[2:])
+
+    if sequence:
+        for i in range(T - 1, 0, -1):
+            y, a, g = sweep(i, i - 1, y, a, g)
+            y = z_out[:, i - 1]                  # reset to the stored forward value (adjoint.py:132)
+            a = a + grad_out[:, i - 1]           # (adjoint.py:133)
+    else:
+        y, a, g = sweep(T - 1, 0, y, a, g)
+        a = a + grad_out[:, 0]
+    return a, list(g)

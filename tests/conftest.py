@@ -1,0 +1,22 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    """The C-ABI library on a live GPU; GPU tests must never silently fall back."""
+    import torch
+    import ncde_amd
+    assert torch.cuda.is_available(), "GPU test run without a GPU"
+    return ncde_amd.lib()

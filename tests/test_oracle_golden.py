@@ -1,0 +1,70 @@
+"""CPU: the oracle (oracle/ncde_oracle.py) against the golden vectors produced by the imported
+reference (oracle/gen_golden.py).  This is what pins the oracle; GPU parity tests then compare the
+HIP path with both the oracle and these same fixtures."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+import ncde_oracle as orc
+
+# forward: the restatement is bit-exact vs the reference on this image; allow 1 ulp-ish slack for
+# other hosts' MKL kernels.  adjoint: hand VJPs vs autograd differ in summation order only.
+TOL_Z, TOL_G = 2e-6, 2e-5
+
+
+@pytest.mark.parametrize("name", gu.SOLVE_CASES)
+def test_oracle_matches_reference_golden(name):
+    case = gu.load_case(name)
+    m = case["meta"]
+    field = gu.oracle_field(case)
+    ctl = orc.Control(case["coeffs"], m["kind"])
+    nfe = [0]
+    z = orc.solve_forward(ctl, field, case["z0"], m["method"], m["sequence"], nfe=nfe)
+    ex = case["expect"]
+    assert z.shape == ex["z_out"].shape
+    assert gu.relerr(z, ex["z_out"]) <= TOL_Z
+    dz0, gp = orc.solve_adjoint(ctl, field, z, ex["grad_out"], m["method"], m["sequence"], nfe=nfe)
+    assert gu.relerr(dz0, ex["dz0"]) <= TOL_G
+    for pname, g in zip(m["param_names"], gp):
+        if "d" + pname in ex:
+            assert gu.relerr(g, ex["d" + pname]) <= TOL_G, pname
+        else:
+            assert gu.relerr(g.numpy()[::16], ex["d" + pname + "__rows16"]) <= TOL_G, pname
+            assert gu.relerr(g.double().sum(0).numpy(), ex["d" + pname + "__colsum"]) <= TOL_G, pname
+    stages = {"rk4": 4, "midpoint": 2, "euler": 1}[m["method"]]
+    assert nfe[0] == 2 * stages * (ctl.n_knots - 1)      # same nfe accounting as base.py:90 (fwd + adjoint)
+
+
+def test_oracle_full_size_cfg2_forward():
+    """BASELINE config 2 at full size (B=4096, T=399): z_T from the reference, inputs regenerated."""
+    f = np.load(os.path.join(gu.GOLD, "g5_cfg2_full.npz"))
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    coeffs = gu.data.make_rectilinear_coeffs(4096, 200, 19, missing=0.3, seed=1234)
+    p = gu.data.make_field_weights(32, 32, 20, seed=0)
+    rw = gu.data.make_readin_weights(32, 20, 1, seed=0)
+    z0 = (coeffs[:, 0] @ rw["Wi"].T + rw["bi"]).astype(np.float32)
+    field = orc.Field.original(p, 32, 20, 3)
+    zT = orc.solve_forward(orc.Control(coeffs, "linear"), field, z0, "rk4", False)[:, -1]
+    assert gu.relerr(zT, f["zT"]) <= TOL_Z
+
+
+def test_knot_index_rule():
+    """Left piece at an exact knot (bucketize right=False), clamped -- SURVEY.md §3.1."""
+    ctl = orc.Control(np.zeros((1, 6, 2), np.float32), "linear")
+    third = torch.tensor(1.0) * (1 / 3)
+    got = [ctl.piece(torch.tensor(float(n))) for n in range(6)]
+    assert got == [0, 0, 1, 2, 3, 4]
+    assert ctl.piece(torch.tensor(2.0) + third) == 2
+    assert ctl.piece(torch.tensor(7.0)) == 4 and ctl.piece(torch.tensor(-1.0)) == 0
+
+
+def test_manifest_records_oracle_pin():
+    with open(os.path.join(gu.GOLD, "MANIFEST.json")) as fh:
+        man = json.load(fh)
+    for rec in man:
+        if "oracle_vs_ref" in rec and isinstance(rec["oracle_vs_ref"], dict):
+            assert rec["oracle_vs_ref"]["z"] <= TOL_Z and rec["oracle_vs_ref"]["dtheta"] <= TOL_G
