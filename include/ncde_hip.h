@@ -1,0 +1,133 @@
+/*
+ * ncde_hip.h -- C-ABI of libncde_hip.so, the MI355X (gfx950) Neural-CDE fixed-step integrator.
+ *
+ * The reference (jambo6/online-neural-cdes) has no FFI layer: its hot path is two Python callables,
+ *   torchcde.cdeint(X, func, z0, t, adjoint=True, ...)        modules/torchcde/torchcde/solver.py:140-238
+ *   NeuralCDE.forward(inputs)                                  src/ncde/ncde.py:214-243
+ * which expand to the Python time loop of torchdiffeq's FixedGridODESolver.integrate
+ * (modules/torchdiffeq/torchdiffeq/_impl/solvers.py:94-119) and, for the backward pass,
+ * OdeintAdjointMethod.backward (modules/torchdiffeq/torchdiffeq/_impl/adjoint.py:37-145).
+ * The entry points below are what a maintainer of the reference would bind (ctypes, see
+ * INTEGRATION.md) to replace exactly those two loops.
+ *
+ * Conventions
+ *   - every pointer inside NcdeProblem is a DEVICE pointer to fp32 data owned by the caller;
+ *   - the library is stateless and re-entrant; work is enqueued on `stream` (a hipStream_t, NULL =
+ *     default stream) and the calls never synchronise and never allocate;
+ *   - scratch memory is passed in: ask ncde_workspace_bytes(), hand over `workspace`;
+ *   - return value 0 = success, negative = NcdeStatus; ncde_last_error_string() describes the last
+ *     failure of the calling thread.  Nothing throws across the boundary.
+ */
+#ifndef NCDE_HIP_H
+#define NCDE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NCDE_ABI_VERSION 1
+#define NCDE_MAX_LAYERS 8
+
+typedef enum NcdeStatus {
+    NCDE_OK = 0,
+    NCDE_ERR_INVALID = -1,      /* malformed problem (maps to ValueError / AssertionError in Python)    */
+    NCDE_ERR_UNSUPPORTED = -2,  /* well-formed but outside what the kernels cover                      */
+    NCDE_ERR_WORKSPACE = -3,    /* workspace too small                                                 */
+    NCDE_ERR_HIP = -4           /* a HIP runtime call failed (launch error, no device, ...)            */
+} NcdeStatus;
+
+/* control-path evaluator: replaces LinearInterpolation.derivative (interpolation_linear.py:212-234)
+ * and NaturalCubicSpline.derivative (interpolation_cubic.py:315-336) on the default integer grid. */
+typedef enum NcdeInterp { NCDE_INTERP_LINEAR = 0, NCDE_INTERP_CUBIC = 1 } NcdeInterp;
+
+/* fixed-step solver: replaces Euler / Midpoint / RK4 (3/8 rule) of fixed_grid.py:6-29,
+ * rk_common.py:106-114 with options={'step_size': 1}. */
+typedef enum NcdeMethod { NCDE_EULER = 0, NCDE_MIDPOINT = 1, NCDE_RK4_38 = 2 } NcdeMethod;
+
+/* which times the solution is reported at: t = X.interval (2 outputs: z(0), z(T-1)) or
+ * t = X.grid_points (every knot), the two cases src/ncde/ncde.py:219-225 uses. */
+typedef enum NcdeOutput { NCDE_OUT_INTERVAL = 0, NCDE_OUT_KNOTS = 1 } NcdeOutput;
+
+/* kernel family selection (ncde_forward/ncde_adjoint `flags`) */
+#define NCDE_FLAG_AUTO 0u
+#define NCDE_FLAG_FORCE_GENERIC 1u  /* never use a shape-specialised kernel */
+#define NCDE_FLAG_FORCE_FAST 2u     /* fail with NCDE_ERR_UNSUPPORTED if no specialised kernel fits */
+
+typedef struct NcdeProblem {
+    int32_t abi_version;  /* = NCDE_ABI_VERSION */
+    int32_t batch;        /* B */
+    int32_t n_knots;      /* T: knots of the control path (linear: coeffs rows; cubic: rows + 1) */
+    int32_t channels;     /* C: control channels incl. time */
+    int32_t hidden;       /* H: state size */
+    int32_t interp;       /* NcdeInterp */
+    int32_t method;       /* NcdeMethod */
+    int32_t output;       /* NcdeOutput */
+    uint32_t flags;       /* NCDE_FLAG_* */
+
+    /* vector field f_theta (src/ncde/vector_fields/base.py:64-69, 83-104):
+     *   x_0 = z;  x_l = relu(W_l x_{l-1} + b_l), l = 1..n_layers;  M = tanh(Wo x_n + bo) viewed [H, C]
+     * layer_W[l] is [layer_out[l], layer_in[l]] row-major (torch Linear layout); the same pointer may
+     * appear in several slots (the reference shares ONE inner layer nl-1 times, base.py:66-68).
+     * Wo is [H*C, layer_out[n_layers-1]] with row index h*C + c. */
+    int32_t n_layers;
+    int32_t layer_in[NCDE_MAX_LAYERS];
+    int32_t layer_out[NCDE_MAX_LAYERS];
+    const float* layer_W[NCDE_MAX_LAYERS];
+    const float* layer_b[NCDE_MAX_LAYERS];
+    const float* Wo;
+    const float* bo;
+
+    /* control-path coefficients, row-major, element strides:
+     *   linear/rectilinear: coeffs[b][t][c], t < T           (linear_interpolation_coeffs output)
+     *   cubic:              coeffs[b][p][4C] = a|b|2c|3d, p < T-1 (natural_cubic_coeffs output)    */
+    const float* coeffs;
+    int64_t coeffs_stride_b;
+    int64_t coeffs_stride_t;
+
+    const float* z0; /* [B, H] contiguous */
+} NcdeProblem;
+
+/* gradient outputs of the adjoint sweep; aliasing must mirror NcdeProblem.layer_W/layer_b
+ * (a shared layer receives the SUM over its uses).  Buffers are overwritten, not accumulated. */
+typedef struct NcdeGrads {
+    float* grad_z0;                      /* [B, H] */
+    float* grad_layer_W[NCDE_MAX_LAYERS];
+    float* grad_layer_b[NCDE_MAX_LAYERS];
+    float* grad_Wo;
+    float* grad_bo;
+} NcdeGrads;
+
+int ncde_version(void);
+const char* ncde_last_error_string(void);
+
+/* number of solution rows per sample: 2 (interval) or T (knots) */
+int ncde_num_outputs(const NcdeProblem* p);
+
+/* scratch bytes needed by ncde_forward (pass = 0) / ncde_adjoint (pass = 1); negative = NcdeStatus */
+int64_t ncde_workspace_bytes(const NcdeProblem* p, int pass);
+
+/* name of the kernel family the call would dispatch to ("generic", "fast_h32_c20", ...); NULL on error */
+const char* ncde_kernel_name(const NcdeProblem* p, int pass);
+
+/* Forward solve.  out: [B, n_out, H]; row 0 is z0, then the solution at the requested times.
+ * Replaces odeint(...)/FixedGridODESolver.integrate under torch.no_grad (adjoint.py:24-33). */
+int ncde_forward(const NcdeProblem* p, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Continuous-adjoint reverse sweep (adjoint.py:37-145): given the forward outputs z_out [B,n_out,H]
+ * and dL/dz_out grad_out [B,n_out,H], writes dL/dz0 and dL/dtheta. */
+int ncde_adjoint(const NcdeProblem* p, const float* z_out, const float* grad_out, const NcdeGrads* grads,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* Timing helper for benchmarks: runs `iters` back-to-back launches of the dominant kernel of the given
+ * pass on `stream`, bracketed by HIP events on that same stream, and returns the mean milliseconds per
+ * launch in *ms_per_launch (this call DOES synchronise). */
+int ncde_time_kernel(const NcdeProblem* p, int pass, float* out, const float* grad_out, const NcdeGrads* grads,
+                     void* workspace, size_t workspace_bytes, void* stream, int iters, float* ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NCDE_HIP_H */

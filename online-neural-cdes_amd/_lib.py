@@ -1,0 +1,110 @@
+"""ctypes binding of libncde_hip.so (C-ABI declared in include/ncde_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or fails to load, ``lib()``
+raises.  Build it with ``python __graft_entry__.py`` (or ``make -C online-neural-cdes_amd/csrc``).
+"""
+import ctypes
+import os
+
+NCDE_ABI_VERSION = 1
+NCDE_MAX_LAYERS = 8
+
+INTERP = {"linear": 0, "cubic": 1}
+METHOD = {"euler": 0, "midpoint": 1, "rk4": 2}
+OUT_INTERVAL, OUT_KNOTS = 0, 1
+FLAG_AUTO, FLAG_FORCE_GENERIC, FLAG_FORCE_FAST = 0, 1, 2
+
+_c_float_p = ctypes.c_void_p  # device pointers are passed as integers
+
+
+class NcdeProblem(ctypes.Structure):
+    _fields_ = [
+        ("abi_version", ctypes.c_int32),
+        ("batch", ctypes.c_int32),
+        ("n_knots", ctypes.c_int32),
+        ("channels", ctypes.c_int32),
+        ("hidden", ctypes.c_int32),
+        ("interp", ctypes.c_int32),
+        ("method", ctypes.c_int32),
+        ("output", ctypes.c_int32),
+        ("flags", ctypes.c_uint32),
+        ("n_layers", ctypes.c_int32),
+        ("layer_in", ctypes.c_int32 * NCDE_MAX_LAYERS),
+        ("layer_out", ctypes.c_int32 * NCDE_MAX_LAYERS),
+        ("layer_W", _c_float_p * NCDE_MAX_LAYERS),
+        ("layer_b", _c_float_p * NCDE_MAX_LAYERS),
+        ("Wo", _c_float_p),
+        ("bo", _c_float_p),
+        ("coeffs", _c_float_p),
+        ("coeffs_stride_b", ctypes.c_int64),
+        ("coeffs_stride_t", ctypes.c_int64),
+        ("z0", _c_float_p),
+    ]
+
+
+class NcdeGrads(ctypes.Structure):
+    _fields_ = [
+        ("grad_z0", _c_float_p),
+        ("grad_layer_W", _c_float_p * NCDE_MAX_LAYERS),
+        ("grad_layer_b", _c_float_p * NCDE_MAX_LAYERS),
+        ("grad_Wo", _c_float_p),
+        ("grad_bo", _c_float_p),
+    ]
+
+
+EXPORTS = (
+    "ncde_version", "ncde_last_error_string", "ncde_num_outputs", "ncde_workspace_bytes",
+    "ncde_kernel_name", "ncde_forward", "ncde_adjoint", "ncde_time_kernel",
+)
+
+_LIB = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libncde_hip.so")
+
+
+class NcdeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP extension is not built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise NcdeError(
+            "libncde_hip.so is not built (%s). Run `python __graft_entry__.py` or "
+            "`make -C online-neural-cdes_amd/csrc`; there is no CPU fallback." % LIB_PATH)
+    h = ctypes.CDLL(LIB_PATH)
+    P = ctypes.POINTER(NcdeProblem)
+    G = ctypes.POINTER(NcdeGrads)
+    vp, sz = ctypes.c_void_p, ctypes.c_size_t
+    h.ncde_version.restype = ctypes.c_int
+    h.ncde_last_error_string.restype = ctypes.c_char_p
+    h.ncde_num_outputs.argtypes = [P]
+    h.ncde_num_outputs.restype = ctypes.c_int
+    h.ncde_workspace_bytes.argtypes = [P, ctypes.c_int]
+    h.ncde_workspace_bytes.restype = ctypes.c_int64
+    h.ncde_kernel_name.argtypes = [P, ctypes.c_int]
+    h.ncde_kernel_name.restype = ctypes.c_char_p
+    h.ncde_forward.argtypes = [P, vp, vp, sz, vp]
+    h.ncde_forward.restype = ctypes.c_int
+    h.ncde_adjoint.argtypes = [P, vp, vp, G, vp, sz, vp]
+    h.ncde_adjoint.restype = ctypes.c_int
+    h.ncde_time_kernel.argtypes = [P, ctypes.c_int, vp, vp, G, vp, sz, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+    h.ncde_time_kernel.restype = ctypes.c_int
+    if h.ncde_version() != NCDE_ABI_VERSION:
+        raise NcdeError("libncde_hip.so ABI %d != binding %d" % (h.ncde_version(), NCDE_ABI_VERSION))
+    _LIB = h
+    return h
+
+
+def check(rc, what):
+    """Map a negative NcdeStatus to the exception class the reference raises for the same mistake."""
+    if rc >= 0:
+        return rc
+    msg = "%s: %s" % (what, (lib().ncde_last_error_string() or b"").decode())
+    if rc == -1:
+        raise ValueError(msg)            # malformed input (cf. solver.py:189-190, misc.py:224-226)
+    if rc == -2:
+        raise NotImplementedError(msg)
+    raise NcdeError(msg)

@@ -1,0 +1,81 @@
+// Shared device-side definitions for the Neural-CDE kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ncde_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NCDE_TILE 16  // samples per workgroup tile = N of v_mfma_f32_16x16x4_f32
+
+// Kernel argument block (passed by value).
+struct KArgs {
+    int B, T, C, H, interp, method, output, n_layers, n_pieces, n_out;
+    int din[NCDE_MAX_LAYERS], dout[NCDE_MAX_LAYERS];
+    const float* W[NCDE_MAX_LAYERS];
+    const float* b[NCDE_MAX_LAYERS];
+    const float* Wo;
+    const float* bo;
+    const float* coeffs;
+    long long cs_b, cs_t;
+    const float* z0;
+    float* out;  // forward: [B, n_out, H]
+    // adjoint
+    const float* z_out;
+    const float* grad_out;
+    float* grad_z0;
+    float* gpart;  // [gridDim.x][theta_size] per-workgroup parameter-gradient partials
+    int gW_off[NCDE_MAX_LAYERS], gb_off[NCDE_MAX_LAYERS];
+    int gWo_off, gbo_off, theta_size;
+    int gacc_in_lds;  // generic adjoint: keep the partial in LDS and flush at the end
+};
+
+__device__ __forceinline__ int ru4(int x) { return (x + 3) & ~3; }
+__device__ __forceinline__ int ru16(int x) { return (x + 15) & ~15; }
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    // D[16x16] += A[16x4] * B[4x16]; lane l supplies A[l&15][l>>4], B[l>>4][l&15];
+    // D: col = l&15, row = 4*(l>>4) + reg.
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// tanh via exp2 + rcp (two transcendental issues); |abs err| < 2e-7 over the whole range.
+__device__ __forceinline__ float tanh_dev(float x) {
+    const float ax = __builtin_fabsf(x);
+    const float e = __builtin_amdgcn_exp2f(ax * -2.8853900817779268f);  // exp(-2|x|)
+    const float r = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+    return __builtin_copysignf(r, x);
+}
+
+// Number of stages and the fp32 stage-time offsets torchdiffeq produces with dt = 1
+// (fixed_grid.py:6-29, rk_common.py:111-113: dt*(1/3), dt*(2/3) rounded to fp32).
+__device__ __forceinline__ int n_stages(int method) { return method == NCDE_RK4_38 ? 4 : (method == NCDE_MIDPOINT ? 2 : 1); }
+__device__ __forceinline__ float stage_offset(int method, int j) {
+    if (method == NCDE_RK4_38) return j == 0 ? 0.0f : (j == 1 ? 0.333333343267440796f : (j == 2 ? 0.666666686534881592f : 1.0f));
+    if (method == NCDE_MIDPOINT) return j == 0 ? 0.0f : 0.5f;
+    return 0.0f;
+}
+// RK quadrature weight of stage j (what multiplies k_j in y1 = y0 + sum_j w_j k_j).
+__device__ __forceinline__ float stage_weight(int method, int j) {
+    if (method == NCDE_RK4_38) return (j == 0 || j == 3) ? 0.125f : 0.375f;
+    if (method == NCDE_MIDPOINT) return j == 0 ? 0.0f : 1.0f;
+    return 1.0f;
+}
+
+// bucketize(t, knots, right=False) - 1 clamped to [0, n_pieces-1]: the LEFT piece at an exact knot
+// (interpolation_linear.py:212-219).
+__device__ __forceinline__ int piece_index(float t, int n_pieces) {
+    int idx = (int)__builtin_ceilf(t) - 1;
+    idx = idx < 0 ? 0 : idx;
+    return idx > n_pieces - 1 ? n_pieces - 1 : idx;
+}
+
+// sum over the 16 lanes of a row (lanes sharing lane>>4); every lane gets the total.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+}

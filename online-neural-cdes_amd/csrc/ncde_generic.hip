@@ -1,0 +1,470 @@
+// Generic (runtime-dimension) Neural-CDE kernels for gfx950.
+//
+// One workgroup = one tile of 16 samples, 4 waves.  All activations live in LDS as [unit][sample]
+// (sample fastest), which is simultaneously the B-operand image (k = unit, n = sample) and the
+// A-operand image (m = unit, k = sample) of v_mfma_f32_16x16x4_f32, so every GEMM of the forward
+// stage, of the VJP and of the weight gradient is an MFMA chain fed from LDS (activations) and
+// global/L2 (weights).  The whole time loop runs inside the kernel: the state never leaves the CU.
+//
+// This family covers ANY (H, layer widths, C, T, B); shape-specialised register-resident kernels
+// live in ncde_fast.hip.  Reference semantics restated (relative to /root/reference):
+//   stage loop          modules/torchdiffeq/torchdiffeq/_impl/solvers.py:103-117, fixed_grid.py:6-29,
+//                       rk_common.py:106-114
+//   f_theta(z).dX/dt    src/ncde/vector_fields/base.py:83-104, modules/torchcde/torchcde/solver.py:112-137
+//   dX/dt               modules/torchcde/torchcde/interpolation_linear.py:212-234, interpolation_cubic.py:315-336
+//   adjoint sweep       modules/torchdiffeq/torchdiffeq/_impl/adjoint.py:37-145, misc.py:152-159
+#include "ncde_common.h"
+
+#define GEN_NW 4
+#define GEN_THREADS (64 * GEN_NW)
+#define GEN_MAXJT 8  // hidden widths up to 128 in the adjoint kernel
+
+namespace {
+
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// dX/dt(t) for the 16 samples of the tile -> DX[c*16 + s]  (rows c >= C and samples >= B are zero)
+__device__ void load_dx(const KArgs& a, int b0, int idx, float frac, float* DX, int Cp, int tid) {
+    for (int e = tid; e < 16 * Cp; e += GEN_THREADS) {
+        const int s = e / Cp, c = e - s * Cp;
+        const int b = b0 + s;
+        float v = 0.0f;
+        if (c < a.C && b < a.B) {
+            const float* p = a.coeffs + (long long)b * a.cs_b + (long long)idx * a.cs_t;
+            if (a.interp == NCDE_INTERP_LINEAR) {
+                v = p[a.cs_t + c] - p[c];
+            } else {
+                const float bb = p[a.C + c], cc = p[2 * a.C + c], dd = p[3 * a.C + c];
+                const float inner = cc + dd * frac;
+                v = bb + inner * frac;
+            }
+        }
+        DX[c * 16 + s] = v;
+    }
+}
+
+// out[n][s] = relu(sum_k W[n][k] in[k][s] + bias[n]) for n < ru16(N) (rows >= N come out as 0).
+__device__ void dense_relu(const float* __restrict__ W, const float* __restrict__ bias, int N, int K,
+                           const float* in, float* out, int wave, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    const int ntiles = (N + 15) >> 4, nks = (K + 3) >> 2;
+    for (int t = wave; t < ntiles; t += GEN_NW) {
+        const int rowA = 16 * t + li;
+        const bool rv = rowA < N;
+        const float* wrow = W + (long long)(rv ? rowA : 0) * K;
+        f32x4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * t + 4 * lk + r;
+            acc[r] = row < N ? bias[row] : 0.0f;
+        }
+#pragma unroll 4
+        for (int ks = 0; ks < nks; ++ks) {
+            const int k = 4 * ks + lk;
+            const float av = (rv && k < K) ? wrow[k] : 0.0f;
+            acc = mfma16(av, in[k * 16 + li], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(16 * t + 4 * lk + r) * 16 + li] = fmaxf(acc[r], 0.0f);
+    }
+}
+
+struct StageCombine {
+    // Butcher bookkeeping on one state array set (Y0, K1, K2) given the fresh stage derivative k.
+    // Returns the next stage input (or the new state after the last stage); `last` tells which.
+    __device__ static __forceinline__ float apply(int method, int j, float k, float& y0, float& k1, float& k2, bool& last) {
+        last = false;
+        if (method == NCDE_RK4_38) {
+            if (j == 0) { k1 = k; return y0 + k * 0.333333343267440796f; }
+            if (j == 1) { k2 = k; return y0 + (k - k1 * 0.333333343267440796f); }
+            if (j == 2) { const float ys = y0 + ((k1 - k2) + k); k2 = k2 + k; return ys; }
+            last = true;
+            y0 = y0 + ((k1 + 3.0f * k2) + k) * 0.125f;
+            return y0;
+        }
+        if (method == NCDE_MIDPOINT) {
+            if (j == 0) return y0 + k * 0.5f;
+            last = true;
+            y0 = y0 + k;
+            return y0;
+        }
+        last = true;
+        y0 = y0 + k;
+        return y0;
+    }
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_fwd_generic(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int b0 = blockIdx.x * NCDE_TILE;
+    const int H = a.H, C = a.C, Hp = ru16(H), Cp = ru4(C);
+    int Dp = Hp;
+    for (int l = 0; l < a.n_layers; ++l) Dp = max(Dp, ru16(a.dout[l]));
+    const int HS = Hp * 16, DS = Dp * 16;
+    float* YS = lds;
+    float* ACT0 = YS + HS;
+    float* ACT1 = ACT0 + DS;
+    float* Y0 = ACT1 + DS;
+    float* K1 = Y0 + HS;
+    float* K2 = K1 + HS;
+    float* KO = K2 + HS;
+    float* DX = KO + HS;
+    const int total = 5 * HS + 2 * DS + Cp * 16;
+    for (int e = tid; e < total; e += GEN_THREADS) lds[e] = 0.0f;
+    __syncthreads();
+    for (int e = tid; e < HS; e += GEN_THREADS) {
+        const int h = e >> 4, s = e & 15, b = b0 + s;
+        if (h < H && b < a.B) {
+            const float v = a.z0[(long long)b * H + h];
+            Y0[e] = v;
+            YS[e] = v;
+            a.out[((long long)b * a.n_out) * H + h] = v;
+        }
+    }
+    const int S = n_stages(a.method);
+    const int dlast = a.n_layers ? a.dout[a.n_layers - 1] : H;
+    const int nks_o = (dlast + 3) >> 2, nhb = Hp >> 2, ncq = Cp >> 2;
+    int cur_idx = -1;
+    for (int n = 0; n < a.T - 1; ++n) {
+        for (int j = 0; j < S; ++j) {
+            const float t = (float)n + stage_offset(a.method, j);
+            const int idx = piece_index(t, a.n_pieces);
+            if (a.interp != NCDE_INTERP_LINEAR || idx != cur_idx) {
+                load_dx(a, b0, idx, t - (float)idx, DX, Cp, tid);
+                cur_idx = idx;
+            }
+            __syncthreads();
+            const float* in = YS;
+            for (int l = 0; l < a.n_layers; ++l) {
+                float* outb = (l & 1) ? ACT1 : ACT0;
+                dense_relu(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane);
+                __syncthreads();
+                in = outb;
+            }
+            // output layer + tanh + channel contraction; tile rows (g, r) <-> (h = 4hb+g, c = 4cq+r)
+            for (int hb = wave; hb < nhb; hb += GEN_NW) {
+                float kacc = 0.0f;
+                const int hA = 4 * hb + (li >> 2), hD = 4 * hb + lk;
+                for (int cq = 0; cq < ncq; ++cq) {
+                    const int cA = 4 * cq + (li & 3);
+                    const bool rv = hA < H && cA < C;
+                    const float* wrow = a.Wo + (long long)(rv ? hA * C + cA : 0) * dlast;
+                    f32x4 acc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 4 * cq + r;
+                        acc[r] = (hD < H && c < C) ? a.bo[hD * C + c] : 0.0f;
+                    }
+#pragma unroll 4
+                    for (int ks = 0; ks < nks_o; ++ks) {
+                        const int k = 4 * ks + lk;
+                        const float av = (rv && k < dlast) ? wrow[k] : 0.0f;
+                        acc = mfma16(av, in[k * 16 + li], acc);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) kacc = fmaf(tanh_dev(acc[r]), DX[(4 * cq + r) * 16 + li], kacc);
+                }
+                KO[hD * 16 + li] = kacc;
+            }
+            __syncthreads();
+            for (int e = tid; e < HS; e += GEN_THREADS) {
+                float y0 = Y0[e], k1 = K1[e], k2 = K2[e];
+                bool last;
+                const float ys = StageCombine::apply(a.method, j, KO[e], y0, k1, k2, last);
+                YS[e] = ys;
+                K1[e] = k1;
+                K2[e] = k2;
+                if (last) {
+                    Y0[e] = y0;
+                    const int h = e >> 4, s = e & 15, b = b0 + s;
+                    if (h < H && b < a.B) {
+                        if (a.output == NCDE_OUT_KNOTS) a.out[((long long)b * a.n_out + (n + 1)) * H + h] = y0;
+                        else if (n == a.T - 2) a.out[((long long)b * a.n_out + 1) * H + h] = y0;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// adjoint (reverse sweep of y, a, g_theta)
+// ------------------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_adj_generic(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int b0 = blockIdx.x * NCDE_TILE;
+    const int H = a.H, C = a.C, Hp = ru16(H), Cp = ru4(C), L = a.n_layers;
+    int Dp = Hp;
+    for (int l = 0; l < L; ++l) Dp = max(Dp, ru16(a.dout[l]));
+    const int HS = Hp * 16, DS = Dp * 16;
+    // state arrays [Hp][16]
+    float* YS = lds;           // y stage input (= x_0)
+    float* AS = YS + HS;       // a stage input
+    float* Y0 = AS + HS;
+    float* A0 = Y0 + HS;
+    float* KY1 = A0 + HS;
+    float* KY2 = KY1 + HS;
+    float* KA1 = KY2 + HS;
+    float* KA2 = KA1 + HS;
+    float* KOY = KA2 + HS;     // f(y).dX of the stage
+    float* KOA = KOY + HS;     // a^T df/dy of the stage
+    float* X = KOA + HS;       // x_1..x_L, [L][Dp][16]
+    float* G0 = X + (L > 0 ? L : 1) * DS;  // dL/dx ping
+    float* G1 = G0 + DS;       // dL/dpre pong
+    float* PW2 = G1 + DS;      // partial buffers of waves 2,3 (waves 0,1 use G0,G1)
+    float* DX = PW2 + 2 * DS;
+    float* SC = DX + Cp * 16;  // per-wave 16x17 transpose scratch
+    float* GL = SC + GEN_NW * 16 * 17;  // parameter-gradient partial when it fits in LDS
+    const int total = 10 * HS + ((L > 0 ? L : 1) + 4) * DS + Cp * 16 + GEN_NW * 16 * 17 + (a.gacc_in_lds ? a.theta_size : 0);
+    for (int e = tid; e < total; e += GEN_THREADS) lds[e] = 0.0f;
+    float* gacc = a.gacc_in_lds ? GL : a.gpart + (long long)blockIdx.x * a.theta_size;
+    if (!a.gacc_in_lds)
+        for (int e = tid; e < a.theta_size; e += GEN_THREADS) gacc[e] = 0.0f;
+    __syncthreads();
+    const int last_row = a.n_out - 1;
+    for (int e = tid; e < HS; e += GEN_THREADS) {
+        const int h = e >> 4, s = e & 15, b = b0 + s;
+        if (h < H && b < a.B) {
+            const long long o = ((long long)b * a.n_out + last_row) * H + h;
+            const float y = a.z_out[o], g = a.grad_out[o];
+            Y0[e] = y; YS[e] = y; A0[e] = g; AS[e] = g;
+        }
+    }
+    const int S = n_stages(a.method);
+    const int dlast = L ? a.dout[L - 1] : H;
+    const int nks_o = (dlast + 3) >> 2, nhb = Hp >> 2, ncq = Cp >> 2, njt = (dlast + 15) >> 4;
+    float* sc = SC + wave * 16 * 17;
+    for (int n = a.T - 1; n >= 1; --n) {  // reverse step: knot n -> n-1, negated time s: -n -> -(n-1)
+        for (int j = 0; j < S; ++j) {
+            const float s0 = -(float)n;
+            const float t = -(s0 + stage_offset(a.method, j));
+            const int idx = piece_index(t, a.n_pieces);
+            const float w = stage_weight(a.method, j);
+            load_dx(a, b0, idx, t - (float)idx, DX, Cp, tid);
+            __syncthreads();
+            // ---- recompute the stage forward, keeping x_1..x_L -------------------------------------
+            const float* in = YS;
+            for (int l = 0; l < L; ++l) {
+                float* outb = X + l * DS;
+                dense_relu(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane);
+                __syncthreads();
+                in = outb;
+            }
+            // ---- output layer: f, dP = a (x) dX * tanh', dbo, dWo, partial dL/dx_L -----------------
+            f32x4 accJ[GEN_MAXJT];
+#pragma unroll
+            for (int jt = 0; jt < GEN_MAXJT; ++jt) accJ[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int hb = wave; hb < nhb; hb += GEN_NW) {
+                float kacc = 0.0f;
+                const int hA = 4 * hb + (li >> 2), hD = 4 * hb + lk;
+                const float aval = AS[hD * 16 + li];
+                for (int cq = 0; cq < ncq; ++cq) {
+                    const int cA = 4 * cq + (li & 3);
+                    const bool rv = hA < H && cA < C;
+                    const float* wrow = a.Wo + (long long)(rv ? hA * C + cA : 0) * dlast;
+                    f32x4 acc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 4 * cq + r;
+                        acc[r] = (hD < H && c < C) ? a.bo[hD * C + c] : 0.0f;
+                    }
+#pragma unroll 4
+                    for (int ks = 0; ks < nks_o; ++ks) {
+                        const int k = 4 * ks + lk;
+                        const float av = (rv && k < dlast) ? wrow[k] : 0.0f;
+                        acc = mfma16(av, in[k * 16 + li], acc);
+                    }
+                    float dP[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float m = tanh_dev(acc[r]);
+                        const float dx = DX[(4 * cq + r) * 16 + li];
+                        kacc = fmaf(m, dx, kacc);
+                        dP[r] = (aval * dx) * (1.0f - m * m);
+                    }
+                    // data gradient: dL/dx_L[j][s] += sum_u Wo[u][j] dP[u][s]; k-step <-> r, k-sub <-> lane>>4
+#pragma unroll
+                    for (int jt = 0; jt < GEN_MAXJT; ++jt) {
+                        if (jt < njt) {
+                            const int jcol = 16 * jt + li;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int c = 4 * cq + r;
+                                const float av = (hD < H && c < C && jcol < dlast) ? a.Wo[(long long)(hD * C + c) * dlast + jcol] : 0.0f;
+                                accJ[jt] = mfma16(av, dP[r], accJ[jt]);
+                            }
+                        }
+                    }
+                    if (w != 0.0f) {
+                        // bias gradient: sum over the 16 samples of the tile
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float sum = row16_sum(dP[r]);
+                            const int c = 4 * cq + r;
+                            if (li == 0 && hD < H && c < C) gacc[a.gbo_off + hD * C + c] += w * sum;
+                        }
+                        // weight gradient: dWo[u][j] += w sum_s dP[u][s] x_L[j][s] (samples are the K dim)
+                        wave_lds_fence();
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sc[(4 * lk + r) * 17 + li] = w * dP[r];
+                        wave_lds_fence();
+                        for (int jt = 0; jt < njt; ++jt) {
+                            f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int ks = 0; ks < 4; ++ks) g = mfma16(sc[li * 17 + 4 * ks + lk], in[(16 * jt + li) * 16 + 4 * ks + lk], g);
+                            const int jcol = 16 * jt + li;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int c = 4 * cq + r;
+                                if (hD < H && c < C && jcol < dlast) gacc[a.gWo_off + (long long)(hD * C + c) * dlast + jcol] += g[r];
+                            }
+                        }
+                    }
+                }
+                KOY[hD * 16 + li] = kacc;
+            }
+            // per-wave partial of dL/dx_L -> LDS, then summed over the 4 waves
+            {
+                float* pw = wave == 0 ? G0 : (wave == 1 ? G1 : PW2 + (wave - 2) * DS);
+#pragma unroll
+                for (int jt = 0; jt < GEN_MAXJT; ++jt)
+                    if (jt < njt) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pw[(16 * jt + 4 * lk + r) * 16 + li] = accJ[jt][r];
+                    }
+            }
+            __syncthreads();
+            const int DL = ru16(dlast) * 16;
+            if (L == 0) {
+                for (int e = tid; e < HS; e += GEN_THREADS) KOA[e] = (G0[e] + G1[e]) + (PW2[e] + PW2[DS + e]);
+                __syncthreads();
+            } else {
+                // dL/dpre_L = dL/dx_L * relu'(x_L)
+                for (int e = tid; e < DL; e += GEN_THREADS) {
+                    const float gsum = (G0[e] + G1[e]) + (PW2[e] + PW2[DS + e]);
+                    G1[e] = in[e] > 0.0f ? gsum : 0.0f;
+                }
+                __syncthreads();
+                float* gpre = G1;
+                float* gx = G0;
+                for (int l = L - 1; l >= 0; --l) {
+                    const int N = a.dout[l], K = a.din[l];
+                    const float* xin = l == 0 ? YS : X + (l - 1) * DS;
+                    if (w != 0.0f) {
+                        // bias gradient
+                        for (int jj = tid; jj < N; jj += GEN_THREADS) {
+                            float sum = 0.0f;
+#pragma unroll
+                            for (int s = 0; s < 16; ++s) sum += gpre[jj * 16 + s];
+                            gacc[a.gb_off[l] + jj] += w * sum;
+                        }
+                        // weight gradient tiles (jt, it)
+                        const int njt_l = (N + 15) >> 4, nit_l = (K + 15) >> 4;
+                        for (int tt = wave; tt < njt_l * nit_l; tt += GEN_NW) {
+                            const int jt = tt / nit_l, it = tt - jt * nit_l;
+                            f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int ks = 0; ks < 4; ++ks)
+                                g = mfma16(gpre[(16 * jt + li) * 16 + 4 * ks + lk], xin[(16 * it + li) * 16 + 4 * ks + lk], g);
+                            const int col = 16 * it + li;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = 16 * jt + 4 * lk + r;
+                                if (row < N && col < K) gacc[a.gW_off[l] + (long long)row * K + col] += w * g[r];
+                            }
+                        }
+                    }
+                    // data gradient: dL/dx_{l-1}[i][s] = sum_j W_l[j][i] dpre[j][s]
+                    float* outb = l == 0 ? KOA : gx;
+                    const int nit = (K + 15) >> 4, nks = (N + 3) >> 2;
+                    for (int it = wave; it < nit; it += GEN_NW) {
+                        const int col = 16 * it + li;
+                        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+                        for (int ks = 0; ks < nks; ++ks) {
+                            const int k = 4 * ks + lk;
+                            const float av = (k < N && col < K) ? a.W[l][(long long)k * K + col] : 0.0f;
+                            acc = mfma16(av, gpre[k * 16 + li], acc);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * it + 4 * lk + r;
+                            float v = acc[r];
+                            if (l > 0) v = xin[row * 16 + li] > 0.0f ? v : 0.0f;  // fold relu' of x_{l-1}
+                            outb[row * 16 + li] = v;
+                        }
+                    }
+                    __syncthreads();
+                    float* tmp = gpre; gpre = gx; gx = tmp;
+                }
+            }
+            // ---- Butcher bookkeeping in negated time: dy/ds = -f, da/ds = +a^T df/dy ----------------
+            for (int e = tid; e < HS; e += GEN_THREADS) {
+                float y0 = Y0[e], k1 = KY1[e], k2 = KY2[e];
+                bool last;
+                const float ys = StageCombine::apply(a.method, j, -KOY[e], y0, k1, k2, last);
+                YS[e] = ys; KY1[e] = k1; KY2[e] = k2;
+                float a0 = A0[e], q1 = KA1[e], q2 = KA2[e];
+                const float as = StageCombine::apply(a.method, j, KOA[e], a0, q1, q2, last);
+                KA1[e] = q1; KA2[e] = q2;
+                if (!last) {
+                    AS[e] = as;
+                } else {
+                    const int h = e >> 4, s = e & 15, b = b0 + s;
+                    const bool valid = h < H && b < a.B;
+                    if (a.output == NCDE_OUT_KNOTS) {  // reset y to the stored value, add dL/dz at this knot
+                        const long long o = ((long long)b * a.n_out + (n - 1)) * H + h;
+                        y0 = valid ? a.z_out[o] : 0.0f;
+                        a0 = a0 + (valid ? a.grad_out[o] : 0.0f);
+                    } else if (n == 1) {
+                        a0 = a0 + (valid ? a.grad_out[((long long)b * a.n_out) * H + h] : 0.0f);
+                    }
+                    Y0[e] = y0; YS[e] = y0; A0[e] = a0; AS[e] = a0;
+                    if (n == 1 && valid) a.grad_z0[(long long)b * H + h] = a0;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (a.gacc_in_lds) {
+        float* dst = a.gpart + (long long)blockIdx.x * a.theta_size;
+        for (int e = tid; e < a.theta_size; e += GEN_THREADS) dst[e] = GL[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: deterministic reduction of per-workgroup partials + scatter into the caller's gradient buffers
+// ------------------------------------------------------------------------------------------------
+struct ReduceSegs {
+    int n;
+    int off[2 * NCDE_MAX_LAYERS + 2];
+    int len[2 * NCDE_MAX_LAYERS + 2];
+    float* dst[2 * NCDE_MAX_LAYERS + 2];
+};
+
+extern "C" __global__ __launch_bounds__(256) void ncde_reduce_partials(const float* __restrict__ gpart, int n_part,
+                                                                        int theta_size, ReduceSegs segs) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= theta_size) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 3 < n_part; p += 4) {
+        s0 += gpart[(long long)p * theta_size + k];
+        s1 += gpart[(long long)(p + 1) * theta_size + k];
+        s2 += gpart[(long long)(p + 2) * theta_size + k];
+        s3 += gpart[(long long)(p + 3) * theta_size + k];
+    }
+    for (; p < n_part; ++p) s0 += gpart[(long long)p * theta_size + k];
+    const float total = (s0 + s1) + (s2 + s3);
+    for (int i = 0; i < segs.n; ++i)
+        if (k >= segs.off[i] && k < segs.off[i] + segs.len[i]) segs.dst[i][k - segs.off[i]] = total;
+}

@@ -1,0 +1,228 @@
+"""``cdeint``: drop-in for ``torchcde.cdeint`` (/root/reference/modules/torchcde/torchcde/solver.py:140-238)
+backed by the fused HIP kernels behind the C-ABI of include/ncde_hip.h.
+
+What the reference does per call -- wrap (X, func) in a vector field, hand it to torchdiffeq's Python
+time loop (solvers.py:94-119) and, for the backward pass, to OdeintAdjointMethod (adjoint.py:37-145)
+-- happens here in ONE kernel launch per direction.  There is no unfused or CPU fallback: a request
+outside the fused path raises NotImplementedError naming the reason.
+"""
+import ctypes
+import warnings
+
+import torch
+
+from . import _lib
+from .interpolation import LinearInterpolation, NaturalCubicSpline
+
+_FIXED_METHODS = ("euler", "midpoint", "rk4")
+_ALL_METHODS = ("dopri8", "dopri5", "bosh3", "fehlberg2", "adaptive_heun", "euler", "midpoint", "rk4",
+                "explicit_adams", "implicit_adams", "fixed_adams", "scipy_solver")
+
+
+class FieldSpec:
+    """What the fused kernels need to know about ``func``: the Linear+ReLU stack (entries may repeat
+    the same Parameters = a shared layer) and the final Linear (+tanh, viewed [H, C])."""
+
+    def __init__(self, layers, Wo, bo):
+        self.layers = list(layers)
+        self.Wo, self.bo = Wo, bo
+
+    def unique_params(self):
+        seen, out = set(), []
+        for p in [q for wb in self.layers for q in wb] + [self.Wo, self.bo]:
+            if id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+        return out
+
+
+def _field_spec(func):
+    if hasattr(func, "fused_spec"):
+        return func.fused_spec()
+    raise NotImplementedError(
+        "cdeint: `func` must expose fused_spec() (e.g. ncde_amd.OriginalVectorField or ncde_amd.MLPField); "
+        "arbitrary Python vector fields are outside the fused MI355X path")
+
+
+def _time_mode(X, t):
+    """-> _lib.OUT_INTERVAL / OUT_KNOTS.  Tagged tensors from X.interval / X.grid_points avoid a device sync."""
+    kind = getattr(t, "_ncde_kind", None)
+    if kind is not None and getattr(t, "_ncde_owner", None) == id(X):
+        return _lib.OUT_KNOTS if kind == "knots" else _lib.OUT_INTERVAL
+    tv = torch.as_tensor(t).detach().cpu().double()
+    assert tv.dim() == 1, "t must be one dimensional"
+    assert (tv[1:] > tv[:-1]).all(), "t must be strictly increasing or decreasing"  # misc.py:336-343
+    n = X.n_knots
+    if tv.numel() == n and torch.equal(tv, torch.arange(n, dtype=torch.double)):
+        return _lib.OUT_KNOTS
+    if tv.numel() == 2 and tv[0] == 0 and tv[1] == n - 1:
+        return _lib.OUT_INTERVAL
+    raise NotImplementedError("cdeint: t must be X.interval or X.grid_points on the fused path")
+
+
+def build_problem(coeffs, interp, z0, spec, method, output, flags=0):
+    """Fill an NcdeProblem from torch tensors (all must stay alive while the call is in flight)."""
+    p = _lib.NcdeProblem()
+    p.abi_version = _lib.NCDE_ABI_VERSION
+    B, H = z0.shape
+    p.batch, p.hidden = B, H
+    if interp == "linear":
+        p.n_knots, p.channels = coeffs.shape[1], coeffs.shape[2]
+    else:
+        p.n_knots, p.channels = coeffs.shape[1] + 1, coeffs.shape[2] // 4
+    p.interp = _lib.INTERP[interp]
+    p.method = _lib.METHOD[method]
+    p.output = output
+    p.flags = flags
+    if len(spec.layers) > _lib.NCDE_MAX_LAYERS:
+        raise NotImplementedError("at most %d hidden layers" % _lib.NCDE_MAX_LAYERS)
+    p.n_layers = len(spec.layers)
+    for i, (w, b) in enumerate(spec.layers):
+        p.layer_out[i], p.layer_in[i] = w.shape
+        p.layer_W[i], p.layer_b[i] = w.data_ptr(), b.data_ptr()
+    p.Wo, p.bo = spec.Wo.data_ptr(), spec.bo.data_ptr()
+    d_last = spec.layers[-1][0].shape[0] if spec.layers else H
+    if tuple(spec.Wo.shape) != (H * p.channels, d_last):
+        raise ValueError("final layer must be [H*C, d_last] = [%d, %d], got %s" % (H * p.channels, d_last, tuple(spec.Wo.shape)))
+    p.coeffs = coeffs.data_ptr()
+    p.coeffs_stride_b, p.coeffs_stride_t = coeffs.stride(0), coeffs.stride(1)
+    p.z0 = z0.data_ptr()
+    return p
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _workspace(p, pass_, device):
+    need = _lib.check(_lib.lib().ncde_workspace_bytes(ctypes.byref(p), pass_), "ncde_workspace_bytes")
+    return torch.empty(max(int(need), 256), dtype=torch.uint8, device=device)
+
+
+def _check_tensor(x, name):
+    if not (x.is_cuda and x.dtype == torch.float32):
+        raise NotImplementedError("cdeint fused path needs fp32 tensors on the GPU; %s is %s on %s" % (name, x.dtype, x.device))
+
+
+class _FusedCdeint(torch.autograd.Function):
+    """forward = ncde_forward, backward = ncde_adjoint (the continuous adjoint of adjoint.py:37-145)."""
+
+    @staticmethod
+    def forward(ctx, z0, coeffs, cfg, *params):
+        spec = cfg["spec"]
+        z0c = z0.detach().contiguous()
+        p = build_problem(coeffs, cfg["interp"], z0c, spec, cfg["method"], cfg["output"], cfg["flags"])
+        n_out = coeffs.shape[1] + (1 if cfg["interp"] == "cubic" else 0) if cfg["output"] == _lib.OUT_KNOTS else 2
+        out = torch.empty(z0.shape[0], n_out, z0.shape[1], dtype=torch.float32, device=z0.device)
+        ws = _workspace(p, 0, z0.device)
+        rc = _lib.lib().ncde_forward(ctypes.byref(p), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr())
+        _lib.check(rc, "ncde_forward")
+        ctx.cfg = cfg
+        ctx.coeffs = coeffs
+        ctx.save_for_backward(out, *params)
+        ctx.z0_shape = z0.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        cfg = ctx.cfg
+        if not cfg["adjoint"]:
+            raise NotImplementedError("adjoint=False (backprop through the solver) is not implemented on the fused "
+                                      "path yet; use adjoint=True")
+        out, *params = ctx.saved_tensors
+        spec, coeffs = cfg["spec"], ctx.coeffs
+        dev = out.device
+        grad_out = grad_out.contiguous().float()
+        z0 = out[:, 0].contiguous()
+        p = build_problem(coeffs, cfg["interp"], z0, spec, cfg["method"], cfg["output"], cfg["flags"])
+        uniq = spec.unique_params()
+        gbuf = {id(q): torch.empty_like(q, memory_format=torch.contiguous_format) for q in uniq}
+        g = _lib.NcdeGrads()
+        grad_z0 = torch.empty(ctx.z0_shape, dtype=torch.float32, device=dev)
+        g.grad_z0 = grad_z0.data_ptr()
+        for i, (w, b) in enumerate(spec.layers):
+            g.grad_layer_W[i], g.grad_layer_b[i] = gbuf[id(w)].data_ptr(), gbuf[id(b)].data_ptr()
+        g.grad_Wo, g.grad_bo = gbuf[id(spec.Wo)].data_ptr(), gbuf[id(spec.bo)].data_ptr()
+        ws = _workspace(p, 1, dev)
+        rc = _lib.lib().ncde_adjoint(ctypes.byref(p), out.data_ptr(), grad_out.data_ptr(), ctypes.byref(g),
+                                     ws.data_ptr(), ws.numel(), _stream_ptr())
+        _lib.check(rc, "ncde_adjoint")
+        if cfg["func"] is not None and hasattr(cfg["func"], "nfe"):
+            cfg["func"].nfe += cfg["nfe_per_solve"]
+        grads = []
+        for q, needs in zip(params, ctx.needs_input_grad[3:]):
+            grads.append(gbuf[id(q)] if needs else None)
+        return (grad_z0 if ctx.needs_input_grad[0] else None, None, None, *grads)
+
+
+def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
+    r"""Solve ``z_t = z_{t_0} + \int f(z_s) dX_s``; returns ``[batch, len(t), hidden]`` like the reference.
+
+    Same arguments as ``torchcde.cdeint`` (solver.py:140).  Fused path requirements: X a
+    LinearInterpolation / NaturalCubicSpline on its default integer grid, ``func`` exposing
+    ``fused_spec()``, ``method`` in {euler, midpoint, rk4} with ``options={'step_size': 1}``,
+    ``vector_field_type='matmul'``, fp32 CUDA tensors, ``t`` = X.interval or X.grid_points.
+    """
+    if vector_field_type not in ("matmul", "evaluate", "derivative"):
+        raise ValueError("vector_field_type string not recognised")
+    kwargs.setdefault("atol", 1e-6)
+    kwargs.setdefault("rtol", 1e-4)
+    method = kwargs.pop("method", None)
+    options = dict(kwargs.pop("options", None) or {})
+    flags = kwargs.pop("kernel_flags", 0)
+    adjoint_params = kwargs.pop("adjoint_params", None)
+    kwargs.pop("atol"), kwargs.pop("rtol")
+    for k in kwargs:
+        warnings.warn("cdeint: Unexpected arguments {}".format({k: kwargs[k]}))  # misc.py:9-11
+    if method is None:
+        method = "dopri5"
+    if method not in _ALL_METHODS:
+        raise ValueError('Invalid method "{}". Must be one of {}'.format(method, '{"' + '", "'.join(_ALL_METHODS) + '"}.'))
+    if method not in _FIXED_METHODS:
+        raise NotImplementedError("method '%s': only the fixed-step solvers %s run on the fused path" % (method, _FIXED_METHODS))
+    if vector_field_type != "matmul":
+        raise NotImplementedError("vector_field_type='%s' is not fused yet (only 'matmul')" % vector_field_type)
+    if not isinstance(X, (LinearInterpolation, NaturalCubicSpline)):
+        raise NotImplementedError("X must be ncde_amd.LinearInterpolation or ncde_amd.NaturalCubicSpline")
+    if not X._default_grid:
+        raise NotImplementedError("controls with a user-supplied knot grid t are outside the fused path")
+    step = options.pop("step_size", None)
+    if step is None or float(step) != 1.0:
+        raise NotImplementedError("options={'step_size': 1} is required (the reference's NeuralCDE setting, ncde.py:130-134)")
+    options.pop("perturb", None)
+    for k in options:
+        warnings.warn("cdeint: Unexpected arguments {}".format({k: options[k]}))
+    if not torch.is_tensor(z0):
+        raise NotImplementedError("tuple-valued z0 is outside the fused path")
+    if z0.dim() != 2:
+        raise NotImplementedError("z0 must be [batch, hidden]")
+    coeffs = X.fused_coeffs
+    if coeffs.dim() != 3:
+        raise NotImplementedError("coeffs must be [batch, time, channels]")
+    _check_tensor(z0, "z0")
+    _check_tensor(coeffs, "coeffs")
+    if coeffs.stride(2) != 1:
+        coeffs = coeffs.contiguous()
+    if coeffs.shape[0] != z0.shape[0]:
+        raise ValueError("batch of X (%d) != batch of z0 (%d)" % (coeffs.shape[0], z0.shape[0]))
+    spec = _field_spec(func)
+    uniq = spec.unique_params()
+    for q in uniq:
+        _check_tensor(q, "a vector-field parameter")
+        if not q.is_contiguous():
+            raise NotImplementedError("vector-field parameters must be contiguous")
+    if adjoint:
+        ap = set(id(q) for q in adjoint_params) if adjoint_params is not None else set()
+        for buffer in X.buffers():
+            if buffer.requires_grad and id(buffer) not in ap:
+                warnings.warn("One of the inputs to the control path X requires gradients but is not listed in "
+                              "`options['adjoint_params']`. It will not receive a gradient when using the adjoint method.")
+    output = _time_mode(X, t)
+    stages = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
+    nfe = stages * (X.n_knots - 1)
+    cfg = {"spec": spec, "interp": X.interp_name, "method": method, "output": output, "flags": flags,
+           "adjoint": bool(adjoint), "func": func, "nfe_per_solve": nfe}
+    out = _FusedCdeint.apply(z0, coeffs.detach(), cfg, *uniq)
+    if hasattr(func, "nfe"):
+        func.nfe += nfe
+    return out
