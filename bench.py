@@ -1,0 +1,251 @@
+#!/usr/bin/env python
+"""Benchmark of the Neural-CDE hot path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
+forward solve (fused kernel) + loss + continuous-adjoint backward (fused kernel) + [N>1: one RCCL
+all-reduce of the flat gradient] + Adam update, on BASELINE.json configs[1]/[2] (B=4096 per GPU, 200 raw
+observations -> 399 rectilinear knots, 20 channels incl. time, H=HH=32, nl=3, RK4-3/8, step 1).
+`value` = sample-steps/s = (samples processed by all ranks) * (T-1) / time, fp32 throughout.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import ncde_amd  # noqa: E402
+from ncde_amd import _lib, distributed as D, solver  # noqa: E402
+
+CONFIGS = {
+    # name: (B per GPU, raw length, channels incl. time, H, HH, nl, interpolation, solver, missing)
+    "cfg2": dict(B=4096, L=200, C=20, H=32, HH=32, nl=3, interpolation="rectilinear", solver="rk4", missing=0.3),
+    "cfg4": dict(B=8192, L=182, C=4, H=64, HH=64, nl=3, interpolation="cubic", solver="midpoint", missing=0.0),
+}
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def stages_of(method):
+    return {"rk4": 4, "midpoint": 2, "euler": 1}[method]
+
+
+def flops_forward_per_sample_step(c):
+    """S * 2 * (H*HH + (nl-1)*HH^2 + HH*H*C + H*C)."""
+    return stages_of(c["solver"]) * 2 * (c["H"] * c["HH"] + (c["nl"] - 1) * c["HH"] ** 2 + c["HH"] * c["H"] * c["C"] + c["H"] * c["C"])
+
+
+def bytes_forward_per_sample_step(c):
+    return (12 if c["interpolation"] == "cubic" else 4) * c["C"]
+
+
+def make_inputs(c, B, offset):
+    if c["interpolation"] == "rectilinear":
+        return ncde_amd.data.make_rectilinear_coeffs(B, c["L"], c["C"] - 1, missing=c["missing"], seed=1234, batch_offset=offset)
+    if c["interpolation"] == "cubic":
+        return ncde_amd.data.make_cubic_coeffs(B, c["L"], c["C"] - 1, seed=1234, batch_offset=offset)
+    return ncde_amd.data.make_linear_coeffs(B, c["L"], c["C"] - 1, seed=1234, batch_offset=offset)
+
+
+def make_model(c, device):
+    model = ncde_amd.NeuralCDE(c["C"], c["H"], 1, hidden_hidden_dim=c["HH"], num_layers=c["nl"],
+                               interpolation=c["interpolation"], adjoint=True, solver=c["solver"])
+    fw = ncde_amd.data.make_field_weights(c["H"], c["HH"], c["C"], seed=0)
+    rw = ncde_amd.data.make_readin_weights(c["H"], c["C"], 1, seed=0)
+    sd = {"initial_linear.weight": rw["Wi"], "initial_linear.bias": rw["bi"],
+          "final_linear.weight": rw["Wf"], "final_linear.bias": rw["bf"],
+          "func.net_to_hh.0.weight": fw["W0"], "func.net_to_hh.0.bias": fw["b0"],
+          "func.tanh_output_layer.0.weight": fw["Wo"], "func.tanh_output_layer.0.bias": fw["bo"]}
+    for i in range(1, c["nl"]):
+        sd[f"func.net_to_hh.{2 * i}.weight"] = fw["W1"]
+        sd[f"func.net_to_hh.{2 * i}.bias"] = fw["b1"]
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return model.to(device), fw, rw
+
+
+def time_kernels(model, c, coeffs, iters=3):
+    """HIP-event timing (on the launch stream, inside the C-ABI) of the forward and adjoint kernels."""
+    dev = coeffs.device
+    spec = model.func.fused_spec()
+    interp = "cubic" if c["interpolation"] == "cubic" else "linear"
+    with torch.no_grad():
+        z0 = model.initial_linear(coeffs[:, 0, :c["C"]]).contiguous()
+    p = solver.build_problem(coeffs, interp, z0, spec, c["solver"], _lib.OUT_INTERVAL, 0)
+    lib = _lib.lib()
+    out = torch.empty(z0.shape[0], 2, c["H"], device=dev)
+    ws0 = solver._workspace(p, 0, dev)
+    ms = ctypes.c_float(0)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.ncde_time_kernel(ctypes.byref(p), 0, out.data_ptr(), None, None, ws0.data_ptr(), ws0.numel(), stream,
+                                    iters, ctypes.byref(ms)), "time fwd")
+    ms_fwd = ms.value
+    gout = torch.randn_like(out)
+    uniq = spec.unique_params()
+    gbuf = {id(q): torch.empty_like(q) for q in uniq}
+    g = _lib.NcdeGrads()
+    gz0 = torch.empty_like(z0)
+    g.grad_z0 = gz0.data_ptr()
+    for i, (w, b) in enumerate(spec.layers):
+        g.grad_layer_W[i], g.grad_layer_b[i] = gbuf[id(w)].data_ptr(), gbuf[id(b)].data_ptr()
+    g.grad_Wo, g.grad_bo = gbuf[id(spec.Wo)].data_ptr(), gbuf[id(spec.bo)].data_ptr()
+    ws1 = solver._workspace(p, 1, dev)
+    _lib.check(lib.ncde_time_kernel(ctypes.byref(p), 1, out.data_ptr(), gout.data_ptr(), ctypes.byref(g), ws1.data_ptr(),
+                                    ws1.numel(), stream, iters, ctypes.byref(ms)), "time adj")
+    names = ((lib.ncde_kernel_name(ctypes.byref(p), 0) or b"?").decode(), (lib.ncde_kernel_name(ctypes.byref(p), 1) or b"?").decode())
+    return ms_fwd, ms.value, names
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box
+    shows 256 logical CPUs but grants 16; spinning 256 OpenMP threads on 16 CPUs takes minutes per solve)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(c, fw, rw, sample_B):
+    """The oracle (torch-CPU restatement of the reference op sequence, pinned to the reference by
+    oracle/gen_golden.py) timed on this host's cores: forward + adjoint on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ncde_oracle as orc
+    torch.set_num_threads(host_cores())
+    coeffs = make_inputs(c, sample_B, 0)
+    kind = "cubic" if c["interpolation"] == "cubic" else "linear"
+    field = orc.Field.original(fw, c["H"], c["C"], c["nl"])
+    ctl = orc.Control(coeffs, kind)
+    z0 = torch.from_numpy(coeffs[:, 0, :c["C"]]) @ torch.from_numpy(rw["Wi"]).t() + torch.from_numpy(rw["bi"])
+    gout = torch.ones(sample_B, 2, c["H"])
+    orc.solve_forward(orc.Control(coeffs[:32], kind), field, z0[:32], c["solver"], False)  # warm the thread pool
+    t0 = time.time()
+    z = orc.solve_forward(ctl, field, z0, c["solver"], False)
+    t1 = time.time()
+    orc.solve_adjoint(ctl, field, z, gout, c["solver"], False)
+    t2 = time.time()
+    steps = sample_B * (ctl.n_knots - 1)
+    return {"value": steps / (t2 - t0), "unit": "sample-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle/ncde_oracle.py forward+adjoint on B=%d of the same workload (T=%d), %.1f s; forward only: %.3e sample-steps/s"
+                      % (sample_B, ctl.n_knots, t2 - t0, steps / (t1 - t0))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU (weak) / global (strong) batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=1024)
+    args = ap.parse_args()
+
+    rank, local_rank, world = D.env_world()
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU fallback for the product path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    D.init_process_group("nccl")
+    c = dict(CONFIGS[args.config])
+    if args.scaling == "weak":
+        B_local = args.batch or c["B"]
+        B_total, lo = B_local * world, rank * B_local
+    else:
+        B_total = args.batch or c["B"]
+        lo, hi = D.shard_bounds(B_total, rank, world)
+        B_local = hi - lo
+    coeffs = torch.from_numpy(make_inputs(c, B_local, lo)).to(dev)
+    T = coeffs.shape[1] + (1 if c["interpolation"] == "cubic" else 0)
+    labels = (torch.from_numpy(ncde_amd.data.uniform01(7, B_total, stream=5)[lo:lo + B_local]) > 0.5).float().to(dev).unsqueeze(1)
+    model, fw, rw = make_model(c, dev)
+    bucket = D.FlatGradAllReduce(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+
+    def step():
+        return D.train_step(model, bucket, opt, coeffs, labels, loss_fn)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    assert torch.isfinite(loss).item(), "training diverged"
+
+    # forward-only throughput (inference), same inputs
+    with torch.no_grad():
+        model(coeffs)
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        for _ in range(args.steps):
+            model(coeffs)
+        torch.cuda.synchronize()
+        tf = (time.perf_counter() - tf0) / args.steps
+
+    if rank == 0:
+        ms_fwd, ms_adj, names = time_kernels(model, c, coeffs)
+        steps_per_launch = B_local * (T - 1)
+        f_fwd = flops_forward_per_sample_step(c)
+        f_adj = 3 * f_fwd     # stage recompute + VJP wrt z + VJP wrt theta
+        by_fwd = bytes_forward_per_sample_step(c)
+
+        def roof(ms, flops, nbytes, name):
+            tf_s = flops * steps_per_launch / (ms * 1e-3) / 1e12
+            return {"bound": "mfma", "kernel": name, "achieved": round(tf_s, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf_s / PEAK_FP32_TFLOPS, 4), "traffic": None, "ms_per_launch": round(ms, 4),
+                    "hbm_algorithmic_GBs": round(nbytes * steps_per_launch / (ms * 1e-3) / 1e9, 2),
+                    "hbm_frac": round(nbytes * steps_per_launch / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6)}
+
+        rec = {
+            "metric": "solved integration steps/sec (fwd+adjoint)",
+            "value": B_total * (T - 1) * args.steps / dt,
+            "unit": "sample-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE %s: %s interpolation, %s step 1, B=%d per GPU (global %d), raw L=%d -> T=%d knots, "
+                                   "C=%d, H=HH=%d, nl=%d; step = forward + adjoint backward + %sAdam"
+                                   % (args.config, c["interpolation"], c["solver"], B_local, B_total, c["L"], T, c["C"], c["H"],
+                                      c["nl"], "RCCL grad all-reduce + " if world > 1 else ""),
+                       "global_batch": B_total, "seq_len": c["L"], "parallelism": "dp%d" % world},
+            "forward_only_value": B_local * (T - 1) / tf, "forward_only_ms": tf * 1e3,
+            "roofline": roof(ms_adj, f_adj, by_fwd, names[1]),
+            "roofline_forward": roof(ms_fwd, f_fwd, by_fwd, names[0]),
+            "loss": float(loss),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            rec["cpu_baseline"] = cpu_baseline(c, fw, rw, args.cpu_sample)
+            rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
+        print(json.dumps(rec))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

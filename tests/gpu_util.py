@@ -35,7 +35,37 @@ def run_case(case, flags=_lib.FLAG_AUTO, device="cuda", need_grads=True):
         gout = torch.from_numpy(case["expect"]["grad_out"]).to(device)
         (out * gout).sum().backward()
         res["dz0"] = z0.grad.cpu().numpy()
-        res["grads"] = {k: v.grad.cpu().numpy() for k, v in func.p.items()}
+        res["grads"] = {k: (v.grad.cpu().numpy() if v.grad is not None else None) for k, v in func.p.items()}
         res["nfe"] = func.nfe
     torch.cuda.synchronize()
     return res
+
+
+def run_adjoint_direct(case, z_out, flags=_lib.FLAG_AUTO, device="cuda"):
+    """Call ncde_adjoint through the C-ABI on a GIVEN forward solution (e.g. the reference's own z_out):
+    isolates the adjoint kernel from forward round-off (a last-bit change of z can flip a ReLU mask)."""
+    import ctypes
+    from ncde_amd import solver
+    m = case["meta"]
+    coeffs = torch.from_numpy(case["coeffs"]).to(device)
+    func = CaseField(case["params"], case["layers"], device)
+    spec = func.fused_spec()
+    z_out = torch.from_numpy(np.ascontiguousarray(z_out)).to(device)
+    gout = torch.from_numpy(case["expect"]["grad_out"]).to(device).contiguous()
+    z0 = z_out[:, 0].contiguous()
+    p = solver.build_problem(coeffs, m["kind"], z0, spec, m["method"],
+                             _lib.OUT_KNOTS if m["sequence"] else _lib.OUT_INTERVAL, flags)
+    uniq = spec.unique_params()
+    gbuf = {id(q): torch.full_like(q, float("nan")) for q in uniq}
+    g = _lib.NcdeGrads()
+    gz0 = torch.full_like(z0, float("nan"))
+    g.grad_z0 = gz0.data_ptr()
+    for i, (w, b) in enumerate(spec.layers):
+        g.grad_layer_W[i], g.grad_layer_b[i] = gbuf[id(w)].data_ptr(), gbuf[id(b)].data_ptr()
+    g.grad_Wo, g.grad_bo = gbuf[id(spec.Wo)].data_ptr(), gbuf[id(spec.bo)].data_ptr()
+    ws = solver._workspace(p, 1, device)
+    rc = _lib.lib().ncde_adjoint(ctypes.byref(p), z_out.data_ptr(), gout.data_ptr(), ctypes.byref(g), ws.data_ptr(),
+                                 ws.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "ncde_adjoint")
+    torch.cuda.synchronize()
+    return {"dz0": gz0.cpu().numpy(), "grads": {k: gbuf[id(v)].cpu().numpy() for k, v in func.p.items() if id(v) in gbuf}}

@@ -17,30 +17,42 @@ pytestmark = pytest.mark.gpu
 
 TOL_Z, TOL_DTHETA, TOL_DZ0 = 1e-4, 1e-3, 2e-3
 # what we actually expect from an exact-fp32 MFMA implementation; tightened guard against regressions
-TIGHT_Z, TIGHT_G = 2e-5, 2e-4
+TIGHT_Z, TIGHT_G = 2e-5, 2e-5
+E2E_G = 2e-4   # end-to-end gradient guard on the fixed seeded cases below (no ReLU-mask flips occur on them)
 
 FLAGS = {"generic": 1, "auto": 0}
 
 
-def _check_case(name, flags, gpu_lib):
-    import gpu_util
-    case = gu.load_case(name)
-    res = gpu_util.run_case(case, flags=flags)
-    ex = case["expect"]
-    m = case["meta"]
-    assert res["z_out"].shape == ex["z_out"].shape
-    ez = gu.relerr(res["z_out"], ex["z_out"])
-    assert ez <= TOL_Z and ez <= TIGHT_Z, ("z", ez)
-    edz = gu.relerr(res["dz0"], ex["dz0"])
-    assert edz <= TOL_DZ0 and edz <= TIGHT_G, ("dz0", edz)
+def _grad_errors(case, res):
+    ex, m = case["expect"], case["meta"]
+    errs = {"dz0": gu.relerr(res["dz0"], ex["dz0"])}
     for pname in m["param_names"]:
         g = res["grads"][pname]
         if "d" + pname in ex:
-            e = gu.relerr(g, ex["d" + pname])
+            errs[pname] = gu.relerr(g, ex["d" + pname])
         else:
-            e = max(gu.relerr(g[::16], ex["d" + pname + "__rows16"]),
-                    gu.relerr(g.astype(np.float64).sum(0), ex["d" + pname + "__colsum"]))
-        assert e <= TOL_DTHETA and e <= TIGHT_G, (pname, e)
+            errs[pname] = max(gu.relerr(g[::16], ex["d" + pname + "__rows16"]),
+                              gu.relerr(g.astype(np.float64).sum(0), ex["d" + pname + "__colsum"]))
+    return errs
+
+
+def _check_case(name, flags):
+    """End to end (forward kernel -> adjoint kernel) against the reference, at the documented tolerances;
+    then the adjoint kernel in isolation (fed the reference's own forward solution) at the tight ones --
+    a last-bit difference in z can flip a ReLU mask and move one sample's gradient by ~1e-4, which is
+    fp32 behaviour of the model, not a kernel error (seen on g3_cubic_rk4_seq, sample 0)."""
+    import gpu_util
+    case = gu.load_case(name)
+    res = gpu_util.run_case(case, flags=flags)
+    ex, m = case["expect"], case["meta"]
+    assert res["z_out"].shape == ex["z_out"].shape
+    ez = gu.relerr(res["z_out"], ex["z_out"])
+    assert ez <= TOL_Z and ez <= TIGHT_Z, ("z", ez)
+    for k, e in _grad_errors(case, res).items():
+        assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), ("end-to-end", k, e)
+    iso = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=flags)
+    for k, e in _grad_errors(case, iso).items():
+        assert e <= TIGHT_G, ("adjoint kernel on reference z_out", k, e)
     stages = {"rk4": 4, "midpoint": 2, "euler": 1}[m["method"]]
     n_knots = ex["z_out"].shape[1] if m["sequence"] else (case["coeffs"].shape[1] + (m["kind"] == "cubic"))
     assert res["nfe"] == 2 * stages * (n_knots - 1)
@@ -48,12 +60,12 @@ def _check_case(name, flags, gpu_lib):
 
 @pytest.mark.parametrize("name", gu.SOLVE_CASES)
 def test_generic_kernels_match_reference_golden(name, gpu_lib):
-    _check_case(name, FLAGS["generic"], gpu_lib)
+    _check_case(name, FLAGS["generic"])
 
 
 @pytest.mark.parametrize("name", gu.SOLVE_CASES)
 def test_auto_dispatch_matches_reference_golden(name, gpu_lib):
-    _check_case(name, FLAGS["auto"], gpu_lib)
+    _check_case(name, FLAGS["auto"])
 
 
 def test_full_size_cfg2_forward_vs_reference(gpu_lib):
@@ -94,9 +106,9 @@ def test_ragged_batch_and_determinism(gpu_lib):
         z = orc.solve_forward(ctl, field, sub["z0"], "rk4", False)
         dz0, gp = orc.solve_adjoint(ctl, field, z, sub["expect"]["grad_out"], "rk4", False)
         assert gu.relerr(r1["z_out"], z) <= TIGHT_Z
-        assert gu.relerr(r1["dz0"], dz0) <= TIGHT_G
+        assert gu.relerr(r1["dz0"], dz0) <= E2E_G
         for pname, g in zip(case["meta"]["param_names"], gp):
-            assert gu.relerr(r1["grads"][pname], g) <= TIGHT_G, pname
+            assert gu.relerr(r1["grads"][pname], g) <= E2E_G, pname
 
 
 def test_sample_independence_and_linearity_of_adjoint(gpu_lib):
@@ -139,5 +151,5 @@ def test_module_level_matches_reference(gpu_lib):
         (out * torch.from_numpy(f[vname + "__w"]).cuda()).sum().backward()
         for k, prm in model.named_parameters():
             ref = f[f"{vname}__grad__{k}"]
-            assert gu.relerr(prm.grad.cpu().numpy(), ref) <= TIGHT_G, (vname, k)
+            assert gu.relerr(prm.grad.cpu().numpy(), ref) <= E2E_G, (vname, k)
         assert model.nfe == int(f[vname + "__nfe"]), vname

@@ -42,7 +42,7 @@ def test_oracle_matches_reference_golden(name):
 def test_oracle_full_size_cfg2_forward():
     """BASELINE config 2 at full size (B=4096, T=399): z_T from the reference, inputs regenerated."""
     f = np.load(os.path.join(gu.GOLD, "g5_cfg2_full.npz"))
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(min(8, len(os.sched_getaffinity(0))))
     coeffs = gu.data.make_rectilinear_coeffs(4096, 200, 19, missing=0.3, seed=1234)
     p = gu.data.make_field_weights(32, 32, 20, seed=0)
     rw = gu.data.make_readin_weights(32, 20, 1, seed=0)
