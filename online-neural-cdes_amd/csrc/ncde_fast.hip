@@ -17,6 +17,7 @@
 #include <cstring>
 
 #include "ncde_common.h"
+#include "ncde_host.h"
 
 namespace {
 
@@ -246,6 +247,471 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_fwd_fast(KArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// adjoint: reverse sweep of (y, a, g_theta) -- adjoint.py:37-145 as ONE persistent kernel
+// ------------------------------------------------------------------------------------------------
+// Per stage and wave (one 16-sample tile per workgroup, NW waves):
+//   forward recompute   register-to-register as in ncde_fwd_fast (hidden layers replicated per wave)
+//   own output tiles    P -> m = tanh(P); f += m.dX; dP = a (x) dX * (1 - m^2)
+//   dL/dx_L partial     A = Wo^T (LDS image, ds_read_b128 = 4 k-steps), B = dP straight from the D registers
+//                       (k-step <-> r, k-sub <-> lane>>4), summed over the NW waves through LDS
+//   hidden backward     W1^T / W0^T chains, again register-to-register (same unit permutation)
+//   weight gradients    samples are the K dimension: both operands are re-read from wave-private
+//                       [unit][sample] LDS images with ONE ds_read_b128 per 4 k-steps (k <-> sample 4*kk+q)
+//                       and accumulated in registers for the whole solve (dWo: own tiles; dW1/dW0: one
+//                       16x16 tile per wave); bias gradients accumulate per lane and are reduced over the
+//                       16 samples once, at the end.
+template <int H, int HH, int C, int NL, int NW, int INTERP, int METHOD>
+__global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
+    constexpr int CP = (C + 3) & ~3, CQ = CP / 4, HB = H / 4, HT = HH / 16, KH = HH / 4, NB = HB / NW;
+    constexpr int S = kStages<METHOD>;
+    constexpr int NT = 64 * NW;
+    constexpr int DXW = INTERP == NCDE_INTERP_LINEAR ? CP : 3 * CP;
+    constexpr int EPT = (16 * DXW + NT - 1) / NT;
+    constexpr int NTILE = NB * CQ;              // output tiles owned by a wave
+    constexpr int HT0 = H / 16;                 // column tiles of dW0
+    constexpr int TPW1 = HT * HT / NW, TPW0 = HT * HT0 / NW;
+    constexpr int XS = 20;                      // padded sample stride of the [unit][sample] images
+    constexpr int IMG = (H + NL * HH) * XS;     // z, x_1..x_NL
+    constexpr int PRIV = IMG + HH * XS;            // dP tile scratch aliases the dL/dpre image (disjoint phases)
+    static_assert(H % (4 * NW) == 0 && HH % 16 == 0 && H % 16 == 0 && NB <= 4, "shape not tileable");
+    static_assert((HT * HT) % NW == 0 && (HT * HT0) % NW == 0, "weight-gradient tiles must split evenly over the waves");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* zx = lds;                              // [2][H*16]   stage-state exchange
+    float* dxs = zx + 2 * H * 16;                 // [3][16*DXW] control-path ring
+    float* red = dxs + 3 * 16 * DXW;              // [NW][HH*16] dL/dx_L partials
+    float* woT = red + NW * HH * 16;              // [NW][NTILE][HT][64][4]
+    float* boL = woT + NW * NTILE * HT * 256;     // [NW][NTILE][4][4]
+    float* privbase = boL + NW * NTILE * 16;      // [NW][PRIV]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = lane & 15, g = lane >> 4;
+    const int b0 = blockIdx.x * NCDE_TILE;
+    const int bs = b0 + s;
+    const bool valid = bs < a.B;
+    float* priv = privbase + wave * PRIV;
+    float* img = priv;                            // rows: z [0,H), x_l [H+(l-1)*HH, H+l*HH)
+    float* dpimg = priv + IMG;                    // [HH][XS]   w * dL/dpre of the current layer
+    float* dptile = dpimg;                        // [16][XS]   w * dP of the current output tile (aliases dpimg)
+    const float* woTw = woT + wave * NTILE * HT * 256;
+    const float* boLw = boL + wave * NTILE * 16;
+
+    // ---- weights -> registers / LDS images ------------------------------------------------------------
+    float w0[HT][HB], w1[HT][KH], wo[NB][CQ][KH], w1T[HT][KH], w0T[KH];
+    f32x4 bias0[HT], bias1[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+        const int unitA = 4 * (4 * t + (s & 3)) + (s >> 2);
+#pragma unroll
+        for (int ks = 0; ks < HB; ++ks) w0[t][ks] = a.W[0][unitA * H + 4 * ks + g];
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) {
+            w1[t][ks] = a.W[1][unitA * HH + 4 * ks + g];
+            w1T[t][ks] = a.W[1][(4 * ks + g) * HH + unitA];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int unitD = 4 * (4 * t + r) + g;
+            bias0[t][r] = a.b[0][unitD];
+            bias1[t][r] = a.b[1][unitD];
+        }
+    }
+    {   // W0^T rows for the state entries this wave owns: tile row i <-> h = 4*(wave*NB + (i&3)) + (i>>2)
+        const int r_own = s & 3;
+        const int hrow = 4 * (wave * NB + r_own) + (s >> 2);
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) w0T[ks] = r_own < NB ? a.W[0][(4 * ks + g) * H + hrow] : 0.0f;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int hb = wave * NB + nb;
+#pragma unroll
+        for (int cq = 0; cq < CQ; ++cq) {
+            const int hA = 4 * hb + (s >> 2), cA = 4 * cq + (s & 3);
+#pragma unroll
+            for (int ks = 0; ks < KH; ++ks) wo[nb][cq][ks] = cA < C ? a.Wo[(hA * C + cA) * HH + 4 * ks + g] : 0.0f;
+        }
+    }
+    for (int e = tid; e < NW * NTILE * HT * 256; e += NT) {  // Wo^T image
+        const int r = e & 3, l = (e >> 2) & 63, rest = e >> 8;
+        const int tp = rest % HT, tau = (rest / HT) % NTILE, wv = rest / (HT * NTILE);
+        const int nb = tau / CQ, cq = tau - nb * CQ;
+        const int h = 4 * (wv * NB + nb) + (l >> 4), c = 4 * cq + r;
+        const int jrow = 4 * (4 * tp + (l & 3)) + ((l & 15) >> 2);
+        woT[e] = c < C ? a.Wo[(h * C + c) * HH + jrow] : 0.0f;
+    }
+    for (int e = tid; e < NW * NTILE * 16; e += NT) {  // bo image [wave][tile][g][r]
+        const int r = e & 3, gg = (e >> 2) & 3, rest = e >> 4;
+        const int tau = rest % NTILE, wv = rest / NTILE;
+        const int nb = tau / CQ, cq = tau - nb * CQ;
+        const int h = 4 * (wv * NB + nb) + gg, c = 4 * cq + r;
+        boL[e] = c < C ? a.bo[h * C + c] : 0.0f;
+    }
+
+    // ---- control-path staging (reverse order: piece p needs rows p+1 and p) ----------------------------
+    const float* eptr[EPT];
+    float eprev[EPT], enext[EPT];
+    bool eok[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = tid + q * NT;
+        const int es = e / DXW, ec = e - es * DXW;
+        const int part = ec / CP, c = ec - part * CP;
+        eok[q] = e < 16 * DXW && c < C && (b0 + es) < a.B;
+        const long long base = (long long)(eok[q] ? b0 + es : 0) * a.cs_b;
+        eptr[q] = a.coeffs + base + (INTERP == NCDE_INTERP_LINEAR ? c : (part + 1) * C + c);
+        eprev[q] = 0.0f;
+        enext[q] = 0.0f;
+    }
+    auto stage_load = [&](int piece) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) enext[q] = eok[q] ? eptr[q][(long long)piece * a.cs_t] : 0.0f;
+    };
+    auto stage_store = [&](int piece) {
+        float* dst = dxs + (piece % 3) * 16 * DXW;
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = tid + q * NT;
+            if (e < 16 * DXW) dst[e] = INTERP == NCDE_INTERP_LINEAR ? eprev[q] - enext[q] : enext[q];
+            eprev[q] = enext[q];
+        }
+    };
+    const int p_hi = a.n_pieces - 1;
+    if (INTERP == NCDE_INTERP_LINEAR) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) eprev[q] = eok[q] ? eptr[q][(long long)(p_hi + 1) * a.cs_t] : 0.0f;  // last row
+    }
+    stage_load(p_hi);
+    stage_store(p_hi);
+    if (p_hi >= 1) {
+        stage_load(p_hi - 1);
+        stage_store(p_hi - 1);
+    }
+
+    // ---- state ------------------------------------------------------------------------------------------
+    const int last_row = a.n_out - 1;
+    float y0[NB], ky1[NB], ky2[NB], a0[NB], ka1[NB], ka2[NB], as_[NB], zreg[HB];
+#pragma unroll
+    for (int ks = 0; ks < HB; ++ks) zreg[ks] = valid ? a.z_out[((long long)bs * a.n_out + last_row) * H + 4 * ks + g] : 0.0f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const long long o = ((long long)bs * a.n_out + last_row) * H + 4 * (wave * NB + nb) + g;
+        y0[nb] = valid ? a.z_out[o] : 0.0f;
+        a0[nb] = valid ? a.grad_out[o] : 0.0f;
+        as_[nb] = a0[nb];
+        ky1[nb] = ky2[nb] = ka1[nb] = ka2[nb] = 0.0f;
+    }
+    // ---- gradient accumulators ----------------------------------------------------------------------------
+    f32x4 gWo[NTILE][HT], gW1[TPW1], gW0[TPW0], gbo[NTILE];
+    float gb1[KH], gb0[KH];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NTILE; ++i) {
+        gbo[i] = zero4;
+#pragma unroll
+        for (int t = 0; t < HT; ++t) gWo[i][t] = zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < TPW1; ++i) gW1[i] = zero4;
+#pragma unroll
+    for (int i = 0; i < TPW0; ++i) gW0[i] = zero4;
+#pragma unroll
+    for (int i = 0; i < KH; ++i) gb1[i] = gb0[i] = 0.0f;
+    __syncthreads();
+
+    int zpar = 0;
+    for (int n = a.T - 1; n >= 1; --n) {  // reverse step: knot n -> n-1 (negated time -n -> -(n-1))
+        if (n - 3 >= 0) stage_load(n - 3);  // piece needed by the NEXT-next step; stored at the end of this one
+        float ynext[NB], gnext[NB], znext[HB];
+        if (a.output == NCDE_OUT_KNOTS) {
+#pragma unroll
+            for (int ks = 0; ks < HB; ++ks) znext[ks] = valid ? a.z_out[((long long)bs * a.n_out + (n - 1)) * H + 4 * ks + g] : 0.0f;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const long long o = ((long long)bs * a.n_out + (n - 1)) * H + 4 * (wave * NB + nb) + g;
+                ynext[nb] = valid ? a.z_out[o] : 0.0f;
+                gnext[nb] = valid ? a.grad_out[o] : 0.0f;
+            }
+        }
+#pragma unroll 1
+        for (int j = 0; j < S; ++j) {
+            const float t = -(-(float)n + stage_offset(METHOD, j));
+            const int idx = piece_index(t, a.n_pieces);
+            const float frac = t - (float)idx;
+            const float wq = stage_weight(METHOD, j);
+            const float* dxp = dxs + (idx % 3) * 16 * DXW + s * DXW;
+            // ---- forward recompute; keep x_1..x_NL (registers) and their [unit][sample] images (LDS) ------
+            float x[NL][KH];
+            {
+                f32x4 acc[HT];
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt) acc[tt] = bias0[tt];
+#pragma unroll
+                for (int ks = 0; ks < HB; ++ks)
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt) acc[tt] = mfma16(w0[tt][ks], zreg[ks], acc[tt]);
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[0][4 * tt + r] = fmaxf(acc[tt][r], 0.0f);
+#pragma unroll
+                for (int l = 1; l < NL; ++l) {
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt) acc[tt] = bias1[tt];
+#pragma unroll
+                    for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+                        for (int tt = 0; tt < HT; ++tt) acc[tt] = mfma16(w1[tt][ks], x[l - 1][ks], acc[tt]);
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) x[l][4 * tt + r] = fmaxf(acc[tt][r], 0.0f);
+                }
+            }
+            if (wq != 0.0f) {
+#pragma unroll
+                for (int ks = 0; ks < HB; ++ks) img[(4 * ks + g) * XS + s] = zreg[ks];
+#pragma unroll
+                for (int l = 0; l < NL; ++l)
+#pragma unroll
+                    for (int ks = 0; ks < KH; ++ks) img[(H + l * HH + 4 * ks + g) * XS + s] = x[l][ks];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            // B operands of the dWo GEMM: x_NL[j = 16t + n][samples 4g..4g+3]
+            f32x4 xB[HT];
+            if (wq != 0.0f) {
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt) xB[tt] = *reinterpret_cast<const f32x4*>(img + (H + (NL - 1) * HH + 16 * tt + s) * XS + 4 * g);
+            }
+            // ---- output tiles owned by this wave ---------------------------------------------------------------
+            float kout[NB];
+            f32x4 accJ[HT];
+#pragma unroll
+            for (int tt = 0; tt < HT; ++tt) accJ[tt] = zero4;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) kout[nb] = 0.0f;
+#pragma unroll
+            for (int cq = 0; cq < CQ; ++cq) {
+                f32x4 o[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) o[nb] = *reinterpret_cast<const f32x4*>(boLw + ((nb * CQ + cq) * 4 + g) * 4);
+#pragma unroll
+                for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) o[nb] = mfma16(wo[nb][cq][ks], x[NL - 1][ks], o[nb]);
+                f32x4 dx;
+                if constexpr (INTERP == NCDE_INTERP_LINEAR) {
+                    dx = *reinterpret_cast<const f32x4*>(dxp + 4 * cq);
+                } else {
+                    const f32x4 cb = *reinterpret_cast<const f32x4*>(dxp + 4 * cq);
+                    const f32x4 cc = *reinterpret_cast<const f32x4*>(dxp + CP + 4 * cq);
+                    const f32x4 cd = *reinterpret_cast<const f32x4*>(dxp + 2 * CP + 4 * cq);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float inner = cc[r] + cd[r] * frac;
+                        dx[r] = cb[r] + inner * frac;
+                    }
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int tau = nb * CQ + cq;
+                    f32x4 dP;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float m = tanh_dev(o[nb][r]);
+                        kout[nb] = fmaf(m, dx[r], kout[nb]);
+                        dP[r] = (as_[nb] * dx[r]) * (1.0f - m * m);
+                    }
+                    // dL/dx_L partial: k-step <-> r
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt) {
+                        const f32x4 av = *reinterpret_cast<const f32x4*>(woTw + ((tau * HT + tt) * 64 + lane) * 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) accJ[tt] = mfma16(av[r], dP[r], accJ[tt]);
+                    }
+                    if (wq != 0.0f) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = wq * dP[r];
+                            gbo[tau][r] += v;
+                            dptile[(4 * g + r) * XS + s] = v;
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        const f32x4 av = *reinterpret_cast<const f32x4*>(dptile + s * XS + 4 * g);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) gWo[tau][tt] = mfma16(av[q], xB[tt][q], gWo[tau][tt]);
+                    }
+                }
+            }
+            // ---- sum the dL/dx_L partials over the waves --------------------------------------------------------
+            float gpre[KH];
+            if constexpr (NW == 1) {
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gpre[4 * tt + r] = accJ[tt][r];
+            } else {
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[wave * HH * 16 + (4 * (4 * tt + r) + g) * 16 + s] = accJ[tt][r];
+                __syncthreads();
+#pragma unroll
+                for (int ks = 0; ks < KH; ++ks) {
+                    float v = red[(4 * ks + g) * 16 + s];
+#pragma unroll
+                    for (int wv = 1; wv < NW; ++wv) v += red[wv * HH * 16 + (4 * ks + g) * 16 + s];
+                    gpre[ks] = v;
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < KH; ++ks) gpre[ks] = x[NL - 1][ks] > 0.0f ? gpre[ks] : 0.0f;
+            // ---- hidden layers backward (shared W1), then W0 ------------------------------------------------------
+#pragma unroll
+            for (int l = NL - 1; l >= 1; --l) {  // layer with input x_l (x[l-1]) and output x_{l+1} (x[l])
+                if (wq != 0.0f) {
+#pragma unroll
+                    for (int ks = 0; ks < KH; ++ks) {
+                        const float v = wq * gpre[ks];
+                        gb1[ks] += v;
+                        dpimg[(4 * ks + g) * XS + s] = v;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int k = 0; k < TPW1; ++k) {
+                        const int id = wave * TPW1 + k, tr = id / HT, tc = id - tr * HT;
+                        const f32x4 av = *reinterpret_cast<const f32x4*>(dpimg + (16 * tr + s) * XS + 4 * g);
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(img + (H + (l - 1) * HH + 16 * tc + s) * XS + 4 * g);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) gW1[k] = mfma16(av[q], bv[q], gW1[k]);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                f32x4 acc[HT];
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt) acc[tt] = zero4;
+#pragma unroll
+                for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt) acc[tt] = mfma16(w1T[tt][ks], gpre[ks], acc[tt]);
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gpre[4 * tt + r] = x[l - 1][4 * tt + r] > 0.0f ? acc[tt][r] : 0.0f;
+            }
+            if (wq != 0.0f) {
+#pragma unroll
+                for (int ks = 0; ks < KH; ++ks) {
+                    const float v = wq * gpre[ks];
+                    gb0[ks] += v;
+                    dpimg[(4 * ks + g) * XS + s] = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < TPW0; ++k) {
+                    const int id = wave * TPW0 + k, tr = id / HT0, tc = id - tr * HT0;
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(dpimg + (16 * tr + s) * XS + 4 * g);
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(img + (16 * tc + s) * XS + 4 * g);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) gW0[k] = mfma16(av[q], bv[q], gW0[k]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            f32x4 vy = zero4;  // a^T df/dy for the state entries this wave owns
+#pragma unroll
+            for (int ks = 0; ks < KH; ++ks) vy = mfma16(w0T[ks], gpre[ks], vy);
+            // ---- Butcher bookkeeping in negated time: dy/ds = -f, da/ds = +a^T df/dy ----------------------------
+            float ys[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                ys[nb] = Combine<METHOD>::apply(j, -kout[nb], y0[nb], ky1[nb], ky2[nb]);
+                as_[nb] = Combine<METHOD>::apply(j, vy[nb], a0[nb], ka1[nb], ka2[nb]);
+            }
+            if (j == S - 1) {
+                if (a.output == NCDE_OUT_KNOTS) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        y0[nb] = ynext[nb];
+                        ys[nb] = ynext[nb];
+                        a0[nb] += gnext[nb];
+                        as_[nb] = a0[nb];
+                    }
+                } else if (n == 1) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        a0[nb] += valid ? a.grad_out[((long long)bs * a.n_out) * H + 4 * (wave * NB + nb) + g] : 0.0f;
+                        as_[nb] = a0[nb];
+                    }
+                }
+                if (n - 3 >= 0) stage_store(n - 3);
+            }
+            if (j == S - 1 && a.output == NCDE_OUT_KNOTS) {
+#pragma unroll
+                for (int ks = 0; ks < HB; ++ks) zreg[ks] = znext[ks];
+                __syncthreads();  // publishes the control-path ring slot written above
+            } else if constexpr (NW == 1) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) zreg[nb] = ys[nb];
+            } else {
+                float* zw = zx + zpar * H * 16;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) zw[(4 * (wave * NB + nb) + g) * 16 + s] = ys[nb];
+                __syncthreads();
+#pragma unroll
+                for (int ks = 0; ks < HB; ++ks) zreg[ks] = zw[(4 * ks + g) * 16 + s];
+                zpar ^= 1;
+            }
+        }
+    }
+    // ---- write-out: dL/dz0 and this workgroup's parameter-gradient partial ------------------------------------
+    if (valid) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) a.grad_z0[(long long)bs * H + 4 * (wave * NB + nb) + g] = a0[nb];
+    }
+    float* gp = a.gpart + (long long)blockIdx.x * a.theta_size;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int cq = 0; cq < CQ; ++cq) {
+            const int tau = nb * CQ + cq;
+            const int h = 4 * (wave * NB + nb) + g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 4 * cq + r;
+                if (c < C) {
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt) gp[a.gWo_off + (h * C + c) * HH + 16 * tt + s] = gWo[tau][tt][r];
+                }
+                const float sum = row16_sum(gbo[tau][r]);
+                if (s == 0 && c < C) gp[a.gbo_off + h * C + c] = sum;
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < TPW1; ++k) {
+        const int id = wave * TPW1 + k, tr = id / HT, tc = id - tr * HT;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gp[a.gW_off[1] + (16 * tr + 4 * g + r) * HH + 16 * tc + s] = gW1[k][r];
+    }
+#pragma unroll
+    for (int k = 0; k < TPW0; ++k) {
+        const int id = wave * TPW0 + k, tr = id / HT0, tc = id - tr * HT0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gp[a.gW_off[0] + (16 * tr + 4 * g + r) * H + 16 * tc + s] = gW0[k][r];
+    }
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks) {
+        const float s1 = row16_sum(gb1[ks]), s0 = row16_sum(gb0[ks]);
+        if (wave == 0 && s == 0) {
+            gp[a.gb_off[1] + 4 * ks + g] = s1;
+            gp[a.gb_off[0] + 4 * ks + g] = s0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // dispatch tables
 // ------------------------------------------------------------------------------------------------
 struct Shape {
@@ -268,16 +734,45 @@ FwdFn pick_fwd(int interp, int method) {
     return nullptr;
 }
 
+template <int H, int HH, int C, int NL, int NW>
+FwdFn pick_adj(int interp, int method) {
+#define NCDE_PICK(I, M) \
+    if (interp == I && method == M) return ncde_adj_fast<H, HH, C, NL, NW, I, M>;
+    NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_RK4_38)
+    NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_MIDPOINT)
+    NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_EULER)
+    NCDE_PICK(NCDE_INTERP_CUBIC, NCDE_RK4_38)
+    NCDE_PICK(NCDE_INTERP_CUBIC, NCDE_MIDPOINT)
+    NCDE_PICK(NCDE_INTERP_CUBIC, NCDE_EULER)
+#undef NCDE_PICK
+    return nullptr;
+}
+
+template <int H, int HH, int C, int NL, int NW>
+size_t adj_lds_bytes(int interp) {
+    constexpr int CP = (C + 3) & ~3, CQ = CP / 4, HT = HH / 16, NB = H / 4 / NW, NTILE = NB * CQ;
+    const int DXW = interp == NCDE_INTERP_LINEAR ? CP : 3 * CP;
+    constexpr int PRIV = (H + NL * HH) * 20 + HH * 20;
+    return sizeof(float) * (size_t)(2 * H * 16 + 3 * 16 * DXW + NW * HH * 16 + NW * NTILE * HT * 256 + NW * NTILE * 16 + NW * PRIV);
+}
+
 struct FastEntry {
     Shape shape;
     int nw;
     FwdFn (*fwd)(int, int);
     const char* fwd_name;
+    int adj_layers;                 // n_layers the adjoint instantiation is built for (0 = none)
+    FwdFn (*adj)(int, int);
+    size_t (*adj_lds)(int);
+    const char* adj_name;
 };
 
 const FastEntry kFast[] = {
-    {{32, 32, 20}, 4, pick_fwd<32, 32, 20, 4>, "ncde_fwd_fast<H32,HH32,C20,NW4>"},   // BASELINE cfg2 / cfg3
-    {{64, 64, 4}, 4, pick_fwd<64, 64, 4, 4>, "ncde_fwd_fast<H64,HH64,C4,NW4>"},       // BASELINE cfg4
+    // BASELINE cfg2 / cfg3
+    {{32, 32, 20}, 4, pick_fwd<32, 32, 20, 4>, "ncde_fwd_fast<H32,HH32,C20,NW4>",
+     3, pick_adj<32, 32, 20, 3, 4>, adj_lds_bytes<32, 32, 20, 3, 4>, "ncde_adj_fast<H32,HH32,C20,NL3,NW4>"},
+    // BASELINE cfg4 (adjoint: generic family for now -- the per-wave LDS images do not fit at HH=64)
+    {{64, 64, 4}, 4, pick_fwd<64, 64, 4, 4>, "ncde_fwd_fast<H64,HH64,C4,NW4>", 0, nullptr, nullptr, nullptr},
 };
 
 const FastEntry* find_entry(const NcdeProblem* p) {
@@ -291,37 +786,26 @@ const FastEntry* find_entry(const NcdeProblem* p) {
     return nullptr;
 }
 
-void fill_kargs_fast(const NcdeProblem* p, KArgs* a) {
-    memset(a, 0, sizeof(*a));
-    a->B = p->batch; a->T = p->n_knots; a->C = p->channels; a->H = p->hidden;
-    a->interp = p->interp; a->method = p->method; a->output = p->output; a->n_layers = p->n_layers;
-    a->n_pieces = p->n_knots - 1;
-    a->n_out = p->output == NCDE_OUT_KNOTS ? p->n_knots : 2;
-    for (int l = 0; l < p->n_layers; ++l) {
-        a->din[l] = p->layer_in[l]; a->dout[l] = p->layer_out[l];
-        a->W[l] = p->layer_W[l]; a->b[l] = p->layer_b[l];
-    }
-    a->Wo = p->Wo; a->bo = p->bo; a->coeffs = p->coeffs;
-    a->cs_b = p->coeffs_stride_b; a->cs_t = p->coeffs_stride_t;
-    a->z0 = p->z0;
-}
-
 }  // namespace
 
 bool ncde_fast_supported(const NcdeProblem* p, int pass) {
-    if (pass != 0) return false;
-    return find_entry(p) != nullptr;
+    const FastEntry* e = find_entry(p);
+    if (!e) return false;
+    if (pass == 0) return true;
+    return e->adj != nullptr && e->adj_layers == p->n_layers;
 }
 
 const char* ncde_fast_kernel_name(const NcdeProblem* p, int pass) {
+    if (!ncde_fast_supported(p, pass)) return nullptr;
     const FastEntry* e = find_entry(p);
-    if (!e || pass != 0) return nullptr;
-    return e->fwd_name;
+    return pass == 0 ? e->fwd_name : e->adj_name;
 }
 
 int64_t ncde_fast_workspace_bytes(const NcdeProblem* p, int pass) {
-    (void)p;
-    return pass == 0 ? 256 : NCDE_ERR_UNSUPPORTED;
+    if (!ncde_fast_supported(p, pass)) return NCDE_ERR_UNSUPPORTED;
+    if (pass == 0) return 256;
+    const Layout y = make_layout(p);
+    return (int64_t)sizeof(float) * (int64_t)y.n_wg * (int64_t)y.theta_size + 256;
 }
 
 int ncde_fast_forward(const NcdeProblem* p, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -330,14 +814,30 @@ int ncde_fast_forward(const NcdeProblem* p, float* out, void* ws, size_t ws_byte
     if (!e) return NCDE_ERR_UNSUPPORTED;
     FwdFn fn = e->fwd(p->interp, p->method);
     if (!fn) return NCDE_ERR_UNSUPPORTED;
+    const Layout y = make_layout(p);
     KArgs a;
-    fill_kargs_fast(p, &a);
+    fill_kargs(p, y, &a);
     a.out = out;
-    const int n_wg = (p->batch + NCDE_TILE - 1) / NCDE_TILE;
-    hipLaunchKernelGGL(fn, dim3(n_wg), dim3(64 * e->nw), 0, st, a);
+    hipLaunchKernelGGL(fn, dim3(y.n_wg), dim3(64 * e->nw), 0, st, a);
     return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
 }
 
-int ncde_fast_adjoint(const NcdeProblem*, const float*, const float*, const NcdeGrads*, void*, size_t, hipStream_t, bool) {
-    return NCDE_ERR_UNSUPPORTED;
+int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* grad_out, const NcdeGrads* g, void* ws,
+                      size_t ws_bytes, hipStream_t st, bool main_kernel_only) {
+    (void)ws_bytes;
+    if (!ncde_fast_supported(p, 1)) return NCDE_ERR_UNSUPPORTED;
+    const FastEntry* e = find_entry(p);
+    FwdFn fn = e->adj(p->interp, p->method);
+    if (!fn) return NCDE_ERR_UNSUPPORTED;
+    const Layout y = make_layout(p);
+    KArgs a;
+    fill_kargs(p, y, &a);
+    a.z_out = z_out; a.grad_out = grad_out; a.grad_z0 = g->grad_z0;
+    a.gpart = (float*)ws;
+    const size_t lds = e->adj_lds(p->interp);
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NCDE_ERR_HIP;
+    hipLaunchKernelGGL(fn, dim3(y.n_wg), dim3(64 * e->nw), lds, st, a);
+    if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
+    if (main_kernel_only) return NCDE_OK;
+    return launch_reduce_partials(p, y, g, (const float*)ws, y.n_wg, st);
 }

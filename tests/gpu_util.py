@@ -30,7 +30,7 @@ def run_case(case, flags=_lib.FLAG_AUTO, device="cuda", need_grads=True):
     t = X.grid_points if m["sequence"] else X.interval
     out = ncde_amd.cdeint(X, func, z0, t, adjoint=True, method=m["method"], options={"step_size": 1},
                           kernel_flags=flags)
-    res = {"z_out": out.detach().cpu().numpy(), "nfe_fwd": func.nfe}
+    res = {"z_out": out.detach().cpu().numpy(), "nfe_fwd": func.nfe, "kernels": kernel_names(case, flags, device)}
     if need_grads:
         gout = torch.from_numpy(case["expect"]["grad_out"]).to(device)
         (out * gout).sum().backward()
@@ -69,3 +69,17 @@ def run_adjoint_direct(case, z_out, flags=_lib.FLAG_AUTO, device="cuda"):
     _lib.check(rc, "ncde_adjoint")
     torch.cuda.synchronize()
     return {"dz0": gz0.cpu().numpy(), "grads": {k: gbuf[id(v)].cpu().numpy() for k, v in func.p.items() if id(v) in gbuf}}
+
+
+def kernel_names(case, flags=_lib.FLAG_AUTO, device="cuda"):
+    """(forward, adjoint) kernel family names the C-ABI would dispatch this case to."""
+    import ctypes
+    from ncde_amd import solver
+    m = case["meta"]
+    coeffs = torch.from_numpy(case["coeffs"]).to(device)
+    func = CaseField(case["params"], case["layers"], device)
+    z0 = torch.from_numpy(case["z0"]).to(device)
+    p = solver.build_problem(coeffs, m["kind"], z0, func.fused_spec(), m["method"],
+                             _lib.OUT_KNOTS if m["sequence"] else _lib.OUT_INTERVAL, flags)
+    lib = _lib.lib()
+    return tuple((lib.ncde_kernel_name(ctypes.byref(p), k) or b"?").decode() for k in (0, 1))

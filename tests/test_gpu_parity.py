@@ -153,3 +153,58 @@ def test_module_level_matches_reference(gpu_lib):
             ref = f[f"{vname}__grad__{k}"]
             assert gu.relerr(prm.grad.cpu().numpy(), ref) <= E2E_G, (vname, k)
         assert model.nfe == int(f[vname + "__nfe"]), vname
+
+
+def _seeded_case(interp, method, seq, B, L, C, H, HH, nl, seed):
+    """A fresh case (inputs from the deterministic generator, expectation from the oracle)."""
+    import torch as _t
+    import ncde_oracle as orc
+    if interp == "cubic":
+        coeffs = gu.data.make_cubic_coeffs(B, L, C - 1, seed=seed)
+        x0 = coeffs[:, 0, :C]
+    else:
+        coeffs = gu.data.make_rectilinear_coeffs(B, L, C - 1, missing=0.3, seed=seed)
+        x0 = coeffs[:, 0]
+    p = gu.data.make_field_weights(H, HH, C, seed=seed + 1)
+    rw = gu.data.make_readin_weights(H, C, 1, seed=seed + 1)
+    z0 = (x0 @ rw["Wi"].T + rw["bi"]).astype(np.float32)
+    layers = [("W0", "b0")] + [("W1", "b1")] * (nl - 1)
+    names = ["W0", "b0"] + (["W1", "b1"] if nl > 1 else []) + ["Wo", "bo"]
+    case = {"meta": {"kind": interp, "method": method, "sequence": seq, "param_names": names,
+                     "dims": {"C": C, "H": H, "HH": HH, "nl": nl}, "field": "original"},
+            "coeffs": coeffs, "z0": z0, "params": p, "layers": layers, "H": H, "C": C}
+    field = gu.oracle_field(case)
+    ctl = orc.Control(coeffs, interp)
+    z = orc.solve_forward(ctl, field, z0, method, seq)
+    gout = (gu.data.normal(seed + 2, z.numel(), stream=1).reshape(z.shape) / np.sqrt(z.shape[1])).astype(np.float32)
+    dz0, gp = orc.solve_adjoint(ctl, field, z, gout, method, seq)
+    case["expect"] = {"z_out": z.numpy(), "grad_out": gout, "dz0": dz0.numpy()}
+    for n_, g_ in zip(names, gp):
+        case["expect"]["d" + n_] = g_.numpy()
+    return case
+
+
+FAST_SHAPES = [(20, 32, 32, 3), (4, 64, 64, 3)]   # (C, H, HH, nl) with a shape-specialised kernel
+
+
+@pytest.mark.parametrize("shape", FAST_SHAPES)
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+@pytest.mark.parametrize("method", ["rk4", "midpoint", "euler"])
+@pytest.mark.parametrize("seq", [False, True])
+def test_fast_kernels_vs_oracle(shape, interp, method, seq, gpu_lib):
+    """Every instantiation of the shape-specialised family (interp x method x output mode), ragged batch,
+    against the oracle; the adjoint kernel is additionally checked in isolation on the oracle's z."""
+    import ctypes
+    import gpu_util
+    from ncde_amd import _lib
+    C, H, HH, nl = shape
+    case = _seeded_case(interp, method, seq, B=21, L=9, C=C, H=H, HH=HH, nl=nl, seed=100 + C)
+    res = gpu_util.run_case(case, flags=_lib.FLAG_AUTO)
+    assert res["kernels"][0].startswith("ncde_fwd_fast"), res["kernels"]
+    ex = case["expect"]
+    assert gu.relerr(res["z_out"], ex["z_out"]) <= TIGHT_Z
+    for k, e in _grad_errors(case, res).items():
+        assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), ("end-to-end", k, e)
+    iso = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_AUTO)
+    for k, e in _grad_errors(case, iso).items():
+        assert e <= TIGHT_G, ("adjoint kernel on oracle z_out", res["kernels"][1], k, e)
