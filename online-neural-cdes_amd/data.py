@@ -76,6 +76,33 @@ def rectilinear_prep(x, time_index):
     return np.ascontiguousarray(rep[..., :-1, :])
 
 
+def linear_interpolation_coeffs(x, rectilinear=None):
+    """Host-side mirror of torchcde.linear_interpolation_coeffs on the default integer time grid
+    (interpolation_linear.py:131-180): optional rectilinear preparation (``rectilinear`` = index of the
+    time channel), then every remaining NaN is filled by linear interpolation between its observed
+    neighbours, with the first/last observation extended to the ends; all-NaN channels become zero."""
+    x = np.array(x, dtype=np.float32, copy=True)
+    if rectilinear is not None:
+        assert isinstance(rectilinear, int) and 0 <= rectilinear < x.shape[-1], "bad time channel index"
+        assert not np.isnan(x[..., rectilinear]).any(), "There exist nan values in the time column which is not allowed."
+        x = rectilinear_prep(x, rectilinear)
+    if not np.isnan(x).any():
+        return x
+    flat = x.reshape(-1, x.shape[-2], x.shape[-1])
+    grid = np.arange(x.shape[-2], dtype=np.float64)
+    for b in range(flat.shape[0]):
+        for c in range(flat.shape[2]):
+            col = flat[b, :, c]
+            bad = np.isnan(col)
+            if not bad.any():
+                continue
+            if bad.all():
+                col[:] = 0.0
+            else:
+                col[bad] = np.interp(grid[bad], grid[~bad], col[~bad].astype(np.float64)).astype(np.float32)
+    return x
+
+
 def natural_cubic_coeffs(x):
     """Natural cubic spline through x[..., L, C] on the integer grid t = 0..L-1 (no missing values).
 

@@ -1,0 +1,199 @@
+"""CPU tests of the host side: C-ABI surface (loads, exports, validation -- no compute without a GPU),
+control-path mirrors, coefficient preparation known answers, argument/error behaviour of cdeint."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import ncde_amd
+from ncde_amd import _lib, solver
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _problem(B=32, T=49, C=20, H=32, HH=32, nl=3, interp=0, method=2, output=0, flags=0):
+    """A structurally valid problem with dummy (never dereferenced) device pointers."""
+    p = _lib.NcdeProblem()
+    p.abi_version = _lib.NCDE_ABI_VERSION
+    p.batch, p.n_knots, p.channels, p.hidden = B, T, C, H
+    p.interp, p.method, p.output, p.flags = interp, method, output, flags
+    p.n_layers = nl
+    for l in range(nl):
+        p.layer_in[l], p.layer_out[l] = (H if l == 0 else HH), HH
+        p.layer_W[l] = 0x1000 if l == 0 else 0x2000
+        p.layer_b[l] = 0x1100 if l == 0 else 0x2100
+    p.Wo, p.bo, p.coeffs, p.z0 = 0x3000, 0x3100, 0x4000, 0x5000
+    p.coeffs_stride_b, p.coeffs_stride_t = T * C, (4 * C if interp == 1 else C)
+    return p
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = ncde_amd.lib()
+    header = open(os.path.join(ROOT, "include", "ncde_hip.h")).read()
+    declared = set(re.findall(r"\b(ncde_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ncde_version() == _lib.NCDE_ABI_VERSION
+
+
+def test_struct_layout_matches_header():
+    # 9 int32 + n_layers + 2*8 int32, 2*8 pointers, 3 pointers, 2 int64, 1 pointer (with natural alignment)
+    assert ctypes.sizeof(_lib.NcdeProblem) == 4 * 10 + 4 * 16 + 8 * 16 + 8 * 3 + 8 * 2 + 8
+    assert ctypes.sizeof(_lib.NcdeGrads) == 8 * (1 + 16 + 2)
+
+
+def test_validation_and_error_strings_without_gpu():
+    lib = ncde_amd.lib()
+    p = _problem()
+    assert lib.ncde_num_outputs(ctypes.byref(p)) == 2
+    p.output = _lib.OUT_KNOTS
+    assert lib.ncde_num_outputs(ctypes.byref(p)) == 49
+    bad = _problem(T=1)
+    assert lib.ncde_workspace_bytes(ctypes.byref(bad), 0) == -1
+    assert b"at least 2" in lib.ncde_last_error_string()
+    bad = _problem(method=7)
+    assert lib.ncde_workspace_bytes(ctypes.byref(bad), 0) == -1
+    assert b"Invalid method" in lib.ncde_last_error_string()
+    bad = _problem()
+    bad.layer_in[1] = 17
+    assert lib.ncde_num_outputs(ctypes.byref(bad)) == -1
+    with pytest.raises(ValueError):
+        _lib.check(-1, "x")
+    with pytest.raises(NotImplementedError):
+        _lib.check(-2, "x")
+    with pytest.raises(ncde_amd.NcdeError):
+        _lib.check(-4, "x")
+
+
+def test_kernel_family_selection():
+    lib = ncde_amd.lib()
+    name = lambda p, k: (lib.ncde_kernel_name(ctypes.byref(p), k) or b"").decode()
+    p = _problem()                                    # BASELINE cfg2 shape -> specialised kernels
+    assert name(p, 0).startswith("ncde_fwd_fast") and name(p, 1).startswith("ncde_adj_fast")
+    assert name(_problem(flags=_lib.FLAG_FORCE_GENERIC), 0) == "ncde_fwd_generic"
+    q = _problem(C=5, H=16, HH=24)                    # arbitrary shape -> generic family
+    assert name(q, 0) == "ncde_fwd_generic" and name(q, 1) == "ncde_adj_generic"
+    q.flags = _lib.FLAG_FORCE_FAST
+    assert lib.ncde_workspace_bytes(ctypes.byref(q), 0) == -2
+    # adjoint workspace = one |theta| partial per 16-sample workgroup
+    theta = 32 * 32 + 32 + 32 * 32 + 32 + 640 * 32 + 640
+    assert lib.ncde_workspace_bytes(ctypes.byref(p), 1) == 4 * 2 * theta + 256
+    un = _problem(C=80, H=128, HH=512, nl=2)          # too wide for the generic adjoint's LDS plan
+    assert lib.ncde_workspace_bytes(ctypes.byref(un), 1) == -2
+
+
+def test_control_paths_match_oracle_control():
+    import ncde_oracle as orc
+    lin = ncde_amd.data.make_rectilinear_coeffs(3, 6, 4, missing=0.3, seed=5)
+    cub = ncde_amd.data.make_cubic_coeffs(3, 7, 3, seed=6)
+    for coeffs, cls, kind in ((lin, ncde_amd.LinearInterpolation, "linear"), (cub, ncde_amd.NaturalCubicSpline, "cubic")):
+        X, ctl = cls(torch.from_numpy(coeffs)), orc.Control(coeffs, kind)
+        assert X.n_knots == ctl.n_knots and X.channels == ctl.channels
+        assert torch.equal(X.evaluate(0), ctl.x0())
+        assert torch.equal(X.grid_points, torch.arange(ctl.n_knots, dtype=torch.float32))
+        assert torch.equal(X.interval, torch.tensor([0.0, ctl.n_knots - 1]))
+        for tv in (0.0, 0.25, 1.0, 1.0 + 1 / 3, 2.5, float(ctl.n_knots - 1)):
+            t = torch.tensor(tv)
+            assert torch.allclose(X.derivative(t), ctl.derivative(t), rtol=0, atol=0), (kind, tv)
+
+
+def test_rectilinear_preparation_known_answer():
+    """Same hand example as the reference's test (modules/torchcde/test/test_linear_interpolation.py:117-152)."""
+    nan = float("nan")
+    x = np.array([[[0.1, 0.4], [0.2, nan], [0.9, 1.1]],
+                  [[0.2, nan], [0.3, 2.0], [0.3, nan]]], dtype=np.float32)
+    want = np.array([[[0.1, 0.4], [0.2, 0.4], [0.2, 0.4], [0.9, 0.4], [0.9, 1.1]],
+                     [[0.2, 2.0], [0.3, 2.0], [0.3, 2.0], [0.3, 2.0], [0.3, 2.0]]], dtype=np.float32)
+    got = ncde_amd.data.linear_interpolation_coeffs(x, rectilinear=0)
+    assert np.array_equal(got, want)
+    assert np.array_equal(ncde_amd.data.linear_interpolation_coeffs(x[:, :, ::-1].copy(), rectilinear=1), want[:, :, ::-1])
+    bad = x.copy()
+    bad[0, 1, 0] = nan
+    with pytest.raises(AssertionError):
+        ncde_amd.data.linear_interpolation_coeffs(bad, rectilinear=0)
+    # interior gaps are filled linearly, all-NaN channels become 0
+    y = np.array([[[0.0, nan], [nan, nan], [2.0, nan]]], dtype=np.float32)
+    assert np.array_equal(ncde_amd.data.linear_interpolation_coeffs(y), np.array([[[0, 0], [1, 0], [2, 0]]], np.float32))
+
+
+def test_natural_cubic_reproduces_linear_data_and_interpolates_knots():
+    """Properties the reference tests for its spline (test_natural_cubic_spline.py:102-141)."""
+    L, C = 9, 3
+    t = np.arange(L, dtype=np.float32)[:, None]
+    x = (t * np.array([0.5, -1.25, 2.0], np.float32) + np.array([1.0, 0.0, -3.0], np.float32))[None]
+    X = ncde_amd.NaturalCubicSpline(torch.from_numpy(ncde_amd.data.natural_cubic_coeffs(x)))
+    for tv in (0.0, 0.3, 4.0, 6.75, 8.0):
+        assert torch.allclose(X.derivative(torch.tensor(tv)), torch.tensor([[0.5, -1.25, 2.0]]), atol=1e-4)
+        assert torch.allclose(X.evaluate(torch.tensor(tv)), torch.from_numpy(x[:, 0] + tv * np.array([0.5, -1.25, 2.0], np.float32)), atol=1e-4)
+    y = ncde_amd.data.synthetic_series(2, 12, 2, seed=3)
+    Y = ncde_amd.NaturalCubicSpline(torch.from_numpy(ncde_amd.data.natural_cubic_coeffs(y)))
+    for k in range(12):
+        assert torch.allclose(Y.evaluate(torch.tensor(float(k))), torch.from_numpy(y[:, k]), atol=1e-5)
+
+
+def test_generator_is_deterministic_and_shardable():
+    a = ncde_amd.data.make_rectilinear_coeffs(8, 10, 3, missing=0.3, seed=1234)
+    b = ncde_amd.data.make_rectilinear_coeffs(8, 10, 3, missing=0.3, seed=1234)
+    assert np.array_equal(a, b) and not np.isnan(a).any()
+    lo = ncde_amd.data.make_rectilinear_coeffs(4, 10, 3, missing=0.3, seed=1234, batch_offset=0)
+    hi = ncde_amd.data.make_rectilinear_coeffs(4, 10, 3, missing=0.3, seed=1234, batch_offset=4)
+    assert np.array_equal(np.concatenate([lo, hi]), a)     # rank shards tile the global batch exactly
+    assert a.shape == (8, 19, 4) and np.all(np.diff(a[:, :, 0], axis=1) >= 0)
+
+
+def test_module_state_dict_layout_and_weight_sharing():
+    m = ncde_amd.NeuralCDE(5, 16, 3, hidden_hidden_dim=24, num_layers=4)
+    keys = set(m.state_dict().keys())
+    assert keys == {"initial_linear.weight", "initial_linear.bias", "final_linear.weight", "final_linear.bias",
+                    "func.net_to_hh.0.weight", "func.net_to_hh.0.bias", "func.net_to_hh.2.weight", "func.net_to_hh.2.bias",
+                    "func.net_to_hh.4.weight", "func.net_to_hh.4.bias", "func.net_to_hh.6.weight", "func.net_to_hh.6.bias",
+                    "func.tanh_output_layer.0.weight", "func.tanh_output_layer.0.bias"}
+    spec = m.func.fused_spec()
+    assert len(spec.layers) == 4 and spec.layers[1][0] is spec.layers[2][0] is spec.layers[3][0]
+    assert len(spec.unique_params()) == 6 and len(list(m.func.parameters())) == 6
+    assert tuple(spec.Wo.shape) == (16 * 5, 24)
+    assert m.func(None, torch.zeros(2, 16)).shape == (2, 16, 5) and m.nfe == 1
+
+
+def test_cdeint_argument_errors_mirror_the_reference():
+    X = ncde_amd.LinearInterpolation(torch.zeros(2, 5, 3))
+    f = ncde_amd.OriginalVectorField(3, 4, 8, 2)
+    z0 = torch.zeros(2, 4)
+    with pytest.raises(ValueError, match="vector_field_type"):
+        ncde_amd.cdeint(X, f, z0, X.interval, vector_field_type="bogus")
+    with pytest.raises(ValueError, match="Invalid method"):
+        ncde_amd.cdeint(X, f, z0, X.interval, method="rk5", options={"step_size": 1})
+    with pytest.raises(NotImplementedError, match="dopri5"):
+        ncde_amd.cdeint(X, f, z0, X.interval)                       # the reference's default is adaptive dopri5
+    with pytest.raises(NotImplementedError, match="step_size"):
+        ncde_amd.cdeint(X, f, z0, X.interval, method="rk4")
+    with pytest.raises(NotImplementedError, match="fused_spec"):
+        solver._field_spec(torch.nn.Linear(4, 12))      # arbitrary Python vector fields are refused, not emulated
+
+
+def test_no_cpu_fallback_product_path_fails_loudly_on_cpu_tensors():
+    X = ncde_amd.LinearInterpolation(torch.zeros(2, 5, 3))
+    f = ncde_amd.OriginalVectorField(3, 4, 8, 2)
+    with pytest.raises(NotImplementedError, match="GPU"):
+        ncde_amd.cdeint(X, f, torch.zeros(2, 4), X.interval, method="rk4", options={"step_size": 1})
+    m = ncde_amd.NeuralCDE(3, 4, 1, hidden_hidden_dim=8)
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(2, 5, 3))
+    with pytest.raises(NotImplementedError, match="dopri5"):
+        ncde_amd.NeuralCDE(3, 4, 1, solver="dopri5")
+
+
+def test_time_mode_detection():
+    X = ncde_amd.LinearInterpolation(torch.zeros(2, 5, 3))
+    assert solver._time_mode(X, X.interval) == _lib.OUT_INTERVAL
+    assert solver._time_mode(X, X.grid_points) == _lib.OUT_KNOTS
+    assert solver._time_mode(X, torch.tensor([0.0, 4.0])) == _lib.OUT_INTERVAL
+    assert solver._time_mode(X, torch.arange(5.0)) == _lib.OUT_KNOTS
+    with pytest.raises(AssertionError):
+        solver._time_mode(X, torch.tensor([0.0, 2.0, 1.0]))
+    with pytest.raises(NotImplementedError):
+        solver._time_mode(X, torch.tensor([0.0, 2.5]))
