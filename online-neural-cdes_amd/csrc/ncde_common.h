@@ -40,12 +40,28 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// tanh via exp2 + rcp (two transcendental issues); |abs err| < 2e-7 over the whole range.
+// tanh(x) = 1 - 2/(exp(2x)+1): mul, v_exp, add, v_rcp, fma (two transcendental issues).  Saturates correctly
+// (exp -> inf gives 1, exp -> 0 gives -1); absolute error < 2e-7 over the whole range.
 __device__ __forceinline__ float tanh_dev(float x) {
-    const float ax = __builtin_fabsf(x);
-    const float e = __builtin_amdgcn_exp2f(ax * -2.8853900817779268f);  // exp(-2|x|)
-    const float r = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
-    return __builtin_copysignf(r, x);
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);  // exp(2x)
+    const float r = __builtin_amdgcn_rcpf(e + 1.0f);
+    return __builtin_fmaf(-2.0f, r, 1.0f);
+}
+
+// tanh of a pre-activation that was ALREADY scaled by 2*log2(e) (the specialised kernels fold that factor
+// into Wo and bo when they load them): v_exp, add, v_rcp, fma.
+#define NCDE_TANH_PRESCALE 2.8853900817779268f
+__device__ __forceinline__ float tanh_prescaled(float x2l) {
+    const float e = __builtin_amdgcn_exp2f(x2l);
+    const float r = __builtin_amdgcn_rcpf(e + 1.0f);
+    return __builtin_fmaf(-2.0f, r, 1.0f);
+}
+
+// relu as ONE v_max_f32 (fmaxf() costs two: hipcc canonicalises the MFMA result first)
+__device__ __forceinline__ float relu_dev(float x) {
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+    return y;
 }
 
 // Number of stages and the fp32 stage-time offsets torchdiffeq produces with dt = 1

@@ -42,13 +42,25 @@ struct Combine {
     }
 };
 
+// DS instructions of one wave are executed by the LDS in issue order, so a ds_read that follows a ds_write
+// of the same wave (any lanes) sees the data without an s_waitcnt; only the COMPILER must keep the order.
+__device__ __forceinline__ void wave_lds_order() { asm volatile("" ::: "memory"); }
+
 template <int METHOD> constexpr int kStages = METHOD == NCDE_RK4_38 ? 4 : (METHOD == NCDE_MIDPOINT ? 2 : 1);
 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int H, int HH, int C, int NW, int INTERP, int METHOD>
+template <int H, int HH, int C, int NW, int INTERP, int METHOD, int PROF = 0>
 __global__ __launch_bounds__(64 * NW, 1) void ncde_fwd_fast(KArgs a) {
+    // PROF = 1: s_memtime phase counters (debug builds of the dispatcher only; see tools/profile_phases.py)
+    unsigned long long prof[4] = {0, 0, 0, 0}, tlast = 0;
+#define NCDE_TICK(k)                                                \
+    if constexpr (PROF != 0) {                                      \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        prof[k] += now_ - tlast;                                    \
+        tlast = now_;                                               \
+    }
     constexpr int CP = (C + 3) & ~3, CQ = CP / 4, HB = H / 4, HT = HH / 16, KH = HH / 4, NB = HB / NW;
     constexpr int S = kStages<METHOD>;
     constexpr int NT = 64 * NW;
@@ -90,11 +102,11 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_fwd_fast(KArgs a) {
         for (int cq = 0; cq < CQ; ++cq) {
             const int hA = 4 * hb + (s >> 2), cA = 4 * cq + (s & 3);
 #pragma unroll
-            for (int ks = 0; ks < KH; ++ks) wo[nb][cq][ks] = cA < C ? a.Wo[(hA * C + cA) * HH + 4 * ks + g] : 0.0f;
+            for (int ks = 0; ks < KH; ++ks) wo[nb][cq][ks] = cA < C ? NCDE_TANH_PRESCALE * a.Wo[(hA * C + cA) * HH + 4 * ks + g] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = 4 * cq + r;
-                biaso[nb][cq][r] = c < C ? a.bo[(4 * hb + g) * C + c] : 0.0f;
+                biaso[nb][cq][r] = c < C ? NCDE_TANH_PRESCALE * a.bo[(4 * hb + g) * C + c] : 0.0f;
             }
         }
     }
@@ -153,6 +165,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_fwd_fast(KArgs a) {
 
     const int n_inner = a.n_layers - 1;
     int zpar = 0;
+    if constexpr (PROF != 0) tlast = __builtin_readcyclecounter();
     for (int n = 0; n < a.T - 1; ++n) {
         if (n + 1 < a.n_pieces) stage_load(n + 1);  // prefetch next piece; consumed at the end of the step
 #pragma unroll
@@ -173,7 +186,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_fwd_fast(KArgs a) {
 #pragma unroll
             for (int tt = 0; tt < HT; ++tt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hB[4 * tt + r] = fmaxf(acc[tt][r], 0.0f);
+                for (int r = 0; r < 4; ++r) hB[4 * tt + r] = relu_dev(acc[tt][r]);
             for (int rep = 0; rep < n_inner; ++rep) {
 #pragma unroll
                 for (int tt = 0; tt < HT; ++tt) acc[tt] = bias1[tt];
@@ -184,39 +197,60 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_fwd_fast(KArgs a) {
 #pragma unroll
                 for (int tt = 0; tt < HT; ++tt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) hB[4 * tt + r] = fmaxf(acc[tt][r], 0.0f);
+                    for (int r = 0; r < 4; ++r) hB[4 * tt + r] = relu_dev(acc[tt][r]);
             }
+            NCDE_TICK(0)
             // ---- output layer tiles owned by this wave: tanh + channel contraction -------------------
+            // software pipeline over cq: the MFMA chains of tile group cq run while the VALU finishes
+            // tanh + contraction of group cq-1 (one wave per SIMD: overlap exists only where VALU
+            // instructions sit between MFMAs in program order, hence the explicit interleave hints)
             float kout[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) kout[nb] = 0.0f;
+            f32x4 oprev[NB];
 #pragma unroll
-            for (int cq = 0; cq < CQ; ++cq) {
+            for (int cq = 0; cq <= CQ; ++cq) {
                 f32x4 o[NB];
+                if (cq < CQ) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) o[nb] = biaso[nb][cq];
+                    for (int nb = 0; nb < NB; ++nb) o[nb] = biaso[nb][cq];
 #pragma unroll
-                for (int ks = 0; ks < KH; ++ks)
+                    for (int ks = 0; ks < KH; ++ks)
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) o[nb] = mfma16(wo[nb][cq][ks], hB[ks], o[nb]);
-                f32x4 dx;
-                if constexpr (INTERP == NCDE_INTERP_LINEAR) {
-                    dx = *reinterpret_cast<const f32x4*>(dxp + 4 * cq);
-                } else {
-                    const f32x4 cb = *reinterpret_cast<const f32x4*>(dxp + 4 * cq);
-                    const f32x4 cc = *reinterpret_cast<const f32x4*>(dxp + CP + 4 * cq);
-                    const f32x4 cd = *reinterpret_cast<const f32x4*>(dxp + 2 * CP + 4 * cq);
+                        for (int nb = 0; nb < NB; ++nb) o[nb] = mfma16(wo[nb][cq][ks], hB[ks], o[nb]);
+                }
+                if (cq > 0) {
+                    const int cp = cq - 1;
+                    f32x4 dx;
+                    if constexpr (INTERP == NCDE_INTERP_LINEAR) {
+                        dx = *reinterpret_cast<const f32x4*>(dxp + 4 * cp);
+                    } else {
+                        const f32x4 cb = *reinterpret_cast<const f32x4*>(dxp + 4 * cp);
+                        const f32x4 cc = *reinterpret_cast<const f32x4*>(dxp + CP + 4 * cp);
+                        const f32x4 cd = *reinterpret_cast<const f32x4*>(dxp + 2 * CP + 4 * cp);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float inner = cc[r] + cd[r] * frac;
-                        dx[r] = cb[r] + inner * frac;
+                        for (int r = 0; r < 4; ++r) {
+                            const float inner = cc[r] + cd[r] * frac;
+                            dx[r] = cb[r] + inner * frac;
+                        }
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) kout[nb] = fmaf(tanh_prescaled(oprev[nb][r]), dx[r], kout[nb]);
+                }
+                if (cq > 0 && cq < CQ) {
+                    // per MFMA of group cq: 3 VALU (+ transcendental) slots of group cq-1's epilogue
+#pragma unroll
+                    for (int i = 0; i < KH * NB; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // VALU
                     }
                 }
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) kout[nb] = fmaf(tanh_dev(o[nb][r]), dx[r], kout[nb]);
+                for (int nb = 0; nb < NB; ++nb) oprev[nb] = o[nb];
             }
+            NCDE_TICK(1)
             // ---- Butcher bookkeeping for the owned state entries, then exchange the stage input ------
             float ys[NB];
 #pragma unroll
@@ -242,8 +276,313 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_fwd_fast(KArgs a) {
                 for (int ks = 0; ks < HB; ++ks) zreg[ks] = zw[(4 * ks + g) * 16 + s];
                 zpar ^= 1;
             }
+            NCDE_TICK(2)
         }
     }
+    if constexpr (PROF != 0) {
+        if (lane == 0) {
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.gpart) + ((long long)blockIdx.x * NW + wave) * 4;
+            dst[0] = prof[0]; dst[1] = prof[1]; dst[2] = prof[2]; dst[3] = prof[3];
+        }
+    }
+#undef NCDE_TICK
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward, split-bf16 variant: fp32-equivalent GEMMs on the bf16 matrix cores
+// ------------------------------------------------------------------------------------------------
+// gfx950 runs fp32-input MFMA at the fp32 VECTOR rate (1/16 of bf16).  Every fp32 value is split EXACTLY
+// into three bf16 pieces x = hi + mid + lo (8+8+8 mantissa bits) and a product a*b is evaluated as the six
+// partial products whose weight is >= 2^-16 (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi); each bf16 x bf16
+// product is exact in the fp32 accumulator and the dropped terms are <= 3 * 2^-24 relative -- fp32 round-off
+// class.  6 x v_mfma_f32_16x16x32_bf16 replace 8 x v_mfma_f32_16x16x4_f32 at ~1/2 the cycles each.
+// Lane (s, g) supplies k = 32c + 8g + j of a K chunk c, so with output rows permuted as
+// tile t, D-row (g, r) <-> unit 32*(t>>1) + 8g + 4*(t&1) + r the D registers of a layer are again exactly the
+// (to-be-split) B operand of the next layer.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct Split3 {
+    u32x4 hi, mid, lo;  // 8 bf16 each: element j in dword j>>1, even j in the low half
+};
+
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const unsigned b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
+    const float r0 = x0 - __uint_as_float(b0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(b1 & 0xFFFF0000u);  // exact
+    const unsigned c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
+    const float l0 = r0 - __uint_as_float(c0 & 0xFFFF0000u), l1 = r1 - __uint_as_float(c1 & 0xFFFF0000u);  // exact
+    hi = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+    mid = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
+    lo = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+}
+
+__device__ __forceinline__ Split3 split8(const float* v) {
+    Split3 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned h_, m_, l_;
+        split_pair(v[2 * q], v[2 * q + 1], h_, m_, l_);
+        o.hi[q] = h_;
+        o.mid[q] = m_;
+        o.lo[q] = l_;
+    }
+    return o;
+}
+
+__device__ __forceinline__ f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// c += A * B over one K chunk of 32, fp32-equivalent (smallest partial products first)
+__device__ __forceinline__ f32x4 mfma_split(const Split3& A, const Split3& B, f32x4 c) {
+    c = mfma_bf(A.lo, B.hi, c);
+    c = mfma_bf(A.hi, B.lo, c);
+    c = mfma_bf(A.mid, B.mid, c);
+    c = mfma_bf(A.mid, B.hi, c);
+    c = mfma_bf(A.hi, B.mid, c);
+    c = mfma_bf(A.hi, B.hi, c);
+    return c;
+}
+
+template <int H, int HH, int C, int NW, int INTERP, int METHOD, int PROF = 0>
+__global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs a) {
+    unsigned long long prof[4] = {0, 0, 0, 0}, tlast = 0;
+#define NCDE_TICK(k)                                                \
+    if constexpr (PROF != 0) {                                      \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        prof[k] += now_ - tlast;                                    \
+        tlast = now_;                                               \
+    }
+    constexpr int CP = (C + 3) & ~3, CQ = CP / 4, HB = H / 4, HT = HH / 16, NB = HB / NW;
+    constexpr int KC0 = H / 32, KC = HH / 32;  // K chunks of layer 0 / of the HH-wide layers
+    constexpr int S = kStages<METHOD>;
+    constexpr int NT = 64 * NW;
+    constexpr int DXW = INTERP == NCDE_INTERP_LINEAR ? CP : 3 * CP;
+    constexpr int EPT = (16 * DXW + NT - 1) / NT;
+    static_assert(H % (4 * NW) == 0 && HH % 32 == 0 && H % 32 == 0, "shape not tileable");
+    __shared__ __attribute__((aligned(16))) float zx[2][H * 16];
+    __shared__ __attribute__((aligned(16))) float dxs[3][16 * DXW];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = lane & 15, g = lane >> 4;
+    const int b0 = blockIdx.x * NCDE_TILE;
+    const int bs = b0 + s;
+    const bool valid = bs < a.B;
+
+    // ---- weights -> split bf16 A operands in registers ------------------------------------------------
+    Split3 w0[HT][KC0], w1[HT][KC], wo[NB][CQ][KC];
+    f32x4 bias0[HT], bias1[HT], biaso[NB][CQ];
+    const bool has_inner = a.n_layers > 1;
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+        // A row i = s <-> D row (g' = i>>2, r' = i&3) <-> unit 32*(t>>1) + 8g' + 4*(t&1) + r'
+        const int unitA = 32 * (t >> 1) + 8 * (s >> 2) + 4 * (t & 1) + (s & 3);
+        float tmp[8];
+#pragma unroll
+        for (int c = 0; c < KC0; ++c) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tmp[j] = a.W[0][unitA * H + 32 * c + 8 * g + j];
+            w0[t][c] = split8(tmp);
+        }
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tmp[j] = has_inner ? a.W[1][unitA * HH + 32 * c + 8 * g + j] : 0.0f;
+            w1[t][c] = split8(tmp);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int unitD = 32 * (t >> 1) + 8 * g + 4 * (t & 1) + r;
+            bias0[t][r] = a.b[0][unitD];
+            bias1[t][r] = has_inner ? a.b[1][unitD] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int hb = wave * NB + nb;
+#pragma unroll
+        for (int cq = 0; cq < CQ; ++cq) {
+            const int hA = 4 * hb + (s >> 2), cA = 4 * cq + (s & 3);
+            float tmp[8];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tmp[j] = cA < C ? NCDE_TANH_PRESCALE * a.Wo[(hA * C + cA) * HH + 32 * c + 8 * g + j] : 0.0f;
+                wo[nb][cq][c] = split8(tmp);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cc = 4 * cq + r;
+                biaso[nb][cq][r] = cc < C ? NCDE_TANH_PRESCALE * a.bo[(4 * hb + g) * C + cc] : 0.0f;
+            }
+        }
+    }
+
+    // ---- control-path staging (identical to ncde_fwd_fast) ------------------------------------------------
+    const float* eptr[EPT];
+    float eprev[EPT], enext[EPT];
+    bool eok[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = tid + q * NT;
+        const int es = e / DXW, ec = e - es * DXW;
+        const int part = ec / CP, c = ec - part * CP;
+        eok[q] = e < 16 * DXW && c < C && (b0 + es) < a.B;
+        const long long base = (long long)(eok[q] ? b0 + es : 0) * a.cs_b;
+        eptr[q] = a.coeffs + base + (INTERP == NCDE_INTERP_LINEAR ? c : (part + 1) * C + c);
+        eprev[q] = 0.0f;
+        enext[q] = 0.0f;
+    }
+    auto stage_load = [&](int piece) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int row = INTERP == NCDE_INTERP_LINEAR ? piece + 1 : piece;
+            enext[q] = eok[q] ? eptr[q][(long long)row * a.cs_t] : 0.0f;
+        }
+    };
+    auto stage_store = [&](int piece) {
+        float* dst = dxs[piece % 3];
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = tid + q * NT;
+            if (e < 16 * DXW) dst[e] = INTERP == NCDE_INTERP_LINEAR ? enext[q] - eprev[q] : enext[q];
+            eprev[q] = enext[q];
+        }
+    };
+    if (INTERP == NCDE_INTERP_LINEAR) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) eprev[q] = eok[q] ? eptr[q][0] : 0.0f;
+    }
+    stage_load(0);
+    stage_store(0);
+
+    // ---- state: lane (s, g) keeps z[s][32c + 8g + j] as the layer-0 B operand ----------------------------
+    float y0[NB], k1[NB], k2[NB], zreg[KC0][8];
+#pragma unroll
+    for (int c = 0; c < KC0; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zreg[c][j] = valid ? a.z0[(long long)bs * H + 32 * c + 8 * g + j] : 0.0f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        y0[nb] = valid ? a.z0[(long long)bs * H + 4 * (wave * NB + nb) + g] : 0.0f;
+        k1[nb] = 0.0f;
+        k2[nb] = 0.0f;
+        if (valid) a.out[((long long)bs * a.n_out) * H + 4 * (wave * NB + nb) + g] = y0[nb];
+    }
+    __syncthreads();
+
+    const int n_inner = a.n_layers - 1;
+    int zpar = 0;
+    if constexpr (PROF != 0) tlast = __builtin_readcyclecounter();
+    for (int n = 0; n < a.T - 1; ++n) {
+        if (n + 1 < a.n_pieces) stage_load(n + 1);
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            const float t = (float)n + stage_offset(METHOD, j);
+            const int idx = piece_index(t, a.n_pieces);
+            const float frac = t - (float)idx;
+            const float* dxp = dxs[idx % 3] + s * DXW;
+            // ---- hidden layers ---------------------------------------------------------------------------
+            f32x4 acc[HT];
+            float hv[KC][8];
+            Split3 xb[KC];
+            {
+                Split3 zb[KC0];
+#pragma unroll
+                for (int c = 0; c < KC0; ++c) zb[c] = split8(zreg[c]);
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt) acc[tt] = bias0[tt];
+#pragma unroll
+                for (int c = 0; c < KC0; ++c)
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt) acc[tt] = mfma_split(w0[tt][c], zb[c], acc[tt]);
+            }
+#pragma unroll
+            for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hv[tt >> 1][4 * (tt & 1) + r] = relu_dev(acc[tt][r]);
+#pragma unroll
+            for (int c = 0; c < KC; ++c) xb[c] = split8(hv[c]);
+            for (int rep = 0; rep < n_inner; ++rep) {
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt) acc[tt] = bias1[tt];
+#pragma unroll
+                for (int c = 0; c < KC; ++c)
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt) acc[tt] = mfma_split(w1[tt][c], xb[c], acc[tt]);
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hv[tt >> 1][4 * (tt & 1) + r] = relu_dev(acc[tt][r]);
+#pragma unroll
+                for (int c = 0; c < KC; ++c) xb[c] = split8(hv[c]);
+            }
+            NCDE_TICK(0)
+            // ---- output layer tiles owned by this wave: tanh + channel contraction -----------------------
+            float kout[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) kout[nb] = 0.0f;
+#pragma unroll
+            for (int cq = 0; cq < CQ; ++cq) {
+                f32x4 o[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) o[nb] = biaso[nb][cq];
+#pragma unroll
+                for (int c = 0; c < KC; ++c)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) o[nb] = mfma_split(wo[nb][cq][c], xb[c], o[nb]);
+                f32x4 dx;
+                if constexpr (INTERP == NCDE_INTERP_LINEAR) {
+                    dx = *reinterpret_cast<const f32x4*>(dxp + 4 * cq);
+                } else {
+                    const f32x4 cb = *reinterpret_cast<const f32x4*>(dxp + 4 * cq);
+                    const f32x4 cc = *reinterpret_cast<const f32x4*>(dxp + CP + 4 * cq);
+                    const f32x4 cd = *reinterpret_cast<const f32x4*>(dxp + 2 * CP + 4 * cq);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float inner = cc[r] + cd[r] * frac;
+                        dx[r] = cb[r] + inner * frac;
+                    }
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) kout[nb] = fmaf(tanh_prescaled(o[nb][r]), dx[r], kout[nb]);
+            }
+            NCDE_TICK(1)
+            float ys[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) ys[nb] = Combine<METHOD>::apply(j, kout[nb], y0[nb], k1[nb], k2[nb]);
+            if (j == S - 1) {
+                if (valid && (a.output == NCDE_OUT_KNOTS || n == a.T - 2)) {
+                    const int row = a.output == NCDE_OUT_KNOTS ? n + 1 : 1;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) a.out[((long long)bs * a.n_out + row) * H + 4 * (wave * NB + nb) + g] = ys[nb];
+                }
+                if (n + 1 < a.n_pieces) stage_store(n + 1);
+            }
+            {
+                float* zw = zx[zpar];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) zw[(4 * (wave * NB + nb) + g) * 16 + s] = ys[nb];
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < KC0; ++c)
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) zreg[c][jj] = zw[(32 * c + 8 * g + jj) * 16 + s];
+                zpar ^= 1;
+            }
+            NCDE_TICK(2)
+        }
+    }
+    if constexpr (PROF != 0) {
+        if (lane == 0) {
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.gpart) + ((long long)blockIdx.x * NW + wave) * 4;
+            dst[0] = prof[0]; dst[1] = prof[1]; dst[2] = prof[2]; dst[3] = prof[3];
+        }
+    }
+#undef NCDE_TICK
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -260,8 +599,15 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_fwd_fast(KArgs a) {
 //                       and accumulated in registers for the whole solve (dWo: own tiles; dW1/dW0: one
 //                       16x16 tile per wave); bias gradients accumulate per lane and are reduced over the
 //                       16 samples once, at the end.
-template <int H, int HH, int C, int NL, int NW, int INTERP, int METHOD>
+template <int H, int HH, int C, int NL, int NW, int INTERP, int METHOD, int PROF = 0>
 __global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
+    unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+#define NCDE_TICK(k)                                                \
+    if constexpr (PROF != 0) {                                      \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        prof[k] += now_ - tlast;                                    \
+        tlast = now_;                                               \
+    }
     constexpr int CP = (C + 3) & ~3, CQ = CP / 4, HB = H / 4, HT = HH / 16, KH = HH / 4, NB = HB / NW;
     constexpr int S = kStages<METHOD>;
     constexpr int NT = 64 * NW;
@@ -329,7 +675,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
         for (int cq = 0; cq < CQ; ++cq) {
             const int hA = 4 * hb + (s >> 2), cA = 4 * cq + (s & 3);
 #pragma unroll
-            for (int ks = 0; ks < KH; ++ks) wo[nb][cq][ks] = cA < C ? a.Wo[(hA * C + cA) * HH + 4 * ks + g] : 0.0f;
+            for (int ks = 0; ks < KH; ++ks) wo[nb][cq][ks] = cA < C ? NCDE_TANH_PRESCALE * a.Wo[(hA * C + cA) * HH + 4 * ks + g] : 0.0f;
         }
     }
     for (int e = tid; e < NW * NTILE * HT * 256; e += NT) {  // Wo^T image
@@ -345,7 +691,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
         const int tau = rest % NTILE, wv = rest / NTILE;
         const int nb = tau / CQ, cq = tau - nb * CQ;
         const int h = 4 * (wv * NB + nb) + gg, c = 4 * cq + r;
-        boL[e] = c < C ? a.bo[h * C + c] : 0.0f;
+        boL[e] = c < C ? NCDE_TANH_PRESCALE * a.bo[h * C + c] : 0.0f;
     }
 
     // ---- control-path staging (reverse order: piece p needs rows p+1 and p) ----------------------------
@@ -420,6 +766,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
     __syncthreads();
 
     int zpar = 0;
+    if constexpr (PROF != 0) tlast = __builtin_readcyclecounter();
     for (int n = a.T - 1; n >= 1; --n) {  // reverse step: knot n -> n-1 (negated time -n -> -(n-1))
         if (n - 3 >= 0) stage_load(n - 3);  // piece needed by the NEXT-next step; stored at the end of this one
         float ynext[NB], gnext[NB], znext[HB];
@@ -453,7 +800,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
 #pragma unroll
                 for (int tt = 0; tt < HT; ++tt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) x[0][4 * tt + r] = fmaxf(acc[tt][r], 0.0f);
+                    for (int r = 0; r < 4; ++r) x[0][4 * tt + r] = relu_dev(acc[tt][r]);
 #pragma unroll
                 for (int l = 1; l < NL; ++l) {
 #pragma unroll
@@ -465,7 +812,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
 #pragma unroll
                     for (int tt = 0; tt < HT; ++tt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) x[l][4 * tt + r] = fmaxf(acc[tt][r], 0.0f);
+                        for (int r = 0; r < 4; ++r) x[l][4 * tt + r] = relu_dev(acc[tt][r]);
                 }
             }
             if (wq != 0.0f) {
@@ -475,8 +822,9 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
                 for (int l = 0; l < NL; ++l)
 #pragma unroll
                     for (int ks = 0; ks < KH; ++ks) img[(H + l * HH + 4 * ks + g) * XS + s] = x[l][ks];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wave_lds_order();
             }
+            NCDE_TICK(0)
             // B operands of the dWo GEMM: x_NL[j = 16t + n][samples 4g..4g+3]
             f32x4 xB[HT];
             if (wq != 0.0f) {
@@ -518,7 +866,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
                     f32x4 dP;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float m = tanh_dev(o[nb][r]);
+                        const float m = tanh_prescaled(o[nb][r]);
                         kout[nb] = fmaf(m, dx[r], kout[nb]);
                         dP[r] = (as_[nb] * dx[r]) * (1.0f - m * m);
                     }
@@ -536,9 +884,9 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
                             gbo[tau][r] += v;
                             dptile[(4 * g + r) * XS + s] = v;
                         }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        wave_lds_order();
                         const f32x4 av = *reinterpret_cast<const f32x4*>(dptile + s * XS + 4 * g);
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        wave_lds_order();
 #pragma unroll
                         for (int tt = 0; tt < HT; ++tt)
 #pragma unroll
@@ -546,6 +894,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
                     }
                 }
             }
+            NCDE_TICK(1)
             // ---- sum the dL/dx_L partials over the waves --------------------------------------------------------
             float gpre[KH];
             if constexpr (NW == 1) {
@@ -569,6 +918,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
             }
 #pragma unroll
             for (int ks = 0; ks < KH; ++ks) gpre[ks] = x[NL - 1][ks] > 0.0f ? gpre[ks] : 0.0f;
+            NCDE_TICK(2)
             // ---- hidden layers backward (shared W1), then W0 ------------------------------------------------------
 #pragma unroll
             for (int l = NL - 1; l >= 1; --l) {  // layer with input x_l (x[l-1]) and output x_{l+1} (x[l])
@@ -579,7 +929,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
                         gb1[ks] += v;
                         dpimg[(4 * ks + g) * XS + s] = v;
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    wave_lds_order();
 #pragma unroll
                     for (int k = 0; k < TPW1; ++k) {
                         const int id = wave * TPW1 + k, tr = id / HT, tc = id - tr * HT;
@@ -588,7 +938,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) gW1[k] = mfma16(av[q], bv[q], gW1[k]);
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    wave_lds_order();
                 }
                 f32x4 acc[HT];
 #pragma unroll
@@ -609,7 +959,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
                     gb0[ks] += v;
                     dpimg[(4 * ks + g) * XS + s] = v;
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wave_lds_order();
 #pragma unroll
                 for (int k = 0; k < TPW0; ++k) {
                     const int id = wave * TPW0 + k, tr = id / HT0, tc = id - tr * HT0;
@@ -618,8 +968,9 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) gW0[k] = mfma16(av[q], bv[q], gW0[k]);
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wave_lds_order();
             }
+            NCDE_TICK(3)
             f32x4 vy = zero4;  // a^T df/dy for the state entries this wave owns
 #pragma unroll
             for (int ks = 0; ks < KH; ++ks) vy = mfma16(w0T[ks], gpre[ks], vy);
@@ -664,8 +1015,16 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
                 for (int ks = 0; ks < HB; ++ks) zreg[ks] = zw[(4 * ks + g) * 16 + s];
                 zpar ^= 1;
             }
+            NCDE_TICK(4)
         }
     }
+    if constexpr (PROF != 0) {
+        if (lane == 0) {
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.out) + ((long long)blockIdx.x * NW + wave) * 6;
+            for (int k = 0; k < 6; ++k) dst[k] = prof[k];
+        }
+    }
+#undef NCDE_TICK
     // ---- write-out: dL/dz0 and this workgroup's parameter-gradient partial ------------------------------------
     if (valid) {
 #pragma unroll
@@ -734,6 +1093,20 @@ FwdFn pick_fwd(int interp, int method) {
     return nullptr;
 }
 
+template <int H, int HH, int C, int NW>
+FwdFn pick_fwd_bf3(int interp, int method) {
+#define NCDE_PICK(I, M) \
+    if (interp == I && method == M) return ncde_fwd_fast_bf3<H, HH, C, NW, I, M>;
+    NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_RK4_38)
+    NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_MIDPOINT)
+    NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_EULER)
+    NCDE_PICK(NCDE_INTERP_CUBIC, NCDE_RK4_38)
+    NCDE_PICK(NCDE_INTERP_CUBIC, NCDE_MIDPOINT)
+    NCDE_PICK(NCDE_INTERP_CUBIC, NCDE_EULER)
+#undef NCDE_PICK
+    return nullptr;
+}
+
 template <int H, int HH, int C, int NL, int NW>
 FwdFn pick_adj(int interp, int method) {
 #define NCDE_PICK(I, M) \
@@ -761,6 +1134,9 @@ struct FastEntry {
     int nw;
     FwdFn (*fwd)(int, int);
     const char* fwd_name;
+    FwdFn (*fwd_bf3)(int, int);     // split-bf16 variant (default); NCDE_FLAG_FP32_MFMA selects `fwd`
+    const char* fwd_bf3_name;
+    int nw_bf3;
     int adj_layers;                 // n_layers the adjoint instantiation is built for (0 = none)
     FwdFn (*adj)(int, int);
     size_t (*adj_lds)(int);
@@ -770,9 +1146,11 @@ struct FastEntry {
 const FastEntry kFast[] = {
     // BASELINE cfg2 / cfg3
     {{32, 32, 20}, 4, pick_fwd<32, 32, 20, 4>, "ncde_fwd_fast<H32,HH32,C20,NW4>",
+     pick_fwd_bf3<32, 32, 20, 4>, "ncde_fwd_fast_bf3<H32,HH32,C20,NW4>", 4,
      3, pick_adj<32, 32, 20, 3, 4>, adj_lds_bytes<32, 32, 20, 3, 4>, "ncde_adj_fast<H32,HH32,C20,NL3,NW4>"},
     // BASELINE cfg4 (adjoint: generic family for now -- the per-wave LDS images do not fit at HH=64)
-    {{64, 64, 4}, 4, pick_fwd<64, 64, 4, 4>, "ncde_fwd_fast<H64,HH64,C4,NW4>", 0, nullptr, nullptr, nullptr},
+    {{64, 64, 4}, 4, pick_fwd<64, 64, 4, 4>, "ncde_fwd_fast<H64,HH64,C4,NW4>",
+     pick_fwd_bf3<64, 64, 4, 4>, "ncde_fwd_fast_bf3<H64,HH64,C4,NW4>", 4, 0, nullptr, nullptr, nullptr},
 };
 
 const FastEntry* find_entry(const NcdeProblem* p) {
@@ -798,18 +1176,20 @@ bool ncde_fast_supported(const NcdeProblem* p, int pass) {
 const char* ncde_fast_kernel_name(const NcdeProblem* p, int pass) {
     if (!ncde_fast_supported(p, pass)) return nullptr;
     const FastEntry* e = find_entry(p);
-    return pass == 0 ? e->fwd_name : e->adj_name;
+    if (pass == 0) return ((p->flags & NCDE_FLAG_FP32_MFMA) == 0 && e->fwd_bf3) ? e->fwd_bf3_name : e->fwd_name;
+    return e->adj_name;
 }
 
 int64_t ncde_fast_workspace_bytes(const NcdeProblem* p, int pass) {
     if (!ncde_fast_supported(p, pass)) return NCDE_ERR_UNSUPPORTED;
-    if (pass == 0) return 256;
     const Layout y = make_layout(p);
-    return (int64_t)sizeof(float) * (int64_t)y.n_wg * (int64_t)y.theta_size + 256;
+    if (pass == 0) return (p->flags & NCDE_FLAG_DEBUG_PROFILE) ? 256 + (int64_t)y.n_wg * 8 * 4 * 8 : 256;
+    return (int64_t)sizeof(float) * (int64_t)y.n_wg * (int64_t)y.theta_size + 256 +
+           ((p->flags & NCDE_FLAG_DEBUG_PROFILE) ? (int64_t)y.n_wg * 4 * 6 * 8 + 256 : 0);
 }
 
 int ncde_fast_forward(const NcdeProblem* p, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
-    (void)ws; (void)ws_bytes;
+    (void)ws_bytes;
     const FastEntry* e = find_entry(p);
     if (!e) return NCDE_ERR_UNSUPPORTED;
     FwdFn fn = e->fwd(p->interp, p->method);
@@ -818,7 +1198,15 @@ int ncde_fast_forward(const NcdeProblem* p, float* out, void* ws, size_t ws_byte
     KArgs a;
     fill_kargs(p, y, &a);
     a.out = out;
-    hipLaunchKernelGGL(fn, dim3(y.n_wg), dim3(64 * e->nw), 0, st, a);
+    const bool bf3 = (p->flags & NCDE_FLAG_FP32_MFMA) == 0 && e->fwd_bf3 != nullptr;
+    if (bf3) fn = e->fwd_bf3(p->interp, p->method);
+    if (p->flags & NCDE_FLAG_DEBUG_PROFILE) {  // phase-cycle counters -> workspace [n_wg][NW][4] u64
+        if (!(e->shape.H == 32 && e->shape.C == 20 && p->interp == NCDE_INTERP_LINEAR && p->method == NCDE_RK4_38)) return NCDE_ERR_UNSUPPORTED;
+        fn = bf3 ? ncde_fwd_fast_bf3<32, 32, 20, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>
+                 : ncde_fwd_fast<32, 32, 20, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>;
+        a.gpart = (float*)ws;
+    }
+    hipLaunchKernelGGL(fn, dim3(y.n_wg), dim3(64 * (bf3 ? e->nw_bf3 : e->nw)), 0, st, a);
     return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
 }
 
@@ -834,6 +1222,11 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     fill_kargs(p, y, &a);
     a.z_out = z_out; a.grad_out = grad_out; a.grad_z0 = g->grad_z0;
     a.gpart = (float*)ws;
+    if (p->flags & NCDE_FLAG_DEBUG_PROFILE) {  // phase-cycle counters -> tail of the workspace [n_wg][NW][6] u64
+        if (!(e->shape.H == 32 && e->shape.C == 20 && p->interp == NCDE_INTERP_LINEAR && p->method == NCDE_RK4_38)) return NCDE_ERR_UNSUPPORTED;
+        fn = ncde_adj_fast<32, 32, 20, 3, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>;
+        a.out = (float*)ws + (size_t)y.n_wg * y.theta_size + 64;
+    }
     const size_t lds = e->adj_lds(p->interp);
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NCDE_ERR_HIP;
     hipLaunchKernelGGL(fn, dim3(y.n_wg), dim3(64 * e->nw), lds, st, a);

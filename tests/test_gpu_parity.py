@@ -200,9 +200,12 @@ def test_fast_kernels_vs_oracle(shape, interp, method, seq, gpu_lib):
     C, H, HH, nl = shape
     case = _seeded_case(interp, method, seq, B=21, L=9, C=C, H=H, HH=HH, nl=nl, seed=100 + C)
     res = gpu_util.run_case(case, flags=_lib.FLAG_AUTO)
-    assert res["kernels"][0].startswith("ncde_fwd_fast"), res["kernels"]
+    assert res["kernels"][0].startswith("ncde_fwd_fast_bf3"), res["kernels"]     # default: split-bf16 GEMMs
     ex = case["expect"]
     assert gu.relerr(res["z_out"], ex["z_out"]) <= TIGHT_Z
+    res32 = gpu_util.run_case(case, flags=_lib.FLAG_FP32_MFMA, need_grads=False)  # plain fp32-input MFMA variant
+    assert res32["kernels"][0].startswith("ncde_fwd_fast<"), res32["kernels"]
+    assert gu.relerr(res32["z_out"], ex["z_out"]) <= TIGHT_Z
     for k, e in _grad_errors(case, res).items():
         assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), ("end-to-end", k, e)
     iso = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_AUTO)
