@@ -15,6 +15,7 @@
 #include "ncde_fast.h"
 
 #include <cstring>
+#include <type_traits>
 
 #include "ncde_common.h"
 #include "ncde_host.h"
@@ -1071,6 +1072,560 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// adjoint, wave-specialised variant: chain waves + gradient waves (two waves per SIMD)
+// ------------------------------------------------------------------------------------------------
+// One wave per SIMD cannot hide its own VALU/LDS latencies and issues at most ~1 instruction per 4-5 cycles
+// (profiles/r01: ncde_adj_fast spends ~20k cycles per stage on 10.9k cycles of MFMA).  Here a workgroup has
+// 8 waves = 4 pairs, wave w (chain, "C") and wave w+4 (gradient, "G") sharing SIMD w and the same h-blocks:
+//   C: everything ON the stage's dependency chain -- forward recompute, output tiles (P, tanh, f, dP),
+//      cross-wave sum of dL/dx_L, hidden-layer backward, a^T df/dy, Butcher bookkeeping, state exchange;
+//   G: every GEMM that only CONSUMES dP / dL/dpre -- the dL/dx_L partial (Wo^T resident in G's registers)
+//      and ALL parameter-gradient accumulation (dWo, dbo, dW1, dW0, db*), i.e. half of the stage's MFMAs and
+//      none of its VALU.  The matrix pipe of SIMD w is fed by G while C is busy in the VALU, and vice versa.
+// Hand-off C -> G is through LDS images plus monotone flag words (stage counter), written after the data by
+// the same wave (DS ops of a wave are performed in order) and polled by G; the dL/dx_L partials come back
+// through the `red` buffer at the stage's first workgroup barrier.  Everything of stage j is consumed before
+// the stage's second barrier, so all images are single-buffered.
+template <int H, int HH, int C, int NL, int INTERP, int METHOD, int PROF = 0>
+__global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
+    unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+#define NCDE_TICK(k)                                                \
+    if constexpr (PROF != 0) {                                      \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        prof[k] += now_ - tlast;                                    \
+        tlast = now_;                                               \
+    }
+    constexpr int NW = 4;  // pairs
+    constexpr int CP = (C + 3) & ~3, CQ = CP / 4, HB = H / 4, HT = HH / 16, KH = HH / 4, NB = HB / NW;
+    constexpr int S = kStages<METHOD>;
+    constexpr int NT = 64 * NW;  // threads that stage the control path (the chain waves)
+    constexpr int DXW = INTERP == NCDE_INTERP_LINEAR ? CP : 3 * CP;
+    constexpr int EPT = (16 * DXW + NT - 1) / NT;
+    constexpr int NTILE = NB * CQ;
+    constexpr int HT0 = H / 16;
+    constexpr int TPW1 = HT * HT / NW, TPW0 = HT * HT0 / NW;
+    constexpr int XROWS = H + NL * HH;         // z, x_1..x_NL
+    constexpr int NFLAG = 2 * NTILE;           // per pair: one flag per tile and stage parity
+    constexpr int NT2 = NTILE / 2;             // dWo tiles done right after barrier A; the rest lag one stage
+    static_assert(H % (4 * NW) == 0 && HH % 16 == 0 && H % 16 == 0 && NB <= 4, "shape not tileable");
+    static_assert((HT * HT) % NW == 0 && (HT * HT0) % NW == 0, "weight-gradient tiles must split evenly over the pairs");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* zx = lds;                                  // [2][H*16]
+    float* dxs = zx + 2 * H * 16;                     // [3][16*DXW]
+    float* red = dxs + 3 * 16 * DXW;                  // [NW][HH*16]
+    float* boL = red + NW * HH * 16;                  // [NW][NTILE][4][4]
+    float* tiles = boL + NW * NTILE * 16;             // [2][NW][NTILE][16][16]  raw dP, [row][sample], by stage parity
+    float* ximg = tiles + 2 * NW * NTILE * 256;       // [2][XROWS][16]  z, x_1..x_NL (written by chain wave 0), by parity
+    float* dpimg = ximg + 2 * XROWS * 16;             // [NL][HH][16]    raw dL/dpre of each hidden layer (chain wave 0)
+    int* flags = reinterpret_cast<int*>(dpimg + NL * HH * 16);  // [NW][NFLAG]
+    // A-operand / bias images of the small transposed weights: read per use so they do not occupy the chain
+    // waves' registers for the whole solve (two waves per SIMD = 256 registers each)
+    float* biasL = reinterpret_cast<float*>(flags + NW * NFLAG);  // [2][HT][4 g][4 r]
+    float* w1TL = biasL + 2 * HT * 16;                // [HT][KH/4][64 lanes][4]
+    float* w0TL = w1TL + HT * (KH / 4) * 256;         // [NW][KH/4][64 lanes][4]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_chain = wave < NW;
+    const int pw = is_chain ? wave : wave - NW;       // pair index = SIMD = owner of h-blocks pw*NB..
+    const int s = lane & 15, g = lane >> 4;
+    const int b0 = blockIdx.x * NCDE_TILE;
+    const int bs = b0 + s;
+    const bool valid = bs < a.B;
+    float* my_tiles = tiles + pw * NTILE * 256;       // + parity * NW*NTILE*256
+    // explicit LDS address space: a generic volatile pointer would be lowered to (slow) flat_store/flat_load
+    volatile __attribute__((address_space(3))) int* my_flags =
+        (volatile __attribute__((address_space(3))) int*)(flags + pw * NFLAG);
+    const float* boLw = boL + pw * NTILE * 16;
+
+    for (int e = tid; e < NW * NFLAG; e += 512) flags[e] = 0;
+    for (int e = tid; e < NW * NTILE * 16; e += 512) {
+        const int r = e & 3, gg = (e >> 2) & 3, rest = e >> 4;
+        const int tau = rest % NTILE, wv = rest / NTILE;
+        const int nb = tau / CQ, cq = tau - nb * CQ;
+        const int h = 4 * (wv * NB + nb) + gg, c = 4 * cq + r;
+        boL[e] = c < C ? NCDE_TANH_PRESCALE * a.bo[h * C + c] : 0.0f;
+    }
+    for (int e = tid; e < 2 * HT * 16; e += 512) {
+        const int r = e & 3, gg = (e >> 2) & 3, t = (e >> 4) % HT, layer = e / (16 * HT);
+        biasL[e] = a.b[layer][4 * (4 * t + r) + gg];
+    }
+    for (int e = tid; e < HT * (KH / 4) * 256; e += 512) {
+        const int q = e & 3, l = (e >> 2) & 63, rest = e >> 8;
+        const int k4 = rest % (KH / 4), t = rest / (KH / 4);
+        const int unitA = 4 * (4 * t + (l & 3)) + ((l & 15) >> 2);
+        w1TL[e] = a.W[1][(4 * (4 * k4 + q) + (l >> 4)) * HH + unitA];
+    }
+    for (int e = tid; e < NW * (KH / 4) * 256; e += 512) {
+        const int q = e & 3, l = (e >> 2) & 63, rest = e >> 8;
+        const int k4 = rest % (KH / 4), wv = rest / (KH / 4);
+        const int r_own = l & 3;
+        const int hrow = 4 * (wv * NB + r_own) + ((l & 15) >> 2);
+        w0TL[e] = r_own < NB ? a.W[0][(4 * (4 * k4 + q) + (l >> 4)) * H + hrow] : 0.0f;
+    }
+    const int n_stage_total = (a.T - 1) * S;
+
+    if (is_chain) {
+        // =================================================================================================
+        // chain wave
+        // =================================================================================================
+        float w0[HT][HB], w1[HT][KH], wo[NB][CQ][KH];
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            const int unitA = 4 * (4 * t + (s & 3)) + (s >> 2);
+#pragma unroll
+            for (int ks = 0; ks < HB; ++ks) w0[t][ks] = a.W[0][unitA * H + 4 * ks + g];
+#pragma unroll
+            for (int ks = 0; ks < KH; ++ks) w1[t][ks] = a.W[1][unitA * HH + 4 * ks + g];
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int hb = pw * NB + nb;
+#pragma unroll
+            for (int cq = 0; cq < CQ; ++cq) {
+                const int hA = 4 * hb + (s >> 2), cA = 4 * cq + (s & 3);
+#pragma unroll
+                for (int ks = 0; ks < KH; ++ks) wo[nb][cq][ks] = cA < C ? NCDE_TANH_PRESCALE * a.Wo[(hA * C + cA) * HH + 4 * ks + g] : 0.0f;
+            }
+        }
+        // control-path staging (reverse order), by the 256 chain threads
+        const float* eptr[EPT];
+        float eprev[EPT], enext[EPT];
+        bool eok[EPT];
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = tid + q * NT;
+            const int es = e / DXW, ec = e - es * DXW;
+            const int part = ec / CP, c = ec - part * CP;
+            eok[q] = e < 16 * DXW && c < C && (b0 + es) < a.B;
+            const long long base = (long long)(eok[q] ? b0 + es : 0) * a.cs_b;
+            eptr[q] = a.coeffs + base + (INTERP == NCDE_INTERP_LINEAR ? c : (part + 1) * C + c);
+            eprev[q] = 0.0f;
+            enext[q] = 0.0f;
+        }
+        auto stage_load = [&](int piece) {
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) enext[q] = eok[q] ? eptr[q][(long long)piece * a.cs_t] : 0.0f;
+        };
+        auto stage_store = [&](int piece) {
+            float* dst = dxs + (piece % 3) * 16 * DXW;
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+                const int e = tid + q * NT;
+                if (e < 16 * DXW) dst[e] = INTERP == NCDE_INTERP_LINEAR ? eprev[q] - enext[q] : enext[q];
+                eprev[q] = enext[q];
+            }
+        };
+        const int p_hi = a.n_pieces - 1;
+        if (INTERP == NCDE_INTERP_LINEAR) {
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) eprev[q] = eok[q] ? eptr[q][(long long)(p_hi + 1) * a.cs_t] : 0.0f;
+        }
+        stage_load(p_hi);
+        stage_store(p_hi);
+        if (p_hi >= 1) {
+            stage_load(p_hi - 1);
+            stage_store(p_hi - 1);
+        }
+        const int last_row = a.n_out - 1;
+        float y0[NB], ky1[NB], ky2[NB], a0[NB], ka1[NB], ka2[NB], as_[NB], zreg[HB];
+#pragma unroll
+        for (int ks = 0; ks < HB; ++ks) zreg[ks] = valid ? a.z_out[((long long)bs * a.n_out + last_row) * H + 4 * ks + g] : 0.0f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const long long o = ((long long)bs * a.n_out + last_row) * H + 4 * (pw * NB + nb) + g;
+            y0[nb] = valid ? a.z_out[o] : 0.0f;
+            a0[nb] = valid ? a.grad_out[o] : 0.0f;
+            as_[nb] = a0[nb];
+            ky1[nb] = ky2[nb] = ka1[nb] = ka2[nb] = 0.0f;
+        }
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+
+        int zpar = 0, sc = 0;
+        if constexpr (PROF != 0) tlast = __builtin_readcyclecounter();
+        for (int n = a.T - 1; n >= 1; --n) {
+            if (n - 3 >= 0) stage_load(n - 3);
+#pragma unroll 1
+            for (int j = 0; j < S; ++j) {
+                ++sc;
+                const float t = -(-(float)n + stage_offset(METHOD, j));
+                const int idx = piece_index(t, a.n_pieces);
+                const float frac = t - (float)idx;
+                const float wq = stage_weight(METHOD, j);
+                const float* dxp = dxs + (idx % 3) * 16 * DXW + s * DXW;
+                // ---- forward recompute ------------------------------------------------------------------------
+                float x[NL][KH];
+                {
+                    f32x4 acc[HT];
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt) acc[tt] = *reinterpret_cast<const f32x4*>(biasL + (tt * 4 + g) * 4);
+#pragma unroll
+                    for (int ks = 0; ks < HB; ++ks)
+#pragma unroll
+                        for (int tt = 0; tt < HT; ++tt) acc[tt] = mfma16(w0[tt][ks], zreg[ks], acc[tt]);
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) x[0][4 * tt + r] = relu_dev(acc[tt][r]);
+#pragma unroll
+                    for (int l = 1; l < NL; ++l) {
+#pragma unroll
+                        for (int tt = 0; tt < HT; ++tt) acc[tt] = *reinterpret_cast<const f32x4*>(biasL + ((HT + tt) * 4 + g) * 4);
+#pragma unroll
+                        for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+                            for (int tt = 0; tt < HT; ++tt) acc[tt] = mfma16(w1[tt][ks], x[l - 1][ks], acc[tt]);
+#pragma unroll
+                        for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) x[l][4 * tt + r] = relu_dev(acc[tt][r]);
+                    }
+                }
+                NCDE_TICK(0)
+                const int par = sc & 1;
+                if (wq != 0.0f && pw == 0) {  // [unit][sample] images for the gradient waves (identical in every pair)
+                    float* xi = ximg + par * XROWS * 16;
+#pragma unroll
+                    for (int ks = 0; ks < HB; ++ks) xi[(4 * ks + g) * 16 + s] = zreg[ks];
+#pragma unroll
+                    for (int l = 0; l < NL; ++l)
+#pragma unroll
+                        for (int ks = 0; ks < KH; ++ks) xi[(H + l * HH + 4 * ks + g) * 16 + s] = x[l][ks];
+                }
+                // ---- output tiles: P, tanh, f, dP -> LDS tile + flag ----------------------------------------------
+                float kout[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) kout[nb] = 0.0f;
+#pragma unroll
+                for (int cq = 0; cq < CQ; ++cq) {
+                    f32x4 o[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) o[nb] = *reinterpret_cast<const f32x4*>(boLw + ((nb * CQ + cq) * 4 + g) * 4);
+#pragma unroll
+                    for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) o[nb] = mfma16(wo[nb][cq][ks], x[NL - 1][ks], o[nb]);
+                    f32x4 dx;
+                    if constexpr (INTERP == NCDE_INTERP_LINEAR) {
+                        dx = *reinterpret_cast<const f32x4*>(dxp + 4 * cq);
+                    } else {
+                        const f32x4 cb = *reinterpret_cast<const f32x4*>(dxp + 4 * cq);
+                        const f32x4 cc = *reinterpret_cast<const f32x4*>(dxp + CP + 4 * cq);
+                        const f32x4 cd = *reinterpret_cast<const f32x4*>(dxp + 2 * CP + 4 * cq);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float inner = cc[r] + cd[r] * frac;
+                            dx[r] = cb[r] + inner * frac;
+                        }
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int tau = nb * CQ + cq;
+                        float* tl = my_tiles + par * (NW * NTILE * 256) + tau * 256;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float m = tanh_prescaled(o[nb][r]);
+                            kout[nb] = fmaf(m, dx[r], kout[nb]);
+                            tl[(4 * g + r) * 16 + s] = (as_[nb] * dx[r]) * (1.0f - m * m);
+                        }
+                        wave_lds_order();
+                        my_flags[par * NTILE + tau] = sc;
+                    }
+                }
+                NCDE_TICK(1)
+                __syncthreads();  // barrier A: the gradient waves have published their dL/dx_L partials
+                NCDE_TICK(2)
+                float gpre[KH];
+#pragma unroll
+                for (int ks = 0; ks < KH; ++ks) {
+                    float v = red[(4 * ks + g) * 16 + s];
+#pragma unroll
+                    for (int wv = 1; wv < NW; ++wv) v += red[wv * HH * 16 + (4 * ks + g) * 16 + s];
+                    gpre[ks] = x[NL - 1][ks] > 0.0f ? v : 0.0f;
+                }
+                // ---- hidden layers backward ---------------------------------------------------------------------
+#pragma unroll
+                for (int l = NL - 1; l >= 1; --l) {
+                    if (wq != 0.0f && pw == 0) {
+#pragma unroll
+                        for (int ks = 0; ks < KH; ++ks) dpimg[(l * HH + 4 * ks + g) * 16 + s] = gpre[ks];
+                    }
+                    f32x4 acc[HT];
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt) acc[tt] = zero4;
+#pragma unroll
+                    for (int k4 = 0; k4 < KH / 4; ++k4)
+#pragma unroll
+                        for (int tt = 0; tt < HT; ++tt) {
+                            const f32x4 wv = *reinterpret_cast<const f32x4*>(w1TL + ((tt * (KH / 4) + k4) * 64 + lane) * 4);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[tt] = mfma16(wv[q], gpre[4 * k4 + q], acc[tt]);
+                        }
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) gpre[4 * tt + r] = x[l - 1][4 * tt + r] > 0.0f ? acc[tt][r] : 0.0f;
+                }
+                if (wq != 0.0f && pw == 0) {
+#pragma unroll
+                    for (int ks = 0; ks < KH; ++ks) dpimg[(4 * ks + g) * 16 + s] = gpre[ks];
+                }
+                f32x4 vy = zero4;
+#pragma unroll
+                for (int k4 = 0; k4 < KH / 4; ++k4) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(w0TL + ((pw * (KH / 4) + k4) * 64 + lane) * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) vy = mfma16(wv[q], gpre[4 * k4 + q], vy);
+                }
+                NCDE_TICK(3)
+                float ys[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    ys[nb] = Combine<METHOD>::apply(j, -kout[nb], y0[nb], ky1[nb], ky2[nb]);
+                    as_[nb] = Combine<METHOD>::apply(j, vy[nb], a0[nb], ka1[nb], ka2[nb]);
+                }
+                if (j == S - 1) {
+                    if (a.output == NCDE_OUT_KNOTS) {  // reset y to the stored knot value, add dL/dz of that knot
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const long long o = ((long long)bs * a.n_out + (n - 1)) * H + 4 * (pw * NB + nb) + g;
+                            y0[nb] = valid ? a.z_out[o] : 0.0f;
+                            ys[nb] = y0[nb];
+                            a0[nb] += valid ? a.grad_out[o] : 0.0f;
+                            as_[nb] = a0[nb];
+                        }
+                    } else if (n == 1) {
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            a0[nb] += valid ? a.grad_out[((long long)bs * a.n_out) * H + 4 * (pw * NB + nb) + g] : 0.0f;
+                            as_[nb] = a0[nb];
+                        }
+                    }
+                    if (n - 3 >= 0) stage_store(n - 3);
+                }
+                if (j == S - 1 && a.output == NCDE_OUT_KNOTS) {
+#pragma unroll
+                    for (int ks = 0; ks < HB; ++ks) zreg[ks] = valid ? a.z_out[((long long)bs * a.n_out + (n - 1)) * H + 4 * ks + g] : 0.0f;
+                    __syncthreads();  // barrier B
+                } else {
+                    float* zw = zx + zpar * H * 16;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) zw[(4 * (pw * NB + nb) + g) * 16 + s] = ys[nb];
+                    __syncthreads();  // barrier B
+#pragma unroll
+                    for (int ks = 0; ks < HB; ++ks) zreg[ks] = zw[(4 * ks + g) * 16 + s];
+                    zpar ^= 1;
+                }
+                NCDE_TICK(4)
+            }
+        }
+        if constexpr (PROF != 0) {
+            if (lane == 0) {
+                unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.out) + ((long long)blockIdx.x * 8 + wave) * 6;
+                for (int k = 0; k < 6; ++k) dst[k] = prof[k];
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) a.grad_z0[(long long)bs * H + 4 * (pw * NB + nb) + g] = a0[nb];
+        }
+    } else {
+        // =================================================================================================
+        // gradient wave
+        // =================================================================================================
+        float woT[NTILE][HT][4];
+#pragma unroll
+        for (int tau = 0; tau < NTILE; ++tau) {
+            const int nb = tau / CQ, cq = tau - nb * CQ;
+            const int h = 4 * (pw * NB + nb) + g;
+#pragma unroll
+            for (int tp = 0; tp < HT; ++tp) {
+                const int jrow = 4 * (4 * tp + (s & 3)) + (s >> 2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 4 * cq + r;
+                    woT[tau][tp][r] = c < C ? a.Wo[(h * C + c) * HH + jrow] : 0.0f;
+                }
+            }
+        }
+        f32x4 gWo[NTILE][HT], gW1[TPW1], gW0[TPW0];
+        float gbo[NTILE], gb1[TPW1], gb0[TPW0];
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NTILE; ++i) {
+            gbo[i] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < HT; ++t) gWo[i][t] = zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < TPW1; ++i) { gW1[i] = zero4; gb1[i] = 0.0f; }
+#pragma unroll
+        for (int i = 0; i < TPW0; ++i) { gW0[i] = zero4; gb0[i] = 0.0f; }
+        __syncthreads();
+
+        auto wait_flag = [&](int slot, int want) {
+            while (__builtin_amdgcn_readfirstlane(my_flags[slot]) != want) __builtin_amdgcn_s_sleep(1);
+            wave_lds_order();
+        };
+        // weight-gradient work on the tiles [t_lo, t_hi) of the parity buffer `par`, produced with stage weight w
+        auto dwo_range = [&](int par, float w, auto t_lo_c, auto t_hi_c) {
+            constexpr int t_lo = decltype(t_lo_c)::value, t_hi = decltype(t_hi_c)::value;
+            const float* xi = ximg + par * XROWS * 16;
+            f32x4 xB[HT];
+#pragma unroll
+            for (int tt = 0; tt < HT; ++tt) {
+                xB[tt] = *reinterpret_cast<const f32x4*>(xi + (H + (NL - 1) * HH + 16 * tt + s) * 16 + 4 * g);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xB[tt][q] *= w;
+            }
+#pragma unroll
+            for (int tau = t_lo; tau < t_hi; ++tau) {
+                const float* tl = my_tiles + par * (NW * NTILE * 256) + tau * 256;
+                const f32x4 av = *reinterpret_cast<const f32x4*>(tl + s * 16 + 4 * g);
+                gbo[tau] += w * ((av[0] + av[1]) + (av[2] + av[3]));
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) gWo[tau][tt] = mfma16(av[q], xB[tt][q], gWo[tau][tt]);
+            }
+        };
+        // hidden-layer weight/bias gradients of the stage whose x images have parity `par`
+        auto dw_hidden = [&](int par, float w) {
+            const float* xi = ximg + par * XROWS * 16;
+#pragma unroll
+            for (int l = NL - 1; l >= 1; --l) {  // layer with input x_l (image rows H+(l-1)*HH), dL/dpre image l
+#pragma unroll
+                for (int k = 0; k < TPW1; ++k) {
+                    const int id = pw * TPW1 + k, tr = id / HT, tc = id - tr * HT;
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(dpimg + (l * HH + 16 * tr + s) * 16 + 4 * g);
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(xi + (H + (l - 1) * HH + 16 * tc + s) * 16 + 4 * g);
+                    if (tc == 0) gb1[k] += w * ((av[0] + av[1]) + (av[2] + av[3]));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) gW1[k] = mfma16(av[q], w * bv[q], gW1[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < TPW0; ++k) {
+                const int id = pw * TPW0 + k, tr = id / HT0, tc = id - tr * HT0;
+                const f32x4 av = *reinterpret_cast<const f32x4*>(dpimg + (16 * tr + s) * 16 + 4 * g);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(xi + (16 * tc + s) * 16 + 4 * g);
+                if (tc == 0) gb0[k] += w * ((av[0] + av[1]) + (av[2] + av[3]));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gW0[k] = mfma16(av[q], w * bv[q], gW0[k]);
+            }
+        };
+        using ic0 = std::integral_constant<int, 0>;
+        using ic_half = std::integral_constant<int, NT2>;
+        using ic_all = std::integral_constant<int, NTILE>;
+        int sc = 0;
+        float wprev = 0.0f;
+        if constexpr (PROF != 0) tlast = __builtin_readcyclecounter();
+        for (int n = a.T - 1; n >= 1; --n) {
+#pragma unroll 1
+            for (int j = 0; j < S; ++j) {
+                ++sc;
+                const int par = sc & 1;
+                const float wq = stage_weight(METHOD, j);
+                // (1) lagged work of the previous stage: runs under the chain wave's forward recompute
+                if (wprev != 0.0f) {
+                    dwo_range(par ^ 1, wprev, ic_half{}, ic_all{});
+                    dw_hidden(par ^ 1, wprev);
+                }
+                NCDE_TICK(3)
+                // (2) dL/dx_L partial, tile by tile as the chain wave publishes dP
+                f32x4 accJ[HT];
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt) accJ[tt] = zero4;
+#pragma unroll
+                for (int tau = 0; tau < NTILE; ++tau) {
+                    NCDE_TICK(0)
+                    wait_flag(par * NTILE + tau, sc);
+                    NCDE_TICK(1)
+                    const float* tl = my_tiles + par * (NW * NTILE * 256) + tau * 256;
+                    float bq[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bq[r] = tl[(4 * g + r) * 16 + s];
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) accJ[tt] = mfma16(woT[tau][tt][r], bq[r], accJ[tt]);
+                }
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[pw * HH * 16 + (4 * (4 * tt + r) + g) * 16 + s] = accJ[tt][r];
+                NCDE_TICK(0)
+                __syncthreads();  // barrier A
+                NCDE_TICK(2)
+                // (3) first half of this stage's dWo: runs under the chain wave's hidden-layer backward
+                if (wq != 0.0f) dwo_range(par, wq, ic0{}, ic_half{});
+                NCDE_TICK(3)
+                __syncthreads();  // barrier B
+                NCDE_TICK(4)
+                wprev = wq;
+            }
+        }
+        if (wprev != 0.0f) {
+            const int par = sc & 1;
+            dwo_range(par, wprev, ic_half{}, ic_all{});
+            dw_hidden(par, wprev);
+        }
+        if constexpr (PROF != 0) {
+            if (lane == 0) {
+                unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.out) + ((long long)blockIdx.x * 8 + wave) * 6;
+                for (int k = 0; k < 6; ++k) dst[k] = prof[k];
+            }
+        }
+        // ---- write-out of this workgroup's parameter-gradient partial ------------------------------------------
+        float* gp = a.gpart + (long long)blockIdx.x * a.theta_size;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int cq = 0; cq < CQ; ++cq) {
+                const int tau = nb * CQ + cq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 4 * cq + r;
+                    const int h = 4 * (pw * NB + nb) + g;
+                    if (c < C) {
+#pragma unroll
+                        for (int tt = 0; tt < HT; ++tt) gp[a.gWo_off + (h * C + c) * HH + 16 * tt + s] = gWo[tau][tt][r];
+                    }
+                }
+                // bias gradient: lane (i = s, kk = g) holds the partial sum of row i over samples 4kk..4kk+3
+                float v = gbo[tau];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                const int hrow = 4 * (pw * NB + nb) + (s >> 2), crow = 4 * cq + (s & 3);
+                if (g == 0 && crow < C) gp[a.gbo_off + hrow * C + crow] = v;
+            }
+#pragma unroll
+        for (int k = 0; k < TPW1; ++k) {
+            const int id = pw * TPW1 + k, tr = id / HT, tc = id - tr * HT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gp[a.gW_off[1] + (16 * tr + 4 * g + r) * HH + 16 * tc + s] = gW1[k][r];
+            float v = gb1[k];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (tc == 0 && g == 0) gp[a.gb_off[1] + 16 * tr + s] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < TPW0; ++k) {
+            const int id = pw * TPW0 + k, tr = id / HT0, tc = id - tr * HT0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gp[a.gW_off[0] + (16 * tr + 4 * g + r) * H + 16 * tc + s] = gW0[k][r];
+            float v = gb0[k];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (tc == 0 && g == 0) gp[a.gb_off[0] + 16 * tr + s] = v;
+        }
+    }
+    (void)n_stage_total;
+#undef NCDE_TICK
+}
+
+// ------------------------------------------------------------------------------------------------
 // dispatch tables
 // ------------------------------------------------------------------------------------------------
 struct Shape {
@@ -1121,6 +1676,29 @@ FwdFn pick_adj(int interp, int method) {
     return nullptr;
 }
 
+template <int H, int HH, int C, int NL>
+FwdFn pick_adj2(int interp, int method) {
+#define NCDE_PICK(I, M) \
+    if (interp == I && method == M) return ncde_adj_fast2<H, HH, C, NL, I, M>;
+    NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_RK4_38)
+    NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_MIDPOINT)
+    NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_EULER)
+    NCDE_PICK(NCDE_INTERP_CUBIC, NCDE_RK4_38)
+    NCDE_PICK(NCDE_INTERP_CUBIC, NCDE_MIDPOINT)
+    NCDE_PICK(NCDE_INTERP_CUBIC, NCDE_EULER)
+#undef NCDE_PICK
+    return nullptr;
+}
+
+template <int H, int HH, int C, int NL>
+size_t adj2_lds_bytes(int interp) {
+    constexpr int NW = 4, CP = (C + 3) & ~3, CQ = CP / 4, NB = H / 4 / NW, NTILE = NB * CQ;
+    const int DXW = interp == NCDE_INTERP_LINEAR ? CP : 3 * CP;
+    return sizeof(float) * (size_t)(2 * H * 16 + 3 * 16 * DXW + NW * HH * 16 + NW * NTILE * 16 + 2 * NW * NTILE * 256 +
+                                    2 * (H + NL * HH) * 16 + NL * HH * 16 + NW * 2 * NTILE + 2 * (HH / 16) * 16 +
+                                    (HH / 16) * (HH / 16) * 256 + NW * (HH / 16) * 256);
+}
+
 template <int H, int HH, int C, int NL, int NW>
 size_t adj_lds_bytes(int interp) {
     constexpr int CP = (C + 3) & ~3, CQ = CP / 4, HT = HH / 16, NB = H / 4 / NW, NTILE = NB * CQ;
@@ -1141,16 +1719,21 @@ struct FastEntry {
     FwdFn (*adj)(int, int);
     size_t (*adj_lds)(int);
     const char* adj_name;
+    FwdFn (*adj2)(int, int);        // EXPERIMENTAL wave-specialised variant, opt-in via NCDE_FLAG_ADJOINT_V2
+    size_t (*adj2_lds)(int);
+    const char* adj2_name;
 };
 
 const FastEntry kFast[] = {
     // BASELINE cfg2 / cfg3
     {{32, 32, 20}, 4, pick_fwd<32, 32, 20, 4>, "ncde_fwd_fast<H32,HH32,C20,NW4>",
      pick_fwd_bf3<32, 32, 20, 4>, "ncde_fwd_fast_bf3<H32,HH32,C20,NW4>", 4,
-     3, pick_adj<32, 32, 20, 3, 4>, adj_lds_bytes<32, 32, 20, 3, 4>, "ncde_adj_fast<H32,HH32,C20,NL3,NW4>"},
+     3, pick_adj<32, 32, 20, 3, 4>, adj_lds_bytes<32, 32, 20, 3, 4>, "ncde_adj_fast<H32,HH32,C20,NL3,NW4>",
+     pick_adj2<32, 32, 20, 3>, adj2_lds_bytes<32, 32, 20, 3>, "ncde_adj_fast2<H32,HH32,C20,NL3,chain+grad>"},
     // BASELINE cfg4 (adjoint: generic family for now -- the per-wave LDS images do not fit at HH=64)
     {{64, 64, 4}, 4, pick_fwd<64, 64, 4, 4>, "ncde_fwd_fast<H64,HH64,C4,NW4>",
-     pick_fwd_bf3<64, 64, 4, 4>, "ncde_fwd_fast_bf3<H64,HH64,C4,NW4>", 4, 0, nullptr, nullptr, nullptr},
+     pick_fwd_bf3<64, 64, 4, 4>, "ncde_fwd_fast_bf3<H64,HH64,C4,NW4>", 4, 0, nullptr, nullptr, nullptr,
+     nullptr, nullptr, nullptr},
 };
 
 const FastEntry* find_entry(const NcdeProblem* p) {
@@ -1177,7 +1760,7 @@ const char* ncde_fast_kernel_name(const NcdeProblem* p, int pass) {
     if (!ncde_fast_supported(p, pass)) return nullptr;
     const FastEntry* e = find_entry(p);
     if (pass == 0) return ((p->flags & NCDE_FLAG_FP32_MFMA) == 0 && e->fwd_bf3) ? e->fwd_bf3_name : e->fwd_name;
-    return e->adj_name;
+    return ((p->flags & NCDE_FLAG_ADJOINT_V2) != 0 && e->adj2) ? e->adj2_name : e->adj_name;
 }
 
 int64_t ncde_fast_workspace_bytes(const NcdeProblem* p, int pass) {
@@ -1185,7 +1768,7 @@ int64_t ncde_fast_workspace_bytes(const NcdeProblem* p, int pass) {
     const Layout y = make_layout(p);
     if (pass == 0) return (p->flags & NCDE_FLAG_DEBUG_PROFILE) ? 256 + (int64_t)y.n_wg * 8 * 4 * 8 : 256;
     return (int64_t)sizeof(float) * (int64_t)y.n_wg * (int64_t)y.theta_size + 256 +
-           ((p->flags & NCDE_FLAG_DEBUG_PROFILE) ? (int64_t)y.n_wg * 4 * 6 * 8 + 256 : 0);
+           ((p->flags & NCDE_FLAG_DEBUG_PROFILE) ? (int64_t)y.n_wg * 8 * 6 * 8 + 256 : 0);
 }
 
 int ncde_fast_forward(const NcdeProblem* p, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -1215,7 +1798,8 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     (void)ws_bytes;
     if (!ncde_fast_supported(p, 1)) return NCDE_ERR_UNSUPPORTED;
     const FastEntry* e = find_entry(p);
-    FwdFn fn = e->adj(p->interp, p->method);
+    const bool v2 = (p->flags & NCDE_FLAG_ADJOINT_V2) != 0 && e->adj2 != nullptr;
+    FwdFn fn = v2 ? e->adj2(p->interp, p->method) : e->adj(p->interp, p->method);
     if (!fn) return NCDE_ERR_UNSUPPORTED;
     const Layout y = make_layout(p);
     KArgs a;
@@ -1224,12 +1808,12 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     a.gpart = (float*)ws;
     if (p->flags & NCDE_FLAG_DEBUG_PROFILE) {  // phase-cycle counters -> tail of the workspace [n_wg][NW][6] u64
         if (!(e->shape.H == 32 && e->shape.C == 20 && p->interp == NCDE_INTERP_LINEAR && p->method == NCDE_RK4_38)) return NCDE_ERR_UNSUPPORTED;
-        fn = ncde_adj_fast<32, 32, 20, 3, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>;
+        fn = v2 ? ncde_adj_fast2<32, 32, 20, 3, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1> : ncde_adj_fast<32, 32, 20, 3, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>;
         a.out = (float*)ws + (size_t)y.n_wg * y.theta_size + 64;
     }
-    const size_t lds = e->adj_lds(p->interp);
+    const size_t lds = v2 ? e->adj2_lds(p->interp) : e->adj_lds(p->interp);
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NCDE_ERR_HIP;
-    hipLaunchKernelGGL(fn, dim3(y.n_wg), dim3(64 * e->nw), lds, st, a);
+    hipLaunchKernelGGL(fn, dim3(y.n_wg), dim3(v2 ? 512 : 64 * e->nw), lds, st, a);
     if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
     if (main_kernel_only) return NCDE_OK;
     return launch_reduce_partials(p, y, g, (const float*)ws, y.n_wg, st);

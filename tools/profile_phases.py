@@ -34,7 +34,7 @@ for flags, label in ((4, "fp32-mfma plain"), (0x104, "fp32-mfma instrumented"), 
 
 # ---- adjoint ----
 theta = 32*32+32+32*32+32+640*32+640
-for flags, label in ((0, "adj plain"), (0x100, "adj instrumented")):
+for flags, label in ((0, "adj v1 plain"), (8, "adj v2 plain"), (0x108, "adj v2 instrumented")):
     p = solver.build_problem(coeffs, "linear", z0, spec, "rk4", _lib.OUT_INTERVAL, flags)
     ws = torch.zeros(int(lib.ncde_workspace_bytes(ctypes.byref(p), 1)), dtype=torch.uint8, device="cuda")
     out = torch.randn(B, 2, 32, device="cuda"); gout = torch.randn(B, 2, 32, device="cuda")
@@ -49,8 +49,9 @@ for flags, label in ((0, "adj plain"), (0x100, "adj instrumented")):
     if flags:
         nwg = B // 16
         off = (nwg * theta + 64) * 4
-        cyc = ws[off: off + nwg * 4 * 6 * 8].view(torch.int64).view(-1, 4, 6).cpu().numpy().astype(np.float64)
+        cyc = ws[off: off + nwg * 8 * 6 * 8].view(torch.int64).view(-1, 8, 6).cpu().numpy().astype(np.float64)
         per = cyc.mean(axis=0) / (398 * 4)
-        print("cycles per stage by wave x phase (fwd recompute | out tiles+dP+dWo | reduce | hidden bwd+dW | vy+rk+exchange):")
+        print("chain rows 0-3: recompute | out tiles | wait barrier A | reduce+hidden bwd+vy | rk+exchange(+barrier B)")
+        print("grad  rows 4-7: tile work   | flag waits | barrier A wait | dW work | barrier B wait")
         print(np.array2string(per[:, :5], precision=0))
         print("total", per[:, :5].sum(axis=1))
