@@ -213,10 +213,25 @@ def main():
         f_adj = 3 * f_fwd     # stage recompute + VJP wrt z + VJP wrt theta
         by_fwd = bytes_forward_per_sample_step(c)
 
+        pmc = {}
+        try:    # HBM bytes per launch measured with rocprofv3 PMC passes (committed summary; bench.py cannot run the profiler)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_cfg2_summary.json")) as fh:
+                pmc = json.load(fh)
+        except (OSError, ValueError):
+            pass
+
+        def traffic_of(name):
+            key = "ncde_fwd_fast_bf3" if "fwd_fast_bf3" in name else ("ncde_adj_fast" if "adj_fast" in name else None)
+            rec_ = pmc.get(key) if (key and args.config == "cfg2" and B_local == 4096) else None
+            if not rec_ or "hbm_read_MB_per_launch_corrected_x2" not in rec_:
+                return None
+            return round((rec_["hbm_read_MB_per_launch_corrected_x2"] + rec_.get("hbm_write_MB_per_launch", 0.0)) * 1e6)
+
         def roof(ms, flops, nbytes, name):
             tf_s = flops * steps_per_launch / (ms * 1e-3) / 1e12
             return {"bound": "mfma", "kernel": name, "achieved": round(tf_s, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf_s / PEAK_FP32_TFLOPS, 4), "traffic": None, "ms_per_launch": round(ms, 4),
+                    "frac": round(tf_s / PEAK_FP32_TFLOPS, 4), "traffic": traffic_of(name), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_pmc_cfg2_summary.json)",
+                    "algorithmic_bytes_per_launch": nbytes * steps_per_launch, "ms_per_launch": round(ms, 4),
                     "hbm_algorithmic_GBs": round(nbytes * steps_per_launch / (ms * 1e-3) / 1e9, 2),
                     "hbm_frac": round(nbytes * steps_per_launch / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6)}
 
@@ -228,6 +243,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "dtype_note": "fp32 in/out and fp32 accumulation; the specialised forward GEMMs run as exact 3-way split-bf16 MFMA (fp32-equivalent, z error 5e-7), the adjoint as fp32-input MFMA",
             "config": {"workload": "BASELINE %s: %s interpolation, %s step 1, B=%d per GPU (global %d), raw L=%d -> T=%d knots, "
                                    "C=%d, H=HH=%d, nl=%d; step = forward + adjoint backward + %sAdam"
                                    % (args.config, c["interpolation"], c["solver"], B_local, B_total, c["L"], T, c["C"], c["H"],
