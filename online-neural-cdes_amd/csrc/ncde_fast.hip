@@ -1334,6 +1334,9 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
                     }
                 }
                 NCDE_TICK(1)
+#ifdef NCDE_V2_NOFLAGS
+                __syncthreads();
+#endif
                 __syncthreads();  // barrier A: the gradient waves have published their dL/dx_L partials
                 NCDE_TICK(2)
                 float gpre[KH];
@@ -1537,10 +1540,15 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
                 f32x4 accJ[HT];
 #pragma unroll
                 for (int tt = 0; tt < HT; ++tt) accJ[tt] = zero4;
+#ifdef NCDE_V2_NOFLAGS
+                __syncthreads();
+#endif
 #pragma unroll
                 for (int tau = 0; tau < NTILE; ++tau) {
                     NCDE_TICK(0)
+#ifndef NCDE_V2_NOFLAGS
                     wait_flag(par * NTILE + tau, sc);
+#endif
                     NCDE_TICK(1)
                     const float* tl = my_tiles + par * (NW * NTILE * 256) + tau * 256;
                     float bq[4];

@@ -13,3 +13,11 @@ for flags, name in ((8, "v2"), (0, "v1")):
     e = np.abs(r1["dz0"] - ex["dz0"]).max(axis=1) / np.abs(ex["dz0"]).max()
     print(name, "deterministic", np.array_equal(r1["dz0"], r2["dz0"]), "dz0 err per sample", np.array2string(e, precision=1))
     print("   grads:", {k: "%.1e" % gu.relerr(r1["grads"][k], ex["d" + k]) for k in r1["grads"]})
+r = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=8)
+err = np.abs(r["dz0"] - ex["dz0"]) / np.abs(ex["dz0"]).max()
+bad = np.argwhere(err > 1e-4)
+print("bad (sample,h):", bad.tolist()[:40])
+for k in r["grads"]:
+    e = np.abs(r["grads"][k] - ex["d" + k]) / np.abs(ex["d" + k]).max()
+    idx = np.argwhere(e > 1e-3)
+    print(k, "n_bad", len(idx), "of", e.size, "first", idx[:6].tolist())
