@@ -57,8 +57,8 @@ typedef enum NcdeOutput { NCDE_OUT_INTERVAL = 0, NCDE_OUT_KNOTS = 1 } NcdeOutput
 #define NCDE_FLAG_FORCE_FAST 2u     /* fail with NCDE_ERR_UNSUPPORTED if no specialised kernel fits */
 #define NCDE_FLAG_FP32_MFMA 4u      /* specialised kernels: plain fp32-input MFMA instead of the (default, fp32-equivalent)
                                        3-way split-bf16 MFMA GEMMs */
-#define NCDE_FLAG_ADJOINT_V2 8u     /* EXPERIMENTAL: chain+gradient wave-specialised adjoint kernel (rk4 is parity-green;
-                                       a hand-off race remains for midpoint/euler on cubic paths -- do not use in production) */
+#define NCDE_FLAG_ADJOINT_V1 8u     /* specialised adjoint: single-role kernel instead of the (default) chain+gradient
+                                       wave-specialised one */
 #define NCDE_FLAG_DEBUG_PROFILE 0x100u /* development: instrumented kernel variant, cycle counters land in the workspace */
 
 typedef struct NcdeProblem {

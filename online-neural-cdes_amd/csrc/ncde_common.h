@@ -57,12 +57,10 @@ __device__ __forceinline__ float tanh_prescaled(float x2l) {
     return __builtin_fmaf(-2.0f, r, 1.0f);
 }
 
-// relu as ONE v_max_f32 (fmaxf() costs two: hipcc canonicalises the MFMA result first)
-__device__ __forceinline__ float relu_dev(float x) {
-    float y;
-    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
-    return y;
-}
+// relu as ONE instruction: v_med3_f32(x, 0, +inf).  (fmaxf() costs two -- hipcc canonicalises the MFMA result
+// first.  Do NOT use inline asm here: an asm statement that reads an MFMA result register directly is invisible
+// to the hazard recognizer, which then omits the MFMA->VALU wait states -- stale accumulators on some schedules.)
+__device__ __forceinline__ float relu_dev(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
 
 // Number of stages and the fp32 stage-time offsets torchdiffeq produces with dt = 1
 // (fixed_grid.py:6-29, rk_common.py:111-113: dt*(1/3), dt*(2/3) rounded to fp32).

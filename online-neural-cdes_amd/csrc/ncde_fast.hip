@@ -982,6 +982,10 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
                 ys[nb] = Combine<METHOD>::apply(j, -kout[nb], y0[nb], ky1[nb], ky2[nb]);
                 as_[nb] = Combine<METHOD>::apply(j, vy[nb], a0[nb], ka1[nb], ka2[nb]);
             }
+            if (PROF == 2 && blockIdx.x == 0 && wave == 0) {  // debug dump: [stage][5][64]
+                float* d = a.out + ((long long)(((a.T - 1 - n) * S + j)) * 5) * 64 + lane;
+                d[0] = kout[0]; d[64] = vy[0]; d[128] = gpre[0]; d[192] = ys[0]; d[256] = as_[0];
+            }
             if (j == S - 1) {
                 if (a.output == NCDE_OUT_KNOTS) {
 #pragma unroll
@@ -1388,6 +1392,10 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
                     ys[nb] = Combine<METHOD>::apply(j, -kout[nb], y0[nb], ky1[nb], ky2[nb]);
                     as_[nb] = Combine<METHOD>::apply(j, vy[nb], a0[nb], ka1[nb], ka2[nb]);
                 }
+                if (PROF == 2 && blockIdx.x == 0 && pw == 0) {  // debug dump: [stage][5][64]
+                    float* d = a.out + ((long long)(sc - 1) * 5) * 64 + lane;
+                    d[0] = kout[0]; d[64] = vy[0]; d[128] = gpre[0]; d[192] = ys[0]; d[256] = as_[0];
+                }
                 if (j == S - 1) {
                     if (a.output == NCDE_OUT_KNOTS) {  // reset y to the stored knot value, add dL/dz of that knot
 #pragma unroll
@@ -1727,7 +1735,7 @@ struct FastEntry {
     FwdFn (*adj)(int, int);
     size_t (*adj_lds)(int);
     const char* adj_name;
-    FwdFn (*adj2)(int, int);        // EXPERIMENTAL wave-specialised variant, opt-in via NCDE_FLAG_ADJOINT_V2
+    FwdFn (*adj2)(int, int);        // wave-specialised variant (default); NCDE_FLAG_ADJOINT_V1 selects `adj`
     size_t (*adj2_lds)(int);
     const char* adj2_name;
 };
@@ -1768,7 +1776,7 @@ const char* ncde_fast_kernel_name(const NcdeProblem* p, int pass) {
     if (!ncde_fast_supported(p, pass)) return nullptr;
     const FastEntry* e = find_entry(p);
     if (pass == 0) return ((p->flags & NCDE_FLAG_FP32_MFMA) == 0 && e->fwd_bf3) ? e->fwd_bf3_name : e->fwd_name;
-    return ((p->flags & NCDE_FLAG_ADJOINT_V2) != 0 && e->adj2) ? e->adj2_name : e->adj_name;
+    return ((p->flags & NCDE_FLAG_ADJOINT_V1) == 0 && e->adj2) ? e->adj2_name : e->adj_name;
 }
 
 int64_t ncde_fast_workspace_bytes(const NcdeProblem* p, int pass) {
@@ -1776,7 +1784,8 @@ int64_t ncde_fast_workspace_bytes(const NcdeProblem* p, int pass) {
     const Layout y = make_layout(p);
     if (pass == 0) return (p->flags & NCDE_FLAG_DEBUG_PROFILE) ? 256 + (int64_t)y.n_wg * 8 * 4 * 8 : 256;
     return (int64_t)sizeof(float) * (int64_t)y.n_wg * (int64_t)y.theta_size + 256 +
-           ((p->flags & NCDE_FLAG_DEBUG_PROFILE) ? (int64_t)y.n_wg * 8 * 6 * 8 + 256 : 0);
+           ((p->flags & NCDE_FLAG_DEBUG_PROFILE) ? (int64_t)y.n_wg * 8 * 6 * 8 + 256 : 0) +
+           ((p->flags & 0x200u) ? (int64_t)p->n_knots * 4 * 5 * 64 * 4 + 256 : 0);
 }
 
 int ncde_fast_forward(const NcdeProblem* p, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -1806,7 +1815,7 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     (void)ws_bytes;
     if (!ncde_fast_supported(p, 1)) return NCDE_ERR_UNSUPPORTED;
     const FastEntry* e = find_entry(p);
-    const bool v2 = (p->flags & NCDE_FLAG_ADJOINT_V2) != 0 && e->adj2 != nullptr;
+    const bool v2 = (p->flags & NCDE_FLAG_ADJOINT_V1) == 0 && e->adj2 != nullptr;
     FwdFn fn = v2 ? e->adj2(p->interp, p->method) : e->adj(p->interp, p->method);
     if (!fn) return NCDE_ERR_UNSUPPORTED;
     const Layout y = make_layout(p);
@@ -1814,6 +1823,11 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     fill_kargs(p, y, &a);
     a.z_out = z_out; a.grad_out = grad_out; a.grad_z0 = g->grad_z0;
     a.gpart = (float*)ws;
+    if (p->flags & 0x200u) {  // development: per-stage chain values of workgroup 0 -> tail of the workspace
+        if (!(e->shape.H == 32 && e->shape.C == 20 && p->interp == NCDE_INTERP_CUBIC && p->method == NCDE_MIDPOINT)) return NCDE_ERR_UNSUPPORTED;
+        fn = v2 ? ncde_adj_fast2<32, 32, 20, 3, NCDE_INTERP_CUBIC, NCDE_MIDPOINT, 2> : ncde_adj_fast<32, 32, 20, 3, 4, NCDE_INTERP_CUBIC, NCDE_MIDPOINT, 2>;
+        a.out = (float*)ws + (size_t)y.n_wg * y.theta_size + 64;
+    }
     if (p->flags & NCDE_FLAG_DEBUG_PROFILE) {  // phase-cycle counters -> tail of the workspace [n_wg][NW][6] u64
         if (!(e->shape.H == 32 && e->shape.C == 20 && p->interp == NCDE_INTERP_LINEAR && p->method == NCDE_RK4_38)) return NCDE_ERR_UNSUPPORTED;
         fn = v2 ? ncde_adj_fast2<32, 32, 20, 3, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1> : ncde_adj_fast<32, 32, 20, 3, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>;

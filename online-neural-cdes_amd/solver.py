@@ -114,8 +114,9 @@ class _FusedCdeint(torch.autograd.Function):
         p = build_problem(coeffs, cfg["interp"], z0c, spec, cfg["method"], cfg["output"], cfg["flags"])
         n_out = coeffs.shape[1] + (1 if cfg["interp"] == "cubic" else 0) if cfg["output"] == _lib.OUT_KNOTS else 2
         out = torch.empty(z0.shape[0], n_out, z0.shape[1], dtype=torch.float32, device=z0.device)
-        ws = _workspace(p, 0, z0.device)
-        rc = _lib.lib().ncde_forward(ctypes.byref(p), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr())
+        with torch.cuda.device(z0.device):   # the C-ABI launches on the calling thread's current device / stream
+            ws = _workspace(p, 0, z0.device)
+            rc = _lib.lib().ncde_forward(ctypes.byref(p), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr())
         _lib.check(rc, "ncde_forward")
         ctx.cfg = cfg
         ctx.coeffs = coeffs
@@ -143,9 +144,10 @@ class _FusedCdeint(torch.autograd.Function):
         for i, (w, b) in enumerate(spec.layers):
             g.grad_layer_W[i], g.grad_layer_b[i] = gbuf[id(w)].data_ptr(), gbuf[id(b)].data_ptr()
         g.grad_Wo, g.grad_bo = gbuf[id(spec.Wo)].data_ptr(), gbuf[id(spec.bo)].data_ptr()
-        ws = _workspace(p, 1, dev)
-        rc = _lib.lib().ncde_adjoint(ctypes.byref(p), out.data_ptr(), grad_out.data_ptr(), ctypes.byref(g),
-                                     ws.data_ptr(), ws.numel(), _stream_ptr())
+        with torch.cuda.device(dev):
+            ws = _workspace(p, 1, dev)
+            rc = _lib.lib().ncde_adjoint(ctypes.byref(p), out.data_ptr(), grad_out.data_ptr(), ctypes.byref(g),
+                                         ws.data_ptr(), ws.numel(), _stream_ptr())
         _lib.check(rc, "ncde_adjoint")
         if cfg["func"] is not None and hasattr(cfg["func"], "nfe"):
             cfg["func"].nfe += cfg["nfe_per_solve"]
