@@ -334,6 +334,11 @@ __device__ __forceinline__ f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16 mfma_bf32(u32x4 a, u32x4 b, f32x16 c) {  // 32x32x16: lane (i=lane&31, kg=lane>>5) holds k = 8kg..8kg+7
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 // c += A * B over one K chunk of 32, fp32-equivalent (smallest partial products first)
 __device__ __forceinline__ f32x4 mfma_split(const Split3& A, const Split3& B, f32x4 c) {
     c = mfma_bf(A.lo, B.hi, c);
@@ -1110,7 +1115,9 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
     constexpr int TPW1 = HT * HT / NW, TPW0 = HT * HT0 / NW;
     constexpr int XROWS = H + NL * HH;         // z, x_1..x_NL
     constexpr int NFLAG = 2 * NTILE;           // per pair: one flag per tile and stage parity
-    constexpr int NT2 = NTILE / 2;             // dWo tiles done right after barrier A; the rest lag one stage
+    constexpr int NT2 = (NTILE / 2) & ~1;      // dWo tiles done right after barrier A (whole 2-tile blocks); the rest lag one stage
+    constexpr int NBLK = NTILE / 2;            // 32-row blocks (tile pairs) of this pair's dWo slice
+    static_assert(NTILE % 2 == 0 && HH == 32, "dWo runs as 32x32x16 split-bf16 blocks: tile pairs x 32 hidden units");
     static_assert(H % (4 * NW) == 0 && HH % 16 == 0 && H % 16 == 0 && NB <= 4, "shape not tileable");
     static_assert((HT * HT) % NW == 0 && (HT * HT0) % NW == 0, "weight-gradient tiles must split evenly over the pairs");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1460,14 +1467,15 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
                 }
             }
         }
-        f32x4 gWo[NTILE][HT], gW1[TPW1], gW0[TPW0];
-        float gbo[NTILE], gb1[TPW1], gb0[TPW0];
+        f32x16 gWo[NBLK];  // dWo block (tiles 2b, 2b+1) x 32 hidden units, D layout of v_mfma_f32_32x32x16_bf16
+        f32x4 gW1[TPW1], gW0[TPW0];
+        float gbo[NBLK], gb1[TPW1], gb0[TPW0];
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < NTILE; ++i) {
+        for (int i = 0; i < NBLK; ++i) {
             gbo[i] = 0.0f;
 #pragma unroll
-            for (int t = 0; t < HT; ++t) gWo[i][t] = zero4;
+            for (int q = 0; q < 16; ++q) gWo[i][q] = 0.0f;
         }
 #pragma unroll
         for (int i = 0; i < TPW1; ++i) { gW1[i] = zero4; gb1[i] = 0.0f; }
@@ -1479,26 +1487,39 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
             while (__builtin_amdgcn_readfirstlane(my_flags[slot]) != want) __builtin_amdgcn_s_sleep(1);
             wave_lds_order();
         };
-        // weight-gradient work on the tiles [t_lo, t_hi) of the parity buffer `par`, produced with stage weight w
+        // dWo of the tiles [t_lo, t_hi) of parity buffer `par` (stage weight w): samples are the K dimension, so
+        // a 2-tile block is ONE 32(rows) x 32(units) x 16(samples) product = 6 split-bf16 MFMAs (fp32-equivalent)
         auto dwo_range = [&](int par, float w, auto t_lo_c, auto t_hi_c) {
             constexpr int t_lo = decltype(t_lo_c)::value, t_hi = decltype(t_hi_c)::value;
+            static_assert(t_lo % 2 == 0 && t_hi % 2 == 0, "whole blocks only");
+            const int i32 = lane & 31, kg = lane >> 5;
             const float* xi = ximg + par * XROWS * 16;
-            f32x4 xB[HT];
+            float bv[8];
+            {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(xi + (H + (NL - 1) * HH + i32) * 16 + 8 * kg);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(xi + (H + (NL - 1) * HH + i32) * 16 + 8 * kg + 4);
 #pragma unroll
-            for (int tt = 0; tt < HT; ++tt) {
-                xB[tt] = *reinterpret_cast<const f32x4*>(xi + (H + (NL - 1) * HH + 16 * tt + s) * 16 + 4 * g);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) xB[tt][q] *= w;
+                for (int q = 0; q < 4; ++q) { bv[q] = w * b0[q]; bv[4 + q] = w * b1[q]; }
             }
+            const Split3 Bs = split8(bv);
 #pragma unroll
-            for (int tau = t_lo; tau < t_hi; ++tau) {
-                const float* tl = my_tiles + par * (NW * NTILE * 256) + tau * 256;
-                const f32x4 av = *reinterpret_cast<const f32x4*>(tl + s * 16 + 4 * g);
-                gbo[tau] += w * ((av[0] + av[1]) + (av[2] + av[3]));
+            for (int blk = t_lo / 2; blk < t_hi / 2; ++blk) {
+                const float* tl = my_tiles + par * (NW * NTILE * 256) + (2 * blk + (i32 >> 4)) * 256 + (i32 & 15) * 16 + 8 * kg;
+                const f32x4 a0v = *reinterpret_cast<const f32x4*>(tl);
+                const f32x4 a1v = *reinterpret_cast<const f32x4*>(tl + 4);
+                float av[8];
 #pragma unroll
-                for (int tt = 0; tt < HT; ++tt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) gWo[tau][tt] = mfma16(av[q], xB[tt][q], gWo[tau][tt]);
+                for (int q = 0; q < 4; ++q) { av[q] = a0v[q]; av[4 + q] = a1v[q]; }
+                gbo[blk] += w * (((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7])));
+                const Split3 As = split8(av);
+                f32x16 c = gWo[blk];
+                c = mfma_bf32(As.lo, Bs.hi, c);
+                c = mfma_bf32(As.hi, Bs.lo, c);
+                c = mfma_bf32(As.mid, Bs.mid, c);
+                c = mfma_bf32(As.mid, Bs.hi, c);
+                c = mfma_bf32(As.hi, Bs.mid, c);
+                c = mfma_bf32(As.hi, Bs.hi, c);
+                gWo[blk] = c;
             }
         };
         // hidden-layer weight/bias gradients of the stage whose x images have parity `par`
@@ -1596,26 +1617,25 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
         // ---- write-out of this workgroup's parameter-gradient partial ------------------------------------------
         float* gp = a.gpart + (long long)blockIdx.x * a.theta_size;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+        for (int blk = 0; blk < NBLK; ++blk) {
+            // D layout of the 32x32 block: col = lane&31 (hidden unit j), row = (q&3) + 8*(q>>2) + 4*(lane>>5)
 #pragma unroll
-            for (int cq = 0; cq < CQ; ++cq) {
-                const int tau = nb * CQ + cq;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = 4 * cq + r;
-                    const int h = 4 * (pw * NB + nb) + g;
-                    if (c < C) {
-#pragma unroll
-                        for (int tt = 0; tt < HT; ++tt) gp[a.gWo_off + (h * C + c) * HH + 16 * tt + s] = gWo[tau][tt][r];
-                    }
-                }
-                // bias gradient: lane (i = s, kk = g) holds the partial sum of row i over samples 4kk..4kk+3
-                float v = gbo[tau];
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
-                const int hrow = 4 * (pw * NB + nb) + (s >> 2), crow = 4 * cq + (s & 3);
-                if (g == 0 && crow < C) gp[a.gbo_off + hrow * C + crow] = v;
+            for (int q = 0; q < 16; ++q) {
+                const int tau = 2 * blk + (q >> 3);                      // row >> 4
+                const int gr = 2 * ((q >> 2) & 1) + (lane >> 5), rr = q & 3;  // in-tile row = 4*gr + rr
+                const int nb = tau / CQ, cq = tau - nb * CQ;
+                const int h = 4 * (pw * NB + nb) + gr, c = 4 * cq + rr;
+                if (c < C) gp[a.gWo_off + (h * C + c) * HH + (lane & 31)] = gWo[blk][q];
             }
+            // bias gradient: lane (i32, kg) holds the partial sum of block row i32 over samples 8kg..8kg+7
+            float v = gbo[blk];
+            v += __shfl_xor(v, 32, 64);
+            const int i32 = lane & 31;
+            const int tau = 2 * blk + (i32 >> 4), rowt = i32 & 15;
+            const int nb = tau / CQ, cq = tau - nb * CQ;
+            const int hrow = 4 * (pw * NB + nb) + (rowt >> 2), crow = 4 * cq + (rowt & 3);
+            if (lane < 32 && crow < C) gp[a.gbo_off + hrow * C + crow] = v;
+        }
 #pragma unroll
         for (int k = 0; k < TPW1; ++k) {
             const int id = pw * TPW1 + k, tr = id / HT, tc = id - tr * HT;
