@@ -1153,7 +1153,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
     for (int e = tid; e < NW * NTILE * 16; e += 512) {
         const int r = e & 3, gg = (e >> 2) & 3, rest = e >> 4;
         const int tau = rest % NTILE, wv = rest / NTILE;
-        const int nb = tau / CQ, cq = tau - nb * CQ;
+        const int nb = tau / CQ, cq = tau - nb * CQ;   // bias image is indexed nb-major by the chain waves
         const int h = 4 * (wv * NB + nb) + gg, c = 4 * cq + r;
         boL[e] = c < C ? NCDE_TANH_PRESCALE * a.bo[h * C + c] : 0.0f;
     }
@@ -1306,6 +1306,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
                 }
                 // ---- output tiles: P, tanh, f, dP -> LDS tile + flag ----------------------------------------------
                 float kout[NB];
+                float sdx = 0.0f;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) kout[nb] = 0.0f;
 #pragma unroll
@@ -1330,20 +1331,27 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
                             dx[r] = cb[r] + inner * frac;
                         }
                     }
+                    // with r = 1/(exp(2P)+1):  tanh = 1 - 2r,  1 - tanh^2 = 4 r (1 - r).  Per value: v_exp, add, v_rcp,
+                    // fma (r - r^2), mul (dP), fma (sum r*dx); f = sum_c dx - 2 sum_c r dx is assembled after the loop.
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sdx += dx[r];
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
-                        const int tau = nb * CQ + cq;
+                        const int tau = cq * NB + nb;  // tiles are numbered in publication order
                         float* tl = my_tiles + par * (NW * NTILE * 256) + tau * 256;
+                        const float a4 = 4.0f * as_[nb];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float m = tanh_prescaled(o[nb][r]);
-                            kout[nb] = fmaf(m, dx[r], kout[nb]);
-                            tl[(4 * g + r) * 16 + s] = (as_[nb] * dx[r]) * (1.0f - m * m);
+                            const float rr = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[nb][r]) + 1.0f);
+                            kout[nb] = fmaf(rr, dx[r], kout[nb]);
+                            tl[(4 * g + r) * 16 + s] = (a4 * dx[r]) * fmaf(-rr, rr, rr);
                         }
                         wave_lds_order();
                         my_flags[par * NTILE + tau] = sc;
                     }
                 }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) kout[nb] = fmaf(-2.0f, kout[nb], sdx);
                 NCDE_TICK(1)
 #ifdef NCDE_V2_NOFLAGS
                 __syncthreads();
@@ -1452,10 +1460,14 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
         // =================================================================================================
         // gradient wave
         // =================================================================================================
+        // (static s_setprio for this younger wave was tried: its own work gets ~40 % faster, the chain wave ~15 %
+        // slower -- zero-sum on the shared SIMD, net -5 %; left at default priority)
+        // (static s_setprio for this younger wave was tried: its own work gets ~40 % faster, the chain wave ~15 %
+        // slower -- zero-sum on the shared SIMD, net -5 %; left at default priority)
         float woT[NTILE][HT][4];
 #pragma unroll
         for (int tau = 0; tau < NTILE; ++tau) {
-            const int nb = tau / CQ, cq = tau - nb * CQ;
+            const int cq = tau / NB, nb = tau - cq * NB;
             const int h = 4 * (pw * NB + nb) + g;
 #pragma unroll
             for (int tp = 0; tp < HT; ++tp) {
@@ -1559,47 +1571,53 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
                 ++sc;
                 const int par = sc & 1;
                 const float wq = stage_weight(METHOD, j);
-                // (1) lagged work of the previous stage: runs under the chain wave's forward recompute
+                // Static schedule against the chain wave's timeline (tiles are published at a steady rate):
+                //   (1a) lagging work of the previous stage that fits before the first tile group is complete
+                //   (2a) dL/dx_L of tile group 0 (ONE flag poll, all LDS reads issued up front)
+                //   (1b) the remaining lagging dWo block
+                //   (2b) dL/dx_L of tile group 1 -> partial -> barrier A
+                constexpr int TG = NTILE / 2;  // tiles per group
                 if (wprev != 0.0f) {
-                    dwo_range(par ^ 1, wprev, ic_half{}, ic_all{});
                     dw_hidden(par ^ 1, wprev);
+                    dwo_range(par ^ 1, wprev, ic_half{}, std::integral_constant<int, NT2 + 2 * ((NTILE - NT2) / 4)>{});
                 }
-                NCDE_TICK(3)
-                // (2) dL/dx_L partial, tile by tile as the chain wave publishes dP
+                NCDE_TICK(0)
                 f32x4 accJ[HT];
 #pragma unroll
                 for (int tt = 0; tt < HT; ++tt) accJ[tt] = zero4;
-#ifdef NCDE_V2_NOFLAGS
-                __syncthreads();
-#endif
+                auto dxl_group = [&](auto t_lo_c, auto t_hi_c) {
+                    constexpr int t_lo = decltype(t_lo_c)::value, t_hi = decltype(t_hi_c)::value;
+                    float bq[t_hi - t_lo][4];
 #pragma unroll
-                for (int tau = 0; tau < NTILE; ++tau) {
-                    NCDE_TICK(0)
-#ifndef NCDE_V2_NOFLAGS
-                    wait_flag(par * NTILE + tau, sc);
-#endif
-                    NCDE_TICK(1)
-                    const float* tl = my_tiles + par * (NW * NTILE * 256) + tau * 256;
-                    float bq[4];
+                    for (int tau = t_lo; tau < t_hi; ++tau)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) bq[r] = tl[(4 * g + r) * 16 + s];
+                        for (int r = 0; r < 4; ++r) bq[tau - t_lo][r] = my_tiles[par * (NW * NTILE * 256) + tau * 256 + (4 * g + r) * 16 + s];
 #pragma unroll
-                    for (int tt = 0; tt < HT; ++tt)
+                    for (int tau = t_lo; tau < t_hi; ++tau)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) accJ[tt] = mfma16(woT[tau][tt][r], bq[r], accJ[tt]);
-                }
+                        for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) accJ[tt] = mfma16(woT[tau][tt][r], bq[tau - t_lo][r], accJ[tt]);
+                };
+                wait_flag(par * NTILE + TG - 1, sc);   // tiles are published in order: the last one covers the group
+                NCDE_TICK(1)
+                dxl_group(ic0{}, std::integral_constant<int, TG>{});
+                if (wprev != 0.0f) dwo_range(par ^ 1, wprev, std::integral_constant<int, NT2 + 2 * ((NTILE - NT2) / 4)>{}, ic_all{});
+                NCDE_TICK(2)
+                wait_flag(par * NTILE + NTILE - 1, sc);
+                NCDE_TICK(3)
+                dxl_group(std::integral_constant<int, TG>{}, ic_all{});
 #pragma unroll
                 for (int tt = 0; tt < HT; ++tt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) red[pw * HH * 16 + (4 * (4 * tt + r) + g) * 16 + s] = accJ[tt][r];
-                NCDE_TICK(0)
-                __syncthreads();  // barrier A
-                NCDE_TICK(2)
-                // (3) first half of this stage's dWo: runs under the chain wave's hidden-layer backward
-                if (wq != 0.0f) dwo_range(par, wq, ic0{}, ic_half{});
-                NCDE_TICK(3)
-                __syncthreads();  // barrier B
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 NCDE_TICK(4)
+                __syncthreads();  // barrier A
+                // (3) first blocks of this stage's dWo: runs under the chain wave's hidden-layer backward
+                if (wq != 0.0f) dwo_range(par, wq, ic0{}, ic_half{});
+                __syncthreads();  // barrier B
+                NCDE_TICK(5)
                 wprev = wq;
             }
         }
@@ -1623,7 +1641,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
             for (int q = 0; q < 16; ++q) {
                 const int tau = 2 * blk + (q >> 3);                      // row >> 4
                 const int gr = 2 * ((q >> 2) & 1) + (lane >> 5), rr = q & 3;  // in-tile row = 4*gr + rr
-                const int nb = tau / CQ, cq = tau - nb * CQ;
+                const int cq = tau / NB, nb = tau - cq * NB;
                 const int h = 4 * (pw * NB + nb) + gr, c = 4 * cq + rr;
                 if (c < C) gp[a.gWo_off + (h * C + c) * HH + (lane & 31)] = gWo[blk][q];
             }
@@ -1632,7 +1650,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
             v += __shfl_xor(v, 32, 64);
             const int i32 = lane & 31;
             const int tau = 2 * blk + (i32 >> 4), rowt = i32 & 15;
-            const int nb = tau / CQ, cq = tau - nb * CQ;
+            const int cq = tau / NB, nb = tau - cq * NB;
             const int hrow = 4 * (pw * NB + nb) + (rowt >> 2), crow = 4 * cq + (rowt & 3);
             if (lane < 32 && crow < C) gp[a.gbo_off + hrow * C + crow] = v;
         }

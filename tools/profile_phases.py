@@ -52,6 +52,6 @@ for flags, label in ((8, "adj v1 plain"), (0, "adj v2 plain"), (0x100, "adj v2 i
         cyc = ws[off: off + nwg * 8 * 6 * 8].view(torch.int64).view(-1, 8, 6).cpu().numpy().astype(np.float64)
         per = cyc.mean(axis=0) / (398 * 4)
         print("chain rows 0-3: recompute | out tiles | wait barrier A | reduce+hidden bwd+vy | rk+exchange(+barrier B)")
-        print("grad  rows 4-7: tile work   | flag waits | barrier A wait | dW work | barrier B wait")
-        print(np.array2string(per[:, :5], precision=0))
-        print("total", per[:, :5].sum(axis=1))
+        print("grad  rows 4-7: (1a) lag work | wait group0 | dxl0+(1b) | wait group1 | dxl1+red | A-wait+(3)+B")
+        print(np.array2string(per[:, :6], precision=0))
+        print("total", per[:, :6].sum(axis=1))
