@@ -59,6 +59,7 @@ typedef enum NcdeOutput { NCDE_OUT_INTERVAL = 0, NCDE_OUT_KNOTS = 1 } NcdeOutput
                                        3-way split-bf16 MFMA GEMMs */
 #define NCDE_FLAG_ADJOINT_V1 8u     /* specialised adjoint: single-role kernel instead of the (default) chain+gradient
                                        wave-specialised one */
+#define NCDE_FLAG_ADJOINT_V2 16u    /* specialised adjoint: chain+gradient kernel with an fp32-MFMA chain (default: split-bf16 chain) */
 #define NCDE_FLAG_DEBUG_PROFILE 0x100u /* development: instrumented kernel variant, cycle counters land in the workspace */
 
 typedef struct NcdeProblem {

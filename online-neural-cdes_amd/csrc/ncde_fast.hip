@@ -1680,6 +1680,600 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// adjoint v3: chain + gradient waves, chain GEMMs as split-bf16 MFMA (H = HH = 32)
+// ------------------------------------------------------------------------------------------------
+// Same role split as ncde_adj_fast2.  Differences:
+//   * every GEMM on the stage's dependency chain (forward recompute, output tiles, hidden-layer backward,
+//     a^T df/dy) runs as 3-way split-bf16 v_mfma_f32_16x16x32_bf16 (fp32-equivalent, see ncde_fwd_fast_bf3):
+//     one K chunk = all 32 hidden units, lane (s, g) <-> k = 8g + j, layer outputs permuted as
+//     tile t, D-row (g, r) <-> unit 8g + 4t + r so D registers feed the next layer's split directly;
+//   * dP tiles are single-buffered and numbered in publication order; the gradient wave does the dL/dx_L
+//     partial per tile group right behind the chain wave and this stage's dWo blocks in its shadow; only the
+//     hidden-layer dW/db lag one stage (x images double-buffered by stage parity);
+//   * the lo pieces of the output-layer weights and the split W1^T / W0^T A-operands live in LDS images.
+template <int NL, int C, int INTERP, int METHOD, int PROF = 0>
+__global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
+    unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+#define NCDE_TICK(k)                                                \
+    if constexpr (PROF != 0) {                                      \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        prof[k] += now_ - tlast;                                    \
+        tlast = now_;                                               \
+    }
+    constexpr int H = 32, HH = 32, NW = 4, HT = 2;
+    constexpr int CP = (C + 3) & ~3, CQ = CP / 4, NB = H / 4 / NW;  // NB = 2 h-blocks per pair
+    constexpr int S = kStages<METHOD>;
+    constexpr int NT = 64 * NW;
+    constexpr int DXW = INTERP == NCDE_INTERP_LINEAR ? CP : 3 * CP;
+    constexpr int EPT = (16 * DXW + NT - 1) / NT;
+    constexpr int NTILE = NB * CQ, NBLK = NTILE / 2;   // tile tau = cq*NB + nb (publication order); block = one cq
+    constexpr int XROWS = H + NL * HH;
+    constexpr int NFLAG = NTILE + 2;
+    constexpr int TG = 2 * ((NBLK + 1) / 2 + (NBLK > 2 ? 0 : 0));  // tiles in the first group (whole blocks)
+    constexpr int BG = 1;   // dWo blocks slotted between the two dL/dx_L groups (the rest run after barrier A)
+    static_assert(NB == 2 && NTILE % 2 == 0, "one 32-row dWo block per cq");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* zx = lds;                                   // [2][H*16]
+    float* dxs = zx + 2 * H * 16;                      // [3][16*DXW]
+    float* red = dxs + 3 * 16 * DXW;                   // [NW][HH*16]
+    float* boL = red + NW * HH * 16;                   // [NW][NB*CQ][4 g][4 r]   (nb-major)
+    float* tiles = boL + NW * NTILE * 16;              // [NW][NTILE][16][16]     raw dP of the current stage
+    float* ximg = tiles + NW * NTILE * 256;            // [2][XROWS][16]          by stage parity (chain wave 0)
+    float* dpimg = ximg + 2 * XROWS * 16;              // [NL][HH][16]            (chain wave 0)
+    int* flags = reinterpret_cast<int*>(dpimg + NL * HH * 16);        // [NW][NFLAG]
+    float* biasL = reinterpret_cast<float*>(flags + NW * NFLAG);      // [2][HT][4 g][4 r]: b[8g + 4t + r]
+    unsigned* w1T3 = reinterpret_cast<unsigned*>(biasL + 2 * HT * 16);  // [HT][3][64][4]  split W1^T A operands
+    unsigned* w0T3 = w1T3 + HT * 3 * 256;                             // [NW][3][64][4]   split W0^T (own state rows)
+    unsigned* woLo = w0T3 + NW * 3 * 256;                             // [NW][NB][CQ][64][4] lo pieces of the Wo A operands
+    unsigned* w1S3 = woLo + NW * NB * CQ * 256;                       // [2 layers][HT][3][64][4]  split W0 / W1 (forward) A operands
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_chain = wave < NW;
+    const int pw = is_chain ? wave : wave - NW;
+    const int s = lane & 15, g = lane >> 4;
+    const int b0 = blockIdx.x * NCDE_TILE;
+    const int bs = b0 + s;
+    const bool valid = bs < a.B;
+    float* my_tiles = tiles + pw * NTILE * 256;
+    volatile __attribute__((address_space(3))) int* my_flags =
+        (volatile __attribute__((address_space(3))) int*)(flags + pw * NFLAG);
+    volatile __attribute__((address_space(3))) int* xflag = (volatile __attribute__((address_space(3))) int*)(flags + NTILE);
+    const float* boLw = boL + pw * NTILE * 16;
+
+    for (int e = tid; e < NW * NFLAG; e += 512) flags[e] = 0;
+    for (int e = tid; e < NW * NTILE * 16; e += 512) {
+        const int r = e & 3, gg = (e >> 2) & 3, rest = e >> 4;
+        const int t2 = rest % NTILE, wv = rest / NTILE;
+        const int nb = t2 / CQ, cq = t2 - nb * CQ;
+        const int h = 4 * (wv * NB + nb) + gg, c = 4 * cq + r;
+        boL[e] = c < C ? NCDE_TANH_PRESCALE * a.bo[h * C + c] : 0.0f;
+    }
+    for (int e = tid; e < 2 * HT * 16; e += 512) {
+        const int r = e & 3, gg = (e >> 2) & 3, t = (e >> 4) % HT, layer = e / (16 * HT);
+        biasL[e] = a.b[layer][8 * gg + 4 * t + r];
+    }
+    if (tid < 64 * HT) {  // split W1^T: A row i <-> output unit 8(i>>2)+4t+(i&3), k = 8kg + jj
+        const int l = tid & 63, t = tid >> 6;
+        const int unit_out = 8 * ((l & 15) >> 2) + 4 * t + (l & 3);
+        float tmp[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) tmp[jj] = a.W[1][(8 * (l >> 4) + jj) * HH + unit_out];
+        const Split3 sp = split8(tmp);
+        *reinterpret_cast<u32x4*>(w1T3 + ((t * 3 + 0) * 64 + l) * 4) = sp.hi;
+        *reinterpret_cast<u32x4*>(w1T3 + ((t * 3 + 1) * 64 + l) * 4) = sp.mid;
+        *reinterpret_cast<u32x4*>(w1T3 + ((t * 3 + 2) * 64 + l) * 4) = sp.lo;
+    } else if (tid >= 64 * HT + 64 * NW && tid < 64 * HT + 64 * NW + 64 * HT) {  // split W0 and W1 (forward), shared by all chain waves
+        const int l = tid & 63, t = (tid >> 6) - HT - NW;
+        const int unitA = 8 * ((l & 15) >> 2) + 4 * t + (l & 3);
+#pragma unroll
+        for (int layer = 0; layer < 2; ++layer) {
+            float tmp[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) tmp[jj] = a.W[layer][unitA * HH + 8 * (l >> 4) + jj];   // H == HH
+            const Split3 sp = split8(tmp);
+            *reinterpret_cast<u32x4*>(w1S3 + (((layer * HT + t) * 3 + 0) * 64 + l) * 4) = sp.hi;
+            *reinterpret_cast<u32x4*>(w1S3 + (((layer * HT + t) * 3 + 1) * 64 + l) * 4) = sp.mid;
+            *reinterpret_cast<u32x4*>(w1S3 + (((layer * HT + t) * 3 + 2) * 64 + l) * 4) = sp.lo;
+        }
+    } else if (tid < 64 * HT + 64 * NW) {  // split W0^T rows of the state entries pair wv owns
+        const int l = tid & 63, wv = (tid >> 6) - HT;
+        const int r_own = l & 3;
+        const int hrow = 4 * (wv * NB + r_own) + ((l & 15) >> 2);
+        float tmp[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) tmp[jj] = r_own < NB ? a.W[0][(8 * (l >> 4) + jj) * H + hrow] : 0.0f;
+        const Split3 sp = split8(tmp);
+        *reinterpret_cast<u32x4*>(w0T3 + ((wv * 3 + 0) * 64 + l) * 4) = sp.hi;
+        *reinterpret_cast<u32x4*>(w0T3 + ((wv * 3 + 1) * 64 + l) * 4) = sp.mid;
+        *reinterpret_cast<u32x4*>(w0T3 + ((wv * 3 + 2) * 64 + l) * 4) = sp.lo;
+    }
+
+    if (is_chain) {
+        // =================================================================================================
+        // chain wave
+        // =================================================================================================
+        u32x4 woHi[NB][CQ], woMid[NB][CQ];
+        unsigned* my_woLo = woLo + pw * NB * CQ * 256;
+        auto fwd_weights = [&](int layer, int tt) {
+            Split3 As;
+            As.hi = *reinterpret_cast<const u32x4*>(w1S3 + (((layer * HT + tt) * 3 + 0) * 64 + lane) * 4);
+            As.mid = *reinterpret_cast<const u32x4*>(w1S3 + (((layer * HT + tt) * 3 + 1) * 64 + lane) * 4);
+            As.lo = *reinterpret_cast<const u32x4*>(w1S3 + (((layer * HT + tt) * 3 + 2) * 64 + lane) * 4);
+            return As;
+        };
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int cq = 0; cq < CQ; ++cq) {
+                const int hA = 4 * (pw * NB + nb) + (s >> 2), cA = 4 * cq + (s & 3);
+                float tmp[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) tmp[jj] = cA < C ? NCDE_TANH_PRESCALE * a.Wo[(hA * C + cA) * HH + 8 * g + jj] : 0.0f;
+                const Split3 sp = split8(tmp);
+                woHi[nb][cq] = sp.hi;
+                woMid[nb][cq] = sp.mid;
+                *reinterpret_cast<u32x4*>(my_woLo + ((nb * CQ + cq) * 64 + lane) * 4) = sp.lo;
+            }
+        // control-path staging (reverse order), by the 256 chain threads
+        const float* eptr[EPT];
+        float eprev[EPT], enext[EPT];
+        bool eok[EPT];
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = tid + q * NT;
+            const int es = e / DXW, ec = e - es * DXW;
+            const int part = ec / CP, c = ec - part * CP;
+            eok[q] = e < 16 * DXW && c < C && (b0 + es) < a.B;
+            const long long base = (long long)(eok[q] ? b0 + es : 0) * a.cs_b;
+            eptr[q] = a.coeffs + base + (INTERP == NCDE_INTERP_LINEAR ? c : (part + 1) * C + c);
+            eprev[q] = 0.0f;
+            enext[q] = 0.0f;
+        }
+        auto stage_load = [&](int piece) {
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) enext[q] = eok[q] ? eptr[q][(long long)piece * a.cs_t] : 0.0f;
+        };
+        auto stage_store = [&](int piece) {
+            float* dst = dxs + (piece % 3) * 16 * DXW;
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+                const int e = tid + q * NT;
+                if (e < 16 * DXW) dst[e] = INTERP == NCDE_INTERP_LINEAR ? eprev[q] - enext[q] : enext[q];
+                eprev[q] = enext[q];
+            }
+        };
+        const int p_hi = a.n_pieces - 1;
+        if (INTERP == NCDE_INTERP_LINEAR) {
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) eprev[q] = eok[q] ? eptr[q][(long long)(p_hi + 1) * a.cs_t] : 0.0f;
+        }
+        stage_load(p_hi);
+        stage_store(p_hi);
+        if (p_hi >= 1) {
+            stage_load(p_hi - 1);
+            stage_store(p_hi - 1);
+        }
+        const int last_row = a.n_out - 1;
+        float y0[NB], ky1[NB], ky2[NB], a0[NB], ka1[NB], ka2[NB], as_[NB], zreg[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) zreg[jj] = valid ? a.z_out[((long long)bs * a.n_out + last_row) * H + 8 * g + jj] : 0.0f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const long long o = ((long long)bs * a.n_out + last_row) * H + 4 * (pw * NB + nb) + g;
+            y0[nb] = valid ? a.z_out[o] : 0.0f;
+            a0[nb] = valid ? a.grad_out[o] : 0.0f;
+            as_[nb] = a0[nb];
+            ky1[nb] = ky2[nb] = ka1[nb] = ka2[nb] = 0.0f;
+        }
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+
+        int zpar = 0, sc = 0;
+        if constexpr (PROF != 0) tlast = __builtin_readcyclecounter();
+        for (int n = a.T - 1; n >= 1; --n) {
+            if (n - 3 >= 0) stage_load(n - 3);
+#pragma unroll 1
+            for (int j = 0; j < S; ++j) {
+                ++sc;
+                const int par = sc & 1;
+                const float t = -(-(float)n + stage_offset(METHOD, j));
+                const int idx = piece_index(t, a.n_pieces);
+                const float frac = t - (float)idx;
+                const float wq = stage_weight(METHOD, j);
+                const float* dxp = dxs + (idx % 3) * 16 * DXW + s * DXW;
+                // ---- forward recompute (split-bf16); x[l][4t+r] <-> unit 8g + 4t + r -----------------------------------
+                float x[NL][8];
+                Split3 xb;
+                {
+                    f32x4 acc[HT];
+                    xb = split8(zreg);
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt) acc[tt] = mfma_split(fwd_weights(0, tt), xb, *reinterpret_cast<const f32x4*>(biasL + (tt * 4 + g) * 4));
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) x[0][4 * tt + r] = relu_dev(acc[tt][r]);
+#pragma unroll
+                    for (int l = 1; l < NL; ++l) {
+                        xb = split8(x[l - 1]);
+#pragma unroll
+                        for (int tt = 0; tt < HT; ++tt) acc[tt] = mfma_split(fwd_weights(1, tt), xb, *reinterpret_cast<const f32x4*>(biasL + ((HT + tt) * 4 + g) * 4));
+#pragma unroll
+                        for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) x[l][4 * tt + r] = relu_dev(acc[tt][r]);
+                    }
+                    xb = split8(x[NL - 1]);
+                }
+                NCDE_TICK(0)
+                if (wq != 0.0f && pw == 0) {  // [unit][sample] images for the gradient waves
+                    float* xi = ximg + par * XROWS * 16;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) xi[(8 * g + jj) * 16 + s] = zreg[jj];
+#pragma unroll
+                    for (int l = 0; l < NL; ++l)
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) xi[(H + l * HH + 8 * g + jj) * 16 + s] = x[l][jj];
+                    wave_lds_order();
+                    *xflag = sc;
+                }
+                // ---- output tiles: P, r = 1/(exp(2P)+1), f, dP -> LDS tile + flag -----------------------------------
+                float kout[NB];
+                float sdx = 0.0f;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) kout[nb] = 0.0f;
+#pragma unroll
+                for (int cq = 0; cq < CQ; ++cq) {
+                    f32x4 o[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        Split3 As;
+                        As.hi = woHi[nb][cq];
+                        As.mid = woMid[nb][cq];
+                        As.lo = *reinterpret_cast<const u32x4*>(my_woLo + ((nb * CQ + cq) * 64 + lane) * 4);
+                        o[nb] = mfma_split(As, xb, *reinterpret_cast<const f32x4*>(boLw + ((nb * CQ + cq) * 4 + g) * 4));
+                    }
+                    f32x4 dx;
+                    if constexpr (INTERP == NCDE_INTERP_LINEAR) {
+                        dx = *reinterpret_cast<const f32x4*>(dxp + 4 * cq);
+                    } else {
+                        const f32x4 cb = *reinterpret_cast<const f32x4*>(dxp + 4 * cq);
+                        const f32x4 cc = *reinterpret_cast<const f32x4*>(dxp + CP + 4 * cq);
+                        const f32x4 cd = *reinterpret_cast<const f32x4*>(dxp + 2 * CP + 4 * cq);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float inner = cc[r] + cd[r] * frac;
+                            dx[r] = cb[r] + inner * frac;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sdx += dx[r];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int tau = cq * NB + nb;
+                        float* tl = my_tiles + tau * 256;
+                        const float a4 = 4.0f * as_[nb];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float rr = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[nb][r]) + 1.0f);
+                            kout[nb] = fmaf(rr, dx[r], kout[nb]);
+                            tl[(4 * g + r) * 16 + s] = (a4 * dx[r]) * fmaf(-rr, rr, rr);
+                        }
+                        wave_lds_order();
+                        my_flags[tau] = sc;
+                    }
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) kout[nb] = fmaf(-2.0f, kout[nb], sdx);
+                NCDE_TICK(1)
+                __syncthreads();  // barrier A: the gradient waves have published their dL/dx_L partials
+                NCDE_TICK(2)
+                float gpre[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    float v = red[(8 * g + jj) * 16 + s];
+#pragma unroll
+                    for (int wv = 1; wv < NW; ++wv) v += red[wv * HH * 16 + (8 * g + jj) * 16 + s];
+                    gpre[jj] = x[NL - 1][jj] > 0.0f ? v : 0.0f;
+                }
+                // ---- hidden layers backward (split-bf16) -----------------------------------------------------------------
+#pragma unroll
+                for (int l = NL - 1; l >= 1; --l) {
+                    if (wq != 0.0f && pw == 0) {
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) dpimg[(l * HH + 8 * g + jj) * 16 + s] = gpre[jj];
+                    }
+                    const Split3 gb = split8(gpre);
+                    f32x4 acc[HT];
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt) {
+                        Split3 As;
+                        As.hi = *reinterpret_cast<const u32x4*>(w1T3 + ((tt * 3 + 0) * 64 + lane) * 4);
+                        As.mid = *reinterpret_cast<const u32x4*>(w1T3 + ((tt * 3 + 1) * 64 + lane) * 4);
+                        As.lo = *reinterpret_cast<const u32x4*>(w1T3 + ((tt * 3 + 2) * 64 + lane) * 4);
+                        acc[tt] = mfma_split(As, gb, zero4);
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) gpre[4 * tt + r] = x[l - 1][4 * tt + r] > 0.0f ? acc[tt][r] : 0.0f;
+                }
+                if (wq != 0.0f && pw == 0) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) dpimg[(8 * g + jj) * 16 + s] = gpre[jj];
+                }
+                f32x4 vy;
+                {
+                    const Split3 gb = split8(gpre);
+                    Split3 As;
+                    As.hi = *reinterpret_cast<const u32x4*>(w0T3 + ((pw * 3 + 0) * 64 + lane) * 4);
+                    As.mid = *reinterpret_cast<const u32x4*>(w0T3 + ((pw * 3 + 1) * 64 + lane) * 4);
+                    As.lo = *reinterpret_cast<const u32x4*>(w0T3 + ((pw * 3 + 2) * 64 + lane) * 4);
+                    vy = mfma_split(As, gb, zero4);
+                }
+                NCDE_TICK(3)
+                float ys[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    ys[nb] = Combine<METHOD>::apply(j, -kout[nb], y0[nb], ky1[nb], ky2[nb]);
+                    as_[nb] = Combine<METHOD>::apply(j, vy[nb], a0[nb], ka1[nb], ka2[nb]);
+                }
+                if (j == S - 1) {
+                    if (a.output == NCDE_OUT_KNOTS) {  // reset y to the stored knot value, add dL/dz of that knot
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const long long o = ((long long)bs * a.n_out + (n - 1)) * H + 4 * (pw * NB + nb) + g;
+                            y0[nb] = valid ? a.z_out[o] : 0.0f;
+                            ys[nb] = y0[nb];
+                            a0[nb] += valid ? a.grad_out[o] : 0.0f;
+                            as_[nb] = a0[nb];
+                        }
+                    } else if (n == 1) {
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            a0[nb] += valid ? a.grad_out[((long long)bs * a.n_out) * H + 4 * (pw * NB + nb) + g] : 0.0f;
+                            as_[nb] = a0[nb];
+                        }
+                    }
+                    if (n - 3 >= 0) stage_store(n - 3);
+                }
+                if (j == S - 1 && a.output == NCDE_OUT_KNOTS) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) zreg[jj] = valid ? a.z_out[((long long)bs * a.n_out + (n - 1)) * H + 8 * g + jj] : 0.0f;
+                    __syncthreads();  // barrier B
+                } else {
+                    float* zw = zx + zpar * H * 16;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) zw[(4 * (pw * NB + nb) + g) * 16 + s] = ys[nb];
+                    __syncthreads();  // barrier B
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) zreg[jj] = zw[(8 * g + jj) * 16 + s];
+                    zpar ^= 1;
+                }
+                NCDE_TICK(4)
+            }
+        }
+        if constexpr (PROF != 0) {
+            if (lane == 0) {
+                unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.out) + ((long long)blockIdx.x * 8 + wave) * 6;
+                for (int k = 0; k < 6; ++k) dst[k] = prof[k];
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) a.grad_z0[(long long)bs * H + 4 * (pw * NB + nb) + g] = a0[nb];
+        }
+    } else {
+        // =================================================================================================
+        // gradient wave
+        // =================================================================================================
+        float woT[NTILE][HT][4];  // fp32 A operands of the dL/dx_L GEMM: output row i <-> unit 8(i>>2)+4t'+(i&3)
+#pragma unroll
+        for (int tau = 0; tau < NTILE; ++tau) {
+            const int cq = tau / NB, nb = tau - cq * NB;
+            const int h = 4 * (pw * NB + nb) + g;
+#pragma unroll
+            for (int tp = 0; tp < HT; ++tp) {
+                const int jrow = 8 * (s >> 2) + 4 * tp + (s & 3);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 4 * cq + r;
+                    woT[tau][tp][r] = c < C ? a.Wo[(h * C + c) * HH + jrow] : 0.0f;
+                }
+            }
+        }
+        f32x16 gWo[NBLK];
+        f32x4 gW1, gW0;      // one 16x16 tile of dW1 / dW0 per pair: tile (tr, tc) = (pw >> 1, pw & 1)
+        float gbo[NBLK], gb1 = 0.0f, gb0 = 0.0f;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        gW1 = zero4;
+        gW0 = zero4;
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) {
+            gbo[i] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) gWo[i][q] = 0.0f;
+        }
+        __syncthreads();
+
+        const int tr = pw >> 1, tc = pw & 1;
+        auto wait_flag = [&](int slot, int want) {
+            while (__builtin_amdgcn_readfirstlane(my_flags[slot]) != want) __builtin_amdgcn_s_sleep(1);
+            wave_lds_order();
+        };
+        // dWo of 2-tile block `blk` (= one cq): 32 rows x 32 units x 16 samples = 6 split-bf16 32x32x16 MFMAs
+        auto dwo_block = [&](const Split3& Bs, float w, int blk) {
+            const int i32 = lane & 31, kg = lane >> 5;
+            const float* tl = my_tiles + (2 * blk + (i32 >> 4)) * 256 + (i32 & 15) * 16 + 8 * kg;
+            const f32x4 a0v = *reinterpret_cast<const f32x4*>(tl);
+            const f32x4 a1v = *reinterpret_cast<const f32x4*>(tl + 4);
+            float av[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { av[q] = a0v[q]; av[4 + q] = a1v[q]; }
+            gbo[blk] += w * (((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7])));
+            const Split3 As = split8(av);
+            f32x16 c = gWo[blk];
+            c = mfma_bf32(As.lo, Bs.hi, c);
+            c = mfma_bf32(As.hi, Bs.lo, c);
+            c = mfma_bf32(As.mid, Bs.mid, c);
+            c = mfma_bf32(As.mid, Bs.hi, c);
+            c = mfma_bf32(As.hi, Bs.mid, c);
+            c = mfma_bf32(As.hi, Bs.hi, c);
+            gWo[blk] = c;
+        };
+        auto x3_split = [&](int par, float w) {
+            const int i32 = lane & 31, kg = lane >> 5;
+            const float* xi = ximg + par * XROWS * 16 + (H + (NL - 1) * HH + i32) * 16 + 8 * kg;
+            const f32x4 b0v = *reinterpret_cast<const f32x4*>(xi);
+            const f32x4 b1v = *reinterpret_cast<const f32x4*>(xi + 4);
+            float bv[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { bv[q] = w * b0v[q]; bv[4 + q] = w * b1v[q]; }
+            return split8(bv);
+        };
+        // hidden-layer dW/db of the stage whose x images have parity `par` (fp32 MFMA, samples are K)
+        auto dw_hidden = [&](int par, float w) {
+            const float* xi = ximg + par * XROWS * 16;
+#pragma unroll
+            for (int l = NL - 1; l >= 1; --l) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(dpimg + (l * HH + 16 * tr + s) * 16 + 4 * g);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(xi + (H + (l - 1) * HH + 16 * tc + s) * 16 + 4 * g);
+                if (tc == 0) gb1 += w * ((av[0] + av[1]) + (av[2] + av[3]));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gW1 = mfma16(av[q], w * bv[q], gW1);
+            }
+            const f32x4 av = *reinterpret_cast<const f32x4*>(dpimg + (16 * tr + s) * 16 + 4 * g);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(xi + (16 * tc + s) * 16 + 4 * g);
+            if (tc == 0) gb0 += w * ((av[0] + av[1]) + (av[2] + av[3]));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gW0 = mfma16(av[q], w * bv[q], gW0);
+        };
+        f32x4 accJ[HT];
+        auto dxl_tiles = [&](auto t_lo_c, auto t_hi_c) {
+            constexpr int t_lo = decltype(t_lo_c)::value, t_hi = decltype(t_hi_c)::value;
+            float bq[t_hi - t_lo][4];
+#pragma unroll
+            for (int tau = t_lo; tau < t_hi; ++tau)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bq[tau - t_lo][r] = my_tiles[tau * 256 + (4 * g + r) * 16 + s];
+#pragma unroll
+            for (int tau = t_lo; tau < t_hi; ++tau)
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accJ[tt] = mfma16(woT[tau][tt][r], bq[tau - t_lo][r], accJ[tt]);
+        };
+        using ic0 = std::integral_constant<int, 0>;
+        using icg = std::integral_constant<int, TG>;
+        using ica = std::integral_constant<int, NTILE>;
+        int sc = 0;
+        float wprev = 0.0f;
+        if constexpr (PROF != 0) tlast = __builtin_readcyclecounter();
+        for (int n = a.T - 1; n >= 1; --n) {
+#pragma unroll 1
+            for (int j = 0; j < S; ++j) {
+                ++sc;
+                const int par = sc & 1;
+                const float wq = stage_weight(METHOD, j);
+                // hidden-layer dW/db of the previous stage, under the chain wave's forward recompute
+                if (wprev != 0.0f) dw_hidden(par ^ 1, wprev);
+                NCDE_TICK(0)
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt) accJ[tt] = zero4;
+                // Per block (= one cq, two tiles, published together): poll, dL/dx_L (16 fp32 MFMAs, on the stage's
+                // critical path).  One dWo block of this stage is slotted in behind block 1 (more would make the wave
+                // fall behind the chain wave); only the LAST block's dL/dx_L trails the chain wave into barrier A.
+                Split3 Bs;
+                bool have_bs = false;
+#pragma unroll
+                for (int blk = 0; blk < NBLK; ++blk) {
+                    NCDE_TICK(2)
+                    wait_flag(2 * blk + 1, sc);
+                    NCDE_TICK(1)
+                    if (blk == 0) dxl_tiles(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+                    else if (blk == 1) dxl_tiles(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+                    else if (blk == 2) { if constexpr (NBLK > 2) dxl_tiles(std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{}); }
+                    else if (blk == 3) { if constexpr (NBLK > 3) dxl_tiles(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{}); }
+                    else if (blk == 4) { if constexpr (NBLK > 4) dxl_tiles(std::integral_constant<int, 8>{}, std::integral_constant<int, 10>{}); }
+                    static_assert(NBLK <= 5, "extend the block dispatch");
+                    if (wq != 0.0f && blk == 1) {
+                        if (!have_bs) {
+                            while (__builtin_amdgcn_readfirstlane(*xflag) != sc) __builtin_amdgcn_s_sleep(1);
+                            wave_lds_order();
+                            Bs = x3_split(par, wq);
+                            have_bs = true;
+                        }
+                        dwo_block(Bs, wq, blk >> 1);
+                    }
+                }
+                NCDE_TICK(3)
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[pw * HH * 16 + (8 * g + 4 * tt + r) * 16 + s] = accJ[tt][r];
+                NCDE_TICK(4)
+                __syncthreads();  // barrier A
+                if (wq != 0.0f) {
+                    if (!have_bs) {
+                        while (__builtin_amdgcn_readfirstlane(*xflag) != sc) __builtin_amdgcn_s_sleep(1);
+                        wave_lds_order();
+                        Bs = x3_split(par, wq);
+                    }
+#pragma unroll
+                    for (int blk = 0; blk < NBLK; ++blk)
+                        if (blk >= 1) dwo_block(Bs, wq, blk);
+
+                }
+                __syncthreads();  // barrier B
+                NCDE_TICK(5)
+                wprev = wq;
+            }
+        }
+        if (wprev != 0.0f) dw_hidden(sc & 1, wprev);
+        if constexpr (PROF != 0) {
+            if (lane == 0) {
+                unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.out) + ((long long)blockIdx.x * 8 + wave) * 6;
+                for (int k = 0; k < 6; ++k) dst[k] = prof[k];
+            }
+        }
+        // ---- write-out of this workgroup's parameter-gradient partial ------------------------------------------
+        float* gp = a.gpart + (long long)blockIdx.x * a.theta_size;
+#pragma unroll
+        for (int blk = 0; blk < NBLK; ++blk) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int nb = q >> 3;                                   // block row >> 4 = tile within the block = nb
+                const int gr = 2 * ((q >> 2) & 1) + (lane >> 5), rr = q & 3;
+                const int h = 4 * (pw * NB + nb) + gr, c = 4 * blk + rr;
+                if (c < C) gp[a.gWo_off + (h * C + c) * HH + (lane & 31)] = gWo[blk][q];
+            }
+            float v = gbo[blk];
+            v += __shfl_xor(v, 32, 64);
+            const int i32 = lane & 31;
+            const int nb = i32 >> 4, rowt = i32 & 15;
+            const int hrow = 4 * (pw * NB + nb) + (rowt >> 2), crow = 4 * blk + (rowt & 3);
+            if (lane < 32 && crow < C) gp[a.gbo_off + hrow * C + crow] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gp[a.gW_off[1] + (16 * tr + 4 * g + r) * HH + 16 * tc + s] = gW1[r];
+            gp[a.gW_off[0] + (16 * tr + 4 * g + r) * H + 16 * tc + s] = gW0[r];
+        }
+        {
+            float v1 = gb1, v0 = gb0;
+            v1 += __shfl_xor(v1, 16, 64); v1 += __shfl_xor(v1, 32, 64);
+            v0 += __shfl_xor(v0, 16, 64); v0 += __shfl_xor(v0, 32, 64);
+            if (tc == 0 && g == 0) {
+                gp[a.gb_off[1] + 16 * tr + s] = v1;
+                gp[a.gb_off[0] + 16 * tr + s] = v0;
+            }
+        }
+    }
+#undef NCDE_TICK
+}
+
+// ------------------------------------------------------------------------------------------------
 // dispatch tables
 // ------------------------------------------------------------------------------------------------
 struct Shape {
@@ -1753,6 +2347,29 @@ size_t adj2_lds_bytes(int interp) {
                                     (HH / 16) * (HH / 16) * 256 + NW * (HH / 16) * 256);
 }
 
+template <int NL, int C>
+FwdFn pick_adj3(int interp, int method) {
+#define NCDE_PICK(I, M) \
+    if (interp == I && method == M) return ncde_adj_fast3<NL, C, I, M>;
+    NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_RK4_38)
+    NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_MIDPOINT)
+    NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_EULER)
+    NCDE_PICK(NCDE_INTERP_CUBIC, NCDE_RK4_38)
+    NCDE_PICK(NCDE_INTERP_CUBIC, NCDE_MIDPOINT)
+    NCDE_PICK(NCDE_INTERP_CUBIC, NCDE_EULER)
+#undef NCDE_PICK
+    return nullptr;
+}
+
+template <int NL, int C>
+size_t adj3_lds_bytes(int interp) {
+    constexpr int H = 32, HH = 32, NW = 4, HT = 2, CP = (C + 3) & ~3, CQ = CP / 4, NB = 2, NTILE = NB * CQ;
+    const int DXW = interp == NCDE_INTERP_LINEAR ? CP : 3 * CP;
+    return sizeof(float) * (size_t)(2 * H * 16 + 3 * 16 * DXW + NW * HH * 16 + NW * NTILE * 16 + NW * NTILE * 256 +
+                                    2 * (H + NL * HH) * 16 + NL * HH * 16 + NW * (NTILE + 2) + 2 * HT * 16 +
+                                    HT * 3 * 256 + NW * 3 * 256 + NW * NB * CQ * 256 + 2 * HT * 3 * 256);
+}
+
 template <int H, int HH, int C, int NL, int NW>
 size_t adj_lds_bytes(int interp) {
     constexpr int CP = (C + 3) & ~3, CQ = CP / 4, HT = HH / 16, NB = H / 4 / NW, NTILE = NB * CQ;
@@ -1773,9 +2390,12 @@ struct FastEntry {
     FwdFn (*adj)(int, int);
     size_t (*adj_lds)(int);
     const char* adj_name;
-    FwdFn (*adj2)(int, int);        // wave-specialised variant (default); NCDE_FLAG_ADJOINT_V1 selects `adj`
+    FwdFn (*adj2)(int, int);        // wave-specialised variant, fp32 chain (NCDE_FLAG_ADJOINT_V2)
     size_t (*adj2_lds)(int);
     const char* adj2_name;
+    FwdFn (*adj3)(int, int);        // wave-specialised variant, split-bf16 chain (default)
+    size_t (*adj3_lds)(int);
+    const char* adj3_name;
 };
 
 const FastEntry kFast[] = {
@@ -1783,11 +2403,12 @@ const FastEntry kFast[] = {
     {{32, 32, 20}, 4, pick_fwd<32, 32, 20, 4>, "ncde_fwd_fast<H32,HH32,C20,NW4>",
      pick_fwd_bf3<32, 32, 20, 4>, "ncde_fwd_fast_bf3<H32,HH32,C20,NW4>", 4,
      3, pick_adj<32, 32, 20, 3, 4>, adj_lds_bytes<32, 32, 20, 3, 4>, "ncde_adj_fast<H32,HH32,C20,NL3,NW4>",
-     pick_adj2<32, 32, 20, 3>, adj2_lds_bytes<32, 32, 20, 3>, "ncde_adj_fast2<H32,HH32,C20,NL3,chain+grad>"},
+     pick_adj2<32, 32, 20, 3>, adj2_lds_bytes<32, 32, 20, 3>, "ncde_adj_fast2<H32,HH32,C20,NL3,chain+grad>",
+     pick_adj3<3, 20>, adj3_lds_bytes<3, 20>, "ncde_adj_fast3<H32,HH32,C20,NL3,chain(bf16x3)+grad>"},
     // BASELINE cfg4 (adjoint: generic family for now -- the per-wave LDS images do not fit at HH=64)
     {{64, 64, 4}, 4, pick_fwd<64, 64, 4, 4>, "ncde_fwd_fast<H64,HH64,C4,NW4>",
      pick_fwd_bf3<64, 64, 4, 4>, "ncde_fwd_fast_bf3<H64,HH64,C4,NW4>", 4, 0, nullptr, nullptr, nullptr,
-     nullptr, nullptr, nullptr},
+     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
 };
 
 const FastEntry* find_entry(const NcdeProblem* p) {
@@ -1814,7 +2435,9 @@ const char* ncde_fast_kernel_name(const NcdeProblem* p, int pass) {
     if (!ncde_fast_supported(p, pass)) return nullptr;
     const FastEntry* e = find_entry(p);
     if (pass == 0) return ((p->flags & NCDE_FLAG_FP32_MFMA) == 0 && e->fwd_bf3) ? e->fwd_bf3_name : e->fwd_name;
-    return ((p->flags & NCDE_FLAG_ADJOINT_V1) == 0 && e->adj2) ? e->adj2_name : e->adj_name;
+    if (p->flags & NCDE_FLAG_ADJOINT_V1) return e->adj_name;
+    if ((p->flags & NCDE_FLAG_ADJOINT_V2) && e->adj2) return e->adj2_name;
+    return e->adj3 ? e->adj3_name : (e->adj2 ? e->adj2_name : e->adj_name);
 }
 
 int64_t ncde_fast_workspace_bytes(const NcdeProblem* p, int pass) {
@@ -1853,8 +2476,10 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     (void)ws_bytes;
     if (!ncde_fast_supported(p, 1)) return NCDE_ERR_UNSUPPORTED;
     const FastEntry* e = find_entry(p);
-    const bool v2 = (p->flags & NCDE_FLAG_ADJOINT_V1) == 0 && e->adj2 != nullptr;
-    FwdFn fn = v2 ? e->adj2(p->interp, p->method) : e->adj(p->interp, p->method);
+    const bool v1 = (p->flags & NCDE_FLAG_ADJOINT_V1) != 0 || (e->adj2 == nullptr && e->adj3 == nullptr);
+    const bool v3 = !v1 && e->adj3 != nullptr && !(p->flags & NCDE_FLAG_ADJOINT_V2);
+    const bool v2 = !v1 && !v3;
+    FwdFn fn = v1 ? e->adj(p->interp, p->method) : (v3 ? e->adj3(p->interp, p->method) : e->adj2(p->interp, p->method));
     if (!fn) return NCDE_ERR_UNSUPPORTED;
     const Layout y = make_layout(p);
     KArgs a;
@@ -1863,17 +2488,18 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     a.gpart = (float*)ws;
     if (p->flags & 0x200u) {  // development: per-stage chain values of workgroup 0 -> tail of the workspace
         if (!(e->shape.H == 32 && e->shape.C == 20 && p->interp == NCDE_INTERP_CUBIC && p->method == NCDE_MIDPOINT)) return NCDE_ERR_UNSUPPORTED;
-        fn = v2 ? ncde_adj_fast2<32, 32, 20, 3, NCDE_INTERP_CUBIC, NCDE_MIDPOINT, 2> : ncde_adj_fast<32, 32, 20, 3, 4, NCDE_INTERP_CUBIC, NCDE_MIDPOINT, 2>;
+        fn = !v1 ? ncde_adj_fast2<32, 32, 20, 3, NCDE_INTERP_CUBIC, NCDE_MIDPOINT, 2> : ncde_adj_fast<32, 32, 20, 3, 4, NCDE_INTERP_CUBIC, NCDE_MIDPOINT, 2>;
         a.out = (float*)ws + (size_t)y.n_wg * y.theta_size + 64;
     }
     if (p->flags & NCDE_FLAG_DEBUG_PROFILE) {  // phase-cycle counters -> tail of the workspace [n_wg][NW][6] u64
         if (!(e->shape.H == 32 && e->shape.C == 20 && p->interp == NCDE_INTERP_LINEAR && p->method == NCDE_RK4_38)) return NCDE_ERR_UNSUPPORTED;
-        fn = v2 ? ncde_adj_fast2<32, 32, 20, 3, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1> : ncde_adj_fast<32, 32, 20, 3, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>;
+        fn = v3 ? ncde_adj_fast3<3, 20, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>
+                : (v2 ? ncde_adj_fast2<32, 32, 20, 3, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1> : ncde_adj_fast<32, 32, 20, 3, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>);
         a.out = (float*)ws + (size_t)y.n_wg * y.theta_size + 64;
     }
-    const size_t lds = v2 ? e->adj2_lds(p->interp) : e->adj_lds(p->interp);
+    const size_t lds = v1 ? e->adj_lds(p->interp) : (v3 ? e->adj3_lds(p->interp) : e->adj2_lds(p->interp));
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NCDE_ERR_HIP;
-    hipLaunchKernelGGL(fn, dim3(y.n_wg), dim3(v2 ? 512 : 64 * e->nw), lds, st, a);
+    hipLaunchKernelGGL(fn, dim3(y.n_wg), dim3(v1 ? 64 * e->nw : 512), lds, st, a);
     if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
     if (main_kernel_only) return NCDE_OK;
     return launch_reduce_partials(p, y, g, (const float*)ws, y.n_wg, st);

@@ -211,9 +211,10 @@ def test_fast_kernels_vs_oracle(shape, interp, method, seq, gpu_lib):
     iso = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_AUTO)
     for k, e in _grad_errors(case, iso).items():
         assert e <= TIGHT_G, ("adjoint kernel on oracle z_out", res["kernels"][1], k, e)
-    if res["kernels"][1].startswith("ncde_adj_fast2"):       # also the single-role specialised adjoint
-        iso1 = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_ADJOINT_V1)
-        for k, e in _grad_errors(case, iso1).items():
-            assert e <= TIGHT_G, ("single-role adjoint kernel on oracle z_out", k, e)
+    if res["kernels"][1].startswith("ncde_adj_fast3"):       # also the other specialised adjoint variants
+        for fl, nm in ((_lib.FLAG_ADJOINT_V1, "single-role"), (_lib.FLAG_ADJOINT_V2, "chain+grad fp32 chain")):
+            iso1 = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=fl)
+            for k, e in _grad_errors(case, iso1).items():
+                assert e <= TIGHT_G, (nm + " adjoint kernel on oracle z_out", k, e)
         again = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_AUTO)     # hand-off protocol: bit-reproducible
         assert np.array_equal(again["dz0"], iso["dz0"]) and all(np.array_equal(again["grads"][k], iso["grads"][k]) for k in iso["grads"])
