@@ -221,7 +221,7 @@ def main():
             pass
 
         def traffic_of(name):
-            key = "ncde_fwd_fast_bf3" if "fwd_fast_bf3" in name else ("ncde_adj_fast" if "adj_fast" in name else None)
+            key = "ncde_fwd_fast_bf3" if "fwd_fast_bf3" in name else ("ncde_adj_fast3" if "adj_fast3" in name else None)
             rec_ = pmc.get(key) if (key and args.config == "cfg2" and B_local == 4096) else None
             if not rec_ or "hbm_read_MB_per_launch_corrected_x2" not in rec_:
                 return None
@@ -243,7 +243,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "dtype_note": "fp32 in/out and fp32 accumulation; the specialised forward GEMMs run as exact 3-way split-bf16 MFMA (fp32-equivalent, z error 5e-7), the adjoint as fp32-input MFMA",
+            "dtype_note": "fp32 in/out and fp32 accumulation; the GEMMs on the dependency chain (forward, adjoint recompute/VJP) and dWo run as exact 3-way split-bf16 MFMA (fp32-equivalent: z error 5e-7, gradients 1e-6 vs the reference), the remaining small GEMMs as fp32-input MFMA",
             "config": {"workload": "BASELINE %s: %s interpolation, %s step 1, B=%d per GPU (global %d), raw L=%d -> T=%d knots, "
                                    "C=%d, H=HH=%d, nl=%d; step = forward + adjoint backward + %sAdam"
                                    % (args.config, c["interpolation"], c["solver"], B_local, B_total, c["L"], T, c["C"], c["H"],
