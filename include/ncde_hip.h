@@ -133,6 +133,18 @@ int ncde_adjoint(const NcdeProblem* p, const float* z_out, const float* grad_out
 int ncde_time_kernel(const NcdeProblem* p, int pass, float* out, const float* grad_out, const NcdeGrads* grads,
                      void* workspace, size_t workspace_bytes, void* stream, int iters, float* ms_per_launch);
 
+/* ---- control-path coefficient construction on the GPU (the step right before the hot path) ----------------
+ * Default integer time grid, fp32.  x: [B, L, C] raw series (NaN = missing), device pointers.
+ * ncde_prepare_linear   replaces torchcde.linear_interpolation_coeffs (interpolation_linear.py:131-180):
+ *                       rectilinear_time_index >= 0 -> rectilinear preparation (out [B, 2L-1, C]), else plain
+ *                       NaN-filled linear knots (out [B, L, C]).
+ * ncde_prepare_cubic    replaces torchcde.natural_cubic_coeffs for series WITHOUT missing values
+ *                       (interpolation_cubic.py:7-53, 170-190): out [B, L-1, 4C] = a|b|2c|3d.
+ * kind = NcdeInterp for the workspace query. */
+int64_t ncde_prepare_workspace_bytes(int kind, int B, int L, int C);
+int ncde_prepare_linear(const float* x, int B, int L, int C, int rectilinear_time_index, float* out, void* stream);
+int ncde_prepare_cubic(const float* x, int B, int L, int C, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

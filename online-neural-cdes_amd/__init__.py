@@ -10,3 +10,4 @@ from .interpolation import LinearInterpolation, NaturalCubicSpline  # noqa: F401
 from .solver import FieldSpec, cdeint  # noqa: F401
 from .vector_fields import MLPField, OriginalVectorField  # noqa: F401
 from .ncde import NeuralCDE  # noqa: F401
+from .coefficients import linear_interpolation_coeffs, natural_cubic_coeffs, natural_cubic_spline_coeffs  # noqa: F401

@@ -55,6 +55,7 @@ class NcdeGrads(ctypes.Structure):
 EXPORTS = (
     "ncde_version", "ncde_last_error_string", "ncde_num_outputs", "ncde_workspace_bytes",
     "ncde_kernel_name", "ncde_forward", "ncde_adjoint", "ncde_time_kernel",
+    "ncde_prepare_workspace_bytes", "ncde_prepare_linear", "ncde_prepare_cubic",
 )
 
 _LIB = None
@@ -92,6 +93,13 @@ def lib():
     h.ncde_adjoint.restype = ctypes.c_int
     h.ncde_time_kernel.argtypes = [P, ctypes.c_int, vp, vp, G, vp, sz, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
     h.ncde_time_kernel.restype = ctypes.c_int
+    i32 = ctypes.c_int
+    h.ncde_prepare_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    h.ncde_prepare_workspace_bytes.restype = ctypes.c_int64
+    h.ncde_prepare_linear.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    h.ncde_prepare_linear.restype = ctypes.c_int
+    h.ncde_prepare_cubic.argtypes = [vp, i32, i32, i32, vp, vp, sz, vp]
+    h.ncde_prepare_cubic.restype = ctypes.c_int
     if h.ncde_version() != NCDE_ABI_VERSION:
         raise NcdeError("libncde_hip.so ABI %d != binding %d" % (h.ncde_version(), NCDE_ABI_VERSION))
     _LIB = h

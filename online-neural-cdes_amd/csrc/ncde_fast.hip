@@ -1709,8 +1709,6 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
     constexpr int NTILE = NB * CQ, NBLK = NTILE / 2;   // tile tau = cq*NB + nb (publication order); block = one cq
     constexpr int XROWS = H + NL * HH;
     constexpr int NFLAG = NTILE + 2;
-    constexpr int TG = 2 * ((NBLK + 1) / 2 + (NBLK > 2 ? 0 : 0));  // tiles in the first group (whole blocks)
-    constexpr int BG = 1;   // dWo blocks slotted between the two dL/dx_L groups (the rest run after barrier A)
     static_assert(NB == 2 && NTILE % 2 == 0, "one 32-row dWo block per cq");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* zx = lds;                                   // [2][H*16]
@@ -2164,9 +2162,6 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) accJ[tt] = mfma16(woT[tau][tt][r], bq[tau - t_lo][r], accJ[tt]);
         };
-        using ic0 = std::integral_constant<int, 0>;
-        using icg = std::integral_constant<int, TG>;
-        using ica = std::integral_constant<int, NTILE>;
         int sc = 0;
         float wprev = 0.0f;
         if constexpr (PROF != 0) tlast = __builtin_readcyclecounter();

@@ -218,3 +218,30 @@ def test_fast_kernels_vs_oracle(shape, interp, method, seq, gpu_lib):
                 assert e <= TIGHT_G, (nm + " adjoint kernel on oracle z_out", k, e)
         again = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_AUTO)     # hand-off protocol: bit-reproducible
         assert np.array_equal(again["dz0"], iso["dz0"]) and all(np.array_equal(again["grads"][k], iso["grads"][k]) for k in iso["grads"])
+
+
+def test_gpu_coefficient_builders_match_reference(gpu_lib):
+    """ncde_prepare_linear / ncde_prepare_cubic against the reference's builders
+    (golden g8) -- bit-exact for the rectilinear preparation and the spline, 1e-6 for the NaN fill -- and at
+    BASELINE size against the host mirrors; then the prepared coefficients drive the solve end to end."""
+    import os
+    import ncde_amd
+    f = np.load(os.path.join(gu.GOLD, "g8_coeffs.npz"))
+    xm = torch.from_numpy(f["x_missing"]).cuda()
+    assert gu.relerr(ncde_amd.linear_interpolation_coeffs(xm).cpu().numpy(), f["linear"]) <= 1e-6
+    assert np.array_equal(ncde_amd.linear_interpolation_coeffs(xm, rectilinear=0).cpu().numpy(), f["rectilinear"])
+    xc = torch.from_numpy(f["x_clean"]).cuda()
+    assert np.array_equal(ncde_amd.natural_cubic_coeffs(xc).cpu().numpy(), f["cubic"])
+    assert np.array_equal(ncde_amd.natural_cubic_coeffs(xc[:, :2].contiguous()).cpu().numpy(), f["cubic_len2"])
+    # extra batch dimensions, as torchcde allows
+    assert np.array_equal(ncde_amd.natural_cubic_coeffs(torch.stack([xc, xc])).cpu().numpy(), np.stack([f["cubic"], f["cubic"]]))
+    with pytest.raises(AssertionError):
+        bad = xm.clone(); bad[0, 1, 0] = float("nan")
+        ncde_amd.linear_interpolation_coeffs(bad, rectilinear=0)
+    # BASELINE cfg2 / cfg4 sizes against the host mirrors (themselves pinned to the reference)
+    x2 = gu.data.synthetic_series(512, 200, 19, missing=0.3, seed=1234)
+    got = ncde_amd.linear_interpolation_coeffs(torch.from_numpy(x2).cuda(), rectilinear=0).cpu().numpy()
+    assert np.array_equal(got, gu.data.make_rectilinear_coeffs(512, 200, 19, missing=0.3, seed=1234))
+    x4 = gu.data.synthetic_series(256, 182, 3, seed=1234)
+    got = ncde_amd.natural_cubic_coeffs(torch.from_numpy(x4).cuda()).cpu().numpy()
+    assert np.array_equal(got, gu.data.natural_cubic_coeffs(x4))

@@ -197,3 +197,20 @@ def test_time_mode_detection():
         solver._time_mode(X, torch.tensor([0.0, 2.0, 1.0]))
     with pytest.raises(NotImplementedError):
         solver._time_mode(X, torch.tensor([0.0, 2.5]))
+
+
+def test_host_coefficient_mirrors_match_reference_golden():
+    """data.py's numpy builders against outputs of the reference's torchcde builders (golden g8)."""
+    import golden_util as gu
+    f = np.load(os.path.join(gu.GOLD, "g8_coeffs.npz"))
+    assert gu.relerr(ncde_amd.data.linear_interpolation_coeffs(f["x_missing"]), f["linear"]) <= 1e-6
+    assert np.array_equal(ncde_amd.data.linear_interpolation_coeffs(f["x_missing"], rectilinear=0), f["rectilinear"])
+    assert np.array_equal(ncde_amd.data.natural_cubic_coeffs(f["x_clean"]), f["cubic"])
+    assert np.array_equal(ncde_amd.data.natural_cubic_coeffs(f["x_clean"][:, :2]), f["cubic_len2"])
+
+
+def test_gpu_coefficient_builders_refuse_cpu_tensors():
+    with pytest.raises(NotImplementedError):
+        ncde_amd.linear_interpolation_coeffs(torch.zeros(2, 5, 3))
+    with pytest.raises(NotImplementedError):
+        ncde_amd.natural_cubic_coeffs(torch.zeros(2, 5, 3))
