@@ -239,3 +239,80 @@ def solve_adjoint(control, field, z_out, grad_out, method="rk4", sequence=False,
         y, a, g = sweep(T - 1, 0, y, a, g)
         a = a + grad_out[:, 0]
     return a, list(g)
+
+
+def solve_discrete_backward(control, field, z0, grad_out, method="rk4", sequence=False):
+    """Exact gradient of the DISCRETISED solve (what ``cdeint(..., adjoint=False)`` + autograd computes:
+    modules/torchcde/torchcde/solver.py:224 picks ``odeint``; backprop runs through
+    solvers.py:94-119 and fixed_grid.py:6-29 / rk_common.py:106-114).  Hand-written reverse sweep:
+    the stage inputs of every step are recomputed from the forward solve, then each step is
+    transposed stage by stage (no autograd).
+
+    grad_out: [B, n_out, H].  Returns (dL/dz0 [B,H], [dL/dparam ...] in Field.unique_params() order).
+    """
+    stage_plan(method)
+    z0 = torch.as_tensor(z0)
+    grad_out = torch.as_tensor(grad_out)
+    T = control.n_knots
+    params = field.unique_params()
+    # forward, keeping the stage inputs and stage times of every step
+    steps = []
+    y = z0
+    for n in range(T - 1):
+        t0, t1 = _f32(n), _f32(n + 1)
+        dt = t1 - t0
+        if method == "euler":
+            ts, Ys = [t0], [y]
+            y = y + dt * field.g(y, control.derivative(t0))
+        elif method == "midpoint":
+            half = 0.5 * dt
+            k1 = field.g(y, control.derivative(t0))
+            ym = y + k1 * half
+            ts, Ys = [t0, t0 + half], [y, ym]
+            y = y + dt * field.g(ym, control.derivative(t0 + half))
+        else:
+            k1 = field.g(y, control.derivative(t0))
+            y2 = y + dt * k1 * _ONE_THIRD
+            k2 = field.g(y2, control.derivative(t0 + dt * _ONE_THIRD))
+            y3 = y + dt * (k2 - k1 * _ONE_THIRD)
+            k3 = field.g(y3, control.derivative(t0 + dt * _TWO_THIRDS))
+            y4 = y + dt * (k1 - k2 + k3)
+            k4 = field.g(y4, control.derivative(t1))
+            ts, Ys = [t0, t0 + dt * _ONE_THIRD, t0 + dt * _TWO_THIRDS, t1], [y, y2, y3, y4]
+            y = y + (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
+        steps.append((ts, Ys, dt))
+
+    g = [torch.zeros_like(p) for p in params]
+
+    def pull(t, Y, ck):
+        """cotangent ck of k = g(t, Y)  ->  cotangent of Y; parameter gradients accumulated."""
+        dx = control.derivative(t)
+        _, saved = field.g(Y, dx, save=True)
+        dY, dp = field.g_vjp(saved, dx, ck)
+        for i, v in enumerate(dp):
+            g[i] = g[i] + v
+        return dY
+
+    a = grad_out[:, -1].clone()
+    for n in range(T - 2, -1, -1):
+        ts, Ys, dt = steps[n]
+        if method == "euler":
+            a = a + pull(ts[0], Ys[0], dt * a)
+        elif method == "midpoint":
+            dYm = pull(ts[1], Ys[1], dt * a)
+            dY1 = pull(ts[0], Ys[0], (0.5 * dt) * dYm)
+            a = a + dYm + dY1
+        else:
+            ck4 = a * dt * 0.125
+            dY4 = pull(ts[3], Ys[3], ck4)
+            ck3 = 3 * ck4 + dt * dY4
+            dY3 = pull(ts[2], Ys[2], ck3)
+            ck2 = 3 * ck4 - dt * dY4 + dt * dY3
+            dY2 = pull(ts[1], Ys[1], ck2)
+            ck1 = ck4 + dt * dY4 - (dt * _ONE_THIRD) * dY3 + (dt * _ONE_THIRD) * dY2
+            dY1 = pull(ts[0], Ys[0], ck1)
+            a = a + dY4 + dY3 + dY2 + dY1
+        if sequence and n > 0:
+            a = a + grad_out[:, n]
+    a = a + grad_out[:, 0]           # row 0 of the solution is z0 itself
+    return a, g

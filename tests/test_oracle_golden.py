@@ -39,6 +39,29 @@ def test_oracle_matches_reference_golden(name):
     assert nfe[0] == 2 * stages * (ctl.n_knots - 1)      # same nfe accounting as base.py:90 (fwd + adjoint)
 
 
+def _check_grads(m, ex, dz0, gp, prefix, tol):
+    assert gu.relerr(dz0, ex[prefix + "dz0"]) <= tol
+    for pname, g in zip(m["param_names"], gp):
+        key = prefix + "d" + pname
+        if key in ex:
+            assert gu.relerr(g, ex[key]) <= tol, pname
+        else:
+            assert gu.relerr(np.asarray(g)[::16], ex[key + "__rows16"]) <= tol, pname
+            assert gu.relerr(np.asarray(g, dtype=np.float64).sum(0), ex[key + "__colsum"]) <= tol, pname
+
+
+@pytest.mark.parametrize("name", gu.SOLVE_CASES)
+def test_oracle_discrete_backward_matches_reference_golden(name):
+    """adjoint=False: the reference backpropagates through the solver with autograd; the oracle's hand-written
+    reverse sweep must give the same gradients (fixtures bp_*)."""
+    case = gu.load_case(name)
+    m = case["meta"]
+    ctl = orc.Control(case["coeffs"], m["kind"])
+    ex = case["expect"]
+    dz0, gp = orc.solve_discrete_backward(ctl, gu.oracle_field(case), case["z0"], ex["grad_out"], m["method"], m["sequence"])
+    _check_grads(m, ex, dz0.numpy(), [g.numpy() for g in gp], "bp_", TOL_G)
+
+
 def test_oracle_full_size_cfg2_forward():
     """BASELINE config 2 at full size (B=4096, T=399): z_T from the reference, inputs regenerated."""
     f = np.load(os.path.join(gu.GOLD, "g5_cfg2_full.npz"))
