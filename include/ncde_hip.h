@@ -112,7 +112,8 @@ const char* ncde_last_error_string(void);
 /* number of solution rows per sample: 2 (interval) or T (knots) */
 int ncde_num_outputs(const NcdeProblem* p);
 
-/* scratch bytes needed by ncde_forward (pass = 0) / ncde_adjoint (pass = 1); negative = NcdeStatus */
+/* scratch bytes needed by ncde_forward[_record] (pass = 0) / ncde_adjoint (pass = 1) / ncde_backward (pass = 2);
+ * negative = NcdeStatus */
 int64_t ncde_workspace_bytes(const NcdeProblem* p, int pass);
 
 /* name of the kernel family the call would dispatch to ("generic", "fast_h32_c20", ...); NULL on error */
@@ -127,9 +128,21 @@ int ncde_forward(const NcdeProblem* p, float* out, void* workspace, size_t works
 int ncde_adjoint(const NcdeProblem* p, const float* z_out, const float* grad_out, const NcdeGrads* grads,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- exact backward of the DISCRETISED solve: what cdeint(..., adjoint=False) + autograd computes in the reference
+ * (modules/torchcde/torchcde/solver.py:224 picks torchdiffeq.odeint; autograd then tapes solvers.py:94-119 and
+ * fixed_grid.py:6-29 / rk_common.py:106-114).  Instead of a tape, the forward records every stage input
+ * ("stage record", [(T-1)*stages][B][H] fp32, caller-owned, ncde_stage_record_bytes() bytes) and the backward
+ * transposes the solve stage by stage, re-evaluating f_theta at the recorded inputs.
+ *   ncde_forward_record  = ncde_forward + the stage record
+ *   ncde_backward        : stage record + dL/dz_out -> dL/dz0, dL/dtheta   (workspace: ncde_workspace_bytes(p, 2)) */
+int64_t ncde_stage_record_bytes(const NcdeProblem* p);
+int ncde_forward_record(const NcdeProblem* p, float* out, float* stages, void* workspace, size_t workspace_bytes, void* stream);
+int ncde_backward(const NcdeProblem* p, const float* stages, const float* grad_out, const NcdeGrads* grads, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
 /* Timing helper for benchmarks: runs `iters` back-to-back launches of the dominant kernel of the given
  * pass on `stream`, bracketed by HIP events on that same stream, and returns the mean milliseconds per
- * launch in *ms_per_launch (this call DOES synchronise). */
+ * launch in *ms_per_launch (this call DOES synchronise).  pass = 1: `out` is z_out; pass = 2: `out` is the stage record. */
 int ncde_time_kernel(const NcdeProblem* p, int pass, float* out, const float* grad_out, const NcdeGrads* grads,
                      void* workspace, size_t workspace_bytes, void* stream, int iters, float* ms_per_launch);
 

@@ -56,6 +56,7 @@ EXPORTS = (
     "ncde_version", "ncde_last_error_string", "ncde_num_outputs", "ncde_workspace_bytes",
     "ncde_kernel_name", "ncde_forward", "ncde_adjoint", "ncde_time_kernel",
     "ncde_prepare_workspace_bytes", "ncde_prepare_linear", "ncde_prepare_cubic",
+    "ncde_stage_record_bytes", "ncde_forward_record", "ncde_backward",
 )
 
 _LIB = None
@@ -93,6 +94,12 @@ def lib():
     h.ncde_adjoint.restype = ctypes.c_int
     h.ncde_time_kernel.argtypes = [P, ctypes.c_int, vp, vp, G, vp, sz, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
     h.ncde_time_kernel.restype = ctypes.c_int
+    h.ncde_stage_record_bytes.argtypes = [P]
+    h.ncde_stage_record_bytes.restype = ctypes.c_int64
+    h.ncde_forward_record.argtypes = [P, vp, vp, vp, sz, vp]
+    h.ncde_forward_record.restype = ctypes.c_int
+    h.ncde_backward.argtypes = [P, vp, vp, G, vp, sz, vp]
+    h.ncde_backward.restype = ctypes.c_int
     i32 = ctypes.c_int
     h.ncde_prepare_workspace_bytes.argtypes = [i32, i32, i32, i32]
     h.ncde_prepare_workspace_bytes.restype = ctypes.c_int64

@@ -58,7 +58,7 @@ int validate(const NcdeProblem* p) {
 int generic_supported(const NcdeProblem* p, const Layout& y, int pass) {
     if (pass == 0 && y.lds_fwd > (size_t)kLdsLimit)
         return fail(NCDE_ERR_UNSUPPORTED, "generic forward needs %zu B of LDS (> %d)", y.lds_fwd, kLdsLimit);
-    if (pass == 1) {
+    if (pass >= 1) {
         if (y.lds_adj > (size_t)kLdsLimit) return fail(NCDE_ERR_UNSUPPORTED, "generic adjoint needs %zu B of LDS (> %d)", y.lds_adj, kLdsLimit);
         if (y.dlast > 128) return fail(NCDE_ERR_UNSUPPORTED, "generic adjoint supports a last hidden width <= 128 (got %d)", y.dlast);
     }
@@ -85,31 +85,36 @@ int launch_reduce(const NcdeProblem* p, const Layout& y, const NcdeGrads* g, con
     return NCDE_OK;
 }
 
-int launch_forward(const NcdeProblem* p, const Layout& y, int family, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
+int launch_forward(const NcdeProblem* p, const Layout& y, int family, float* out, float* stages, void* ws, size_t ws_bytes,
+                   hipStream_t st) {
     if (family == 1) {
-        const int rc = ncde_fast_forward(p, out, ws, ws_bytes, st);
+        const int rc = ncde_fast_forward(p, out, stages, ws, ws_bytes, st);
         if (rc != NCDE_OK) return fail(rc, "fast forward launch failed");
         return NCDE_OK;
     }
     KArgs a;
     fill_kargs(p, y, &a);
     a.out = out;
+    a.stages = stages;
     HIP_TRY(hipFuncSetAttribute((const void*)ncde_fwd_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)y.lds_fwd));
     hipLaunchKernelGGL(ncde_fwd_generic, dim3(y.n_wg), dim3(256), y.lds_fwd, st, a);
     HIP_TRY(hipGetLastError());
     return NCDE_OK;
 }
 
-int launch_adjoint(const NcdeProblem* p, const Layout& y, int family, const float* z_out, const float* grad_out,
-                   const NcdeGrads* g, void* ws, size_t ws_bytes, hipStream_t st, bool main_kernel_only) {
+// discrete = false: continuous adjoint, `src` = z_out; discrete = true: exact backward, `src` = the stage record
+int launch_adjoint(const NcdeProblem* p, const Layout& y, int family, const float* src, const float* grad_out,
+                   const NcdeGrads* g, void* ws, size_t ws_bytes, hipStream_t st, bool main_kernel_only, bool discrete) {
     if (family == 1) {
-        const int rc = ncde_fast_adjoint(p, z_out, grad_out, g, ws, ws_bytes, st, main_kernel_only);
+        const int rc = ncde_fast_adjoint(p, src, grad_out, g, ws, ws_bytes, st, main_kernel_only, discrete);
         if (rc != NCDE_OK) return fail(rc, "fast adjoint launch failed");
         return NCDE_OK;
     }
     KArgs a;
     fill_kargs(p, y, &a);
-    a.z_out = z_out; a.grad_out = grad_out; a.grad_z0 = g->grad_z0;
+    a.grad_out = grad_out; a.grad_z0 = g->grad_z0;
+    if (discrete) { a.stages = const_cast<float*>(src); a.discrete = 1; }
+    else a.z_out = src;
     a.gpart = (float*)ws;
     HIP_TRY(hipFuncSetAttribute((const void*)ncde_adj_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)y.lds_adj));
     hipLaunchKernelGGL(ncde_adj_generic, dim3(y.n_wg), dim3(256), y.lds_adj, st, a);
@@ -142,12 +147,19 @@ int64_t ncde_workspace_bytes(const NcdeProblem* p, int pass) {
     return (int64_t)sizeof(float) * (int64_t)y.n_wg * (int64_t)y.theta_size + 256;
 }
 
+int64_t ncde_stage_record_bytes(const NcdeProblem* p) {
+    const int rc = validate(p);
+    if (rc != NCDE_OK) return rc;
+    const int S = p->method == NCDE_RK4_38 ? 4 : (p->method == NCDE_MIDPOINT ? 2 : 1);
+    return (int64_t)sizeof(float) * (int64_t)(p->n_knots - 1) * S * (int64_t)p->batch * p->hidden;
+}
+
 const char* ncde_kernel_name(const NcdeProblem* p, int pass) {
     if (validate(p) != NCDE_OK) return nullptr;
     const Layout y = make_layout(p);
     const int fam = select_family(p, y, pass);
     if (fam < 0) return nullptr;
-    return fam == 1 ? ncde_fast_kernel_name(p, pass) : (pass == 0 ? "ncde_fwd_generic" : "ncde_adj_generic");
+    return fam == 1 ? ncde_fast_kernel_name(p, pass) : (pass == 0 ? "ncde_fwd_generic" : (pass == 1 ? "ncde_adj_generic" : "ncde_adj_generic<discrete>"));
 }
 
 int ncde_forward(const NcdeProblem* p, float* out, void* workspace, size_t workspace_bytes, void* stream) {
@@ -159,7 +171,33 @@ int ncde_forward(const NcdeProblem* p, float* out, void* workspace, size_t works
     if (fam < 0) return fam;
     const int64_t need = ncde_workspace_bytes(p, 0);
     if (need > 0 && (!workspace || (int64_t)workspace_bytes < need)) return fail(NCDE_ERR_WORKSPACE, "workspace %zu B < %lld B", workspace_bytes, (long long)need);
-    return launch_forward(p, y, fam, out, workspace, workspace_bytes, (hipStream_t)stream);
+    return launch_forward(p, y, fam, out, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ncde_forward_record(const NcdeProblem* p, float* out, float* stages, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = validate(p);
+    if (rc != NCDE_OK) return rc;
+    if (!out || !stages) return fail(NCDE_ERR_INVALID, "out/stages is NULL");
+    if (p->flags & NCDE_FLAG_DEBUG_PROFILE) return fail(NCDE_ERR_UNSUPPORTED, "no instrumented recording forward");
+    const Layout y = make_layout(p);
+    const int fam = select_family(p, y, 0);
+    if (fam < 0) return fam;
+    const int64_t need = ncde_workspace_bytes(p, 0);
+    if (need > 0 && (!workspace || (int64_t)workspace_bytes < need)) return fail(NCDE_ERR_WORKSPACE, "workspace %zu B < %lld B", workspace_bytes, (long long)need);
+    return launch_forward(p, y, fam, out, stages, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ncde_backward(const NcdeProblem* p, const float* stages, const float* grad_out, const NcdeGrads* grads, void* workspace,
+                  size_t workspace_bytes, void* stream) {
+    int rc = validate(p);
+    if (rc != NCDE_OK) return rc;
+    if (!stages || !grad_out || !grads || !grads->grad_z0) return fail(NCDE_ERR_INVALID, "NULL stages/grad_out/grads");
+    const Layout y = make_layout(p);
+    const int fam = select_family(p, y, 2);
+    if (fam < 0) return fam;
+    const int64_t need = ncde_workspace_bytes(p, 2);
+    if (!workspace || (int64_t)workspace_bytes < need) return fail(NCDE_ERR_WORKSPACE, "workspace %zu B < %lld B", workspace_bytes, (long long)need);
+    return launch_adjoint(p, y, fam, stages, grad_out, grads, workspace, workspace_bytes, (hipStream_t)stream, false, true);
 }
 
 int ncde_adjoint(const NcdeProblem* p, const float* z_out, const float* grad_out, const NcdeGrads* grads, void* workspace,
@@ -172,7 +210,7 @@ int ncde_adjoint(const NcdeProblem* p, const float* z_out, const float* grad_out
     if (fam < 0) return fam;
     const int64_t need = ncde_workspace_bytes(p, 1);
     if (!workspace || (int64_t)workspace_bytes < need) return fail(NCDE_ERR_WORKSPACE, "workspace %zu B < %lld B", workspace_bytes, (long long)need);
-    return launch_adjoint(p, y, fam, z_out, grad_out, grads, workspace, workspace_bytes, (hipStream_t)stream, false);
+    return launch_adjoint(p, y, fam, z_out, grad_out, grads, workspace, workspace_bytes, (hipStream_t)stream, false, false);
 }
 
 int ncde_time_kernel(const NcdeProblem* p, int pass, float* out, const float* grad_out, const NcdeGrads* grads, void* workspace,
@@ -180,6 +218,7 @@ int ncde_time_kernel(const NcdeProblem* p, int pass, float* out, const float* gr
     int rc = validate(p);
     if (rc != NCDE_OK) return rc;
     if (iters < 1 || !ms_per_launch) return fail(NCDE_ERR_INVALID, "iters < 1 or NULL result");
+    if (pass < 0 || pass > 2) return fail(NCDE_ERR_INVALID, "pass %d outside {0, 1, 2}", pass);
     const Layout y = make_layout(p);
     const int fam = select_family(p, y, pass);
     if (fam < 0) return fam;
@@ -190,8 +229,8 @@ int ncde_time_kernel(const NcdeProblem* p, int pass, float* out, const float* gr
     // one untimed launch (also sets function attributes), then `iters` timed ones
     for (int it = -1; it < iters; ++it) {
         if (it == 0) HIP_TRY(hipEventRecord(e0, st));
-        if (pass == 0) rc = launch_forward(p, y, fam, out, workspace, workspace_bytes, st);
-        else rc = launch_adjoint(p, y, fam, out, grad_out, grads, workspace, workspace_bytes, st, true);
+        if (pass == 0) rc = launch_forward(p, y, fam, out, nullptr, workspace, workspace_bytes, st);
+        else rc = launch_adjoint(p, y, fam, out, grad_out, grads, workspace, workspace_bytes, st, true, pass == 2);
         if (rc != NCDE_OK) return rc;
     }
     HIP_TRY(hipEventRecord(e1, st));

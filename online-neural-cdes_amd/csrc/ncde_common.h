@@ -29,6 +29,9 @@ struct KArgs {
     int gW_off[NCDE_MAX_LAYERS], gb_off[NCDE_MAX_LAYERS];
     int gWo_off, gbo_off, theta_size;
     int gacc_in_lds;  // generic adjoint: keep the partial in LDS and flush at the end
+    // exact discrete backward (adjoint=False): record of every stage input, [(n*S + j)][B][H]
+    float* stages;    // forward: written when non-null; backward: read
+    int discrete;     // adjoint kernels: 1 = transpose the discretised solve instead of the continuous adjoint
 };
 
 __device__ __forceinline__ int ru4(int x) { return (x + 3) & ~3; }

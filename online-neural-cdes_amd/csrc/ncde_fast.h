@@ -7,6 +7,6 @@
 bool ncde_fast_supported(const NcdeProblem* p, int pass);
 const char* ncde_fast_kernel_name(const NcdeProblem* p, int pass);
 int64_t ncde_fast_workspace_bytes(const NcdeProblem* p, int pass);
-int ncde_fast_forward(const NcdeProblem* p, float* out, void* ws, size_t ws_bytes, hipStream_t st);
+int ncde_fast_forward(const NcdeProblem* p, float* out, float* stages, void* ws, size_t ws_bytes, hipStream_t st);
 int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* grad_out, const NcdeGrads* g, void* ws,
-                      size_t ws_bytes, hipStream_t st, bool main_kernel_only);
+                      size_t ws_bytes, hipStream_t st, bool main_kernel_only, bool discrete);

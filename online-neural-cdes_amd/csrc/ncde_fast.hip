@@ -175,6 +175,11 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_fwd_fast(KArgs a) {
             const int idx = piece_index(t, a.n_pieces);
             const float frac = t - (float)idx;
             const float* dxp = dxs[idx % 3] + s * DXW;
+            if (a.stages != nullptr && wave == ((n * S + j) % NW) && valid) {  // record the stage input (exact backward)
+                float* rec = a.stages + ((long long)(n * S + j) * a.B + bs) * H;
+#pragma unroll
+                for (int ks = 0; ks < HB; ++ks) rec[4 * ks + g] = zreg[ks];
+            }
             // ---- hidden layers, register to register -------------------------------------------------
             f32x4 acc[HT];
             float hB[KH];
@@ -489,6 +494,14 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
             const int idx = piece_index(t, a.n_pieces);
             const float frac = t - (float)idx;
             const float* dxp = dxs[idx % 3] + s * DXW;
+            if (a.stages != nullptr && wave == ((n * S + j) % NW) && valid) {  // record the stage input (exact backward)
+                float* rec = a.stages + ((long long)(n * S + j) * a.B + bs) * H;
+#pragma unroll
+                for (int c = 0; c < KC0; ++c) {
+                    *reinterpret_cast<f32x4*>(rec + 32 * c + 8 * g) = (f32x4){zreg[c][0], zreg[c][1], zreg[c][2], zreg[c][3]};
+                    *reinterpret_cast<f32x4*>(rec + 32 * c + 8 * g + 4) = (f32x4){zreg[c][4], zreg[c][5], zreg[c][6], zreg[c][7]};
+                }
+            }
             // ---- hidden layers ---------------------------------------------------------------------------
             f32x4 acc[HT];
             float hv[KC][8];
@@ -2423,6 +2436,7 @@ bool ncde_fast_supported(const NcdeProblem* p, int pass) {
     const FastEntry* e = find_entry(p);
     if (!e) return false;
     if (pass == 0) return true;
+    if (pass == 2) return false;  // exact discrete backward: generic family only (for now)
     return e->adj != nullptr && e->adj_layers == p->n_layers;
 }
 
@@ -2444,7 +2458,7 @@ int64_t ncde_fast_workspace_bytes(const NcdeProblem* p, int pass) {
            ((p->flags & 0x200u) ? (int64_t)p->n_knots * 4 * 5 * 64 * 4 + 256 : 0);
 }
 
-int ncde_fast_forward(const NcdeProblem* p, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
+int ncde_fast_forward(const NcdeProblem* p, float* out, float* stages, void* ws, size_t ws_bytes, hipStream_t st) {
     (void)ws_bytes;
     const FastEntry* e = find_entry(p);
     if (!e) return NCDE_ERR_UNSUPPORTED;
@@ -2454,6 +2468,7 @@ int ncde_fast_forward(const NcdeProblem* p, float* out, void* ws, size_t ws_byte
     KArgs a;
     fill_kargs(p, y, &a);
     a.out = out;
+    a.stages = stages;
     const bool bf3 = (p->flags & NCDE_FLAG_FP32_MFMA) == 0 && e->fwd_bf3 != nullptr;
     if (bf3) fn = e->fwd_bf3(p->interp, p->method);
     if (p->flags & NCDE_FLAG_DEBUG_PROFILE) {  // phase-cycle counters -> workspace [n_wg][NW][4] u64
@@ -2467,9 +2482,9 @@ int ncde_fast_forward(const NcdeProblem* p, float* out, void* ws, size_t ws_byte
 }
 
 int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* grad_out, const NcdeGrads* g, void* ws,
-                      size_t ws_bytes, hipStream_t st, bool main_kernel_only) {
+                      size_t ws_bytes, hipStream_t st, bool main_kernel_only, bool discrete) {
     (void)ws_bytes;
-    if (!ncde_fast_supported(p, 1)) return NCDE_ERR_UNSUPPORTED;
+    if (!ncde_fast_supported(p, discrete ? 2 : 1)) return NCDE_ERR_UNSUPPORTED;
     const FastEntry* e = find_entry(p);
     const bool v1 = (p->flags & NCDE_FLAG_ADJOINT_V1) != 0 || (e->adj2 == nullptr && e->adj3 == nullptr);
     const bool v3 = !v1 && e->adj3 != nullptr && !(p->flags & NCDE_FLAG_ADJOINT_V2);

@@ -141,6 +141,13 @@ extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_fwd_generic(KArgs
                 cur_idx = idx;
             }
             __syncthreads();
+            if (a.stages) {  // record the stage input for the exact discrete backward
+                float* rec = a.stages + ((long long)(n * S + j) * a.B + b0) * H;
+                for (int e = tid; e < 16 * H; e += GEN_THREADS) {
+                    const int s = e / H, h = e - s * H;
+                    if (b0 + s < a.B) rec[e] = YS[h * 16 + s];
+                }
+            }
             const float* in = YS;
             for (int l = 0; l < a.n_layers; ++l) {
                 float* outb = (l & 1) ? ACT1 : ACT0;
@@ -231,25 +238,40 @@ extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_adj_generic(KArgs
         for (int e = tid; e < a.theta_size; e += GEN_THREADS) gacc[e] = 0.0f;
     __syncthreads();
     const int last_row = a.n_out - 1;
+    const int S = n_stages(a.method);
+    const bool disc = a.discrete != 0;
     for (int e = tid; e < HS; e += GEN_THREADS) {
         const int h = e >> 4, s = e & 15, b = b0 + s;
         if (h < H && b < a.B) {
             const long long o = ((long long)b * a.n_out + last_row) * H + h;
-            const float y = a.z_out[o], g = a.grad_out[o];
-            Y0[e] = y; YS[e] = y; A0[e] = g; AS[e] = g;
+            const float g = a.grad_out[o];
+            A0[e] = g;
+            if (disc) {
+                AS[e] = a.method == NCDE_RK4_38 ? g * 0.125f : g;   // cotangent of the last stage's k
+            } else {
+                const float y = a.z_out[o];
+                Y0[e] = y; YS[e] = y; AS[e] = g;
+            }
         }
     }
-    const int S = n_stages(a.method);
     const int dlast = L ? a.dout[L - 1] : H;
     const int nks_o = (dlast + 3) >> 2, nhb = Hp >> 2, ncq = Cp >> 2, njt = (dlast + 15) >> 4;
     float* sc = SC + wave * 16 * 17;
     for (int n = a.T - 1; n >= 1; --n) {  // reverse step: knot n -> n-1, negated time s: -n -> -(n-1)
         for (int j = 0; j < S; ++j) {
             const float s0 = -(float)n;
-            const float t = -(s0 + stage_offset(a.method, j));
+            // discrete mode walks the stages of forward step n-1 -> n backwards, at their forward times
+            const float t = disc ? (float)(n - 1) + stage_offset(a.method, S - 1 - j) : -(s0 + stage_offset(a.method, j));
             const int idx = piece_index(t, a.n_pieces);
-            const float w = stage_weight(a.method, j);
+            const float w = disc ? 1.0f : stage_weight(a.method, j);
             load_dx(a, b0, idx, t - (float)idx, DX, Cp, tid);
+            if (disc) {
+                const float* rec = a.stages + ((long long)((n - 1) * S + (S - 1 - j)) * a.B + b0) * H;
+                for (int e = tid; e < 16 * H; e += GEN_THREADS) {
+                    const int s = e / H, h = e - s * H;
+                    YS[h * 16 + s] = b0 + s < a.B ? rec[e] : 0.0f;
+                }
+            }
             __syncthreads();
             // ---- recompute the stage forward, keeping x_1..x_L -------------------------------------
             const float* in = YS;
@@ -406,6 +428,40 @@ extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_adj_generic(KArgs
                     __syncthreads();
                     float* tmp = gpre; gpre = gx; gx = tmp;
                 }
+            }
+            if (disc) {
+                // ---- transpose of the Butcher step: KOA = dL/dY_stage; next cotangent / new a ----------------
+                // RK4 (3/8): c4 = a/8; c3 = 3 c4 + d4; c2 = 3 c4 - d4 + d3; c1 = c4 + d4 - d3/3 + d2/3; a += d4+d3+d2+d1
+                for (int e = tid; e < HS; e += GEN_THREADS) {
+                    const float d = KOA[e];
+                    float a0 = A0[e];
+                    bool last = false;
+                    float next = 0.0f;
+                    if (a.method == NCDE_RK4_38) {
+                        const float c4 = a0 * 0.125f;
+                        if (j == 0) { KA1[e] = d; next = 3.0f * c4 + d; }
+                        else if (j == 1) { KA2[e] = d; next = (3.0f * c4 - KA1[e]) + d; }
+                        else if (j == 2) { KY1[e] = d; next = ((c4 + KA1[e]) - 0.333333343267440796f * KA2[e]) + 0.333333343267440796f * d; }
+                        else { a0 = (((a0 + KA1[e]) + KA2[e]) + KY1[e]) + d; last = true; }
+                    } else if (a.method == NCDE_MIDPOINT) {
+                        if (j == 0) { KA1[e] = d; next = 0.5f * d; }
+                        else { a0 = (a0 + KA1[e]) + d; last = true; }
+                    } else {
+                        a0 = a0 + d; last = true;
+                    }
+                    if (last) {
+                        const int h = e >> 4, s = e & 15, b = b0 + s;
+                        const bool valid = h < H && b < a.B;
+                        if (a.output == NCDE_OUT_KNOTS || n == 1)
+                            a0 = a0 + (valid ? a.grad_out[((long long)b * a.n_out + (a.output == NCDE_OUT_KNOTS ? n - 1 : 0)) * H + h] : 0.0f);
+                        A0[e] = a0;
+                        next = a.method == NCDE_RK4_38 ? a0 * 0.125f : a0;
+                        if (n == 1 && valid) a.grad_z0[(long long)b * H + h] = a0;
+                    }
+                    AS[e] = next;
+                }
+                __syncthreads();
+                continue;
             }
             // ---- Butcher bookkeeping in negated time: dy/ds = -f, da/ds = +a^T df/dy ----------------
             for (int e = tid; e < HS; e += GEN_THREADS) {

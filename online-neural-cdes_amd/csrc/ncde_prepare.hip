@@ -146,7 +146,6 @@ __global__ void ncde_cubic_diag_kernel(int L, float* diag_swept) {
     }
 }
 
-thread_local char g_prep_err[256] = "";
 
 }  // namespace
 

@@ -105,7 +105,10 @@ def _check_tensor(x, name):
 
 
 class _FusedCdeint(torch.autograd.Function):
-    """forward = ncde_forward, backward = ncde_adjoint (the continuous adjoint of adjoint.py:37-145)."""
+    """adjoint=True : forward = ncde_forward, backward = ncde_adjoint (continuous adjoint, adjoint.py:37-145).
+    adjoint=False: forward = ncde_forward_record (solution + every stage input), backward = ncde_backward, the exact
+    transpose of the discretised solve -- the gradients autograd produces in the reference when ``odeint`` is
+    taped (solver.py:224), without a tape."""
 
     @staticmethod
     def forward(ctx, z0, coeffs, cfg, *params):
@@ -114,23 +117,35 @@ class _FusedCdeint(torch.autograd.Function):
         p = build_problem(coeffs, cfg["interp"], z0c, spec, cfg["method"], cfg["output"], cfg["flags"])
         n_out = coeffs.shape[1] + (1 if cfg["interp"] == "cubic" else 0) if cfg["output"] == _lib.OUT_KNOTS else 2
         out = torch.empty(z0.shape[0], n_out, z0.shape[1], dtype=torch.float32, device=z0.device)
+        record = (not cfg["adjoint"]) and any(ctx.needs_input_grad)
+        stages = None
         with torch.cuda.device(z0.device):   # the C-ABI launches on the calling thread's current device / stream
             ws = _workspace(p, 0, z0.device)
-            rc = _lib.lib().ncde_forward(ctypes.byref(p), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr())
-        _lib.check(rc, "ncde_forward")
+            if record:
+                nbytes = _lib.check(_lib.lib().ncde_stage_record_bytes(ctypes.byref(p)), "ncde_stage_record_bytes")
+                stages = torch.empty(max(int(nbytes) // 4, 1), dtype=torch.float32, device=z0.device)
+                rc = _lib.lib().ncde_forward_record(ctypes.byref(p), out.data_ptr(), stages.data_ptr(), ws.data_ptr(),
+                                                    ws.numel(), _stream_ptr())
+            else:
+                rc = _lib.lib().ncde_forward(ctypes.byref(p), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr())
+        _lib.check(rc, "ncde_forward_record" if record else "ncde_forward")
         ctx.cfg = cfg
         ctx.coeffs = coeffs
-        ctx.save_for_backward(out, *params)
+        ctx.recorded = record
+        if record:
+            ctx.save_for_backward(out, stages, *params)
+        else:
+            ctx.save_for_backward(out, *params)
         ctx.z0_shape = z0.shape
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         cfg = ctx.cfg
-        if not cfg["adjoint"]:
-            raise NotImplementedError("adjoint=False (backprop through the solver) is not implemented on the fused "
-                                      "path yet; use adjoint=True")
-        out, *params = ctx.saved_tensors
+        if ctx.recorded:
+            out, stages, *params = ctx.saved_tensors
+        else:
+            out, *params = ctx.saved_tensors
         spec, coeffs = cfg["spec"], ctx.coeffs
         dev = out.device
         grad_out = grad_out.contiguous().float()
@@ -145,12 +160,17 @@ class _FusedCdeint(torch.autograd.Function):
             g.grad_layer_W[i], g.grad_layer_b[i] = gbuf[id(w)].data_ptr(), gbuf[id(b)].data_ptr()
         g.grad_Wo, g.grad_bo = gbuf[id(spec.Wo)].data_ptr(), gbuf[id(spec.bo)].data_ptr()
         with torch.cuda.device(dev):
-            ws = _workspace(p, 1, dev)
-            rc = _lib.lib().ncde_adjoint(ctypes.byref(p), out.data_ptr(), grad_out.data_ptr(), ctypes.byref(g),
-                                         ws.data_ptr(), ws.numel(), _stream_ptr())
-        _lib.check(rc, "ncde_adjoint")
-        if cfg["func"] is not None and hasattr(cfg["func"], "nfe"):
-            cfg["func"].nfe += cfg["nfe_per_solve"]
+            if ctx.recorded:
+                ws = _workspace(p, 2, dev)
+                rc = _lib.lib().ncde_backward(ctypes.byref(p), stages.data_ptr(), grad_out.data_ptr(), ctypes.byref(g),
+                                              ws.data_ptr(), ws.numel(), _stream_ptr())
+            else:
+                ws = _workspace(p, 1, dev)
+                rc = _lib.lib().ncde_adjoint(ctypes.byref(p), out.data_ptr(), grad_out.data_ptr(), ctypes.byref(g),
+                                             ws.data_ptr(), ws.numel(), _stream_ptr())
+        _lib.check(rc, "ncde_backward" if ctx.recorded else "ncde_adjoint")
+        if not ctx.recorded and cfg["func"] is not None and hasattr(cfg["func"], "nfe"):
+            cfg["func"].nfe += cfg["nfe_per_solve"]   # the adjoint sweep re-evaluates f (base.py:90); autograd does not
         grads = []
         for q, needs in zip(params, ctx.needs_input_grad[3:]):
             grads.append(gbuf[id(q)] if needs else None)

@@ -241,21 +241,11 @@ def solve_adjoint(control, field, z_out, grad_out, method="rk4", sequence=False,
     return a, list(g)
 
 
-def solve_discrete_backward(control, field, z0, grad_out, method="rk4", sequence=False):
-    """Exact gradient of the DISCRETISED solve (what ``cdeint(..., adjoint=False)`` + autograd computes:
-    modules/torchcde/torchcde/solver.py:224 picks ``odeint``; backprop runs through
-    solvers.py:94-119 and fixed_grid.py:6-29 / rk_common.py:106-114).  Hand-written reverse sweep:
-    the stage inputs of every step are recomputed from the forward solve, then each step is
-    transposed stage by stage (no autograd).
-
-    grad_out: [B, n_out, H].  Returns (dL/dz0 [B,H], [dL/dparam ...] in Field.unique_params() order).
-    """
+def _forward_stages(control, field, z0, method):
+    """Forward solve keeping, per step, the stage times, the stage inputs and dt."""
     stage_plan(method)
     z0 = torch.as_tensor(z0)
-    grad_out = torch.as_tensor(grad_out)
     T = control.n_knots
-    params = field.unique_params()
-    # forward, keeping the stage inputs and stage times of every step
     steps = []
     y = z0
     for n in range(T - 1):
@@ -282,6 +272,27 @@ def solve_discrete_backward(control, field, z0, grad_out, method="rk4", sequence
             y = y + (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
         steps.append((ts, Ys, dt))
 
+    return steps
+
+
+def stage_record(control, field, z0, method="rk4"):
+    """Stage inputs of the forward solve as the C-ABI's stage record: [(T-1)*S, B, H] (step-major, stage-minor)."""
+    return torch.stack([Y for _, Ys, _ in _forward_stages(control, field, z0, method) for Y in Ys], dim=0)
+
+
+def solve_discrete_backward(control, field, z0, grad_out, method="rk4", sequence=False):
+    """Exact gradient of the DISCRETISED solve (what ``cdeint(..., adjoint=False)`` + autograd computes:
+    modules/torchcde/torchcde/solver.py:224 picks ``odeint``; backprop runs through
+    solvers.py:94-119 and fixed_grid.py:6-29 / rk_common.py:106-114).  Hand-written reverse sweep:
+    the stage inputs of every step are recomputed from the forward solve, then each step is
+    transposed stage by stage (no autograd).
+
+    grad_out: [B, n_out, H].  Returns (dL/dz0 [B,H], [dL/dparam ...] in Field.unique_params() order).
+    """
+    grad_out = torch.as_tensor(grad_out)
+    T = control.n_knots
+    params = field.unique_params()
+    steps = _forward_stages(control, field, z0, method)
     g = [torch.zeros_like(p) for p in params]
 
     def pull(t, Y, ck):

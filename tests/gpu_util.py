@@ -20,15 +20,15 @@ class CaseField(torch.nn.Module):
         return ncde_amd.FieldSpec([(self.p[w], self.p[b]) for w, b in self.layer_names], self.p["Wo"], self.p["bo"])
 
 
-def run_case(case, flags=_lib.FLAG_AUTO, device="cuda", need_grads=True):
-    """-> dict(z_out, dz0, grads{name: array}) computed by the HIP path."""
+def run_case(case, flags=_lib.FLAG_AUTO, device="cuda", need_grads=True, adjoint=True):
+    """-> dict(z_out, dz0, grads{name: array}) computed by the HIP path (adjoint=False: exact discrete backward)."""
     m = case["meta"]
     coeffs = torch.from_numpy(case["coeffs"]).to(device)
     X = (ncde_amd.LinearInterpolation if m["kind"] == "linear" else ncde_amd.NaturalCubicSpline)(coeffs)
     func = CaseField(case["params"], case["layers"], device)
     z0 = torch.from_numpy(case["z0"]).to(device).requires_grad_(True)
     t = X.grid_points if m["sequence"] else X.interval
-    out = ncde_amd.cdeint(X, func, z0, t, adjoint=True, method=m["method"], options={"step_size": 1},
+    out = ncde_amd.cdeint(X, func, z0, t, adjoint=adjoint, method=m["method"], options={"step_size": 1},
                           kernel_flags=flags)
     res = {"z_out": out.detach().cpu().numpy(), "nfe_fwd": func.nfe, "kernels": kernel_names(case, flags, device)}
     if need_grads:
@@ -41,9 +41,10 @@ def run_case(case, flags=_lib.FLAG_AUTO, device="cuda", need_grads=True):
     return res
 
 
-def run_adjoint_direct(case, z_out, flags=_lib.FLAG_AUTO, device="cuda"):
+def run_adjoint_direct(case, z_out, flags=_lib.FLAG_AUTO, device="cuda", stages=None):
     """Call ncde_adjoint through the C-ABI on a GIVEN forward solution (e.g. the reference's own z_out):
-    isolates the adjoint kernel from forward round-off (a last-bit change of z can flip a ReLU mask)."""
+    isolates the adjoint kernel from forward round-off (a last-bit change of z can flip a ReLU mask).
+    With `stages` (a stage record [(T-1)*S, B, H]) it calls ncde_backward (exact discrete backward) instead."""
     import ctypes
     from ncde_amd import solver
     m = case["meta"]
@@ -63,16 +64,24 @@ def run_adjoint_direct(case, z_out, flags=_lib.FLAG_AUTO, device="cuda"):
     for i, (w, b) in enumerate(spec.layers):
         g.grad_layer_W[i], g.grad_layer_b[i] = gbuf[id(w)].data_ptr(), gbuf[id(b)].data_ptr()
     g.grad_Wo, g.grad_bo = gbuf[id(spec.Wo)].data_ptr(), gbuf[id(spec.bo)].data_ptr()
-    ws = solver._workspace(p, 1, device)
-    rc = _lib.lib().ncde_adjoint(ctypes.byref(p), z_out.data_ptr(), gout.data_ptr(), ctypes.byref(g), ws.data_ptr(),
-                                 ws.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-    _lib.check(rc, "ncde_adjoint")
+    if stages is not None:
+        rec = torch.from_numpy(np.ascontiguousarray(stages)).to(device)
+        assert rec.numel() * 4 == _lib.lib().ncde_stage_record_bytes(ctypes.byref(p))
+        ws = solver._workspace(p, 2, device)
+        rc = _lib.lib().ncde_backward(ctypes.byref(p), rec.data_ptr(), gout.data_ptr(), ctypes.byref(g), ws.data_ptr(),
+                                      ws.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "ncde_backward")
+    else:
+        ws = solver._workspace(p, 1, device)
+        rc = _lib.lib().ncde_adjoint(ctypes.byref(p), z_out.data_ptr(), gout.data_ptr(), ctypes.byref(g), ws.data_ptr(),
+                                     ws.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "ncde_adjoint")
     torch.cuda.synchronize()
     return {"dz0": gz0.cpu().numpy(), "grads": {k: gbuf[id(v)].cpu().numpy() for k, v in func.p.items() if id(v) in gbuf}}
 
 
 def kernel_names(case, flags=_lib.FLAG_AUTO, device="cuda"):
-    """(forward, adjoint) kernel family names the C-ABI would dispatch this case to."""
+    """(forward, adjoint, discrete backward) kernel family names the C-ABI would dispatch this case to."""
     import ctypes
     from ncde_amd import solver
     m = case["meta"]
@@ -82,4 +91,4 @@ def kernel_names(case, flags=_lib.FLAG_AUTO, device="cuda"):
     p = solver.build_problem(coeffs, m["kind"], z0, func.fused_spec(), m["method"],
                              _lib.OUT_KNOTS if m["sequence"] else _lib.OUT_INTERVAL, flags)
     lib = _lib.lib()
-    return tuple((lib.ncde_kernel_name(ctypes.byref(p), k) or b"?").decode() for k in (0, 1))
+    return tuple((lib.ncde_kernel_name(ctypes.byref(p), k) or b"?").decode() for k in (0, 1, 2))

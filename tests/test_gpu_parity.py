@@ -23,16 +23,18 @@ E2E_G = 2e-4   # end-to-end gradient guard on the fixed seeded cases below (no R
 FLAGS = {"generic": 1, "auto": 0}
 
 
-def _grad_errors(case, res):
+def _grad_errors(case, res, prefix=""):
+    """prefix "" = continuous-adjoint fixtures, "bp_" = adjoint=False (backprop through the solver) fixtures."""
     ex, m = case["expect"], case["meta"]
-    errs = {"dz0": gu.relerr(res["dz0"], ex["dz0"])}
+    errs = {"dz0": gu.relerr(res["dz0"], ex[prefix + "dz0"])}
     for pname in m["param_names"]:
         g = res["grads"][pname]
-        if "d" + pname in ex:
-            errs[pname] = gu.relerr(g, ex["d" + pname])
+        key = prefix + "d" + pname
+        if key in ex:
+            errs[pname] = gu.relerr(g, ex[key])
         else:
-            errs[pname] = max(gu.relerr(g[::16], ex["d" + pname + "__rows16"]),
-                              gu.relerr(g.astype(np.float64).sum(0), ex["d" + pname + "__colsum"]))
+            errs[pname] = max(gu.relerr(g[::16], ex[key + "__rows16"]),
+                              gu.relerr(g.astype(np.float64).sum(0), ex[key + "__colsum"]))
     return errs
 
 
@@ -66,6 +68,29 @@ def test_generic_kernels_match_reference_golden(name, gpu_lib):
 @pytest.mark.parametrize("name", gu.SOLVE_CASES)
 def test_auto_dispatch_matches_reference_golden(name, gpu_lib):
     _check_case(name, FLAGS["auto"])
+
+
+@pytest.mark.parametrize("flags", ["generic", "auto"])
+@pytest.mark.parametrize("name", gu.SOLVE_CASES)
+def test_discrete_backward_matches_reference_golden(name, flags, gpu_lib):
+    """adjoint=False: ncde_forward_record + ncde_backward against the gradients the reference's
+    autograd produces by taping the solver (fixtures bp_*).  End to end at the documented tolerances, then the
+    backward kernel alone, fed the oracle's stage record, at the tight ones."""
+    import gpu_util
+    import ncde_oracle as orc
+    case = gu.load_case(name)
+    m, ex = case["meta"], case["expect"]
+    res = gpu_util.run_case(case, flags=FLAGS[flags], adjoint=False)
+    assert gu.relerr(res["z_out"], ex["z_out"]) <= TIGHT_Z
+    for k, e in _grad_errors(case, res, "bp_").items():
+        assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), ("end-to-end", k, e)
+    rec = orc.stage_record(orc.Control(case["coeffs"], m["kind"]), gu.oracle_field(case), case["z0"], m["method"]).numpy()
+    iso = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=FLAGS[flags], stages=rec)
+    for k, e in _grad_errors(case, iso, "bp_").items():
+        assert e <= TIGHT_G, ("backward kernel on the oracle's stage record", k, e)
+    stages = {"rk4": 4, "midpoint": 2, "euler": 1}[m["method"]]
+    n_knots = ex["z_out"].shape[1] if m["sequence"] else (case["coeffs"].shape[1] + (m["kind"] == "cubic"))
+    assert res["nfe"] == stages * (n_knots - 1)        # autograd does not re-evaluate f (base.py:90 counts forward calls)
 
 
 def test_full_size_cfg2_forward_vs_reference(gpu_lib):
