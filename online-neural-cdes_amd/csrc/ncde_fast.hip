@@ -1704,7 +1704,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
 //     partial per tile group right behind the chain wave and this stage's dWo blocks in its shadow; only the
 //     hidden-layer dW/db lag one stage (x images double-buffered by stage parity);
 //   * the lo pieces of the output-layer weights and the split W1^T / W0^T A-operands live in LDS images.
-template <int NL, int C, int INTERP, int METHOD, int PROF = 0>
+template <int NL, int C, int INTERP, int METHOD, int PROF = 0, int DISC = 0>
 __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
     unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
 #define NCDE_TICK(k)                                                \
@@ -1867,14 +1867,28 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         }
         const int last_row = a.n_out - 1;
         float y0[NB], ky1[NB], ky2[NB], a0[NB], ka1[NB], ka2[NB], as_[NB], zreg[8];
+        // DISC (exact discrete backward): the stage inputs come from the forward's stage record, [(n*S + j)][B][H],
+        // walked backwards (linear index `lin`), fetched one stage ahead; ka1/ka2/ky1 hold dL/dY of stages 4/3/2.
+        f32x4 znext[2];
+        auto rec_fetch = [&](int lin) {
+            const float* rp = a.stages + ((long long)lin * a.B + (valid ? bs : 0)) * H + 8 * g;
+            znext[0] = *reinterpret_cast<const f32x4*>(rp);
+            znext[1] = *reinterpret_cast<const f32x4*>(rp + 4);
+        };
+        if constexpr (DISC != 0) {
+            rec_fetch((a.T - 1) * S - 1);
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) zreg[jj] = valid ? a.z_out[((long long)bs * a.n_out + last_row) * H + 8 * g + jj] : 0.0f;
+            for (int jj = 0; jj < 8; ++jj) zreg[jj] = valid ? znext[jj >> 2][jj & 3] : 0.0f;
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) zreg[jj] = valid ? a.z_out[((long long)bs * a.n_out + last_row) * H + 8 * g + jj] : 0.0f;
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const long long o = ((long long)bs * a.n_out + last_row) * H + 4 * (pw * NB + nb) + g;
-            y0[nb] = valid ? a.z_out[o] : 0.0f;
+            y0[nb] = (DISC == 0 && valid) ? a.z_out[o] : 0.0f;
             a0[nb] = valid ? a.grad_out[o] : 0.0f;
-            as_[nb] = a0[nb];
+            as_[nb] = (DISC != 0 && METHOD == NCDE_RK4_38) ? a0[nb] * 0.125f : a0[nb];
             ky1[nb] = ky2[nb] = ka1[nb] = ka2[nb] = 0.0f;
         }
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -1888,10 +1902,14 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
             for (int j = 0; j < S; ++j) {
                 ++sc;
                 const int par = sc & 1;
-                const float t = -(-(float)n + stage_offset(METHOD, j));
+                const float t = DISC != 0 ? (float)(n - 1) + stage_offset(METHOD, S - 1 - j) : -(-(float)n + stage_offset(METHOD, j));
                 const int idx = piece_index(t, a.n_pieces);
                 const float frac = t - (float)idx;
-                const float wq = stage_weight(METHOD, j);
+                const float wq = DISC != 0 ? 1.0f : stage_weight(METHOD, j);
+                if constexpr (DISC != 0) {
+                    const int lin = (n - 1) * S + (S - 1 - j);
+                    if (lin >= 1) rec_fetch(lin - 1);
+                }
                 const float* dxp = dxs + (idx % 3) * 16 * DXW + s * DXW;
                 // ---- forward recompute (split-bf16); x[l][4t+r] <-> unit 8g + 4t + r -----------------------------------
                 float x[NL][8];
@@ -1968,7 +1986,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float rr = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[nb][r]) + 1.0f);
-                            kout[nb] = fmaf(rr, dx[r], kout[nb]);
+                            if constexpr (DISC == 0) kout[nb] = fmaf(rr, dx[r], kout[nb]);
                             tl[(4 * g + r) * 16 + s] = (a4 * dx[r]) * fmaf(-rr, rr, rr);
                         }
                         wave_lds_order();
@@ -2025,6 +2043,43 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                 }
                 NCDE_TICK(3)
                 float ys[NB];
+                if constexpr (DISC != 0) {
+                    // transpose of the Butcher step (RK4 3/8: c4 = a/8; c3 = 3c4 + d4; c2 = 3c4 - d4 + d3;
+                    // c1 = c4 + d4 - d3/3 + d2/3; a += d4 + d3 + d2 + d1), d = vy = dL/dY of this stage
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const float d = vy[nb];
+                        ys[nb] = 0.0f;
+                        if constexpr (METHOD == NCDE_RK4_38) {
+                            const float c4 = a0[nb] * 0.125f;
+                            if (j == 0) { ka1[nb] = d; as_[nb] = 3.0f * c4 + d; }
+                            else if (j == 1) { ka2[nb] = d; as_[nb] = (3.0f * c4 - ka1[nb]) + d; }
+                            else if (j == 2) { ky1[nb] = d; as_[nb] = ((c4 + ka1[nb]) - 0.333333343267440796f * ka2[nb]) + 0.333333343267440796f * d; }
+                            else { a0[nb] = (((a0[nb] + ka1[nb]) + ka2[nb]) + ky1[nb]) + d; }
+                        } else if constexpr (METHOD == NCDE_MIDPOINT) {
+                            if (j == 0) { ka1[nb] = d; as_[nb] = 0.5f * d; }
+                            else { a0[nb] = (a0[nb] + ka1[nb]) + d; }
+                        } else {
+                            a0[nb] = a0[nb] + d;
+                        }
+                    }
+                    if (j == S - 1) {
+                        if (a.output == NCDE_OUT_KNOTS || n == 1) {
+                            const int row = a.output == NCDE_OUT_KNOTS ? n - 1 : 0;
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+                                a0[nb] += valid ? a.grad_out[((long long)bs * a.n_out + row) * H + 4 * (pw * NB + nb) + g] : 0.0f;
+                        }
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) as_[nb] = METHOD == NCDE_RK4_38 ? a0[nb] * 0.125f : a0[nb];
+                        if (n - 3 >= 0) stage_store(n - 3);
+                    }
+                    __syncthreads();  // barrier B
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) zreg[jj] = valid ? znext[jj >> 2][jj & 3] : 0.0f;
+                    NCDE_TICK(4)
+                    continue;
+                }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     ys[nb] = Combine<METHOD>::apply(j, -kout[nb], y0[nb], ky1[nb], ky2[nb]);
@@ -2183,7 +2238,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
             for (int j = 0; j < S; ++j) {
                 ++sc;
                 const int par = sc & 1;
-                const float wq = stage_weight(METHOD, j);
+                const float wq = DISC != 0 ? 1.0f : stage_weight(METHOD, j);
                 // hidden-layer dW/db of the previous stage, under the chain wave's forward recompute
                 if (wprev != 0.0f) dw_hidden(par ^ 1, wprev);
                 NCDE_TICK(0)
@@ -2370,6 +2425,20 @@ FwdFn pick_adj3(int interp, int method) {
 }
 
 template <int NL, int C>
+FwdFn pick_adj3_disc(int interp, int method) {
+#define NCDE_PICK(I, M) \
+    if (interp == I && method == M) return ncde_adj_fast3<NL, C, I, M, 0, 1>;
+    NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_RK4_38)
+    NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_MIDPOINT)
+    NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_EULER)
+    NCDE_PICK(NCDE_INTERP_CUBIC, NCDE_RK4_38)
+    NCDE_PICK(NCDE_INTERP_CUBIC, NCDE_MIDPOINT)
+    NCDE_PICK(NCDE_INTERP_CUBIC, NCDE_EULER)
+#undef NCDE_PICK
+    return nullptr;
+}
+
+template <int NL, int C>
 size_t adj3_lds_bytes(int interp) {
     constexpr int H = 32, HH = 32, NW = 4, HT = 2, CP = (C + 3) & ~3, CQ = CP / 4, NB = 2, NTILE = NB * CQ;
     const int DXW = interp == NCDE_INTERP_LINEAR ? CP : 3 * CP;
@@ -2404,6 +2473,8 @@ struct FastEntry {
     FwdFn (*adj3)(int, int);        // wave-specialised variant, split-bf16 chain (default)
     size_t (*adj3_lds)(int);
     const char* adj3_name;
+    FwdFn (*adj3_disc)(int, int);   // same kernel transposing the discretised solve (ncde_backward)
+    const char* adj3_disc_name;
 };
 
 const FastEntry kFast[] = {
@@ -2412,11 +2483,12 @@ const FastEntry kFast[] = {
      pick_fwd_bf3<32, 32, 20, 4>, "ncde_fwd_fast_bf3<H32,HH32,C20,NW4>", 4,
      3, pick_adj<32, 32, 20, 3, 4>, adj_lds_bytes<32, 32, 20, 3, 4>, "ncde_adj_fast<H32,HH32,C20,NL3,NW4>",
      pick_adj2<32, 32, 20, 3>, adj2_lds_bytes<32, 32, 20, 3>, "ncde_adj_fast2<H32,HH32,C20,NL3,chain+grad>",
-     pick_adj3<3, 20>, adj3_lds_bytes<3, 20>, "ncde_adj_fast3<H32,HH32,C20,NL3,chain(bf16x3)+grad>"},
+     pick_adj3<3, 20>, adj3_lds_bytes<3, 20>, "ncde_adj_fast3<H32,HH32,C20,NL3,chain(bf16x3)+grad>",
+     pick_adj3_disc<3, 20>, "ncde_adj_fast3<H32,HH32,C20,NL3,chain(bf16x3)+grad,discrete>"},
     // BASELINE cfg4 (adjoint: generic family for now -- the per-wave LDS images do not fit at HH=64)
     {{64, 64, 4}, 4, pick_fwd<64, 64, 4, 4>, "ncde_fwd_fast<H64,HH64,C4,NW4>",
      pick_fwd_bf3<64, 64, 4, 4>, "ncde_fwd_fast_bf3<H64,HH64,C4,NW4>", 4, 0, nullptr, nullptr, nullptr,
-     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
+     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
 };
 
 const FastEntry* find_entry(const NcdeProblem* p) {
@@ -2436,7 +2508,7 @@ bool ncde_fast_supported(const NcdeProblem* p, int pass) {
     const FastEntry* e = find_entry(p);
     if (!e) return false;
     if (pass == 0) return true;
-    if (pass == 2) return false;  // exact discrete backward: generic family only (for now)
+    if (pass == 2) return e->adj3_disc != nullptr && e->adj_layers == p->n_layers;
     return e->adj != nullptr && e->adj_layers == p->n_layers;
 }
 
@@ -2444,6 +2516,7 @@ const char* ncde_fast_kernel_name(const NcdeProblem* p, int pass) {
     if (!ncde_fast_supported(p, pass)) return nullptr;
     const FastEntry* e = find_entry(p);
     if (pass == 0) return ((p->flags & NCDE_FLAG_FP32_MFMA) == 0 && e->fwd_bf3) ? e->fwd_bf3_name : e->fwd_name;
+    if (pass == 2) return e->adj3_disc_name;
     if (p->flags & NCDE_FLAG_ADJOINT_V1) return e->adj_name;
     if ((p->flags & NCDE_FLAG_ADJOINT_V2) && e->adj2) return e->adj2_name;
     return e->adj3 ? e->adj3_name : (e->adj2 ? e->adj2_name : e->adj_name);
@@ -2486,15 +2559,19 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     (void)ws_bytes;
     if (!ncde_fast_supported(p, discrete ? 2 : 1)) return NCDE_ERR_UNSUPPORTED;
     const FastEntry* e = find_entry(p);
-    const bool v1 = (p->flags & NCDE_FLAG_ADJOINT_V1) != 0 || (e->adj2 == nullptr && e->adj3 == nullptr);
-    const bool v3 = !v1 && e->adj3 != nullptr && !(p->flags & NCDE_FLAG_ADJOINT_V2);
+    const bool v1 = !discrete && ((p->flags & NCDE_FLAG_ADJOINT_V1) != 0 || (e->adj2 == nullptr && e->adj3 == nullptr));
+    const bool v3 = discrete || (!v1 && e->adj3 != nullptr && !(p->flags & NCDE_FLAG_ADJOINT_V2));
     const bool v2 = !v1 && !v3;
-    FwdFn fn = v1 ? e->adj(p->interp, p->method) : (v3 ? e->adj3(p->interp, p->method) : e->adj2(p->interp, p->method));
+    FwdFn fn = discrete ? e->adj3_disc(p->interp, p->method)
+                        : (v1 ? e->adj(p->interp, p->method) : (v3 ? e->adj3(p->interp, p->method) : e->adj2(p->interp, p->method)));
     if (!fn) return NCDE_ERR_UNSUPPORTED;
+    if (discrete && (p->flags & (NCDE_FLAG_DEBUG_PROFILE | 0x200u))) return NCDE_ERR_UNSUPPORTED;
     const Layout y = make_layout(p);
     KArgs a;
     fill_kargs(p, y, &a);
-    a.z_out = z_out; a.grad_out = grad_out; a.grad_z0 = g->grad_z0;
+    a.grad_out = grad_out; a.grad_z0 = g->grad_z0;
+    if (discrete) { a.stages = const_cast<float*>(z_out); a.discrete = 1; }
+    else a.z_out = z_out;
     a.gpart = (float*)ws;
     if (p->flags & 0x200u) {  // development: per-stage chain values of workgroup 0 -> tail of the workspace
         if (!(e->shape.H == 32 && e->shape.C == 20 && p->interp == NCDE_INTERP_CUBIC && p->method == NCDE_MIDPOINT)) return NCDE_ERR_UNSUPPORTED;

@@ -206,6 +206,11 @@ def _seeded_case(interp, method, seq, B, L, C, H, HH, nl, seed):
     case["expect"] = {"z_out": z.numpy(), "grad_out": gout, "dz0": dz0.numpy()}
     for n_, g_ in zip(names, gp):
         case["expect"]["d" + n_] = g_.numpy()
+    bdz0, bgp = orc.solve_discrete_backward(ctl, field, z0, gout, method, seq)      # adjoint=False gradients
+    case["expect"]["bp_dz0"] = bdz0.numpy()
+    for n_, g_ in zip(names, bgp):
+        case["expect"]["bp_d" + n_] = g_.numpy()
+    case["stage_record"] = orc.stage_record(ctl, field, z0, method).numpy()
     return case
 
 
@@ -243,6 +248,18 @@ def test_fast_kernels_vs_oracle(shape, interp, method, seq, gpu_lib):
                 assert e <= TIGHT_G, (nm + " adjoint kernel on oracle z_out", k, e)
         again = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_AUTO)     # hand-off protocol: bit-reproducible
         assert np.array_equal(again["dz0"], iso["dz0"]) and all(np.array_equal(again["grads"][k], iso["grads"][k]) for k in iso["grads"])
+    # adjoint=False: recording forward + exact discrete backward
+    resd = gpu_util.run_case(case, flags=_lib.FLAG_AUTO, adjoint=False)
+    assert np.array_equal(resd["z_out"], res["z_out"])                      # recording does not change the solution
+    for k, e in _grad_errors(case, resd, "bp_").items():
+        assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), ("discrete end-to-end", k, e)
+    isod = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_AUTO, stages=case["stage_record"])
+    for k, e in _grad_errors(case, isod, "bp_").items():
+        assert e <= TIGHT_G, ("discrete backward kernel on the oracle's stage record", res["kernels"][2], k, e)
+    if H == 32:
+        assert res["kernels"][2].startswith("ncde_adj_fast3") and "discrete" in res["kernels"][2], res["kernels"]
+        againd = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_AUTO, stages=case["stage_record"])
+        assert np.array_equal(againd["dz0"], isod["dz0"]) and all(np.array_equal(againd["grads"][k], isod["grads"][k]) for k in isod["grads"])
 
 
 def test_gpu_coefficient_builders_match_reference(gpu_lib):
