@@ -30,6 +30,7 @@ CONFIGS = {
     # name: (B per GPU, raw length, channels incl. time, H, HH, nl, interpolation, solver, missing)
     "cfg2": dict(B=4096, L=200, C=20, H=32, HH=32, nl=3, interpolation="rectilinear", solver="rk4", missing=0.3),
     "cfg4": dict(B=8192, L=182, C=4, H=64, HH=64, nl=3, interpolation="cubic", solver="midpoint", missing=0.0),
+    "cfg5": dict(B=4096, L=400, C=80, H=128, HH=128, nl=3, interpolation="rectilinear", solver="rk4", missing=0.6),
 }
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
 PEAK_HBM_GBS = 8000.0
@@ -206,6 +207,17 @@ def main():
         torch.cuda.synchronize()
         tf = (time.perf_counter() - tf0) / args.steps
 
+    # adjoint=False training step (recording forward + exact discrete backward), reported beside the headline
+    model.adjoint = False
+    step()
+    torch.cuda.synchronize()
+    td0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    td = (time.perf_counter() - td0) / args.steps
+    model.adjoint = True
+
     if rank == 0:
         ms_fwd, ms_adj, names = time_kernels(model, c, coeffs)
         steps_per_launch = B_local * (T - 1)
@@ -250,6 +262,8 @@ def main():
                                       c["nl"], "RCCL grad all-reduce + " if world > 1 else ""),
                        "global_batch": B_total, "seq_len": c["L"], "parallelism": "dp%d" % world},
             "forward_only_value": B_local * (T - 1) / tf, "forward_only_ms": tf * 1e3,
+            "adjoint_false_value": B_local * (T - 1) / td, "adjoint_false_ms_per_step": td * 1e3,
+            "adjoint_false_note": "same step with NeuralCDE(adjoint=False): recording forward + exact discrete backward (per rank, no barrier)",
             "roofline": roof(ms_adj, f_adj, by_fwd, names[1]),
             "roofline_forward": roof(ms_fwd, f_fwd, by_fwd, names[0]),
             "loss": float(loss),
