@@ -10,6 +10,7 @@
 #include "ncde_common.h"
 #include "ncde_fast.h"
 #include "ncde_host.h"
+#include "ncde_tiled.h"
 
 extern "C" __global__ void ncde_fwd_generic(KArgs a);
 extern "C" __global__ void ncde_adj_generic(KArgs a);
@@ -66,7 +67,7 @@ int generic_supported(const NcdeProblem* p, const Layout& y, int pass) {
     return NCDE_OK;
 }
 
-// pick the kernel family: 1 = fast, 0 = generic, <0 = error
+// pick the kernel family: 1 = fast (shape-specialised), 2 = tiled (batch-tiled, large hidden), 0 = generic, <0 = error
 int select_family(const NcdeProblem* p, const Layout& y, int pass) {
     const bool fast_ok = ncde_fast_supported(p, pass);
     if (p->flags & NCDE_FLAG_FORCE_FAST) {
@@ -74,6 +75,7 @@ int select_family(const NcdeProblem* p, const Layout& y, int pass) {
         return 1;
     }
     if (fast_ok && !(p->flags & NCDE_FLAG_FORCE_GENERIC)) return 1;
+    if (!(p->flags & NCDE_FLAG_FORCE_GENERIC) && ncde_tiled_supported(p, pass)) return 2;
     const int rc = generic_supported(p, y, pass);
     return rc == NCDE_OK ? 0 : rc;
 }
@@ -90,6 +92,11 @@ int launch_forward(const NcdeProblem* p, const Layout& y, int family, float* out
     if (family == 1) {
         const int rc = ncde_fast_forward(p, out, stages, ws, ws_bytes, st);
         if (rc != NCDE_OK) return fail(rc, "fast forward launch failed");
+        return NCDE_OK;
+    }
+    if (family == 2) {
+        const int rc = ncde_tiled_forward(p, out, stages, ws, ws_bytes, st);
+        if (rc != NCDE_OK) return fail(rc, "tiled forward launch failed");
         return NCDE_OK;
     }
     KArgs a;
@@ -143,6 +150,7 @@ int64_t ncde_workspace_bytes(const NcdeProblem* p, int pass) {
     const int fam = select_family(p, y, pass);
     if (fam < 0) return fam;
     if (fam == 1) return ncde_fast_workspace_bytes(p, pass);
+    if (fam == 2) return ncde_tiled_workspace_bytes(p, pass);
     if (pass == 0) return 256;
     return (int64_t)sizeof(float) * (int64_t)y.n_wg * (int64_t)y.theta_size + 256;
 }
@@ -159,6 +167,7 @@ const char* ncde_kernel_name(const NcdeProblem* p, int pass) {
     const Layout y = make_layout(p);
     const int fam = select_family(p, y, pass);
     if (fam < 0) return nullptr;
+    if (fam == 2) return ncde_tiled_kernel_name(p, pass);
     return fam == 1 ? ncde_fast_kernel_name(p, pass) : (pass == 0 ? "ncde_fwd_generic" : (pass == 1 ? "ncde_adj_generic" : "ncde_adj_generic<discrete>"));
 }
 

@@ -262,6 +262,30 @@ def test_fast_kernels_vs_oracle(shape, interp, method, seq, gpu_lib):
         assert np.array_equal(againd["dz0"], isod["dz0"]) and all(np.array_equal(againd["grads"][k], isod["grads"][k]) for k in isod["grads"])
 
 
+@pytest.mark.parametrize("shape", [(80, 128, 128, 3), (8, 48, 64, 2), (4, 16, 32, 1)])
+@pytest.mark.parametrize("interp,method,seq", [("linear", "rk4", False), ("cubic", "midpoint", True), ("linear", "euler", True)])
+def test_tiled_family_vs_oracle(shape, interp, method, seq, gpu_lib):
+    """The batch-tiled (large-hidden) family: every sample-tile count NS, ragged batch, against the oracle and,
+    bit for bit, against the generic family's operation order is NOT required -- tolerance as everywhere else."""
+    import gpu_util
+    from ncde_amd import _lib
+    C, H, HH, nl = shape
+    case = _seeded_case(interp, method, seq, B=37, L=7, C=C, H=H, HH=HH, nl=nl, seed=300 + C)
+    ex = case["expect"]
+    for flag, ns in ((0, None), (0x1000, 1), (0x2000, 2), (0x4000, 4)):
+        res = gpu_util.run_case(case, flags=flag, need_grads=False)
+        assert res["kernels"][0].startswith("ncde_fwd_tiled"), res["kernels"]
+        if ns:
+            assert res["kernels"][0] == "ncde_fwd_tiled<NS%d>" % ns
+        assert gu.relerr(res["z_out"], ex["z_out"]) <= TIGHT_Z, (flag, gu.relerr(res["z_out"], ex["z_out"]))
+    res = gpu_util.run_case(case, flags=0)                       # gradients through whatever family the backward uses
+    for k, e in _grad_errors(case, res).items():
+        assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), ("end-to-end", k, e)
+    resd = gpu_util.run_case(case, flags=0, adjoint=False)       # stage record written by the tiled forward
+    for k, e in _grad_errors(case, resd, "bp_").items():
+        assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), ("discrete end-to-end", k, e)
+
+
 def test_gpu_coefficient_builders_match_reference(gpu_lib):
     """ncde_prepare_linear / ncde_prepare_cubic against the reference's builders
     (golden g8) -- bit-exact for the rectilinear preparation and the spline, 1e-6 for the NaN fill -- and at
