@@ -117,6 +117,12 @@ int launch_adjoint(const NcdeProblem* p, const Layout& y, int family, const floa
         if (rc != NCDE_OK) return fail(rc, "fast adjoint launch failed");
         return NCDE_OK;
     }
+    if (family == 2) {
+        const int rc = ncde_tiled_adjoint(p, src, grad_out, g, ws, ws_bytes, st, main_kernel_only, discrete);
+        if (rc == NCDE_ERR_INVALID) return fail(rc, "NcdeGrads: NULL destination for a parameter gradient");
+        if (rc != NCDE_OK) return fail(rc, "tiled adjoint launch failed");
+        return NCDE_OK;
+    }
     KArgs a;
     fill_kargs(p, y, &a);
     a.grad_out = grad_out; a.grad_z0 = g->grad_z0;

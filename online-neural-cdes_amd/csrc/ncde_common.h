@@ -32,6 +32,12 @@ struct KArgs {
     // exact discrete backward (adjoint=False): record of every stage input, [(n*S + j)][B][H]
     float* stages;    // forward: written when non-null; backward: read
     int discrete;     // adjoint kernels: 1 = transpose the discretised solve instead of the continuous adjoint
+    // batch-tiled adjoint (ncde_tiled.hip): per-stage records consumed by the output-layer gradient pass
+    float* recA;      // x_L            [stage][sample tile][dlast/4][16][4]
+    float* recB;      // x_L            [stage][sample tile][dlast][16]
+    float* recC;      // w * cotangent  [stage][sample tile][H][16]
+    float* recD;      // dX/dt          [stage][sample tile][C/4][16][4]
+    int gstride;      // floats per workgroup partial in gpart (hidden-layer parameters only)
 };
 
 __device__ __forceinline__ int ru4(int x) { return (x + 3) & ~3; }

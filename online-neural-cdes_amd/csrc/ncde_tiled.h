@@ -8,3 +8,5 @@ bool ncde_tiled_supported(const NcdeProblem* p, int pass);
 const char* ncde_tiled_kernel_name(const NcdeProblem* p, int pass);
 int64_t ncde_tiled_workspace_bytes(const NcdeProblem* p, int pass);
 int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws, size_t ws_bytes, hipStream_t st);
+int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad_out, const NcdeGrads* g, void* ws, size_t ws_bytes,
+                       hipStream_t st, bool main_kernel_only, bool discrete);

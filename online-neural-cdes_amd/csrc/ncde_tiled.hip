@@ -280,6 +280,446 @@ __global__ __launch_bounds__(TL_THREADS) void ncde_fwd_tiled(KArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// adjoint / exact backward, pass A: the reverse sweep (one workgroup = 16 samples)
+// ------------------------------------------------------------------------------------------------
+// With |Wo| = 5.2 MB per workgroup partial, accumulating dL/dWo inside the sweep costs a read-modify-write of the
+// whole matrix per stage and workgroup (2.7 GB per stage at cfg5).  The sweep therefore leaves the output-layer
+// parameter gradient to pass B (ncde_dwo_tiled below) and only RECORDS what that pass needs per stage: x_L (in the
+// two operand layouts), the weighted cotangent and dX/dt.  Everything on the dependency chain stays here:
+//   forward recompute -> P = Wo x_L, m = tanh P, f (y re-integration), dP -> dL/dx_L = Wo^T dP -> hidden layers
+//   backwards (their dW/db accumulate in MFMA accumulator registers for the whole solve) -> Butcher bookkeeping.
+// Wo^T fragments come from the SAME 16-byte panel loads as the forward fragments, transposed through a per-wave LDS
+// scratch (row stride K + 4), so the weight stream is read once per stage.
+#define TL_EADJ 4  // state elements per thread: H * 16 <= TL_EADJ * TL_THREADS
+#define TL_DWT 8   // hidden-layer dW tiles per wave and weight slot: (N/16) * (K/16) <= 8 * TL_NW
+
+namespace {
+
+template <int PK>
+__device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, const float* AS, const float* DX, float* KOY,
+                                              float* scr, int wave, int lane) {
+    constexpr int NSP = 16, SCS = 16 * PK + 4;
+    const int li = lane & 15, lk = lane >> 4;
+    const int C = a.C, nhb = a.H >> 2, ncq = C >> 2, dlast = 16 * PK;
+    f32x4 accJ[PK];
+#pragma unroll
+    for (int jt = 0; jt < PK; ++jt) accJ[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nhb_w = (nhb - wave + TL_NW - 1) / TL_NW;
+    const int nq = nhb_w > 0 ? nhb_w * ncq : 0;
+    auto wrow_of = [&](int q) {
+        const int hb = wave + TL_NW * (q / ncq), cq = q % ncq;
+        return a.Wo + (long long)((4 * hb + (li >> 2)) * C + 4 * cq + (li & 3)) * dlast + 4 * lk;
+    };
+    Panel<PK> Pn;
+    if (nq > 0) Pn = tl_load_panel<PK>(wrow_of(0), 0);
+    float kacc = 0.0f;
+    for (int q = 0; q < nq; ++q) {
+        const int hi = q / ncq, cq = q - hi * ncq, hb = wave + TL_NW * hi;
+        const Panel<PK> P = Pn;
+        Pn = tl_load_panel<PK>(wrow_of(q + 1 < nq ? q + 1 : q), 0);
+#pragma unroll
+        for (int i = 0; i < PK; ++i) *reinterpret_cast<f32x4*>(scr + li * SCS + 16 * i + 4 * lk) = P.v[i];
+        if (cq == 0) kacc = 0.0f;
+        f32x4 acc[1];
+        acc[0] = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb + lk) * C + 4 * cq);
+        tl_mma_panel<1, PK>(P, xL, 0, li, lk, acc);
+        const float aval = AS[(hb * NSP + li) * 4 + lk];
+        const f32x4 dx = *reinterpret_cast<const f32x4*>(DX + (cq * NSP + li) * 4);
+        float dP[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float m = tanh_dev(acc[0][r]);
+            kacc = fmaf(m, dx[r], kacc);
+            dP[r] = (aval * dx[r]) * (1.0f - m * m);
+        }
+        // dL/dx_L[j][s] += sum_u Wo[u][j] dP[u][s]: the tile's 16 rows are the K dim, k = 4 (lane>>4) + r
+#pragma unroll
+        for (int jt = 0; jt < PK; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accJ[jt] = mfma16(scr[(4 * lk + r) * SCS + 16 * jt + li], dP[r], accJ[jt]);
+        if (cq == ncq - 1) KOY[(hb * NSP + li) * 4 + lk] = kacc;
+    }
+    // this wave's partial of dL/dx_L -> its scratch, in the activation layout
+#pragma unroll
+    for (int jt = 0; jt < PK; ++jt) *reinterpret_cast<f32x4*>(scr + ((4 * jt + lk) * NSP + li) * 4) = accJ[jt];
+}
+
+// out[i][s] = sum_j W[j][i] gpre[j][s]  (x relu'(xin[i][s]) when mask); W [N][K] row-major.
+__device__ __forceinline__ void tl_hidden_bwd(const float* __restrict__ W, int N, int K, const float* gpre, const float* xin,
+                                              bool mask, float* out, int wave, int lane) {
+    constexpr int NSP = 16;
+    const int li = lane & 15, lk = lane >> 4;
+    const int nkb = N >> 4;
+    for (int it = wave; it < (K >> 4); it += TL_NW) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* wcol = W + (long long)(4 * lk) * K + 16 * it + li;
+#pragma unroll 4
+        for (int kb = 0; kb < nkb; ++kb) {
+            float av[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[e] = wcol[(long long)(16 * kb + e) * K];
+            const f32x4 Bv = *reinterpret_cast<const f32x4*>(gpre + ((4 * kb + lk) * NSP + li) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma16(av[e], Bv[e], acc);
+        }
+        const int o = ((4 * it + lk) * NSP + li) * 4;
+        if (mask) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xin + o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = xv[r] > 0.0f ? acc[r] : 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(out + o) = acc;
+    }
+}
+
+// dW[j][i] += w sum_s gpre[j][s] xin[i][s] into this wave's accumulator tiles (tile tt = wave + 8 q <-> (jt, it))
+__device__ __forceinline__ void tl_dw_acc(const float* gpre, const float* xin, int N, int K, float w, f32x4 (&dw)[TL_DWT], int wave,
+                                          int lane) {
+    constexpr int NSP = 16;
+    const int li = lane & 15, lk = lane >> 4;
+    const int nit = K >> 4, ntile = (N >> 4) * nit;
+#pragma unroll
+    for (int q = 0; q < TL_DWT; ++q) {
+        const int tt = wave + TL_NW * q;
+        if (tt < ntile) {
+            const int jt = tt / nit, it = tt - jt * nit;
+            const float* ap = gpre + ((4 * jt + (li >> 2)) * NSP + lk) * 4 + (li & 3);
+            const float* bp = xin + ((4 * it + (li >> 2)) * NSP + lk) * 4 + (li & 3);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dw[q] = mfma16(w * ap[16 * ks], bp[16 * ks], dw[q]);
+        }
+    }
+}
+
+}  // namespace
+
+template <int PK>
+__global__ __launch_bounds__(TL_THREADS) void ncde_adj_tiled(KArgs a) {
+    constexpr int NSP = 16, SCW = (16 * (16 * PK + 4) > 16 * PK * NSP) ? 16 * (16 * PK + 4) : 16 * PK * NSP;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b0 = blockIdx.x * NSP;
+    const int H = a.H, C = a.C, L = a.n_layers;
+    int D = H;
+    for (int l = 0; l < L; ++l) D = max(D, a.dout[l]);
+    const int HS = H * NSP, DS = D * NSP;
+    float* YS = lds;               // stage input y (= x_0)
+    float* AS = YS + HS;           // stage cotangent
+    float* KOY = AS + HS;          // f(y).dX of the stage
+    float* KOA = KOY + HS;         // J^T cotangent of the stage
+    float* X = KOA + HS;           // x_1 .. x_L
+    float* G0 = X + L * DS;
+    float* G1 = G0 + DS;
+    float* DX = G1 + DS;           // [C/4][16][4]
+    float* SC = DX + C * NSP;      // per-wave scratch
+    float* scr = SC + wave * SCW;
+    const bool disc = a.discrete != 0;
+    const int S = n_stages(a.method);
+    const int dlast = 16 * PK;
+    const int last_row = a.n_out - 1;
+    const int n_st = gridDim.x;
+
+    float y0[TL_EADJ], ky1[TL_EADJ], ky2[TL_EADJ], a0[TL_EADJ], ka1[TL_EADJ], ka2[TL_EADJ];
+#pragma unroll
+    for (int q = 0; q < TL_EADJ; ++q) {
+        const int e = tid + q * TL_THREADS;
+        y0[q] = ky1[q] = ky2[q] = a0[q] = ka1[q] = ka2[q] = 0.0f;
+        if (e < HS) {
+            const int u = ((e >> 2) / NSP) * 4 + (e & 3), s = (e >> 2) % NSP, b = b0 + s;
+            const long long o = ((long long)b * a.n_out + last_row) * H + u;
+            const float g = b < a.B ? a.grad_out[o] : 0.0f;
+            a0[q] = g;
+            if (disc) {
+                AS[e] = a.method == NCDE_RK4_38 ? g * 0.125f : g;
+                YS[e] = 0.0f;
+            } else {
+                const float y = b < a.B ? a.z_out[o] : 0.0f;
+                y0[q] = y;
+                YS[e] = y;
+                AS[e] = g;
+            }
+        }
+    }
+    // hidden-layer parameter gradients: at most two distinct (W, b) pairs (layer 0, and ONE matrix shared by the rest)
+    f32x4 dw0[TL_DWT], dw1[TL_DWT];
+    float db0 = 0.0f, db1 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < TL_DWT; ++q) dw0[q] = dw1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int sc = 0;
+    for (int n = a.T - 1; n >= 1; --n) {
+        for (int j = 0; j < S; ++j, ++sc) {
+            const float t = disc ? (float)(n - 1) + stage_offset(a.method, S - 1 - j) : -(-(float)n + stage_offset(a.method, j));
+            const int idx = piece_index(t, a.n_pieces);
+            const float w = disc ? 1.0f : stage_weight(a.method, j);
+            tl_load_dx<1>(a, b0, idx, t - (float)idx, DX, tid);
+            if (disc) {
+                const float* rec = a.stages + ((long long)((n - 1) * S + (S - 1 - j)) * a.B + b0) * H;
+                for (int e = tid; e < NSP * H; e += TL_THREADS) {
+                    const int s = e / H, u = e - s * H;
+                    YS[((u >> 2) * NSP + s) * 4 + (u & 3)] = b0 + s < a.B ? rec[e] : 0.0f;
+                }
+            }
+            __syncthreads();
+            // ---- forward recompute, keeping x_1 .. x_L -------------------------------------------------------------
+            const float* in = YS;
+            for (int l = 0; l < L; ++l) {
+                float* outb = X + l * DS;
+                tl_dense_relu<1>(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane);
+                __syncthreads();
+                in = outb;
+            }
+            // ---- output layer: f, dP, per-wave partial of dL/dx_L -----------------------------------------------------
+            tl_output_vjp<PK>(a, in, AS, DX, KOY, scr, wave, lane);
+            // ---- records for pass B (x_L twice, weighted cotangent, dX/dt) --------------------------------------------
+            {
+                const long long tile = (long long)sc * n_st + blockIdx.x;
+                float* ra = a.recA + tile * (dlast * NSP);
+                float* rb = a.recB + tile * (dlast * NSP);
+                float* rc = a.recC + tile * (H * NSP);
+                float* rd = a.recD + tile * (C * NSP);
+                for (int e = tid; e < dlast * NSP; e += TL_THREADS) {
+                    ra[e] = in[e];
+                    const int jj = e >> 4, s = e & 15;
+                    rb[e] = in[((jj >> 2) * NSP + s) * 4 + (jj & 3)];
+                }
+                for (int e = tid; e < H * NSP; e += TL_THREADS) {
+                    const int hh = e >> 4, s = e & 15;
+                    rc[e] = w * AS[((hh >> 2) * NSP + s) * 4 + (hh & 3)];
+                }
+                for (int e = tid; e < C * NSP; e += TL_THREADS) rd[e] = DX[e];
+            }
+            __syncthreads();
+            // ---- dL/dpre_L = (sum of the 8 partials) * relu'(x_L) ---------------------------------------------------------
+            for (int e = tid; e < dlast * NSP; e += TL_THREADS) {
+                float g = 0.0f;
+#pragma unroll
+                for (int wv = 0; wv < TL_NW; ++wv) g += SC[wv * SCW + e];
+                G1[e] = in[e] > 0.0f ? g : 0.0f;
+            }
+            __syncthreads();
+            // ---- hidden layers backwards ----------------------------------------------------------------------------------
+            float* gpre = G1;
+            float* gx = G0;
+            for (int l = L - 1; l >= 0; --l) {
+                const int N = a.dout[l], K = a.din[l];
+                const float* xin = l == 0 ? YS : X + (l - 1) * DS;
+                if (w != 0.0f) {
+                    const bool slot0 = a.gW_off[l] == a.gW_off[0];
+                    if (slot0) tl_dw_acc(gpre, xin, N, K, w, dw0, wave, lane);
+                    else tl_dw_acc(gpre, xin, N, K, w, dw1, wave, lane);
+                    if (tid < N) {
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int s = 0; s < NSP; ++s) sum += gpre[((tid >> 2) * NSP + s) * 4 + (tid & 3)];
+                        if (slot0) db0 += w * sum;
+                        else db1 += w * sum;
+                    }
+                }
+                tl_hidden_bwd(a.W[l], N, K, gpre, xin, l > 0, l == 0 ? KOA : gx, wave, lane);
+                __syncthreads();
+                float* tmp = gpre; gpre = gx; gx = tmp;
+            }
+            // ---- Butcher bookkeeping (registers) ---------------------------------------------------------------------------
+#pragma unroll
+            for (int q = 0; q < TL_EADJ; ++q) {
+                const int e = tid + q * TL_THREADS;
+                if (e < HS) {
+                    const int u = ((e >> 2) / NSP) * 4 + (e & 3), s = (e >> 2) % NSP, b = b0 + s;
+                    const bool valid = b < a.B;
+                    const float d = KOA[e];
+                    if (disc) {
+                        // transpose of the Butcher step: d = dL/dY of this stage (see ncde_generic.hip)
+                        bool last = false;
+                        float next = 0.0f;
+                        if (a.method == NCDE_RK4_38) {
+                            const float c4 = a0[q] * 0.125f;
+                            if (j == 0) { ka1[q] = d; next = 3.0f * c4 + d; }
+                            else if (j == 1) { ka2[q] = d; next = (3.0f * c4 - ka1[q]) + d; }
+                            else if (j == 2) { ky1[q] = d; next = ((c4 + ka1[q]) - 0.333333343267440796f * ka2[q]) + 0.333333343267440796f * d; }
+                            else { a0[q] = (((a0[q] + ka1[q]) + ka2[q]) + ky1[q]) + d; last = true; }
+                        } else if (a.method == NCDE_MIDPOINT) {
+                            if (j == 0) { ka1[q] = d; next = 0.5f * d; }
+                            else { a0[q] = (a0[q] + ka1[q]) + d; last = true; }
+                        } else {
+                            a0[q] = a0[q] + d; last = true;
+                        }
+                        if (last) {
+                            if (a.output == NCDE_OUT_KNOTS || n == 1)
+                                a0[q] += valid ? a.grad_out[((long long)b * a.n_out + (a.output == NCDE_OUT_KNOTS ? n - 1 : 0)) * H + u] : 0.0f;
+                            next = a.method == NCDE_RK4_38 ? a0[q] * 0.125f : a0[q];
+                            if (n == 1 && valid) a.grad_z0[(long long)b * H + u] = a0[q];
+                        }
+                        AS[e] = next;
+                    } else {
+                        // negated time: dy/ds = -f, da/ds = +a^T df/dy; same operation order as StageCombine
+                        const float ky = -KOY[e];
+                        float ys, as;
+                        bool last = false;
+                        if (a.method == NCDE_RK4_38) {
+                            if (j == 0) {
+                                ky1[q] = ky; ys = y0[q] + ky * 0.333333343267440796f;
+                                ka1[q] = d; as = a0[q] + d * 0.333333343267440796f;
+                            } else if (j == 1) {
+                                ky2[q] = ky; ys = y0[q] + (ky - ky1[q] * 0.333333343267440796f);
+                                ka2[q] = d; as = a0[q] + (d - ka1[q] * 0.333333343267440796f);
+                            } else if (j == 2) {
+                                ys = y0[q] + ((ky1[q] - ky2[q]) + ky); ky2[q] = ky2[q] + ky;
+                                as = a0[q] + ((ka1[q] - ka2[q]) + d); ka2[q] = ka2[q] + d;
+                            } else {
+                                y0[q] = y0[q] + ((ky1[q] + 3.0f * ky2[q]) + ky) * 0.125f; ys = y0[q];
+                                a0[q] = a0[q] + ((ka1[q] + 3.0f * ka2[q]) + d) * 0.125f; as = a0[q];
+                                last = true;
+                            }
+                        } else if (a.method == NCDE_MIDPOINT) {
+                            if (j == 0) { ys = y0[q] + ky * 0.5f; as = a0[q] + d * 0.5f; }
+                            else { y0[q] = y0[q] + ky; ys = y0[q]; a0[q] = a0[q] + d; as = a0[q]; last = true; }
+                        } else {
+                            y0[q] = y0[q] + ky; ys = y0[q]; a0[q] = a0[q] + d; as = a0[q]; last = true;
+                        }
+                        if (last) {
+                            if (a.output == NCDE_OUT_KNOTS) {  // reset y to the stored value, add dL/dz at this knot
+                                const long long o = ((long long)b * a.n_out + (n - 1)) * H + u;
+                                y0[q] = valid ? a.z_out[o] : 0.0f;
+                                a0[q] = a0[q] + (valid ? a.grad_out[o] : 0.0f);
+                            } else if (n == 1) {
+                                a0[q] = a0[q] + (valid ? a.grad_out[((long long)b * a.n_out) * H + u] : 0.0f);
+                            }
+                            ys = y0[q];
+                            as = a0[q];
+                            if (n == 1 && valid) a.grad_z0[(long long)b * H + u] = a0[q];
+                        }
+                        YS[e] = ys;
+                        AS[e] = as;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- this workgroup's partial of the hidden-layer parameter gradients ------------------------------------------
+    float* gp = a.gpart + (long long)blockIdx.x * a.gstride;
+    {
+        const int li = lane & 15, lk = lane >> 4;
+        int l1 = -1;
+        for (int l = 1; l < L; ++l)
+            if (a.gW_off[l] != a.gW_off[0]) { l1 = l; break; }
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot) {
+            const int l = slot == 0 ? 0 : l1;
+            if (l < 0) continue;
+            const int N = a.dout[l], K = a.din[l], nit = K >> 4, ntile = (N >> 4) * nit;
+#pragma unroll
+            for (int q = 0; q < TL_DWT; ++q) {
+                const int tt = wave + TL_NW * q;
+                if (tt < ntile) {
+                    const int jt = tt / nit, it = tt - jt * nit;
+                    const f32x4 v = slot == 0 ? dw0[q] : dw1[q];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gp[a.gW_off[l] + (16 * jt + 4 * lk + r) * K + 16 * it + li] = v[r];
+                }
+            }
+            if (tid < N) gp[a.gb_off[l] + tid] = slot == 0 ? db0 : db1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass B: dL/dWo, dL/dbo from the records -- weights and gradient accumulators never leave the registers
+// ------------------------------------------------------------------------------------------------
+// grid = (H*C/16 row tiles, TLB_PARTS); one WAVE = one 16-row tile of Wo x one 1/(4*TLB_PARTS) slice of the sample
+// tiles, for ALL stages: P = Wo_tile x_L + bo is recomputed (PK*4 MFMAs), dP = cot (x) dX (1 - tanh^2 P), and
+// dWo_tile += dP x_L^T (PK*4 MFMAs, samples are the K dim; dP transposed through a 16x17 LDS patch).
+#define TLB_PARTS 4
+template <int PK>
+__global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_st, float* gpartB) {
+    __shared__ float patch[4][16 * 17];
+    __shared__ __attribute__((aligned(16))) float red[4][PK * 256 + 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int C = a.C, H = a.H, ncq = C >> 2, dlast = 16 * PK;
+    const int tile = blockIdx.x, hb = tile / ncq, cq = tile - hb * ncq;
+    const int part = blockIdx.y * 4 + wave, nparts = TLB_PARTS * 4;
+    const Panel<PK> Wp = tl_load_panel<PK>(a.Wo + (long long)((4 * hb + (li >> 2)) * C + 4 * cq + (li & 3)) * dlast + 4 * lk, 0);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb + lk) * C + 4 * cq);
+    f32x4 gW[PK];
+    float gb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jt = 0; jt < PK; ++jt) gW[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float* pt = patch[wave];
+    const int my_n = part < n_st ? (n_st - part + nparts - 1) / nparts : 0;   // sample tiles part, part + nparts, ...
+    const long long nq = (long long)n_sc * my_n;
+    struct Frag {
+        f32x4 xa[PK], xb[PK], dx;
+        float cot;
+    };
+    auto load_frag = [&](long long q) {
+        const long long sc = q / my_n;
+        const int it = part + nparts * (int)(q - sc * my_n);
+        const long long t = sc * n_st + it;
+        Frag f;
+        const float* ra = a.recA + t * (dlast * 16) + (lk * 16 + li) * 4;
+        const float* rb = a.recB + t * (dlast * 16) + li * 16 + 4 * lk;
+#pragma unroll
+        for (int i = 0; i < PK; ++i) {
+            f.xa[i] = *reinterpret_cast<const f32x4*>(ra + i * 256);
+            f.xb[i] = *reinterpret_cast<const f32x4*>(rb + i * 256);
+        }
+        f.dx = *reinterpret_cast<const f32x4*>(a.recD + t * (C * 16) + (cq * 16 + li) * 4);
+        f.cot = a.recC[t * (H * 16) + (4 * hb + lk) * 16 + li];
+        return f;
+    };
+    Frag fn;
+    if (nq > 0) fn = load_frag(0);
+    for (long long q = 0; q < nq; ++q) {
+        const Frag f = fn;
+        fn = load_frag(q + 1 < nq ? q + 1 : q);
+        f32x4 acc = bv;
+#pragma unroll
+        for (int i = 0; i < PK; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma16(Wp.v[i][e], f.xa[i][e], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float m = tanh_dev(acc[r]);
+            const float dp = (f.cot * f.dx[r]) * (1.0f - m * m);
+            gb[r] += dp;
+            pt[(4 * lk + r) * 17 + li] = dp;
+        }
+        float av[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[e] = pt[li * 17 + 4 * lk + e];
+#pragma unroll
+        for (int jt = 0; jt < PK; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gW[jt] = mfma16(av[e], f.xb[jt][e], gW[jt]);
+    }
+    // ---- sum the four waves of the workgroup, write this part-group's partial ----------------------------------------
+#pragma unroll
+    for (int jt = 0; jt < PK; ++jt) *reinterpret_cast<f32x4*>(&red[wave][(jt * 64 + lane) * 4]) = gW[jt];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v = gb[r];
+        v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+        if (li == 0) red[wave][PK * 256 + 4 * lk + r] = v;
+    }
+    __syncthreads();
+    const long long wo_sz = (long long)H * C * dlast, theta_o = wo_sz + (long long)H * C;
+    float* gp = gpartB + (long long)blockIdx.y * theta_o;
+    for (int e = tid; e < PK * 256; e += 256) {
+        const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        const int r = e & 3, ln = (e >> 2) & 63, jt = e >> 8;
+        const int row = (4 * hb + (ln >> 4)) * C + 4 * cq + r;
+        gp[(long long)row * dlast + 16 * jt + (ln & 15)] = v;
+    }
+    if (tid < 16) {
+        const float v = (red[0][PK * 256 + tid] + red[1][PK * 256 + tid]) + (red[2][PK * 256 + tid] + red[3][PK * 256 + tid]);
+        gp[wo_sz + (4 * hb + (tid >> 2)) * C + 4 * cq + (tid & 3)] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 namespace {
@@ -307,6 +747,59 @@ int tiled_fwd_ns(const NcdeProblem* p) {
     return fits(1) ? 1 : 0;
 }
 
+// ---- adjoint / exact backward -------------------------------------------------------------------------------------
+int tiled_adj_pk(const NcdeProblem* p) {
+    const int dlast = p->layer_out[p->n_layers - 1];
+    return (dlast == 128) ? 8 : (dlast == 64 ? 4 : (dlast == 32 ? 2 : (dlast == 16 ? 1 : 0)));
+}
+
+size_t tiled_adj_lds(const NcdeProblem* p) {
+    const int pk = tiled_adj_pk(p), D = tiled_dmax(p);
+    const int scw = std::max(16 * (16 * pk + 4), 16 * pk * 16);
+    return sizeof(float) * (size_t)(4 * p->hidden * 16 + (p->n_layers + 2) * D * 16 + p->channels * 16 + TL_NW * scw);
+}
+
+bool tiled_adj_ok(const NcdeProblem* p) {
+    if (tiled_adj_pk(p) == 0 || p->hidden * 16 > TL_EADJ * TL_THREADS) return false;
+    int l1 = -1;
+    for (int l = 0; l < p->n_layers; ++l) {
+        if (p->layer_out[l] > TL_THREADS || (p->layer_out[l] / 16) * (p->layer_in[l] / 16) > TL_DWT * TL_NW) return false;
+        for (int q = 0; q < l; ++q)
+            if ((p->layer_W[l] == p->layer_W[q]) != (p->layer_b[l] == p->layer_b[q])) return false;
+        if (l >= 1 && p->layer_W[l] != p->layer_W[0]) {   // at most two distinct matrices: layer 0's and ONE other
+            if (l1 < 0) l1 = l;
+            else if (p->layer_W[l] != p->layer_W[l1]) return false;
+        }
+    }
+    return tiled_adj_lds(p) <= (size_t)kLdsLimit;
+}
+
+struct TiledAdjPlan {
+    int n_st, n_sc, gstride;
+    long long recA, recB, recC, recD, gpartA, gpartB, total;   // float offsets into the workspace
+    long long theta_o;
+};
+
+TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
+    TiledAdjPlan t{};
+    const int S = p->method == NCDE_RK4_38 ? 4 : (p->method == NCDE_MIDPOINT ? 2 : 1);
+    const long long dlast = y.dlast;
+    t.n_st = (p->batch + 15) / 16;
+    t.n_sc = (p->n_knots - 1) * S;
+    t.gstride = y.gWo_off;
+    const long long tiles = (long long)t.n_sc * t.n_st;
+    long long off = 64;
+    t.recA = off; off += tiles * dlast * 16;
+    t.recB = off; off += tiles * dlast * 16;
+    t.recC = off; off += tiles * p->hidden * 16;
+    t.recD = off; off += tiles * p->channels * 16;
+    t.gpartA = off; off += (long long)t.n_st * t.gstride;
+    t.theta_o = (long long)p->hidden * p->channels * dlast + (long long)p->hidden * p->channels;
+    t.gpartB = off; off += TLB_PARTS * t.theta_o;
+    t.total = off + 64;
+    return t;
+}
+
 }  // namespace
 
 bool ncde_tiled_supported(const NcdeProblem* p, int pass) {
@@ -315,19 +808,23 @@ bool ncde_tiled_supported(const NcdeProblem* p, int pass) {
     for (int l = 0; l < p->n_layers; ++l)
         if (p->layer_out[l] % 16 || p->layer_in[l] % 16 || !aligned(p->layer_W[l]) || !aligned(p->layer_b[l])) return false;
     if (!aligned(p->Wo) || !aligned(p->bo)) return false;
-    if (pass != 0) return false;
+    if (pass != 0) return tiled_adj_ok(p);
     return tiled_fwd_ns(p) > 0;
 }
 
 const char* ncde_tiled_kernel_name(const NcdeProblem* p, int pass) {
     if (!ncde_tiled_supported(p, pass)) return nullptr;
+    if (pass == 1) return "ncde_adj_tiled+ncde_dwo_tiled";
+    if (pass == 2) return "ncde_adj_tiled<discrete>+ncde_dwo_tiled";
     const int ns = tiled_fwd_ns(p);
     return ns == 4 ? "ncde_fwd_tiled<NS4>" : (ns == 2 ? "ncde_fwd_tiled<NS2>" : "ncde_fwd_tiled<NS1>");
 }
 
 int64_t ncde_tiled_workspace_bytes(const NcdeProblem* p, int pass) {
     if (!ncde_tiled_supported(p, pass)) return NCDE_ERR_UNSUPPORTED;
-    return 256;
+    if (pass == 0) return 256;
+    const Layout y = make_layout(p);
+    return (int64_t)sizeof(float) * tiled_adj_plan(p, y).total;
 }
 
 int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -344,5 +841,55 @@ int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NCDE_ERR_HIP;
     const int nwg = (p->batch + ns * 16 - 1) / (ns * 16);
     hipLaunchKernelGGL(fn, dim3(nwg), dim3(TL_THREADS), lds, st, a);
+    return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
+}
+
+int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad_out, const NcdeGrads* g, void* ws, size_t ws_bytes,
+                       hipStream_t st, bool main_kernel_only, bool discrete) {
+    if (!ncde_tiled_supported(p, discrete ? 2 : 1)) return NCDE_ERR_UNSUPPORTED;
+    const Layout y = make_layout(p);
+    const TiledAdjPlan t = tiled_adj_plan(p, y);
+    if (ws_bytes < sizeof(float) * (size_t)t.total) return NCDE_ERR_WORKSPACE;
+    float* w = (float*)ws;
+    KArgs a;
+    fill_kargs(p, y, &a);
+    a.grad_out = grad_out; a.grad_z0 = g->grad_z0;
+    if (discrete) { a.stages = const_cast<float*>(src); a.discrete = 1; }
+    else a.z_out = src;
+    a.recA = w + t.recA; a.recB = w + t.recB; a.recC = w + t.recC; a.recD = w + t.recD;
+    a.gpart = w + t.gpartA;
+    a.gstride = t.gstride;
+    const int pk = tiled_adj_pk(p);
+    void (*fa)(KArgs) = pk == 8 ? ncde_adj_tiled<8> : (pk == 4 ? ncde_adj_tiled<4> : (pk == 2 ? ncde_adj_tiled<2> : ncde_adj_tiled<1>));
+    void (*fb)(KArgs, int, int, float*) = pk == 8 ? ncde_dwo_tiled<8> : (pk == 4 ? ncde_dwo_tiled<4> : (pk == 2 ? ncde_dwo_tiled<2> : ncde_dwo_tiled<1>));
+    const size_t lds = tiled_adj_lds(p);
+    if (hipFuncSetAttribute((const void*)fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NCDE_ERR_HIP;
+    hipLaunchKernelGGL(fa, dim3(t.n_st), dim3(TL_THREADS), lds, st, a);
+    if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
+    float* gB = w + t.gpartB;
+    hipLaunchKernelGGL(fb, dim3(p->hidden * p->channels / 16, TLB_PARTS), dim3(256), 0, st, a, t.n_sc, t.n_st, gB);
+    if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
+    if (main_kernel_only) return NCDE_OK;
+    // deterministic reductions: hidden-layer partials of the sweep, then the part-group partials of pass B
+    ReduceSegs segs{};
+    int n = 0;
+    for (int l = 0; l < p->n_layers; ++l) {
+        bool first = true;
+        for (int q = 0; q < l; ++q)
+            if (p->layer_W[q] == p->layer_W[l]) first = false;
+        if (!first) continue;
+        if (!g->grad_layer_W[l] || !g->grad_layer_b[l]) return NCDE_ERR_INVALID;
+        segs.off[n] = y.gW_off[l]; segs.len[n] = p->layer_out[l] * p->layer_in[l]; segs.dst[n] = g->grad_layer_W[l]; ++n;
+        segs.off[n] = y.gb_off[l]; segs.len[n] = p->layer_out[l]; segs.dst[n] = g->grad_layer_b[l]; ++n;
+    }
+    segs.n = n;
+    hipLaunchKernelGGL(ncde_reduce_partials, dim3((t.gstride + 255) / 256), dim3(256), 0, st, (const float*)a.gpart, t.n_st, t.gstride, segs);
+    if (!g->grad_Wo || !g->grad_bo) return NCDE_ERR_INVALID;
+    ReduceSegs so{};
+    const int wo_sz = p->hidden * p->channels * y.dlast;
+    so.n = 2;
+    so.off[0] = 0; so.len[0] = wo_sz; so.dst[0] = g->grad_Wo;
+    so.off[1] = wo_sz; so.len[1] = p->hidden * p->channels; so.dst[1] = g->grad_bo;
+    hipLaunchKernelGGL(ncde_reduce_partials, dim3(((int)t.theta_o + 255) / 256), dim3(256), 0, st, (const float*)gB, TLB_PARTS, (int)t.theta_o, so);
     return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
 }
