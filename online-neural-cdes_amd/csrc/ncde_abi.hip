@@ -75,7 +75,7 @@ int select_family(const NcdeProblem* p, const Layout& y, int pass) {
         return 1;
     }
     if (fast_ok && !(p->flags & NCDE_FLAG_FORCE_GENERIC)) return 1;
-    if (!(p->flags & NCDE_FLAG_FORCE_GENERIC) && ncde_tiled_supported(p, pass)) return 2;
+    if (!(p->flags & NCDE_FLAG_FORCE_GENERIC) && ncde_tiled_supported(p, pass) && ncde_tiled_preferred(p, pass)) return 2;
     const int rc = generic_supported(p, y, pass);
     return rc == NCDE_OK ? 0 : rc;
 }

@@ -5,6 +5,7 @@
 #include "ncde_hip.h"
 
 bool ncde_tiled_supported(const NcdeProblem* p, int pass);
+bool ncde_tiled_preferred(const NcdeProblem* p, int pass);
 const char* ncde_tiled_kernel_name(const NcdeProblem* p, int pass);
 int64_t ncde_tiled_workspace_bytes(const NcdeProblem* p, int pass);
 int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws, size_t ws_bytes, hipStream_t st);

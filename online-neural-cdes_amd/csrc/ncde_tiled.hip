@@ -636,7 +636,8 @@ template <int PK>
 __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_st, float* gpartB) {
     __shared__ float patch[4][16 * 17];
     __shared__ __attribute__((aligned(16))) float red[4][PK * 256 + 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int C = a.C, H = a.H, ncq = C >> 2, dlast = 16 * PK;
     const int tile = blockIdx.x, hb = tile / ncq, cq = tile - hb * ncq;
@@ -649,16 +650,17 @@ __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_s
     for (int jt = 0; jt < PK; ++jt) gW[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float* pt = patch[wave];
     const int my_n = part < n_st ? (n_st - part + nparts - 1) / nparts : 0;   // sample tiles part, part + nparts, ...
-    const long long nq = (long long)n_sc * my_n;
     struct Frag {
         f32x4 xa[PK], xb[PK], dx;
         float cot;
     };
-    auto load_frag = [&](long long q) {
-        const long long sc = q / my_n;
-        const int it = part + nparts * (int)(q - sc * my_n);
-        const long long t = sc * n_st + it;
+    // fragment of (stage sc, k-th sample tile of this wave); past the end: the last one again with a zero cotangent
+    auto load_frag = [&](int sc, int k, bool live) {
+        const long long t = (long long)sc * n_st + (part + nparts * k);
         Frag f;
+        f.cot = a.recC[t * (H * 16) + (4 * hb + lk) * 16 + li];
+        if (!live) f.cot = 0.0f;
+        f.dx = *reinterpret_cast<const f32x4*>(a.recD + t * (C * 16) + (cq * 16 + li) * 4);
         const float* ra = a.recA + t * (dlast * 16) + (lk * 16 + li) * 4;
         const float* rb = a.recB + t * (dlast * 16) + li * 16 + 4 * lk;
 #pragma unroll
@@ -666,15 +668,9 @@ __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_s
             f.xa[i] = *reinterpret_cast<const f32x4*>(ra + i * 256);
             f.xb[i] = *reinterpret_cast<const f32x4*>(rb + i * 256);
         }
-        f.dx = *reinterpret_cast<const f32x4*>(a.recD + t * (C * 16) + (cq * 16 + li) * 4);
-        f.cot = a.recC[t * (H * 16) + (4 * hb + lk) * 16 + li];
         return f;
     };
-    Frag fn;
-    if (nq > 0) fn = load_frag(0);
-    for (long long q = 0; q < nq; ++q) {
-        const Frag f = fn;
-        fn = load_frag(q + 1 < nq ? q + 1 : q);
+    auto step = [&](const Frag& f) {
         f32x4 acc = bv;
 #pragma unroll
         for (int i = 0; i < PK; ++i)
@@ -694,6 +690,27 @@ __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_s
         for (int jt = 0; jt < PK; ++jt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) gW[jt] = mfma16(av[e], f.xb[jt][e], gW[jt]);
+    };
+    // two named fragment buffers, loop unrolled by two: the loads of one buffer are in flight while the other computes
+    if (my_n > 0 && n_sc > 0) {
+        int sc = 0, k = 0;          // position of the NEXT fragment to fetch
+        bool live = true;
+        auto fetch = [&]() {
+            const Frag f = load_frag(sc, k, live);
+            if (live) {
+                if (++k == my_n) { k = 0; ++sc; }
+                if (sc == n_sc) { live = false; sc = n_sc - 1; k = my_n - 1; }
+            }
+            return f;
+        };
+        const long long nq = (long long)n_sc * my_n;
+        Frag fA = fetch(), fB;
+        for (long long q = 0; q < nq; q += 2) {
+            fB = fetch();
+            step(fA);
+            fA = fetch();
+            step(fB);
+        }
     }
     // ---- sum the four waves of the workgroup, write this part-group's partial ----------------------------------------
 #pragma unroll
@@ -810,6 +827,16 @@ bool ncde_tiled_supported(const NcdeProblem* p, int pass) {
     if (!aligned(p->Wo) || !aligned(p->bo)) return false;
     if (pass != 0) return tiled_adj_ok(p);
     return tiled_fwd_ns(p) > 0;
+}
+
+// Is the tiled family the better choice?  Forward: yes whenever it applies.  Backward: the record + second-pass
+// scheme pays off once the output-layer matrix is too large for per-workgroup partials in LDS (cfg5: 1.71 s vs
+// 13.5 s generic); for small matrices the generic kernel's in-LDS partial wins (cfg4: 24 ms vs 30 ms).
+bool ncde_tiled_preferred(const NcdeProblem* p, int pass) {
+    if (p->flags & 0x8000u) return true;   // development / tests: force the family wherever it is supported
+    if (pass == 0) return true;
+    const long long wo_bytes = 4LL * p->hidden * p->channels * p->layer_out[p->n_layers - 1];
+    return wo_bytes >= (1LL << 20);
 }
 
 const char* ncde_tiled_kernel_name(const NcdeProblem* p, int pass) {

@@ -278,19 +278,20 @@ def test_tiled_family_vs_oracle(shape, interp, method, seq, gpu_lib):
         if ns:
             assert res["kernels"][0] == "ncde_fwd_tiled<NS%d>" % ns
         assert gu.relerr(res["z_out"], ex["z_out"]) <= TIGHT_Z, (flag, gu.relerr(res["z_out"], ex["z_out"]))
-    res = gpu_util.run_case(case, flags=0)                       # sweep (pass A) + output-layer gradient pass (pass B)
+    FT = 0x8000                                                  # force the tiled backward also where generic is preferred
+    res = gpu_util.run_case(case, flags=FT)                      # sweep (pass A) + output-layer gradient pass (pass B)
     assert res["kernels"][1].startswith("ncde_adj_tiled") and "discrete" in res["kernels"][2], res["kernels"]
     for k, e in _grad_errors(case, res).items():
         assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), ("end-to-end", k, e)
-    iso = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=0)
+    iso = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=FT)
     for k, e in _grad_errors(case, iso).items():
         assert e <= TIGHT_G, ("tiled adjoint on oracle z_out", k, e)
-    again = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=0)
+    again = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=FT)
     assert np.array_equal(again["dz0"], iso["dz0"]) and all(np.array_equal(again["grads"][k], iso["grads"][k]) for k in iso["grads"])
-    resd = gpu_util.run_case(case, flags=0, adjoint=False)       # stage record written by the tiled forward
+    resd = gpu_util.run_case(case, flags=FT, adjoint=False)      # stage record written by the tiled forward
     for k, e in _grad_errors(case, resd, "bp_").items():
         assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), ("discrete end-to-end", k, e)
-    isod = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=0, stages=case["stage_record"])
+    isod = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=FT, stages=case["stage_record"])
     for k, e in _grad_errors(case, isod, "bp_").items():
         assert e <= TIGHT_G, ("tiled discrete backward on the oracle's stage record", k, e)
 
