@@ -16,18 +16,18 @@
 #include "ncde_host.h"
 #include "ncde_tiled.h"
 
-#define TL_NW 8
+#define TL_NW 8   // waves per workgroup of the forward family (the backward sweep runs 4, see ncde_adj_tiled)
 #define TL_THREADS (64 * TL_NW)
-#define TL_EMAX 16  // state elements per thread: H * NS * 16 <= TL_EMAX * TL_THREADS
+#define TL_EMAX 16  // forward: state elements per thread, H * NS * 16 <= TL_EMAX * TL_THREADS (instantiated: 4, 16)
 
 namespace {
 
 // dX/dt(t) of the tile's samples -> DX[(c>>2)][s][c&3]
-template <int NS>
+template <int NS, int NT>
 __device__ __forceinline__ void tl_load_dx(const KArgs& a, int b0, int idx, float frac, float* DX, int tid) {
     constexpr int NSP = NS * 16;
     const int C = a.C;
-    for (int e = tid; e < NSP * C; e += TL_THREADS) {
+    for (int e = tid; e < NSP * C; e += NT) {
         const int s = e / C, c = e - s * C;
         const int b = b0 + s;
         float v = 0.0f;
@@ -78,20 +78,20 @@ __host__ __device__ __forceinline__ int tl_panel_k(int nkb) { return (nkb % 8 ==
 
 // out = relu(W in + bias): W [N][K] row-major in global memory, in/out in the LDS layout above.
 // The (row tile, panel) pairs of this wave form one sequence; the panel of pair q+1 is in flight while pair q computes.
-template <int NS, int PK>
+template <int NS, int PK, int NWV>
 __device__ __forceinline__ void tl_dense_relu_pk(const float* __restrict__ W, const float* __restrict__ bias, int N, int K,
                                                  const float* in, float* out, int wave, int lane) {
     constexpr int NSP = NS * 16;
     const int li = lane & 15, lk = lane >> 4;
     const int npan = (K >> 4) / PK;
-    const int ntile = ((N >> 4) - wave + TL_NW - 1) / TL_NW;       // row tiles wave, wave+8, ...
+    const int ntile = ((N >> 4) - wave + NWV - 1) / NWV;       // row tiles wave, wave+8, ...
     if (ntile <= 0) return;
     const int nq = ntile * npan;
-    auto wrow_of = [&](int q) { return W + (long long)(16 * (wave + TL_NW * (q / npan)) + li) * K + 4 * lk; };
+    auto wrow_of = [&](int q) { return W + (long long)(16 * (wave + NWV * (q / npan)) + li) * K + 4 * lk; };
     Panel<PK> Pn = tl_load_panel<PK>(wrow_of(0), 0);
     f32x4 acc[NS];
     for (int q = 0; q < nq; ++q) {
-        const int ti = q / npan, pan = q - ti * npan, t = wave + TL_NW * ti;
+        const int ti = q / npan, pan = q - ti * npan, t = wave + NWV * ti;
         const Panel<PK> P = Pn;
         {
             const int qn = q + 1 < nq ? q + 1 : q;
@@ -114,30 +114,30 @@ __device__ __forceinline__ void tl_dense_relu_pk(const float* __restrict__ W, co
         }
     }
 }
-template <int NS>
+template <int NS, int NWV>
 __device__ __forceinline__ void tl_dense_relu(const float* __restrict__ W, const float* __restrict__ bias, int N, int K,
                                               const float* in, float* out, int wave, int lane) {
     switch (tl_panel_k(K >> 4)) {
-        case 8: tl_dense_relu_pk<NS, 8>(W, bias, N, K, in, out, wave, lane); break;
-        case 4: tl_dense_relu_pk<NS, 4>(W, bias, N, K, in, out, wave, lane); break;
-        case 2: tl_dense_relu_pk<NS, 2>(W, bias, N, K, in, out, wave, lane); break;
-        default: tl_dense_relu_pk<NS, 1>(W, bias, N, K, in, out, wave, lane); break;
+        case 8: tl_dense_relu_pk<NS, 8, NWV>(W, bias, N, K, in, out, wave, lane); break;
+        case 4: tl_dense_relu_pk<NS, 4, NWV>(W, bias, N, K, in, out, wave, lane); break;
+        case 2: tl_dense_relu_pk<NS, 2, NWV>(W, bias, N, K, in, out, wave, lane); break;
+        default: tl_dense_relu_pk<NS, 1, NWV>(W, bias, N, K, in, out, wave, lane); break;
     }
 }
 
 // output layer + tanh + channel contraction for the h-blocks of this wave -> KO.  Tile rows (g, r) <-> (h = 4hb+g,
 // c = 4cq+r); sequence of (h-block, channel quad, panel) triples, next panel in flight while one computes.
-template <int NS, int PK>
+template <int NS, int PK, int NWV>
 __device__ __forceinline__ void tl_output_pk(const KArgs& a, const float* in, const float* DX, float* KO, int dlast, int wave, int lane) {
     constexpr int NSP = NS * 16;
     const int li = lane & 15, lk = lane >> 4;
     const int C = a.C, nhb = a.H >> 2, ncq = C >> 2;
     const int npan = (dlast >> 4) / PK;
-    const int nhb_w = (nhb - wave + TL_NW - 1) / TL_NW;
+    const int nhb_w = (nhb - wave + NWV - 1) / NWV;
     if (nhb_w <= 0) return;
     const int per_hb = ncq * npan, nq = nhb_w * per_hb;
     auto wrow_of = [&](int q) {
-        const int hb = wave + TL_NW * (q / per_hb), cq = (q % per_hb) / npan;
+        const int hb = wave + NWV * (q / per_hb), cq = (q % per_hb) / npan;
         return a.Wo + (long long)((4 * hb + (li >> 2)) * C + 4 * cq + (li & 3)) * dlast + 4 * lk;
     };
     Panel<PK> Pn = tl_load_panel<PK>(wrow_of(0), 0);
@@ -145,7 +145,7 @@ __device__ __forceinline__ void tl_output_pk(const KArgs& a, const float* in, co
     f32x4 acc[NS];
     for (int q = 0; q < nq; ++q) {
         const int hi = q / per_hb, rem = q - hi * per_hb, cq = rem / npan, pan = rem - cq * npan;
-        const int hb = wave + TL_NW * hi;
+        const int hb = wave + NWV * hi;
         const Panel<PK> P = Pn;
         {
             const int qn = q + 1 < nq ? q + 1 : q;
@@ -176,14 +176,73 @@ __device__ __forceinline__ void tl_output_pk(const KArgs& a, const float* in, co
     }
 }
 
+// Same, for the common case K = 16 PK (one panel = the whole tile row block): a straight-line loop body (no branches:
+// the waitcnt pass then keeps the next tile's loads in flight across the MFMAs), two named buffers, unrolled by two.
+template <int NS, int PK, int NWV>
+__device__ __forceinline__ void tl_output_whole(const KArgs& a, const float* in, const float* DX, float* KO, int wave, int lane) {
+    constexpr int NSP = NS * 16, dlast = 16 * PK;
+    const int li = lane & 15, lk = lane >> 4;
+    const int C = a.C, nhb = a.H >> 2, ncq = C >> 2;
+    const int nhb_w = (nhb - wave + NWV - 1) / NWV;
+    if (nhb_w <= 0) return;
+    const int nq = nhb_w * ncq;
+    struct TileIn {
+        Panel<PK> P;
+        f32x4 bias;
+    };
+    int fhi = 0, fcq = 0, fq = 0;
+    auto fetch = [&]() {
+        const int hb = wave + NWV * fhi;
+        TileIn t;
+        t.P = tl_load_panel<PK>(a.Wo + (long long)((4 * hb + (li >> 2)) * C + 4 * fcq + (li & 3)) * dlast + 4 * lk, 0);
+        t.bias = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb + lk) * C + 4 * fcq);
+        const bool more = fq + 1 < nq, wrap = fcq + 1 == ncq;
+        fq += more ? 1 : 0;
+        fhi += (more && wrap) ? 1 : 0;
+        fcq = more ? (wrap ? 0 : fcq + 1) : fcq;
+        return t;
+    };
+    int chi = 0, ccq = 0;
+    float kacc[NS];
+#pragma unroll
+    for (int st = 0; st < NS; ++st) kacc[st] = 0.0f;
+    auto step = [&](const TileIn& t) {
+        const int hb = wave + NWV * chi;
+        f32x4 acc[NS];
+#pragma unroll
+        for (int st = 0; st < NS; ++st) acc[st] = t.bias;
+        tl_mma_panel<NS, PK>(t.P, in, 0, li, lk, acc);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            const f32x4 dx = *reinterpret_cast<const f32x4*>(DX + (ccq * NSP + st * 16 + li) * 4);
+            float kk = ccq == 0 ? 0.0f : kacc[st];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) kk = fmaf(tanh_dev(acc[st][r]), dx[r], kk);
+            kacc[st] = kk;
+            KO[(hb * NSP + st * 16 + li) * 4 + lk] = kk;     // running sum; the last channel quad leaves the total
+        }
+        const bool wrap = ccq + 1 == ncq;
+        chi += wrap ? 1 : 0;
+        ccq = wrap ? 0 : ccq + 1;
+    };
+    TileIn TA = fetch(), TB;
+    for (int i = 0; i < (nq >> 1); ++i) {
+        TB = fetch();
+        step(TA);
+        TA = fetch();
+        step(TB);
+    }
+    if (nq & 1) step(TA);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int NS>
-__global__ __launch_bounds__(TL_THREADS) void ncde_fwd_tiled(KArgs a) {
-    constexpr int NSP = NS * 16;
+template <int NS, int NWV, int EM>
+__global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
+    constexpr int NSP = NS * 16, NT = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -198,11 +257,11 @@ __global__ __launch_bounds__(TL_THREADS) void ncde_fwd_tiled(KArgs a) {
     float* KO = ACT1 + DS;      // f(z).dX of the stage
     float* DX = KO + HS;        // [C/4][NSP][4]
 
-    // state slice of this thread: element e = tid + q * TL_THREADS of the [H/4][NSP][4] arrays
-    float y0[TL_EMAX], k1[TL_EMAX], k2[TL_EMAX];
+    // state slice of this thread: element e = tid + q * NT of the [H/4][NSP][4] arrays
+    float y0[EM], k1[EM], k2[EM];
 #pragma unroll
-    for (int q = 0; q < TL_EMAX; ++q) {
-        const int e = tid + q * TL_THREADS;
+    for (int q = 0; q < EM; ++q) {
+        const int e = tid + q * NT;
         y0[q] = k1[q] = k2[q] = 0.0f;
         if (e < HS) {
             const int u = ((e >> 2) / NSP) * 4 + (e & 3), s = (e >> 2) % NSP, b = b0 + s;
@@ -221,13 +280,13 @@ __global__ __launch_bounds__(TL_THREADS) void ncde_fwd_tiled(KArgs a) {
             const float t = (float)n + stage_offset(a.method, j);
             const int idx = piece_index(t, a.n_pieces);
             if (a.interp != NCDE_INTERP_LINEAR || idx != cur_idx) {
-                tl_load_dx<NS>(a, b0, idx, t - (float)idx, DX, tid);
+                tl_load_dx<NS, NT>(a, b0, idx, t - (float)idx, DX, tid);
                 cur_idx = idx;
             }
             __syncthreads();
             if (a.stages) {  // record the stage input for the exact discrete backward
                 float* rec = a.stages + ((long long)(n * S + j) * a.B + b0) * H;
-                for (int e = tid; e < NSP * H; e += TL_THREADS) {
+                for (int e = tid; e < NSP * H; e += NT) {
                     const int s = e / H, u = e - s * H;
                     if (b0 + s < a.B) rec[e] = YS[((u >> 2) * NSP + s) * 4 + (u & 3)];
                 }
@@ -235,21 +294,25 @@ __global__ __launch_bounds__(TL_THREADS) void ncde_fwd_tiled(KArgs a) {
             const float* in = YS;
             for (int l = 0; l < a.n_layers; ++l) {
                 float* outb = (l & 1) ? ACT1 : ACT0;
-                tl_dense_relu<NS>(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane);
+                tl_dense_relu<NS, NWV>(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane);
                 __syncthreads();
                 in = outb;
             }
-            switch (tl_panel_k(nkb_o)) {
-                case 8: tl_output_pk<NS, 8>(a, in, DX, KO, dlast, wave, lane); break;
-                case 4: tl_output_pk<NS, 4>(a, in, DX, KO, dlast, wave, lane); break;
-                case 2: tl_output_pk<NS, 2>(a, in, DX, KO, dlast, wave, lane); break;
-                default: tl_output_pk<NS, 1>(a, in, DX, KO, dlast, wave, lane); break;
+            switch (nkb_o) {
+                case 8: tl_output_whole<NS, 8, NWV>(a, in, DX, KO, wave, lane); break;
+                case 4: tl_output_whole<NS, 4, NWV>(a, in, DX, KO, wave, lane); break;
+                case 2: tl_output_whole<NS, 2, NWV>(a, in, DX, KO, wave, lane); break;
+                case 1: tl_output_whole<NS, 1, NWV>(a, in, DX, KO, wave, lane); break;
+                default:
+                    if (tl_panel_k(nkb_o) == 2) tl_output_pk<NS, 2, NWV>(a, in, DX, KO, dlast, wave, lane);
+                    else tl_output_pk<NS, 1, NWV>(a, in, DX, KO, dlast, wave, lane);
+                    break;
             }
             __syncthreads();
             // Butcher bookkeeping (same operation order as ncde_generic.hip's StageCombine)
 #pragma unroll
-            for (int q = 0; q < TL_EMAX; ++q) {
-                const int e = tid + q * TL_THREADS;
+            for (int q = 0; q < EM; ++q) {
+                const int e = tid + q * NT;
                 if (e < HS) {
                     const float k = KO[e];
                     float ys;
@@ -290,12 +353,12 @@ __global__ __launch_bounds__(TL_THREADS) void ncde_fwd_tiled(KArgs a) {
 //   backwards (their dW/db accumulate in MFMA accumulator registers for the whole solve) -> Butcher bookkeeping.
 // Wo^T fragments come from the SAME 16-byte panel loads as the forward fragments, transposed through a per-wave LDS
 // scratch (row stride K + 4), so the weight stream is read once per stage.
-#define TL_EADJ 4  // state elements per thread: H * 16 <= TL_EADJ * TL_THREADS
-#define TL_DWT 8   // hidden-layer dW tiles per wave and weight slot: (N/16) * (K/16) <= 8 * TL_NW
+#define TL_ADJ_NW 8  // waves per workgroup of the sweep.  Measured at cfg5: 8 waves (two per SIMD, 256 registers each, the
+                     // cold hidden-dW accumulators spilled) 736 ms; 4 waves (one per SIMD, 494 registers, no spill) 929 ms
 
 namespace {
 
-template <int PK>
+template <int PK, int NWV>
 __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, const float* AS, const float* DX, float* KOY,
                                               float* scr, int wave, int lane) {
     constexpr int NSP = 16, SCS = 16 * PK + 4;
@@ -304,40 +367,64 @@ __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, c
     f32x4 accJ[PK];
 #pragma unroll
     for (int jt = 0; jt < PK; ++jt) accJ[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nhb_w = (nhb - wave + TL_NW - 1) / TL_NW;
+    const int nhb_w = (nhb - wave + NWV - 1) / NWV;
     const int nq = nhb_w > 0 ? nhb_w * ncq : 0;
-    auto wrow_of = [&](int q) {
-        const int hb = wave + TL_NW * (q / ncq), cq = q % ncq;
-        return a.Wo + (long long)((4 * hb + (li >> 2)) * C + 4 * cq + (li & 3)) * dlast + 4 * lk;
+    struct TileIn {
+        Panel<PK> P;
+        f32x4 bias;
     };
-    Panel<PK> Pn;
-    if (nq > 0) Pn = tl_load_panel<PK>(wrow_of(0), 0);
+    int fhi = 0, fcq = 0, fq = 0;
+    auto fetch = [&]() {
+        const int hb = wave + NWV * fhi;
+        TileIn t;
+        t.P = tl_load_panel<PK>(a.Wo + (long long)((4 * hb + (li >> 2)) * C + 4 * fcq + (li & 3)) * dlast + 4 * lk, 0);
+        t.bias = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb + lk) * C + 4 * fcq);
+        const bool more = fq + 1 < nq, wrap = fcq + 1 == ncq;
+        fq += more ? 1 : 0;
+        fhi += (more && wrap) ? 1 : 0;
+        fcq = more ? (wrap ? 0 : fcq + 1) : fcq;
+        return t;
+    };
+    int chi = 0, ccq = 0;
     float kacc = 0.0f;
-    for (int q = 0; q < nq; ++q) {
-        const int hi = q / ncq, cq = q - hi * ncq, hb = wave + TL_NW * hi;
-        const Panel<PK> P = Pn;
-        Pn = tl_load_panel<PK>(wrow_of(q + 1 < nq ? q + 1 : q), 0);
+    // straight-line body (no branches), two named buffers: the next tile's loads stay in flight across the MFMAs
+    auto step = [&](const TileIn& t) {
+        const int hb = wave + NWV * chi, cq = ccq;
 #pragma unroll
-        for (int i = 0; i < PK; ++i) *reinterpret_cast<f32x4*>(scr + li * SCS + 16 * i + 4 * lk) = P.v[i];
-        if (cq == 0) kacc = 0.0f;
+        for (int i = 0; i < PK; ++i) *reinterpret_cast<f32x4*>(scr + li * SCS + 16 * i + 4 * lk) = t.P.v[i];
         f32x4 acc[1];
-        acc[0] = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb + lk) * C + 4 * cq);
-        tl_mma_panel<1, PK>(P, xL, 0, li, lk, acc);
+        acc[0] = t.bias;
+        tl_mma_panel<1, PK>(t.P, xL, 0, li, lk, acc);
         const float aval = AS[(hb * NSP + li) * 4 + lk];
         const f32x4 dx = *reinterpret_cast<const f32x4*>(DX + (cq * NSP + li) * 4);
         float dP[4];
+        float kk = cq == 0 ? 0.0f : kacc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float m = tanh_dev(acc[0][r]);
-            kacc = fmaf(m, dx[r], kacc);
+            kk = fmaf(m, dx[r], kk);
             dP[r] = (aval * dx[r]) * (1.0f - m * m);
         }
+        kacc = kk;
+        KOY[(hb * NSP + li) * 4 + lk] = kk;      // running sum; the last channel quad leaves the total
         // dL/dx_L[j][s] += sum_u Wo[u][j] dP[u][s]: the tile's 16 rows are the K dim, k = 4 (lane>>4) + r
 #pragma unroll
         for (int jt = 0; jt < PK; ++jt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) accJ[jt] = mfma16(scr[(4 * lk + r) * SCS + 16 * jt + li], dP[r], accJ[jt]);
-        if (cq == ncq - 1) KOY[(hb * NSP + li) * 4 + lk] = kacc;
+        const bool wrap = ccq + 1 == ncq;
+        chi += wrap ? 1 : 0;
+        ccq = wrap ? 0 : ccq + 1;
+    };
+    if (nq > 0) {
+        TileIn TA = fetch(), TB;
+        for (int i = 0; i < (nq >> 1); ++i) {
+            TB = fetch();
+            step(TA);
+            TA = fetch();
+            step(TB);
+        }
+        if (nq & 1) step(TA);
     }
     // this wave's partial of dL/dx_L -> its scratch, in the activation layout
 #pragma unroll
@@ -345,12 +432,13 @@ __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, c
 }
 
 // out[i][s] = sum_j W[j][i] gpre[j][s]  (x relu'(xin[i][s]) when mask); W [N][K] row-major.
+template <int NWV>
 __device__ __forceinline__ void tl_hidden_bwd(const float* __restrict__ W, int N, int K, const float* gpre, const float* xin,
                                               bool mask, float* out, int wave, int lane) {
     constexpr int NSP = 16;
     const int li = lane & 15, lk = lane >> 4;
     const int nkb = N >> 4;
-    for (int it = wave; it < (K >> 4); it += TL_NW) {
+    for (int it = wave; it < (K >> 4); it += NWV) {
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float* wcol = W + (long long)(4 * lk) * K + 16 * it + li;
 #pragma unroll 4
@@ -373,14 +461,15 @@ __device__ __forceinline__ void tl_hidden_bwd(const float* __restrict__ W, int N
 }
 
 // dW[j][i] += w sum_s gpre[j][s] xin[i][s] into this wave's accumulator tiles (tile tt = wave + 8 q <-> (jt, it))
-__device__ __forceinline__ void tl_dw_acc(const float* gpre, const float* xin, int N, int K, float w, f32x4 (&dw)[TL_DWT], int wave,
+template <int NWV>
+__device__ __forceinline__ void tl_dw_acc(const float* gpre, const float* xin, int N, int K, float w, f32x4 (&dw)[64 / NWV], int wave,
                                           int lane) {
     constexpr int NSP = 16;
     const int li = lane & 15, lk = lane >> 4;
     const int nit = K >> 4, ntile = (N >> 4) * nit;
 #pragma unroll
-    for (int q = 0; q < TL_DWT; ++q) {
-        const int tt = wave + TL_NW * q;
+    for (int q = 0; q < 64 / NWV; ++q) {
+        const int tt = wave + NWV * q;
         if (tt < ntile) {
             const int jt = tt / nit, it = tt - jt * nit;
             const float* ap = gpre + ((4 * jt + (li >> 2)) * NSP + lk) * 4 + (li & 3);
@@ -393,8 +482,9 @@ __device__ __forceinline__ void tl_dw_acc(const float* gpre, const float* xin, i
 
 }  // namespace
 
-template <int PK>
-__global__ __launch_bounds__(TL_THREADS) void ncde_adj_tiled(KArgs a) {
+template <int PK, int NWV>
+__global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
+    constexpr int NT = 64 * NWV, TL_EADJ = 2048 / NT, TL_DWT = 64 / NWV;
     constexpr int NSP = 16, SCW = (16 * (16 * PK + 4) > 16 * PK * NSP) ? 16 * (16 * PK + 4) : 16 * PK * NSP;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -423,7 +513,7 @@ __global__ __launch_bounds__(TL_THREADS) void ncde_adj_tiled(KArgs a) {
     float y0[TL_EADJ], ky1[TL_EADJ], ky2[TL_EADJ], a0[TL_EADJ], ka1[TL_EADJ], ka2[TL_EADJ];
 #pragma unroll
     for (int q = 0; q < TL_EADJ; ++q) {
-        const int e = tid + q * TL_THREADS;
+        const int e = tid + q * NT;
         y0[q] = ky1[q] = ky2[q] = a0[q] = ka1[q] = ka2[q] = 0.0f;
         if (e < HS) {
             const int u = ((e >> 2) / NSP) * 4 + (e & 3), s = (e >> 2) % NSP, b = b0 + s;
@@ -453,10 +543,10 @@ __global__ __launch_bounds__(TL_THREADS) void ncde_adj_tiled(KArgs a) {
             const float t = disc ? (float)(n - 1) + stage_offset(a.method, S - 1 - j) : -(-(float)n + stage_offset(a.method, j));
             const int idx = piece_index(t, a.n_pieces);
             const float w = disc ? 1.0f : stage_weight(a.method, j);
-            tl_load_dx<1>(a, b0, idx, t - (float)idx, DX, tid);
+            tl_load_dx<1, NT>(a, b0, idx, t - (float)idx, DX, tid);
             if (disc) {
                 const float* rec = a.stages + ((long long)((n - 1) * S + (S - 1 - j)) * a.B + b0) * H;
-                for (int e = tid; e < NSP * H; e += TL_THREADS) {
+                for (int e = tid; e < NSP * H; e += NT) {
                     const int s = e / H, u = e - s * H;
                     YS[((u >> 2) * NSP + s) * 4 + (u & 3)] = b0 + s < a.B ? rec[e] : 0.0f;
                 }
@@ -466,12 +556,12 @@ __global__ __launch_bounds__(TL_THREADS) void ncde_adj_tiled(KArgs a) {
             const float* in = YS;
             for (int l = 0; l < L; ++l) {
                 float* outb = X + l * DS;
-                tl_dense_relu<1>(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane);
+                tl_dense_relu<1, NWV>(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane);
                 __syncthreads();
                 in = outb;
             }
             // ---- output layer: f, dP, per-wave partial of dL/dx_L -----------------------------------------------------
-            tl_output_vjp<PK>(a, in, AS, DX, KOY, scr, wave, lane);
+            tl_output_vjp<PK, NWV>(a, in, AS, DX, KOY, scr, wave, lane);
             // ---- records for pass B (x_L twice, weighted cotangent, dX/dt) --------------------------------------------
             {
                 const long long tile = (long long)sc * n_st + blockIdx.x;
@@ -479,23 +569,23 @@ __global__ __launch_bounds__(TL_THREADS) void ncde_adj_tiled(KArgs a) {
                 float* rb = a.recB + tile * (dlast * NSP);
                 float* rc = a.recC + tile * (H * NSP);
                 float* rd = a.recD + tile * (C * NSP);
-                for (int e = tid; e < dlast * NSP; e += TL_THREADS) {
+                for (int e = tid; e < dlast * NSP; e += NT) {
                     ra[e] = in[e];
                     const int jj = e >> 4, s = e & 15;
                     rb[e] = in[((jj >> 2) * NSP + s) * 4 + (jj & 3)];
                 }
-                for (int e = tid; e < H * NSP; e += TL_THREADS) {
+                for (int e = tid; e < H * NSP; e += NT) {
                     const int hh = e >> 4, s = e & 15;
                     rc[e] = w * AS[((hh >> 2) * NSP + s) * 4 + (hh & 3)];
                 }
-                for (int e = tid; e < C * NSP; e += TL_THREADS) rd[e] = DX[e];
+                for (int e = tid; e < C * NSP; e += NT) rd[e] = DX[e];
             }
             __syncthreads();
             // ---- dL/dpre_L = (sum of the 8 partials) * relu'(x_L) ---------------------------------------------------------
-            for (int e = tid; e < dlast * NSP; e += TL_THREADS) {
+            for (int e = tid; e < dlast * NSP; e += NT) {
                 float g = 0.0f;
 #pragma unroll
-                for (int wv = 0; wv < TL_NW; ++wv) g += SC[wv * SCW + e];
+                for (int wv = 0; wv < NWV; ++wv) g += SC[wv * SCW + e];
                 G1[e] = in[e] > 0.0f ? g : 0.0f;
             }
             __syncthreads();
@@ -507,8 +597,8 @@ __global__ __launch_bounds__(TL_THREADS) void ncde_adj_tiled(KArgs a) {
                 const float* xin = l == 0 ? YS : X + (l - 1) * DS;
                 if (w != 0.0f) {
                     const bool slot0 = a.gW_off[l] == a.gW_off[0];
-                    if (slot0) tl_dw_acc(gpre, xin, N, K, w, dw0, wave, lane);
-                    else tl_dw_acc(gpre, xin, N, K, w, dw1, wave, lane);
+                    if (slot0) tl_dw_acc<NWV>(gpre, xin, N, K, w, dw0, wave, lane);
+                    else tl_dw_acc<NWV>(gpre, xin, N, K, w, dw1, wave, lane);
                     if (tid < N) {
                         float sum = 0.0f;
 #pragma unroll
@@ -517,14 +607,14 @@ __global__ __launch_bounds__(TL_THREADS) void ncde_adj_tiled(KArgs a) {
                         else db1 += w * sum;
                     }
                 }
-                tl_hidden_bwd(a.W[l], N, K, gpre, xin, l > 0, l == 0 ? KOA : gx, wave, lane);
+                tl_hidden_bwd<NWV>(a.W[l], N, K, gpre, xin, l > 0, l == 0 ? KOA : gx, wave, lane);
                 __syncthreads();
                 float* tmp = gpre; gpre = gx; gx = tmp;
             }
             // ---- Butcher bookkeeping (registers) ---------------------------------------------------------------------------
 #pragma unroll
             for (int q = 0; q < TL_EADJ; ++q) {
-                const int e = tid + q * TL_THREADS;
+                const int e = tid + q * NT;
                 if (e < HS) {
                     const int u = ((e >> 2) / NSP) * 4 + (e & 3), s = (e >> 2) % NSP, b = b0 + s;
                     const bool valid = b < a.B;
@@ -612,7 +702,7 @@ __global__ __launch_bounds__(TL_THREADS) void ncde_adj_tiled(KArgs a) {
             const int N = a.dout[l], K = a.din[l], nit = K >> 4, ntile = (N >> 4) * nit;
 #pragma unroll
             for (int q = 0; q < TL_DWT; ++q) {
-                const int tt = wave + TL_NW * q;
+                const int tt = wave + NWV * q;
                 if (tt < ntile) {
                     const int jt = tt / nit, it = tt - jt * nit;
                     const f32x4 v = slot == 0 ? dw0[q] : dw1[q];
@@ -773,14 +863,14 @@ int tiled_adj_pk(const NcdeProblem* p) {
 size_t tiled_adj_lds(const NcdeProblem* p) {
     const int pk = tiled_adj_pk(p), D = tiled_dmax(p);
     const int scw = std::max(16 * (16 * pk + 4), 16 * pk * 16);
-    return sizeof(float) * (size_t)(4 * p->hidden * 16 + (p->n_layers + 2) * D * 16 + p->channels * 16 + TL_NW * scw);
+    return sizeof(float) * (size_t)(4 * p->hidden * 16 + (p->n_layers + 2) * D * 16 + p->channels * 16 + TL_ADJ_NW * scw);
 }
 
 bool tiled_adj_ok(const NcdeProblem* p) {
-    if (tiled_adj_pk(p) == 0 || p->hidden * 16 > TL_EADJ * TL_THREADS) return false;
+    if (tiled_adj_pk(p) == 0 || p->hidden * 16 > 2048) return false;
     int l1 = -1;
     for (int l = 0; l < p->n_layers; ++l) {
-        if (p->layer_out[l] > TL_THREADS || (p->layer_out[l] / 16) * (p->layer_in[l] / 16) > TL_DWT * TL_NW) return false;
+        if (p->layer_out[l] > 64 * TL_ADJ_NW || (p->layer_out[l] / 16) * (p->layer_in[l] / 16) > 64) return false;
         for (int q = 0; q < l; ++q)
             if ((p->layer_W[l] == p->layer_W[q]) != (p->layer_b[l] == p->layer_b[q])) return false;
         if (l >= 1 && p->layer_W[l] != p->layer_W[0]) {   // at most two distinct matrices: layer 0's and ONE other
@@ -864,7 +954,10 @@ int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws
     a.stages = stages;
     const int ns = tiled_fwd_ns(p);
     const size_t lds = tiled_fwd_lds(p, ns);
-    void (*fn)(KArgs) = ns == 4 ? ncde_fwd_tiled<4> : (ns == 2 ? ncde_fwd_tiled<2> : ncde_fwd_tiled<1>);
+    const bool small = p->hidden * ns * 16 <= 4 * TL_THREADS;   // state slice of <= 4 elements per thread: fewer live registers
+    void (*fn)(KArgs) = ns == 4 ? (small ? ncde_fwd_tiled<4, TL_NW, 4> : ncde_fwd_tiled<4, TL_NW, 16>)
+                                : (ns == 2 ? (small ? ncde_fwd_tiled<2, TL_NW, 4> : ncde_fwd_tiled<2, TL_NW, 16>)
+                                           : (small ? ncde_fwd_tiled<1, TL_NW, 4> : ncde_fwd_tiled<1, TL_NW, 16>));
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NCDE_ERR_HIP;
     const int nwg = (p->batch + ns * 16 - 1) / (ns * 16);
     hipLaunchKernelGGL(fn, dim3(nwg), dim3(TL_THREADS), lds, st, a);
@@ -887,11 +980,11 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     a.gpart = w + t.gpartA;
     a.gstride = t.gstride;
     const int pk = tiled_adj_pk(p);
-    void (*fa)(KArgs) = pk == 8 ? ncde_adj_tiled<8> : (pk == 4 ? ncde_adj_tiled<4> : (pk == 2 ? ncde_adj_tiled<2> : ncde_adj_tiled<1>));
+    void (*fa)(KArgs) = pk == 8 ? ncde_adj_tiled<8, TL_ADJ_NW> : (pk == 4 ? ncde_adj_tiled<4, TL_ADJ_NW> : (pk == 2 ? ncde_adj_tiled<2, TL_ADJ_NW> : ncde_adj_tiled<1, TL_ADJ_NW>));
     void (*fb)(KArgs, int, int, float*) = pk == 8 ? ncde_dwo_tiled<8> : (pk == 4 ? ncde_dwo_tiled<4> : (pk == 2 ? ncde_dwo_tiled<2> : ncde_dwo_tiled<1>));
     const size_t lds = tiled_adj_lds(p);
     if (hipFuncSetAttribute((const void*)fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NCDE_ERR_HIP;
-    hipLaunchKernelGGL(fa, dim3(t.n_st), dim3(TL_THREADS), lds, st, a);
+    hipLaunchKernelGGL(fa, dim3(t.n_st), dim3(64 * TL_ADJ_NW), lds, st, a);
     if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
     float* gB = w + t.gpartB;
     hipLaunchKernelGGL(fb, dim3(p->hidden * p->channels / 16, TLB_PARTS), dim3(256), 0, st, a, t.n_sc, t.n_st, gB);
