@@ -255,7 +255,8 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "dtype_note": "fp32 in/out and fp32 accumulation; the GEMMs on the dependency chain (forward, adjoint recompute/VJP) and dWo run as exact 3-way split-bf16 MFMA (fp32-equivalent: z error 5e-7, gradients 1e-6 vs the reference), the remaining small GEMMs as fp32-input MFMA",
+            "dtype_note": ("fp32 in/out and fp32 accumulation; the GEMMs on the dependency chain (forward, adjoint recompute/VJP) and dWo run as exact 3-way split-bf16 MFMA (fp32-equivalent: z error 5e-7, gradients 1e-6 vs the reference), the remaining small GEMMs as fp32-input MFMA"
+                           if "fast" in names[1] else "fp32 throughout (fp32-input MFMA)"),
             "config": {"workload": "BASELINE %s: %s interpolation, %s step 1, B=%d per GPU (global %d), raw L=%d -> T=%d knots, "
                                    "C=%d, H=HH=%d, nl=%d; step = forward + adjoint backward + %sAdam"
                                    % (args.config, c["interpolation"], c["solver"], B_local, B_total, c["L"], T, c["C"], c["H"],
