@@ -61,6 +61,11 @@ typedef enum NcdeOutput { NCDE_OUT_INTERVAL = 0, NCDE_OUT_KNOTS = 1 } NcdeOutput
                                        wave-specialised one */
 #define NCDE_FLAG_ADJOINT_V2 16u    /* specialised adjoint: chain+gradient kernel with an fp32-MFMA chain (default: split-bf16 chain) */
 #define NCDE_FLAG_DEBUG_PROFILE 0x100u /* development: instrumented kernel variant, cycle counters land in the workspace */
+#define NCDE_FLAG_TILED_NS1 0x1000u    /* batch-tiled forward: force 1 / 2 / 4 sixteen-sample tiles per workgroup     */
+#define NCDE_FLAG_TILED_NS2 0x2000u    /*   (default: the largest that still gives >= 256 workgroups)                 */
+#define NCDE_FLAG_TILED_NS4 0x4000u
+#define NCDE_FLAG_FORCE_TILED 0x8000u  /* use the batch-tiled family wherever it is supported (default: forward always,
+                                          backward when the output-layer matrix is >= 1 MB) */
 
 typedef struct NcdeProblem {
     int32_t abi_version;  /* = NCDE_ABI_VERSION */

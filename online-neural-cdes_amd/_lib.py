@@ -13,6 +13,7 @@ INTERP = {"linear": 0, "cubic": 1}
 METHOD = {"euler": 0, "midpoint": 1, "rk4": 2}
 OUT_INTERVAL, OUT_KNOTS = 0, 1
 FLAG_AUTO, FLAG_FORCE_GENERIC, FLAG_FORCE_FAST, FLAG_FP32_MFMA, FLAG_ADJOINT_V1, FLAG_ADJOINT_V2 = 0, 1, 2, 4, 8, 16
+FLAG_TILED_NS1, FLAG_TILED_NS2, FLAG_TILED_NS4, FLAG_FORCE_TILED = 0x1000, 0x2000, 0x4000, 0x8000
 
 _c_float_p = ctypes.c_void_p  # device pointers are passed as integers
 

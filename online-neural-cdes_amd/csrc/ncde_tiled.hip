@@ -846,9 +846,9 @@ size_t tiled_fwd_lds(const NcdeProblem* p, int ns) {
 // that still leaves >= 256 workgroups (one per CU).  Development flags 0x1000/0x2000/0x4000 force NS = 1/2/4.
 int tiled_fwd_ns(const NcdeProblem* p) {
     auto fits = [&](int ns) { return tiled_fwd_lds(p, ns) <= (size_t)kLdsLimit && p->hidden * ns * 16 <= TL_EMAX * TL_THREADS; };
-    if (p->flags & 0x1000u) return fits(1) ? 1 : 0;
-    if (p->flags & 0x2000u) return fits(2) ? 2 : 0;
-    if (p->flags & 0x4000u) return fits(4) ? 4 : 0;
+    if (p->flags & NCDE_FLAG_TILED_NS1) return fits(1) ? 1 : 0;
+    if (p->flags & NCDE_FLAG_TILED_NS2) return fits(2) ? 2 : 0;
+    if (p->flags & NCDE_FLAG_TILED_NS4) return fits(4) ? 4 : 0;
     for (int ns = 4; ns >= 2; ns >>= 1)
         if (fits(ns) && (p->batch + 16 * ns - 1) / (16 * ns) >= 256) return ns;
     return fits(1) ? 1 : 0;
@@ -923,7 +923,7 @@ bool ncde_tiled_supported(const NcdeProblem* p, int pass) {
 // scheme pays off once the output-layer matrix is too large for per-workgroup partials in LDS (cfg5: 1.71 s vs
 // 13.5 s generic); for small matrices the generic kernel's in-LDS partial wins (cfg4: 24 ms vs 30 ms).
 bool ncde_tiled_preferred(const NcdeProblem* p, int pass) {
-    if (p->flags & 0x8000u) return true;   // development / tests: force the family wherever it is supported
+    if (p->flags & NCDE_FLAG_FORCE_TILED) return true;   // development / tests: force the family wherever it is supported
     if (pass == 0) return true;
     const long long wo_bytes = 4LL * p->hidden * p->channels * p->layer_out[p->n_layers - 1];
     return wo_bytes >= (1LL << 20);
