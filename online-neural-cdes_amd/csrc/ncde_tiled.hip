@@ -718,10 +718,9 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
 // ------------------------------------------------------------------------------------------------
 // pass B: dL/dWo, dL/dbo from the records -- weights and gradient accumulators never leave the registers
 // ------------------------------------------------------------------------------------------------
-// grid = (H*C/16 row tiles, TLB_PARTS); one WAVE = one 16-row tile of Wo x one 1/(4*TLB_PARTS) slice of the sample
+// grid = (H*C/16 row tiles, parts); one WAVE = one 16-row tile of Wo x one 1/(4*parts) slice of the sample
 // tiles, for ALL stages: P = Wo_tile x_L + bo is recomputed (PK*4 MFMAs), dP = cot (x) dX (1 - tanh^2 P), and
 // dWo_tile += dP x_L^T (PK*4 MFMAs, samples are the K dim; dP transposed through a 16x17 LDS patch).
-#define TLB_PARTS 4
 template <int PK>
 __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_st, float* gpartB) {
     __shared__ float patch[4][16 * 17];
@@ -731,7 +730,7 @@ __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_s
     const int li = lane & 15, lk = lane >> 4;
     const int C = a.C, H = a.H, ncq = C >> 2, dlast = 16 * PK;
     const int tile = blockIdx.x, hb = tile / ncq, cq = tile - hb * ncq;
-    const int part = blockIdx.y * 4 + wave, nparts = TLB_PARTS * 4;
+    const int part = blockIdx.y * 4 + wave, nparts = gridDim.y * 4;
     const Panel<PK> Wp = tl_load_panel<PK>(a.Wo + (long long)((4 * hb + (li >> 2)) * C + 4 * cq + (li & 3)) * dlast + 4 * lk, 0);
     const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb + lk) * C + 4 * cq);
     f32x4 gW[PK];
@@ -882,7 +881,7 @@ bool tiled_adj_ok(const NcdeProblem* p) {
 }
 
 struct TiledAdjPlan {
-    int n_st, n_sc, gstride;
+    int n_st, n_sc, gstride, parts;
     long long recA, recB, recC, recD, gpartA, gpartB, total;   // float offsets into the workspace
     long long theta_o;
 };
@@ -902,7 +901,11 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
     t.recD = off; off += tiles * p->channels * 16;
     t.gpartA = off; off += (long long)t.n_st * t.gstride;
     t.theta_o = (long long)p->hidden * p->channels * dlast + (long long)p->hidden * p->channels;
-    t.gpartB = off; off += TLB_PARTS * t.theta_o;
+    // pass B wants >= 4096 waves (four rounds of one wave per SIMD) for balance; each part-group = 4 waves of one row tile
+    const int row_tiles = p->hidden * p->channels / 16;
+    t.parts = 1;
+    while (t.parts < 64 && row_tiles * 4 * t.parts < 4096 && 4 * t.parts * 2 <= t.n_st) t.parts *= 2;
+    t.gpartB = off; off += (long long)t.parts * t.theta_o;
     t.total = off + 64;
     return t;
 }
@@ -919,14 +922,12 @@ bool ncde_tiled_supported(const NcdeProblem* p, int pass) {
     return tiled_fwd_ns(p) > 0;
 }
 
-// Is the tiled family the better choice?  Forward: yes whenever it applies.  Backward: the record + second-pass
-// scheme pays off once the output-layer matrix is too large for per-workgroup partials in LDS (cfg5: 1.71 s vs
-// 13.5 s generic); for small matrices the generic kernel's in-LDS partial wins (cfg4: 24 ms vs 30 ms).
+// Is the tiled family the better choice?  Measured on MI355X it is wherever it applies: forward cfg5 0.51 s vs 2.54 s
+// generic; backward cfg5 1.38 s vs 13.5 s, cfg4 14.1 ms vs 24.0 ms (the generic kernel keeps its per-workgroup
+// gradient partial in global memory once it no longer fits LDS).  The hook stays for shapes that measure otherwise.
 bool ncde_tiled_preferred(const NcdeProblem* p, int pass) {
-    if (p->flags & NCDE_FLAG_FORCE_TILED) return true;   // development / tests: force the family wherever it is supported
-    if (pass == 0) return true;
-    const long long wo_bytes = 4LL * p->hidden * p->channels * p->layer_out[p->n_layers - 1];
-    return wo_bytes >= (1LL << 20);
+    (void)p; (void)pass;
+    return true;
 }
 
 const char* ncde_tiled_kernel_name(const NcdeProblem* p, int pass) {
@@ -987,7 +988,7 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     hipLaunchKernelGGL(fa, dim3(t.n_st), dim3(64 * TL_ADJ_NW), lds, st, a);
     if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
     float* gB = w + t.gpartB;
-    hipLaunchKernelGGL(fb, dim3(p->hidden * p->channels / 16, TLB_PARTS), dim3(256), 0, st, a, t.n_sc, t.n_st, gB);
+    hipLaunchKernelGGL(fb, dim3(p->hidden * p->channels / 16, t.parts), dim3(256), 0, st, a, t.n_sc, t.n_st, gB);
     if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
     if (main_kernel_only) return NCDE_OK;
     // deterministic reductions: hidden-layer partials of the sweep, then the part-group partials of pass B
@@ -1010,6 +1011,6 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     so.n = 2;
     so.off[0] = 0; so.len[0] = wo_sz; so.dst[0] = g->grad_Wo;
     so.off[1] = wo_sz; so.len[1] = p->hidden * p->channels; so.dst[1] = g->grad_bo;
-    hipLaunchKernelGGL(ncde_reduce_partials, dim3(((int)t.theta_o + 255) / 256), dim3(256), 0, st, (const float*)gB, TLB_PARTS, (int)t.theta_o, so);
+    hipLaunchKernelGGL(ncde_reduce_partials, dim3(((int)t.theta_o + 255) / 256), dim3(256), 0, st, (const float*)gB, t.parts, (int)t.theta_o, so);
     return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
 }
