@@ -358,9 +358,16 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
 
 namespace {
 
-template <int PK, int NWV>
+template <int PK>
+struct WoTile {
+    Panel<PK> P;
+    f32x4 bias;
+};
+
+// RES = 1: the (at most two) output tiles of this wave are resident in registers (`res`), nothing is fetched.
+template <int PK, int NWV, int RES>
 __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, const float* AS, const float* DX, float* KOY,
-                                              float* scr, int wave, int lane) {
+                                              float* scr, int wave, int lane, const WoTile<PK>* res) {
     constexpr int NSP = 16, SCS = 16 * PK + 4;
     const int li = lane & 15, lk = lane >> 4;
     const int C = a.C, nhb = a.H >> 2, ncq = C >> 2, dlast = 16 * PK;
@@ -369,10 +376,7 @@ __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, c
     for (int jt = 0; jt < PK; ++jt) accJ[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nhb_w = (nhb - wave + NWV - 1) / NWV;
     const int nq = nhb_w > 0 ? nhb_w * ncq : 0;
-    struct TileIn {
-        Panel<PK> P;
-        f32x4 bias;
-    };
+    using TileIn = WoTile<PK>;
     int fhi = 0, fcq = 0, fq = 0;
     auto fetch = [&]() {
         const int hb = wave + NWV * fhi;
@@ -416,15 +420,20 @@ __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, c
         chi += wrap ? 1 : 0;
         ccq = wrap ? 0 : ccq + 1;
     };
-    if (nq > 0) {
-        TileIn TA = fetch(), TB;
-        for (int i = 0; i < (nq >> 1); ++i) {
-            TB = fetch();
-            step(TA);
-            TA = fetch();
-            step(TB);
+    if constexpr (RES != 0) {
+        if (nq > 0) step(res[0]);
+        if (nq > 1) step(res[1]);
+    } else {
+        if (nq > 0) {
+            TileIn TA = fetch(), TB;
+            for (int i = 0; i < (nq >> 1); ++i) {
+                TB = fetch();
+                step(TA);
+                TA = fetch();
+                step(TB);
+            }
+            if (nq & 1) step(TA);
         }
-        if (nq & 1) step(TA);
     }
     // this wave's partial of dL/dx_L -> its scratch, in the activation layout
 #pragma unroll
@@ -461,14 +470,14 @@ __device__ __forceinline__ void tl_hidden_bwd(const float* __restrict__ W, int N
 }
 
 // dW[j][i] += w sum_s gpre[j][s] xin[i][s] into this wave's accumulator tiles (tile tt = wave + 8 q <-> (jt, it))
-template <int NWV>
-__device__ __forceinline__ void tl_dw_acc(const float* gpre, const float* xin, int N, int K, float w, f32x4 (&dw)[64 / NWV], int wave,
+template <int NWV, int DWT>
+__device__ __forceinline__ void tl_dw_acc(const float* gpre, const float* xin, int N, int K, float w, f32x4 (&dw)[DWT], int wave,
                                           int lane) {
     constexpr int NSP = 16;
     const int li = lane & 15, lk = lane >> 4;
     const int nit = K >> 4, ntile = (N >> 4) * nit;
 #pragma unroll
-    for (int q = 0; q < 64 / NWV; ++q) {
+    for (int q = 0; q < DWT; ++q) {
         const int tt = wave + NWV * q;
         if (tt < ntile) {
             const int jt = tt / nit, it = tt - jt * nit;
@@ -482,9 +491,14 @@ __device__ __forceinline__ void tl_dw_acc(const float* gpre, const float* xin, i
 
 }  // namespace
 
-template <int PK, int NWV>
+// RES = 1 ("everything resident", small square models: H = every layer width = 16 PK <= 64, H*C/16 <= 2 NWV output
+// tiles): every weight fragment a wave needs -- its forward row tile and its transposed tile of the (at most two)
+// hidden matrices, its (at most two) output tiles -- is loaded ONCE and stays in registers, so no phase of a stage
+// waits on an L2 round trip (cfg4: 11.3 -> see DESIGN.md).
+template <int PK, int NWV, int RES = 0>
 __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
-    constexpr int NT = 64 * NWV, TL_EADJ = 2048 / NT, TL_DWT = 64 / NWV;
+    constexpr int NT = 64 * NWV, TL_EADJ = RES ? (16 * 16 * PK + NT - 1) / NT : 2048 / NT;
+    constexpr int TL_DWT = RES ? (PK * PK + NWV - 1) / NWV : 64 / NWV;   // hidden dW tiles per wave and weight slot
     constexpr int NSP = 16, SCW = (16 * (16 * PK + 4) > 16 * PK * NSP) ? 16 * (16 * PK + 4) : 16 * PK * NSP;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -537,31 +551,139 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
 #pragma unroll
     for (int q = 0; q < TL_DWT; ++q) dw0[q] = dw1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // ---- resident weight fragments (RES) -------------------------------------------------------------------------------
+    Panel<PK> wf[2];          // forward row tile `wave` of the layer-0 matrix / of the other matrix
+    f32x4 bfv[2];
+    float wb[2][4 * PK];      // transposed tile `wave` (input units 16 wave ..) of the same two matrices
+    WoTile<PK> wo[2];
+    if constexpr (RES != 0) {
+        const int li = lane & 15, lk = lane >> 4;
+        int l1 = 0;
+        for (int l = 1; l < L; ++l)
+            if (a.gW_off[l] != a.gW_off[0]) { l1 = l; break; }
+        const int K = dlast;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const int l = sl == 0 ? 0 : l1;
+            const int tw = wave < PK ? wave : 0;
+            wf[sl] = tl_load_panel<PK>(a.W[l] + (long long)(16 * tw + li) * K + 4 * lk, 0);
+            bfv[sl] = *reinterpret_cast<const f32x4*>(a.b[l] + 16 * tw + 4 * lk);
+#pragma unroll
+            for (int kb = 0; kb < PK; ++kb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wb[sl][4 * kb + e] = a.W[l][(long long)(16 * kb + 4 * lk + e) * K + 16 * tw + li];
+        }
+        const int nhb = H >> 2, ncq = C >> 2;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int hb = wave + NWV * (q / ncq), cq = q % ncq;
+            if (hb >= nhb) { hb = 0; cq = 0; }
+            wo[q].P = tl_load_panel<PK>(a.Wo + (long long)((4 * hb + (li >> 2)) * C + 4 * cq + (li & 3)) * dlast + 4 * lk, 0);
+            wo[q].bias = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb + lk) * C + 4 * cq);
+        }
+    }
+
+    // dX/dt (and, for the discrete backward, the recorded stage input) of stage (n, j) are fetched into registers one
+    // stage ahead and stored to LDS in the bookkeeping phase, so no stage starts with an exposed global round trip
+    constexpr int DXE = (NSP * 80 + NT - 1) / NT, YSE = TL_EADJ;      // C <= 80 on this path (host check)
+    float dxn[DXE], ysn[YSE];
+    auto stage_time = [&](int n, int j) {
+        return disc ? (float)(n - 1) + stage_offset(a.method, S - 1 - j) : -(-(float)n + stage_offset(a.method, j));
+    };
+    auto prefetch = [&](int n, int j) {
+        const float t = stage_time(n, j);
+        const int idx = piece_index(t, a.n_pieces);
+        const float frac = t - (float)idx;
+#pragma unroll
+        for (int q = 0; q < DXE; ++q) {
+            const int e = tid + q * NT;
+            float v = 0.0f;
+            if (e < NSP * C) {
+                const int s = e / C, c = e - s * C, b = b0 + s;
+                if (b < a.B) {
+                    const float* cp = a.coeffs + (long long)b * a.cs_b + (long long)idx * a.cs_t;
+                    if (a.interp == NCDE_INTERP_LINEAR) {
+                        v = cp[a.cs_t + c] - cp[c];
+                    } else {
+                        const float bb = cp[C + c], cc = cp[2 * C + c], dd = cp[3 * C + c];
+                        const float inner = cc + dd * frac;
+                        v = bb + inner * frac;
+                    }
+                }
+            }
+            dxn[q] = v;
+        }
+        if (disc) {
+            const float* rec = a.stages + ((long long)((n - 1) * S + (S - 1 - j)) * a.B + b0) * H;
+#pragma unroll
+            for (int q = 0; q < YSE; ++q) {
+                const int e = tid + q * NT;
+                float v = 0.0f;
+                if (e < NSP * H) {
+                    const int s = e / H;
+                    if (b0 + s < a.B) v = rec[e];
+                }
+                ysn[q] = v;
+            }
+        }
+    };
+    auto publish = [&]() {
+#pragma unroll
+        for (int q = 0; q < DXE; ++q) {
+            const int e = tid + q * NT;
+            if (e < NSP * C) {
+                const int s = e / C, c = e - s * C;
+                DX[((c >> 2) * NSP + s) * 4 + (c & 3)] = dxn[q];
+            }
+        }
+        if (disc) {
+#pragma unroll
+            for (int q = 0; q < YSE; ++q) {
+                const int e = tid + q * NT;
+                if (e < NSP * H) {
+                    const int s = e / H, u = e - s * H;
+                    YS[((u >> 2) * NSP + s) * 4 + (u & 3)] = ysn[q];
+                }
+            }
+        }
+    };
+    prefetch(a.T - 1, 0);
+    publish();
+    __syncthreads();
+
     int sc = 0;
     for (int n = a.T - 1; n >= 1; --n) {
         for (int j = 0; j < S; ++j, ++sc) {
-            const float t = disc ? (float)(n - 1) + stage_offset(a.method, S - 1 - j) : -(-(float)n + stage_offset(a.method, j));
-            const int idx = piece_index(t, a.n_pieces);
             const float w = disc ? 1.0f : stage_weight(a.method, j);
-            tl_load_dx<1, NT>(a, b0, idx, t - (float)idx, DX, tid);
-            if (disc) {
-                const float* rec = a.stages + ((long long)((n - 1) * S + (S - 1 - j)) * a.B + b0) * H;
-                for (int e = tid; e < NSP * H; e += NT) {
-                    const int s = e / H, u = e - s * H;
-                    YS[((u >> 2) * NSP + s) * 4 + (u & 3)] = b0 + s < a.B ? rec[e] : 0.0f;
-                }
+            {   // next stage's inputs; consumed (publish) in this stage's bookkeeping phase
+                const int jn = j + 1 < S ? j + 1 : 0, nn = j + 1 < S ? n : n - 1;
+                if (nn >= 1) prefetch(nn, jn);
             }
-            __syncthreads();
             // ---- forward recompute, keeping x_1 .. x_L -------------------------------------------------------------
             const float* in = YS;
             for (int l = 0; l < L; ++l) {
                 float* outb = X + l * DS;
-                tl_dense_relu<1, NWV>(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane);
+                if constexpr (RES != 0) {
+                    if (wave < PK) {
+                        const int li = lane & 15, lk = lane >> 4;
+                        const bool s0 = a.gW_off[l] == a.gW_off[0];
+                        f32x4 acc[1];
+                        acc[0] = s0 ? bfv[0] : bfv[1];
+                        if (s0) tl_mma_panel<1, PK>(wf[0], in, 0, li, lk, acc);
+                        else tl_mma_panel<1, PK>(wf[1], in, 0, li, lk, acc);
+                        f32x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = relu_dev(acc[0][r]);
+                        *reinterpret_cast<f32x4*>(outb + ((4 * wave + lk) * NSP + li) * 4) = o;
+                    }
+                } else {
+                    tl_dense_relu<1, NWV>(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane);
+                }
                 __syncthreads();
                 in = outb;
             }
             // ---- output layer: f, dP, per-wave partial of dL/dx_L -----------------------------------------------------
-            tl_output_vjp<PK, NWV>(a, in, AS, DX, KOY, scr, wave, lane);
+            tl_output_vjp<PK, NWV, RES>(a, in, AS, DX, KOY, scr, wave, lane, wo);
             // ---- records for pass B (x_L twice, weighted cotangent, dX/dt) --------------------------------------------
             {
                 const long long tile = (long long)sc * n_st + blockIdx.x;
@@ -597,8 +719,8 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                 const float* xin = l == 0 ? YS : X + (l - 1) * DS;
                 if (w != 0.0f) {
                     const bool slot0 = a.gW_off[l] == a.gW_off[0];
-                    if (slot0) tl_dw_acc<NWV>(gpre, xin, N, K, w, dw0, wave, lane);
-                    else tl_dw_acc<NWV>(gpre, xin, N, K, w, dw1, wave, lane);
+                    if (slot0) tl_dw_acc<NWV, TL_DWT>(gpre, xin, N, K, w, dw0, wave, lane);
+                    else tl_dw_acc<NWV, TL_DWT>(gpre, xin, N, K, w, dw1, wave, lane);
                     if (tid < N) {
                         float sum = 0.0f;
 #pragma unroll
@@ -607,7 +729,28 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                         else db1 += w * sum;
                     }
                 }
-                tl_hidden_bwd<NWV>(a.W[l], N, K, gpre, xin, l > 0, l == 0 ? KOA : gx, wave, lane);
+                if constexpr (RES != 0) {
+                    if (wave < PK) {
+                        const int li = lane & 15, lk = lane >> 4;
+                        const bool s0 = a.gW_off[l] == a.gW_off[0];
+                        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kb = 0; kb < PK; ++kb) {
+                            const f32x4 Bv = *reinterpret_cast<const f32x4*>(gpre + ((4 * kb + lk) * NSP + li) * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc = mfma16(s0 ? wb[0][4 * kb + e] : wb[1][4 * kb + e], Bv[e], acc);
+                        }
+                        const int o = ((4 * wave + lk) * NSP + li) * 4;
+                        if (l > 0) {
+                            const f32x4 xv = *reinterpret_cast<const f32x4*>(xin + o);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[r] = xv[r] > 0.0f ? acc[r] : 0.0f;
+                        }
+                        *reinterpret_cast<f32x4*>((l == 0 ? KOA : gx) + o) = acc;
+                    }
+                } else {
+                    tl_hidden_bwd<NWV>(a.W[l], N, K, gpre, xin, l > 0, l == 0 ? KOA : gx, wave, lane);
+                }
                 __syncthreads();
                 float* tmp = gpre; gpre = gx; gx = tmp;
             }
@@ -685,6 +828,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                     }
                 }
             }
+            publish();
             __syncthreads();
         }
     }
@@ -866,7 +1010,7 @@ size_t tiled_adj_lds(const NcdeProblem* p) {
 }
 
 bool tiled_adj_ok(const NcdeProblem* p) {
-    if (tiled_adj_pk(p) == 0 || p->hidden * 16 > 2048) return false;
+    if (tiled_adj_pk(p) == 0 || p->hidden * 16 > 2048 || p->channels > 80) return false;
     int l1 = -1;
     for (int l = 0; l < p->n_layers; ++l) {
         if (p->layer_out[l] > 64 * TL_ADJ_NW || (p->layer_out[l] / 16) * (p->layer_in[l] / 16) > 64) return false;
@@ -981,7 +1125,13 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     a.gpart = w + t.gpartA;
     a.gstride = t.gstride;
     const int pk = tiled_adj_pk(p);
-    void (*fa)(KArgs) = pk == 8 ? ncde_adj_tiled<8, TL_ADJ_NW> : (pk == 4 ? ncde_adj_tiled<4, TL_ADJ_NW> : (pk == 2 ? ncde_adj_tiled<2, TL_ADJ_NW> : ncde_adj_tiled<1, TL_ADJ_NW>));
+    // small square models: every weight fragment register-resident (see ncde_adj_tiled)
+    bool res = pk <= 4 && p->hidden == 16 * pk && p->hidden * p->channels / 16 <= 2 * TL_ADJ_NW;
+    for (int l = 0; l < p->n_layers; ++l) res = res && p->layer_out[l] == 16 * pk && p->layer_in[l] == 16 * pk;
+    void (*fa)(KArgs) = pk == 8 ? ncde_adj_tiled<8, TL_ADJ_NW>
+                                : (pk == 4 ? (res ? ncde_adj_tiled<4, TL_ADJ_NW, 1> : ncde_adj_tiled<4, TL_ADJ_NW>)
+                                           : (pk == 2 ? (res ? ncde_adj_tiled<2, TL_ADJ_NW, 1> : ncde_adj_tiled<2, TL_ADJ_NW>)
+                                                      : (res ? ncde_adj_tiled<1, TL_ADJ_NW, 1> : ncde_adj_tiled<1, TL_ADJ_NW>)));
     void (*fb)(KArgs, int, int, float*) = pk == 8 ? ncde_dwo_tiled<8> : (pk == 4 ? ncde_dwo_tiled<4> : (pk == 2 ? ncde_dwo_tiled<2> : ncde_dwo_tiled<1>));
     const size_t lds = tiled_adj_lds(p);
     if (hipFuncSetAttribute((const void*)fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NCDE_ERR_HIP;
