@@ -156,8 +156,9 @@ int ncde_time_kernel(const NcdeProblem* p, int pass, float* out, const float* gr
  * ncde_prepare_linear   replaces torchcde.linear_interpolation_coeffs (interpolation_linear.py:131-180):
  *                       rectilinear_time_index >= 0 -> rectilinear preparation (out [B, 2L-1, C]), else plain
  *                       NaN-filled linear knots (out [B, L, C]).
- * ncde_prepare_cubic    replaces torchcde.natural_cubic_coeffs for series WITHOUT missing values
- *                       (interpolation_cubic.py:7-53, 170-190): out [B, L-1, 4C] = a|b|2c|3d.
+ * ncde_prepare_cubic    replaces torchcde.natural_cubic_coeffs (interpolation_cubic.py:7-165, 170-190; NaN = missing:
+ *                       ends filled from the first/last observation, spline through the observed knots):
+ *                       out [B, L-1, 4C] = a|b|2c|3d.
  * kind = NcdeInterp for the workspace query. */
 int64_t ncde_prepare_workspace_bytes(int kind, int B, int L, int C);
 int ncde_prepare_linear(const float* x, int B, int L, int C, int rectilinear_time_index, float* out, void* stream);

@@ -41,12 +41,10 @@ def linear_interpolation_coeffs(x, t=None, rectilinear=None):
 
 
 def natural_cubic_coeffs(x, t=None):
-    """a | b | 2c | 3d of the natural cubic spline through x (no missing values)."""
+    """a | b | 2c | 3d of the natural cubic spline through x; NaNs are missing values."""
     if t is not None:
         raise NotImplementedError("only the default integer time grid is supported")
     x3 = _check(x)
-    if torch.isnan(x3).any():
-        raise NotImplementedError("natural cubic coefficients with missing values are not implemented on the GPU path")
     B, L, C = x3.shape
     out = torch.empty(B, L - 1, 4 * C, dtype=torch.float32, device=x.device)
     need = _lib.check(_lib.lib().ncde_prepare_workspace_bytes(_lib.INTERP["cubic"], B, L, C), "ncde_prepare_workspace_bytes")

@@ -74,24 +74,107 @@ __global__ __launch_bounds__(256) void ncde_linear_coeffs_kernel(const float* __
     }
 }
 
-// natural cubic spline on the integer grid, no missing values.  out[b][p][4C] = a | b | 2c | 3d of piece p.
+// natural cubic spline on the integer grid.  out[b][p][4C] = a | b | 2c | 3d of piece p.
 // ws[b][i][c] keeps the forward-swept right-hand side; the swept diagonal depends on i only (recomputed).
+// Series with missing values (interpolation_cubic.py:77-165): ends filled from the first / last observation, spline
+// through the observed knots only (non-uniform spacing, so the swept diagonal is per series: wd), then every unit
+// interval [time, time+1) gets the piece that covers it, re-expanded around `time` (offset = t_knot - time).
+__device__ void cubic_series_missing(const float* xs, float* os, float* wb, float* wd, int L, int C, int first, int last) {
+    const long long sC = C;
+    auto val = [&](int i) { return i < first ? xs[first * sC] : (i > last ? xs[last * sC] : xs[i * sC]); };
+    // forward sweep over the knots: knot p is processed when the next knot q is known (r_p = 1/(t_q - t_p))
+    int pp = -1, p = 0;                 // index 0 is always a knot after the fill
+    float xp = val(0), r_prev = 0.0f, scaled_prev = 0.0f, nd_prev = 0.0f, nb_prev = 0.0f;
+    for (int q = 1; q < L; ++q) {
+        const float xq = val(q);
+        if (isnan(xq)) continue;
+        const float td = (float)q - (float)p;
+        const float r = 1.0f / td, r2 = r * r;
+        const float three = 3.0f * (xq - xp);
+        const float scaled = three * r2;
+        float diag, rhs;
+        if (pp < 0) { diag = r * 2.0f; rhs = scaled; }
+        else { diag = (r + r_prev) * 2.0f; rhs = scaled + scaled_prev; }
+        float nd, nb;
+        if (pp < 0) { nd = diag; nb = rhs; }
+        else {
+            const float w = r_prev / nd_prev;
+            nd = diag - w * r_prev;
+            nb = rhs - w * nb_prev;
+        }
+        wd[p * sC] = nd;
+        wb[p * sC] = nb;
+        pp = p; p = q; xp = xq; r_prev = r; scaled_prev = scaled; nd_prev = nd; nb_prev = nb;
+    }
+    // last knot (index L-1): diag = (0 + r_prev) * 2, rhs = 0 + scaled_prev
+    float kd_next;
+    {
+        const float diag = (0.0f + r_prev) * 2.0f, rhs = 0.0f + scaled_prev;
+        const float w = r_prev / nd_prev;
+        const float nd = diag - w * r_prev, nb = rhs - w * nb_prev;
+        kd_next = nb / nd;
+    }
+    // back substitution, coefficients per knot interval, expansion onto the unit intervals (right to left)
+    int q = L - 1;
+    float xq = val(q);
+    for (int i = L - 2; i >= 0; --i) {
+        const float xi = val(i);
+        if (isnan(xi)) continue;
+        const float td = (float)q - (float)i;
+        const float r = 1.0f / td, r2 = r * r;
+        const float kd = (wb[i * sC] - r * kd_next) / wd[i * sC];
+        const float three = 3.0f * (xq - xi), six = 2.0f * three;
+        const float two_c = ((six * r - 4.0f * kd) - 2.0f * kd_next) * r;
+        const float three_d = (-six * r + 3.0f * (kd + kd_next)) * r2;
+        for (int time = q - 1; time >= i; --time) {
+            const float off = (float)i - (float)time;
+            const float a_in = (0.5f * two_c - three_d * off / 3.0f) * off;
+            float* o = os + (long long)time * 4 * C;
+            o[0] = xi + (a_in - kd) * off;
+            o[C] = kd + (three_d * off - two_c) * off;
+            o[2 * C] = two_c - 2.0f * three_d * off;
+            o[3 * C] = three_d;
+        }
+        q = i; xq = xi; kd_next = kd;
+    }
+}
+
 __global__ __launch_bounds__(256) void ncde_cubic_coeffs_kernel(const float* __restrict__ x, int B, int L, int C,
                                                                  float* __restrict__ out, float* __restrict__ ws,
-                                                                 const float* __restrict__ diag_swept) {
+                                                                 const float* __restrict__ diag_swept, float* __restrict__ ws_d) {
     const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (tid >= (long long)B * C) return;
     const int b = (int)(tid / C), c = (int)(tid - (long long)b * C);
     const float* xs = x + (long long)b * L * C + c;
     float* os = out + (long long)b * (L - 1) * 4 * C + c;
+    // missing values?  (NaN anywhere in the series)
+    int first = -1, last = -1, n_obs = 0;
+    for (int i = 0; i < L; ++i)
+        if (!isnan(xs[(long long)i * C])) {
+            if (first < 0) first = i;
+            last = i;
+            ++n_obs;
+        }
+    if (n_obs == 0) {  // no observation at all: the zero path
+        for (int i = 0; i < L - 1; ++i) {
+            float* o = os + (long long)i * 4 * C;
+            o[0] = 0.0f; o[C] = 0.0f; o[2 * C] = 0.0f; o[3 * C] = 0.0f;
+        }
+        return;
+    }
     if (L == 2) {
-        os[0] = xs[0];
-        os[C] = xs[C] - xs[0];
+        const float x0 = xs[first * (long long)C], x1 = xs[last * (long long)C];   // ends filled from the observations
+        os[0] = x0;
+        os[C] = x1 - x0;
         os[2 * C] = 0.0f;
         os[3 * C] = 0.0f;
         return;
     }
     float* wb = ws + (long long)b * L * C + c;
+    if (n_obs < L) {
+        cubic_series_missing(xs, os, wb, ws_d + (long long)b * L * C + c, L, C, first, last);
+        return;
+    }
     // rhs_i = 3 (x_i - x_{i-1}) + 3 (x_{i+1} - x_i) with unit knot spacing; Thomas forward sweep
     float x_prev = xs[0], x_cur = xs[C];
     float scaled_prev = (3.0f * (x_cur - x_prev)) * 1.0f;  // three_path_diffs * reciprocal^2
@@ -153,7 +236,7 @@ extern "C" {
 
 int64_t ncde_prepare_workspace_bytes(int kind, int B, int L, int C) {
     if (B < 1 || L < 2 || C < 1) return NCDE_ERR_INVALID;
-    if (kind == NCDE_INTERP_CUBIC) return (int64_t)sizeof(float) * ((int64_t)B * L * C + L) + 256;
+    if (kind == NCDE_INTERP_CUBIC) return (int64_t)sizeof(float) * (2 * (int64_t)B * L * C + L) + 256;
     return 256;
 }
 
@@ -169,11 +252,12 @@ int ncde_prepare_cubic(const float* x, int B, int L, int C, float* out, void* wo
     if (!x || !out || !workspace || B < 1 || L < 2 || C < 1) return NCDE_ERR_INVALID;
     if ((int64_t)workspace_bytes < ncde_prepare_workspace_bytes(NCDE_INTERP_CUBIC, B, L, C)) return NCDE_ERR_WORKSPACE;
     float* ws = (float*)workspace;
-    float* diag = ws + (size_t)B * L * C;
+    float* ws_d = ws + (size_t)B * L * C;
+    float* diag = ws_d + (size_t)B * L * C;
     hipLaunchKernelGGL(ncde_cubic_diag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, L, diag);
     const long long n = (long long)B * C;
     hipLaunchKernelGGL(ncde_cubic_coeffs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, B, L, C, out,
-                       ws, diag);
+                       ws, diag, ws_d);
     return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
 }
 

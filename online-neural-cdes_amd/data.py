@@ -103,13 +103,94 @@ def linear_interpolation_coeffs(x, rectilinear=None):
     return x
 
 
+def _natural_cubic_series_missing(x):
+    """One scalar series x[L] with NaNs = missing -> (a, b, 2c, 3d)[L-1] on every unit interval, following
+    interpolation_cubic.py:77-165 (``natural_cubic_coeffs``: ends filled from the first/last observation, spline on
+    the observed knots, then re-expanded around the left end of every unit interval)."""
+    f32 = np.float32
+    L = x.shape[0]
+    obs = np.where(~np.isnan(x))[0]
+    if obs.size == 0:
+        z = np.zeros(L - 1, dtype=f32)
+        return z, z.copy(), z.copy(), z.copy()
+    x = x.copy()
+    x[:obs[0]] = x[obs[0]]
+    x[obs[-1] + 1:] = x[obs[-1]]
+    kn = np.where(~np.isnan(x))[0]
+    tk = kn.astype(f32)
+    xk = x[kn]
+    m = kn.size
+    if m == 2:
+        a_k = xk[:1]
+        b_k = (xk[1:] - xk[:1]) / (tk[1:] - tk[:1])
+        c_k = np.zeros(1, dtype=f32)
+        d_k = np.zeros(1, dtype=f32)
+    else:
+        td = tk[1:] - tk[:-1]
+        r = (f32(1) / td).astype(f32)
+        r2 = r * r
+        three = f32(3) * (xk[1:] - xk[:-1])
+        six = f32(2) * three
+        scaled = three * r2
+        diag = np.empty(m, dtype=f32)
+        diag[:-1] = r
+        diag[-1] = 0
+        diag[1:] += r
+        diag *= f32(2)
+        rhs = np.empty(m, dtype=f32)
+        rhs[:-1] = scaled
+        rhs[-1] = 0
+        rhs[1:] += scaled
+        nd = np.empty(m, dtype=f32)
+        nb = np.empty(m, dtype=f32)
+        nd[0], nb[0] = diag[0], rhs[0]
+        for i in range(1, m):
+            w = f32(r[i - 1] / nd[i - 1])
+            nd[i] = f32(diag[i] - f32(w * r[i - 1]))
+            nb[i] = f32(rhs[i] - f32(w * nb[i - 1]))
+        kd = np.empty(m, dtype=f32)
+        kd[m - 1] = f32(nb[m - 1] / nd[m - 1])
+        for i in range(m - 2, -1, -1):
+            kd[i] = f32(f32(nb[i] - f32(r[i] * kd[i + 1])) / nd[i])
+        a_k = xk[:-1]
+        b_k = kd[:-1]
+        c_k = ((six * r - f32(4) * kd[:-1]) - f32(2) * kd[1:]) * r
+        d_k = (-six * r + f32(3) * (kd[:-1] + kd[1:])) * r2
+    a = np.empty(L - 1, dtype=f32)
+    b = np.empty(L - 1, dtype=f32)
+    c2 = np.empty(L - 1, dtype=f32)
+    d3 = np.empty(L - 1, dtype=f32)
+    k = 0
+    for time in range(L - 1):
+        while k + 1 < m - 1 and kn[k + 1] <= time:
+            k += 1
+        off = f32(tk[k] - f32(time))
+        a_in = f32(f32(f32(f32(0.5) * c_k[k]) - f32(f32(d_k[k] * off) / f32(3))) * off)
+        a[time] = f32(a_k[k] + f32(f32(a_in - b_k[k]) * off))
+        b[time] = f32(b_k[k] + f32(f32(f32(d_k[k] * off) - c_k[k]) * off))
+        c2[time] = f32(c_k[k] - f32(f32(f32(2) * d_k[k]) * off))
+        d3[time] = d_k[k]
+    return a, b, c2, d3
+
+
 def natural_cubic_coeffs(x):
-    """Natural cubic spline through x[..., L, C] on the integer grid t = 0..L-1 (no missing values).
+    """Natural cubic spline through x[..., L, C] on the integer grid t = 0..L-1; NaNs are missing values.
 
     Returns [..., L-1, 4C] = a || b || 2c || 3d per piece, the layout NaturalCubicSpline consumes
     (interpolation_cubic.py:189, 294-298).  fp32 arithmetic in the reference's operation order.
     """
     x = np.asarray(x, dtype=np.float32)
+    if np.isnan(x).any():
+        lead = x.shape[:-2]
+        L, C = x.shape[-2:]
+        flat = x.reshape(-1, L, C)
+        out = np.empty((flat.shape[0], L - 1, 4 * C), dtype=np.float32)
+        with np.errstate(all="ignore"):
+            for i in range(flat.shape[0]):
+                for c in range(C):
+                    a, b, c2, d3 = _natural_cubic_series_missing(flat[i, :, c])
+                    out[i, :, c], out[i, :, C + c], out[i, :, 2 * C + c], out[i, :, 3 * C + c] = a, b, c2, d3
+        return out.reshape(*lead, L - 1, 4 * C)
     xt = np.swapaxes(x, -1, -2)  # [..., C, L]
     length = xt.shape[-1]
     f32 = np.float32

@@ -169,7 +169,37 @@ def z0_from(coeffs0, rw):
     return (coeffs0 @ rw["Wi"].T + rw["bi"]).astype(np.float32)
 
 
+def gen_g8():
+    # ---- G8: coefficient builders (the step before the path; SURVEY.md §8f row 2) -------------------------
+    B, L, C = 6, 12, 4
+    xr = data.synthetic_series(B, L, C - 1, missing=0.4, seed=31)
+    xr[1, 0, 2] = np.nan          # a leading gap (back-filled from the first observation)
+    xr[2, :, 3] = np.nan          # a channel with no observation at all (becomes 0)
+    xr[3, -3:, 1] = np.nan        # a trailing gap
+    with np.errstate(all="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            lin_ref = torchcde.linear_interpolation_coeffs(torch.from_numpy(xr.copy())).numpy()
+            rect_ref = torchcde.linear_interpolation_coeffs(torch.from_numpy(xr.copy()), rectilinear=0).numpy()
+    xc = data.synthetic_series(B, L, C - 1, missing=0.0, seed=32)
+    cub_ref = torchcde.natural_cubic_coeffs(torch.from_numpy(xc)).numpy()
+    cub2_ref = torchcde.natural_cubic_coeffs(torch.from_numpy(xc[:, :2].copy())).numpy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cubm_ref = torchcde.natural_cubic_coeffs(torch.from_numpy(xr.copy())).numpy()
+    assert np.array_equal(data.natural_cubic_coeffs(xr), cubm_ref)      # host mirror: bit-exact incl. missing values
+    print("host mirrors vs reference: linear", relerr(data.linear_interpolation_coeffs(xr), lin_ref),
+          "rectilinear", relerr(data.linear_interpolation_coeffs(xr, rectilinear=0), rect_ref),
+          "cubic", relerr(data.natural_cubic_coeffs(xc), cub_ref))
+    np.savez_compressed(os.path.join(GOLD, "g8_coeffs.npz"), x_missing=xr, linear=lin_ref, rectilinear=rect_ref,
+                        x_clean=xc, cubic=cub_ref, cubic_len2=cub2_ref, cubic_missing=cubm_ref)
+
+
 def main():
+    if "--only-g8" in sys.argv:
+        gen_g8()
+        return
     report = []
     # ---- G1: toy (cfg1): 3-point 1-D BM + time, rectilinear -> T=5, C=2, H=8, width 128 ---------
     B, L, C, H = 64, 3, 2, 8
@@ -270,26 +300,7 @@ def main():
                                        "dims": {"C": C, "H": H, "HH": HH, "nl": nl, "OUT": OUT}}))
     np.savez_compressed(os.path.join(GOLD, "g7_module.npz"), **rec)
 
-    # ---- G8: coefficient builders (the step before the path; SURVEY.md §8f row 2) -------------------------
-    B, L, C = 6, 12, 4
-    xr = data.synthetic_series(B, L, C - 1, missing=0.4, seed=31)
-    xr[1, 0, 2] = np.nan          # a leading gap (back-filled from the first observation)
-    xr[2, :, 3] = np.nan          # a channel with no observation at all (becomes 0)
-    xr[3, -3:, 1] = np.nan        # a trailing gap
-    with np.errstate(all="ignore"):
-        import warnings
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            lin_ref = torchcde.linear_interpolation_coeffs(torch.from_numpy(xr.copy())).numpy()
-            rect_ref = torchcde.linear_interpolation_coeffs(torch.from_numpy(xr.copy()), rectilinear=0).numpy()
-    xc = data.synthetic_series(B, L, C - 1, missing=0.0, seed=32)
-    cub_ref = torchcde.natural_cubic_coeffs(torch.from_numpy(xc)).numpy()
-    cub2_ref = torchcde.natural_cubic_coeffs(torch.from_numpy(xc[:, :2].copy())).numpy()
-    print("host mirrors vs reference: linear", relerr(data.linear_interpolation_coeffs(xr), lin_ref),
-          "rectilinear", relerr(data.linear_interpolation_coeffs(xr, rectilinear=0), rect_ref),
-          "cubic", relerr(data.natural_cubic_coeffs(xc), cub_ref))
-    np.savez_compressed(os.path.join(GOLD, "g8_coeffs.npz"), x_missing=xr, linear=lin_ref, rectilinear=rect_ref,
-                        x_clean=xc, cubic=cub_ref, cubic_len2=cub2_ref)
+    gen_g8()
 
     # ---- G5: full-size cfg2 forward z_T (inputs regenerated by tests from the generator) ---------
     if "--no-full" not in sys.argv:

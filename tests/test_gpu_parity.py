@@ -309,6 +309,12 @@ def test_gpu_coefficient_builders_match_reference(gpu_lib):
     xc = torch.from_numpy(f["x_clean"]).cuda()
     assert np.array_equal(ncde_amd.natural_cubic_coeffs(xc).cpu().numpy(), f["cubic"])
     assert np.array_equal(ncde_amd.natural_cubic_coeffs(xc[:, :2].contiguous()).cpu().numpy(), f["cubic_len2"])
+    # missing values: ends filled, spline through the observed knots, re-expanded per unit interval -- bit-exact
+    assert np.array_equal(ncde_amd.natural_cubic_coeffs(xm).cpu().numpy(), f["cubic_missing"])
+    xr2 = gu.data.synthetic_series(64, 40, 7, missing=0.5, seed=77)
+    xr2[:, 0, 1:3] = np.nan
+    xr2[3, :, 4] = np.nan
+    assert np.array_equal(ncde_amd.natural_cubic_coeffs(torch.from_numpy(xr2).cuda()).cpu().numpy(), gu.data.natural_cubic_coeffs(xr2))
     # extra batch dimensions, as torchcde allows
     assert np.array_equal(ncde_amd.natural_cubic_coeffs(torch.stack([xc, xc])).cpu().numpy(), np.stack([f["cubic"], f["cubic"]]))
     with pytest.raises(AssertionError):

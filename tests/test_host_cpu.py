@@ -207,6 +207,7 @@ def test_host_coefficient_mirrors_match_reference_golden():
     assert np.array_equal(ncde_amd.data.linear_interpolation_coeffs(f["x_missing"], rectilinear=0), f["rectilinear"])
     assert np.array_equal(ncde_amd.data.natural_cubic_coeffs(f["x_clean"]), f["cubic"])
     assert np.array_equal(ncde_amd.data.natural_cubic_coeffs(f["x_clean"][:, :2]), f["cubic_len2"])
+    assert np.array_equal(ncde_amd.data.natural_cubic_coeffs(f["x_missing"]), f["cubic_missing"])   # NaN = missing values
 
 
 def test_gpu_coefficient_builders_refuse_cpu_tensors():
