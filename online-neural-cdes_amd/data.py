@@ -297,6 +297,23 @@ def make_field_weights(hidden, hidden_hidden, in_channels, seed=0, layer_dims=No
     return p
 
 
+def make_variant_weights(hidden, hidden_hidden, in_channels, seed=0, kind="original", mode="matmul"):
+    """Parameters of the reference's vector-field variants (src/ncde/vector_fields/gating.py, base.py:56-69):
+    the inner net takes H (matmul) or H+C (evaluate / derivative) inputs, the heads have H*C (matmul) or H rows;
+    'minimal' adds the sigmoid head (Wg, bg), 'gru' additionally the reset net (Wr, br)."""
+    d0 = hidden if mode == "matmul" else hidden + in_channels
+    rows = hidden * in_channels if mode == "matmul" else hidden
+    p = {}
+    p["W0"], p["b0"] = linear_weights(seed, 1, hidden_hidden, d0)
+    p["W1"], p["b1"] = linear_weights(seed, 2, hidden_hidden, hidden_hidden)
+    p["Wo"], p["bo"] = linear_weights(seed, 3, rows, hidden_hidden)
+    if kind in ("minimal", "gru"):
+        p["Wg"], p["bg"] = linear_weights(seed, 6, rows, hidden_hidden)
+    if kind == "gru":
+        p["Wr"], p["br"] = linear_weights(seed, 7, d0, d0)
+    return p
+
+
 def make_readin_weights(hidden, in_channels, out_dim, seed=0):
     wi, bi = linear_weights(seed, 4, hidden, in_channels)
     wf, bf = linear_weights(seed, 5, out_dim, hidden)

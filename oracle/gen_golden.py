@@ -34,6 +34,7 @@ sys.modules["autots.preprocessing"] = _pre
 import torchcde  # noqa: E402  (the reference's vendored copy)
 from src.ncde import NeuralCDE as RefNeuralCDE  # noqa: E402
 from src.ncde.vector_fields.base import OriginalVectorField as RefField  # noqa: E402
+from src.ncde.vector_fields.gating import GRUGatedVectorField as RefGRU, MinimalGatedVectorField as RefMinimal  # noqa: E402
 
 import ncde_amd  # noqa: E402
 import ncde_oracle as orc  # noqa: E402
@@ -169,6 +170,83 @@ def z0_from(coeffs0, rw):
     return (coeffs0 @ rw["Wi"].T + rw["bi"]).astype(np.float32)
 
 
+def ref_field_variant(p, C, H, HH, nl, kind, mode):
+    cls = {"original": RefField, "minimal": RefMinimal, "gru": RefGRU}[kind]
+    f = cls(input_dim=C, hidden_dim=H, hidden_hidden_dim=HH, num_layers=nl, vector_field_type=mode)
+    with torch.no_grad():
+        f.net_to_hh[0].weight.copy_(torch.from_numpy(p["W0"]))
+        f.net_to_hh[0].bias.copy_(torch.from_numpy(p["b0"]))
+        if nl > 1:
+            f.net_to_hh[2].weight.copy_(torch.from_numpy(p["W1"]))
+            f.net_to_hh[2].bias.copy_(torch.from_numpy(p["b1"]))
+        head = f.tanh_output_layer if kind == "original" else f.tanh_net
+        head[0].weight.copy_(torch.from_numpy(p["Wo"]))
+        head[0].bias.copy_(torch.from_numpy(p["bo"]))
+        if kind != "original":
+            f.sigmoid_net[0].weight.copy_(torch.from_numpy(p["Wg"]))
+            f.sigmoid_net[0].bias.copy_(torch.from_numpy(p["bg"]))
+        if kind == "gru":
+            f.reset_net[0].weight.copy_(torch.from_numpy(p["Wr"]))
+            f.reset_net[0].bias.copy_(torch.from_numpy(p["br"]))
+    return f
+
+
+def gen_g9():
+    """Vector-field variants: original / minimal / gru x matmul / evaluate / derivative."""
+    report = []
+    B, L, C, H, HH, nl = 12, 6, 5, 16, 24, 3
+    rect = data.make_rectilinear_coeffs(B, L, C - 1, missing=0.3, seed=41)
+    cub = data.make_cubic_coeffs(B, 2 * L, C - 1, seed=42)
+    for kind in ("original", "minimal", "gru"):
+        for mode in ("matmul", "evaluate", "derivative"):
+            if kind == "original" and mode == "matmul":
+                continue
+            for coeffs, interp, method, seq in ((rect, "linear", "rk4", True), (cub, "cubic", "midpoint", False)):
+                p = data.make_variant_weights(H, HH, C, seed=5, kind=kind, mode=mode)
+                rw = data.make_readin_weights(H, C, 1, seed=5)
+                z0 = z0_from(coeffs[:, 0, :C], rw)
+                func = ref_field_variant(p, C, H, HH, nl, kind, mode)
+                ofield = orc.Field.variant(p, H, C, nl, kind, mode)
+                names = [n for n in ("W0", "b0", "W1", "b1", "Wr", "br", "Wg", "bg", "Wo", "bo") if n in p]
+                n_out = (coeffs.shape[1] + (1 if interp == "cubic" else 0)) if seq else 2
+                gout = grad_out_like((B, n_out, H), seed=9)
+                c = torch.from_numpy(coeffs)
+                X = torchcde.LinearInterpolation(c) if interp == "linear" else torchcde.NaturalCubicSpline(c)
+                t = X.grid_points if seq else X.interval
+                res = {}
+                for adj in (True, False):
+                    z0t = torch.from_numpy(z0).clone().requires_grad_(True)
+                    for q in func.parameters():
+                        q.grad = None
+                    out = torchcde.cdeint(X, func, z0t, t, adjoint=adj, vector_field_type=mode, method=method, options={"step_size": 1})
+                    (out * torch.from_numpy(gout)).sum().backward()
+                    res[adj] = (out.detach(), z0t.grad.detach(), [q.grad.detach().clone() for q in func.parameters()])
+                assert [tuple(q.shape) for q in func.parameters()] == [tuple(p[n].shape) for n in names], "parameter order"
+                ctl = orc.Control(coeffs, interp)
+                z_or = orc.solve_forward(ctl, ofield, z0, method, seq)
+                dz0_or, gp_or = orc.solve_adjoint(ctl, ofield, z_or, gout, method, seq)
+                dz0_ob, gp_ob = orc.solve_discrete_backward(ctl, ofield, z0, gout, method, seq)
+                z_ref, dz0_ref, gp_ref = res[True]
+                _, dz0_bp, gp_bp = res[False]
+                e = {"z": relerr(z_or, z_ref), "dz0": relerr(dz0_or, dz0_ref), "dtheta": max(relerr(a, b) for a, b in zip(gp_or, gp_ref)),
+                     "bp_dz0": relerr(dz0_ob, dz0_bp), "bp_dtheta": max(relerr(a, b) for a, b in zip(gp_ob, gp_bp))}
+                name = f"g9_{kind}_{mode}_{interp}_{method}"
+                print(f"{name:40s} oracle-vs-ref: " + " ".join(f"{k} {v:.2e}" for k, v in e.items()))
+                assert e["z"] <= 2e-6 and max(e["dz0"], e["dtheta"], e["bp_dz0"], e["bp_dtheta"]) <= 2e-5, "oracle does not reproduce the reference"
+                rec = {"z_out": z_ref.numpy(), "dz0": dz0_ref.numpy(), "grad_out": gout, "bp_dz0": dz0_bp.numpy(), "coeffs": coeffs, "z0": z0}
+                for n, g, gb in zip(names, gp_ref, gp_bp):
+                    rec["d" + n], rec["bp_d" + n] = g.numpy(), gb.numpy()
+                for k, v in p.items():
+                    rec["p_" + k] = v
+                meta = {"name": name, "kind": interp, "method": method, "sequence": bool(seq), "field": "variant", "field_kind": kind,
+                        "field_mode": mode, "dims": {"C": C, "H": H, "HH": HH, "nl": nl}, "param_names": names, "oracle_vs_ref": e}
+                rec["meta"] = np.array(json.dumps(meta))
+                np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+                report.append(meta)
+    with open(os.path.join(GOLD, "MANIFEST_variants.json"), "w") as f:
+        json.dump(report, f, indent=1)
+
+
 def gen_g8():
     # ---- G8: coefficient builders (the step before the path; SURVEY.md §8f row 2) -------------------------
     B, L, C = 6, 12, 4
@@ -197,6 +275,9 @@ def gen_g8():
 
 
 def main():
+    if "--only-g9" in sys.argv:
+        gen_g9()
+        return
     if "--only-g8" in sys.argv:
         gen_g8()
         return
@@ -301,6 +382,7 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "g7_module.npz"), **rec)
 
     gen_g8()
+    gen_g9()
 
     # ---- G5: full-size cfg2 forward z_T (inputs regenerated by tests from the generator) ---------
     if "--no-full" not in sys.argv:

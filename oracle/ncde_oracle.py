@@ -34,58 +34,103 @@ def _f32(x):
 
 
 class Field:
-    """MLP vector field f_theta: R^H -> R^{H x C}.
+    """Vector field f_theta.
 
-    ``layers`` is a list of (W, b) applied as Linear+ReLU; the same (W, b) tensors may appear several
-    times (the reference's OriginalVectorField repeats ONE inner layer nl-1 times, base.py:66-68).
-    ``Wo [H*C, d_last], bo [H*C]`` is the final Linear followed by tanh; row index = h*C + c.
+    ``layers`` is a list of (W, b) applied as Linear+ReLU (the "inner net", H or H+C -> HH -> ... -> HH); the same
+    (W, b) tensors may appear several times (the reference repeats ONE inner layer nl-1 times, base.py:66-68).
+    ``Wo, bo`` is the tanh head.  Variants (src/ncde/vector_fields/gating.py, solver.py:112-137):
+      kind  'original' : M = tanh(Wo hh + bo)
+            'minimal'  : M = sigmoid(Wg hh + bg) * tanh(Wo hh + bo)                       (gating.py:7-32)
+            'gru'      : M = sigmoid(Wg net(u) + bg) * tanh(Wo net(sigmoid(Wr u + br) * u) + bo)   (gating.py:35-61)
+      mode  'matmul'    : u = z, M viewed [H, C], output M . dX/dt        (row index of the heads = h*C + c)
+            'evaluate'  : u = [z, X(t)],     output M  (heads have H rows, no contraction)   (solver.py:123-126)
+            'derivative': u = [z, dX/dt(t)], output M
     """
 
-    def __init__(self, layers, Wo, bo, hidden, channels):
+    def __init__(self, layers, Wo, bo, hidden, channels, kind="original", mode="matmul", Wg=None, bg=None, Wr=None, br=None):
         self.layers = [(torch.as_tensor(w), torch.as_tensor(b)) for w, b in layers]
         self.Wo = torch.as_tensor(Wo)
         self.bo = torch.as_tensor(bo)
         self.H = hidden
         self.C = channels
-        assert self.Wo.shape[0] == hidden * channels
+        self.kind, self.mode = kind, mode
+        self.Wg = None if Wg is None else torch.as_tensor(Wg)
+        self.bg = None if bg is None else torch.as_tensor(bg)
+        self.Wr = None if Wr is None else torch.as_tensor(Wr)
+        self.br = None if br is None else torch.as_tensor(br)
+        assert kind in ("original", "minimal", "gru") and mode in ("matmul", "evaluate", "derivative")
+        assert self.Wo.shape[0] == (hidden * channels if mode == "matmul" else hidden)
 
     @staticmethod
     def original(p, hidden, channels, num_layers):
         """OriginalVectorField parameter dict {W0,b0,W1,b1,Wo,bo} -> Field (W1 shared nl-1 times)."""
+        return Field.variant(p, hidden, channels, num_layers)
+
+    @staticmethod
+    def variant(p, hidden, channels, num_layers, kind="original", mode="matmul"):
+        """Parameter dict {W0,b0,[W1,b1],Wo,bo,[Wg,bg],[Wr,br]} -> Field."""
         t = {k: torch.as_tensor(v) for k, v in p.items()}
         layers = [(t["W0"], t["b0"])]
         layers += [(t["W1"], t["b1"])] * (num_layers - 1)
-        return Field(layers, t["Wo"], t["bo"], hidden, channels)
+        return Field(layers, t["Wo"], t["bo"], hidden, channels, kind, mode, t.get("Wg"), t.get("bg"), t.get("Wr"), t.get("br"))
 
     def unique_params(self):
-        """De-duplicated parameter tensors in first-use order (adjoint.py:176-183 / nn.Module.parameters())."""
+        """De-duplicated parameter tensors in nn.Module.parameters() order of the reference modules: inner net, then
+        (reset net), (sigmoid head), tanh head (adjoint.py:176-183; gating.py registers reset, sigmoid, tanh in that order)."""
         seen, out = set(), []
         for w, b in self.layers:
             for p in (w, b):
                 if id(p) not in seen:
                     seen.add(id(p))
                     out.append(p)
+        if self.kind == "gru":
+            out += [self.Wr, self.br]
+        if self.kind in ("minimal", "gru"):
+            out += [self.Wg, self.bg]
         out += [self.Wo, self.bo]
         return out
 
-    # -- forward of f_theta(z) . dX -----------------------------------------------------------
-    def g(self, z, dx, save=False):
-        x = z
-        acts = [z]
+    def _net(self, u):
+        acts = [u]
+        x = u
         for w, b in self.layers:
             x = torch.relu(torch.addmm(b, x, w.t()))
             acts.append(x)
-        m = torch.tanh(torch.addmm(self.bo, x, self.Wo.t())).view(-1, self.H, self.C)
-        out = (m @ dx.unsqueeze(-1)).squeeze(-1)
+        return acts
+
+    # -- forward: dz/dt for state z and control input cin (dX/dt for matmul/derivative, X(t) for evaluate) --------------
+    def g(self, z, cin, save=False):
+        u = z if self.mode == "matmul" else torch.cat([z, cin], dim=-1)
+        sv = {"u": u}
+        if self.kind == "gru":
+            rg = torch.sigmoid(torch.addmm(self.br, u, self.Wr.t()))
+            sv["rg"] = rg
+            acts_i = self._net(u)
+            acts_r = self._net(rg * u)
+            sv["acts_i"], sv["acts_r"] = acts_i, acts_r
+            hh_s, hh_t = acts_i[-1], acts_r[-1]
+        else:
+            acts = self._net(u)
+            sv["acts_i"] = sv["acts_r"] = acts
+            hh_s = hh_t = acts[-1]
+        th = torch.tanh(torch.addmm(self.bo, hh_t, self.Wo.t()))
+        sv["th"] = th
+        if self.kind == "original":
+            m = th
+        else:
+            sg = torch.sigmoid(torch.addmm(self.bg, hh_s, self.Wg.t()))
+            sv["sg"] = sg
+            m = sg * th
+        if self.mode == "matmul":
+            out = (m.view(-1, self.H, self.C) @ cin.unsqueeze(-1)).squeeze(-1)
+        else:
+            out = m
         if save:
-            return out, (acts, m)
+            return out, sv
         return out
 
-    # -- VJP of g wrt (z, params) for cotangent c [B, H] ----------------------------------------
-    def g_vjp(self, saved, dx, c):
-        acts, m = saved
-        dm = c.unsqueeze(-1) * dx.unsqueeze(-2)                      # [B,H,C]
-        dp = (dm * (1 - m * m)).reshape(-1, self.H * self.C)          # tanh'
+    # -- VJP of g wrt (z, params) for cotangent c [B, H] ----------------------------------------------------------------
+    def g_vjp(self, sv, cin, c):
         grads = {}
 
         def acc(p, v):
@@ -94,16 +139,47 @@ class Field:
             else:
                 grads[id(p)] = v
 
-        acc(self.bo, dp.sum(0))
-        acc(self.Wo, dp.t() @ acts[-1])
-        dxl = dp @ self.Wo
-        for li in range(len(self.layers) - 1, -1, -1):
-            w, b = self.layers[li]
-            dpre = dxl * (acts[li + 1] > 0).to(dxl.dtype)
-            acc(b, dpre.sum(0))
-            acc(w, dpre.t() @ acts[li])
-            dxl = dpre @ w
-        return dxl, [grads[id(p)] for p in self.unique_params()]
+        def net_bwd(acts, dxl):
+            for li in range(len(self.layers) - 1, -1, -1):
+                w, b = self.layers[li]
+                dpre = dxl * (acts[li + 1] > 0).to(dxl.dtype)
+                acc(b, dpre.sum(0))
+                acc(w, dpre.t() @ acts[li])
+                dxl = dpre @ w
+            return dxl
+
+        if self.mode == "matmul":
+            dm = (c.unsqueeze(-1) * cin.unsqueeze(-2)).reshape(-1, self.H * self.C)
+        else:
+            dm = c
+        th = sv["th"]
+        if self.kind == "original":
+            dpt = dm * (1 - th * th)
+        else:
+            sg = sv["sg"]
+            dpt = (dm * sg) * (1 - th * th)
+            dps = (dm * th) * (sg * (1 - sg))
+        acc(self.bo, dpt.sum(0))
+        acc(self.Wo, dpt.t() @ sv["acts_r"][-1])
+        if self.kind == "original":
+            du = net_bwd(sv["acts_r"], dpt @ self.Wo)
+        elif self.kind == "minimal":
+            acc(self.bg, dps.sum(0))
+            acc(self.Wg, dps.t() @ sv["acts_i"][-1])
+            du = net_bwd(sv["acts_i"], dpt @ self.Wo + dps @ self.Wg)
+        else:
+            acc(self.bg, dps.sum(0))
+            acc(self.Wg, dps.t() @ sv["acts_i"][-1])
+            d_ru = net_bwd(sv["acts_r"], dpt @ self.Wo)          # cotangent of rg * u
+            du = net_bwd(sv["acts_i"], dps @ self.Wg)
+            rg, u = sv["rg"], sv["u"]
+            du = du + d_ru * rg
+            dpr = (d_ru * u) * (rg * (1 - rg))
+            acc(self.br, dpr.sum(0))
+            acc(self.Wr, dpr.t() @ u)
+            du = du + dpr @ self.Wr
+        dz = du[:, :self.H]
+        return dz, [grads[id(p)] for p in self.unique_params()]
 
 
 class Control:
@@ -138,6 +214,22 @@ class Control:
         tv = float(t)
         idx = int(math.ceil(tv)) - 1
         return max(0, min(idx, self.n_pieces - 1))
+
+    def evaluate(self, t):
+        """X(t) (interpolation_linear.py:221-229, interpolation_cubic.py:324-329)."""
+        idx = self.piece(t)
+        frac = t - _f32(idx)
+        if self.kind == "linear":
+            prev, nxt = self.coeffs[..., idx, :], self.coeffs[..., idx + 1, :]
+            diff_t = _f32(idx + 1) - _f32(idx)
+            return prev + frac * (nxt - prev) / diff_t
+        inner = 0.5 * self.two_c[..., idx, :] + self.three_d[..., idx, :] * frac / 3
+        inner = self.b[..., idx, :] + inner * frac
+        return self.a[..., idx, :] + inner * frac
+
+    def field_input(self, t, mode):
+        """What the vector field receives besides z: dX/dt(t) ('matmul', 'derivative') or X(t) ('evaluate')."""
+        return self.evaluate(t) if mode == "evaluate" else self.derivative(t)
 
     def derivative(self, t):
         idx = self.piece(t)
@@ -182,7 +274,7 @@ def solve_forward(control, field, z0, method="rk4", sequence=False, nfe=None):
     def fn(t, state):
         if nfe is not None:
             nfe[0] += 1
-        return (field.g(state[0], control.derivative(t)),)
+        return (field.g(state[0], control.field_input(t, field.mode)),)
 
     ys = [z0]
     y = (z0,)
@@ -214,7 +306,7 @@ def solve_adjoint(control, field, z_out, grad_out, method="rk4", sequence=False,
             nfe[0] += 1
         y, a = state[0], state[1]
         t = -s
-        dx = control.derivative(t)
+        dx = control.field_input(t, field.mode)
         f, saved = field.g(y, dx, save=True)
         vjp_y, vjp_p = field.g_vjp(saved, dx, -a)
         return (-f, -vjp_y) + tuple(-v for v in vjp_p)
@@ -253,21 +345,21 @@ def _forward_stages(control, field, z0, method):
         dt = t1 - t0
         if method == "euler":
             ts, Ys = [t0], [y]
-            y = y + dt * field.g(y, control.derivative(t0))
+            y = y + dt * field.g(y, control.field_input(t0, field.mode))
         elif method == "midpoint":
             half = 0.5 * dt
-            k1 = field.g(y, control.derivative(t0))
+            k1 = field.g(y, control.field_input(t0, field.mode))
             ym = y + k1 * half
             ts, Ys = [t0, t0 + half], [y, ym]
-            y = y + dt * field.g(ym, control.derivative(t0 + half))
+            y = y + dt * field.g(ym, control.field_input(t0 + half, field.mode))
         else:
-            k1 = field.g(y, control.derivative(t0))
+            k1 = field.g(y, control.field_input(t0, field.mode))
             y2 = y + dt * k1 * _ONE_THIRD
-            k2 = field.g(y2, control.derivative(t0 + dt * _ONE_THIRD))
+            k2 = field.g(y2, control.field_input(t0 + dt * _ONE_THIRD, field.mode))
             y3 = y + dt * (k2 - k1 * _ONE_THIRD)
-            k3 = field.g(y3, control.derivative(t0 + dt * _TWO_THIRDS))
+            k3 = field.g(y3, control.field_input(t0 + dt * _TWO_THIRDS, field.mode))
             y4 = y + dt * (k1 - k2 + k3)
-            k4 = field.g(y4, control.derivative(t1))
+            k4 = field.g(y4, control.field_input(t1, field.mode))
             ts, Ys = [t0, t0 + dt * _ONE_THIRD, t0 + dt * _TWO_THIRDS, t1], [y, y2, y3, y4]
             y = y + (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
         steps.append((ts, Ys, dt))
@@ -297,7 +389,7 @@ def solve_discrete_backward(control, field, z0, grad_out, method="rk4", sequence
 
     def pull(t, Y, ck):
         """cotangent ck of k = g(t, Y)  ->  cotangent of Y; parameter gradients accumulated."""
-        dx = control.derivative(t)
+        dx = control.field_input(t, field.mode)
         _, saved = field.g(Y, dx, save=True)
         dY, dp = field.g_vjp(saved, dx, ck)
         for i, v in enumerate(dp):

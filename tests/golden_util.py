@@ -18,6 +18,10 @@ SOLVE_CASES = [
 ]
 
 
+VARIANT_CASES = ["g9_%s_%s_%s" % (k, m, tail) for k in ("original", "minimal", "gru") for m in ("matmul", "evaluate", "derivative")
+                 for tail in ("linear_rk4", "cubic_midpoint") if not (k == "original" and m == "matmul")]
+
+
 def _z0_from(c0, rw):
     return (c0 @ rw["Wi"].T + rw["bi"]).astype(np.float32)
 
@@ -42,7 +46,7 @@ def load_case(name):
         params = data.make_field_weights(128, 128, 80, seed=3)
         z0 = _z0_from(coeffs[:, 0], data.make_readin_weights(128, 80, 1, seed=3))
     d = meta["dims"]
-    if meta["field"] == "original":
+    if meta["field"] in ("original", "variant"):
         layers = [("W0", "b0")] + [("W1", "b1")] * (d["nl"] - 1)
     else:
         layers = [("W0", "b0"), ("W1", "b1")]
@@ -54,7 +58,9 @@ def oracle_field(case):
     import ncde_oracle as orc
     import torch
     t = {k: torch.from_numpy(v) for k, v in case["params"].items()}
-    return orc.Field([(t[w], t[b]) for w, b in case["layers"]], t["Wo"], t["bo"], case["H"], case["C"])
+    m = case["meta"]
+    return orc.Field([(t[w], t[b]) for w, b in case["layers"]], t["Wo"], t["bo"], case["H"], case["C"],
+                     m.get("field_kind", "original"), m.get("field_mode", "matmul"), t.get("Wg"), t.get("bg"), t.get("Wr"), t.get("br"))
 
 
 def relerr(a, b):

@@ -62,6 +62,22 @@ def test_oracle_discrete_backward_matches_reference_golden(name):
     _check_grads(m, ex, dz0.numpy(), [g.numpy() for g in gp], "bp_", TOL_G)
 
 
+@pytest.mark.parametrize("name", gu.VARIANT_CASES)
+def test_oracle_field_variants_match_reference_golden(name):
+    """Gated vector fields and the evaluate / derivative input modes: forward, continuous
+    adjoint and exact discrete backward of the oracle against the reference's own outputs."""
+    case = gu.load_case(name)
+    m, ex = case["meta"], case["expect"]
+    field = gu.oracle_field(case)
+    ctl = orc.Control(case["coeffs"], m["kind"])
+    z = orc.solve_forward(ctl, field, case["z0"], m["method"], m["sequence"])
+    assert gu.relerr(z, ex["z_out"]) <= TOL_Z
+    dz0, gp = orc.solve_adjoint(ctl, field, z, ex["grad_out"], m["method"], m["sequence"])
+    _check_grads(m, ex, dz0.numpy(), [g.numpy() for g in gp], "", TOL_G)
+    dz0, gp = orc.solve_discrete_backward(ctl, field, case["z0"], ex["grad_out"], m["method"], m["sequence"])
+    _check_grads(m, ex, dz0.numpy(), [g.numpy() for g in gp], "bp_", TOL_G)
+
+
 def test_oracle_full_size_cfg2_forward():
     """BASELINE config 2 at full size (B=4096, T=399): z_T from the reference, inputs regenerated."""
     f = np.load(os.path.join(gu.GOLD, "g5_cfg2_full.npz"))
