@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NCDE_ABI_VERSION 1
+#define NCDE_ABI_VERSION 2 /* version-1 structs (without the trailing field_kind .. br members) are still accepted */
 #define NCDE_MAX_LAYERS 8
 
 typedef enum NcdeStatus {
@@ -99,7 +99,27 @@ typedef struct NcdeProblem {
     int64_t coeffs_stride_t;
 
     const float* z0; /* [B, H] contiguous */
+
+    /* ---- ABI version 2: vector-field variants (read only when abi_version >= 2; version 1 = original / matmul) ----
+     * field_kind  (src/ncde/vector_fields/gating.py:7-61)
+     *   NCDE_FIELD_ORIGINAL  M = tanh(Wo hh + bo)
+     *   NCDE_FIELD_MINIMAL   M = sigmoid(Wg hh + bg) * tanh(Wo hh + bo)
+     *   NCDE_FIELD_GRU       M = sigmoid(Wg net(u) + bg) * tanh(Wo net(sigmoid(Wr u + br) * u) + bo)
+     * field_input (vector_field_type of cdeint, modules/torchcde/torchcde/solver.py:112-137)
+     *   NCDE_INPUT_MATMUL      u = z;             heads have H*C rows, dz/dt = M[H,C] . dX/dt
+     *   NCDE_INPUT_EVALUATE    u = [z, X(t)];     heads have H rows,   dz/dt = M        (layer_in[0] = H + C)
+     *   NCDE_INPUT_DERIVATIVE  u = [z, dX/dt(t)]; heads have H rows,   dz/dt = M
+     * Wg, bg: the sigmoid head (same shape as Wo, bo); Wr [d0, d0], br [d0]: the GRU reset net, d0 = layer_in[0]. */
+    int32_t field_kind;
+    int32_t field_input;
+    const float* Wg;
+    const float* bg;
+    const float* Wr;
+    const float* br;
 } NcdeProblem;
+
+typedef enum NcdeFieldKind { NCDE_FIELD_ORIGINAL = 0, NCDE_FIELD_MINIMAL = 1, NCDE_FIELD_GRU = 2 } NcdeFieldKind;
+typedef enum NcdeFieldInput { NCDE_INPUT_MATMUL = 0, NCDE_INPUT_EVALUATE = 1, NCDE_INPUT_DERIVATIVE = 2 } NcdeFieldInput;
 
 /* gradient outputs of the adjoint sweep; aliasing must mirror NcdeProblem.layer_W/layer_b
  * (a shared layer receives the SUM over its uses).  Buffers are overwritten, not accumulated. */
@@ -109,6 +129,11 @@ typedef struct NcdeGrads {
     float* grad_layer_b[NCDE_MAX_LAYERS];
     float* grad_Wo;
     float* grad_bo;
+    /* read only when the problem's abi_version >= 2 and the field kind has these parameters */
+    float* grad_Wg;
+    float* grad_bg;
+    float* grad_Wr;
+    float* grad_br;
 } NcdeGrads;
 
 int ncde_version(void);

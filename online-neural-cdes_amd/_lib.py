@@ -6,12 +6,14 @@ raises.  Build it with ``python __graft_entry__.py`` (or ``make -C online-neural
 import ctypes
 import os
 
-NCDE_ABI_VERSION = 1
+NCDE_ABI_VERSION = 2
 NCDE_MAX_LAYERS = 8
 
 INTERP = {"linear": 0, "cubic": 1}
 METHOD = {"euler": 0, "midpoint": 1, "rk4": 2}
 OUT_INTERVAL, OUT_KNOTS = 0, 1
+FIELD_KIND = {"original": 0, "minimal": 1, "gru": 2}
+FIELD_INPUT = {"matmul": 0, "evaluate": 1, "derivative": 2}
 FLAG_AUTO, FLAG_FORCE_GENERIC, FLAG_FORCE_FAST, FLAG_FP32_MFMA, FLAG_ADJOINT_V1, FLAG_ADJOINT_V2 = 0, 1, 2, 4, 8, 16
 FLAG_TILED_NS1, FLAG_TILED_NS2, FLAG_TILED_NS4, FLAG_FORCE_TILED = 0x1000, 0x2000, 0x4000, 0x8000
 
@@ -40,6 +42,13 @@ class NcdeProblem(ctypes.Structure):
         ("coeffs_stride_b", ctypes.c_int64),
         ("coeffs_stride_t", ctypes.c_int64),
         ("z0", _c_float_p),
+        # ABI version 2: vector-field variants
+        ("field_kind", ctypes.c_int32),
+        ("field_input", ctypes.c_int32),
+        ("Wg", _c_float_p),
+        ("bg", _c_float_p),
+        ("Wr", _c_float_p),
+        ("br", _c_float_p),
     ]
 
 
@@ -50,6 +59,10 @@ class NcdeGrads(ctypes.Structure):
         ("grad_layer_b", _c_float_p * NCDE_MAX_LAYERS),
         ("grad_Wo", _c_float_p),
         ("grad_bo", _c_float_p),
+        ("grad_Wg", _c_float_p),
+        ("grad_bg", _c_float_p),
+        ("grad_Wr", _c_float_p),
+        ("grad_br", _c_float_p),
     ]
 
 

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 
@@ -11,6 +12,7 @@
 #include "ncde_fast.h"
 #include "ncde_host.h"
 #include "ncde_tiled.h"
+#include "ncde_variant.h"
 
 extern "C" __global__ void ncde_fwd_generic(KArgs a);
 extern "C" __global__ void ncde_adj_generic(KArgs a);
@@ -33,9 +35,20 @@ int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(NCDE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// Copy the caller's struct into a full version-2 struct: a version-1 caller passes a shorter struct (no trailing
+// field_kind .. br members), which reads as the original field with the matmul input.
+int normalize(const NcdeProblem* in, NcdeProblem* out) {
+    if (!in) return fail(NCDE_ERR_INVALID, "problem is NULL");
+    if (in->abi_version != 1 && in->abi_version != NCDE_ABI_VERSION)
+        return fail(NCDE_ERR_INVALID, "abi_version %d not in {1, %d}", in->abi_version, NCDE_ABI_VERSION);
+    memset(out, 0, sizeof(*out));
+    memcpy(out, in, in->abi_version >= 2 ? sizeof(NcdeProblem) : offsetof(NcdeProblem, field_kind));
+    out->abi_version = NCDE_ABI_VERSION;
+    return NCDE_OK;
+}
+
 int validate(const NcdeProblem* p) {
     if (!p) return fail(NCDE_ERR_INVALID, "problem is NULL");
-    if (p->abi_version != NCDE_ABI_VERSION) return fail(NCDE_ERR_INVALID, "abi_version %d != %d", p->abi_version, NCDE_ABI_VERSION);
     if (p->batch < 1 || p->channels < 1 || p->hidden < 1) return fail(NCDE_ERR_INVALID, "batch/channels/hidden must be >= 1");
     if (p->n_knots < 2) return fail(NCDE_ERR_INVALID, "Must have a time dimension of size at least 2 (n_knots=%d)", p->n_knots);
     if (p->interp != NCDE_INTERP_LINEAR && p->interp != NCDE_INTERP_CUBIC) return fail(NCDE_ERR_INVALID, "unknown interp %d", p->interp);
@@ -43,7 +56,12 @@ int validate(const NcdeProblem* p) {
         return fail(NCDE_ERR_INVALID, "Invalid method %d. Must be one of {euler, midpoint, rk4}", p->method);
     if (p->output != NCDE_OUT_INTERVAL && p->output != NCDE_OUT_KNOTS) return fail(NCDE_ERR_INVALID, "unknown output mode %d", p->output);
     if (p->n_layers < 0 || p->n_layers > NCDE_MAX_LAYERS) return fail(NCDE_ERR_INVALID, "n_layers %d outside [0, %d]", p->n_layers, NCDE_MAX_LAYERS);
-    int d = p->hidden;
+    if (p->field_kind < NCDE_FIELD_ORIGINAL || p->field_kind > NCDE_FIELD_GRU) return fail(NCDE_ERR_INVALID, "unknown field_kind %d", p->field_kind);
+    if (p->field_input < NCDE_INPUT_MATMUL || p->field_input > NCDE_INPUT_DERIVATIVE)
+        return fail(NCDE_ERR_INVALID, "vector_field_type string not recognised (field_input %d)", p->field_input);
+    if (p->field_kind != NCDE_FIELD_ORIGINAL && (!p->Wg || !p->bg)) return fail(NCDE_ERR_INVALID, "gated field: NULL Wg/bg");
+    if (p->field_kind == NCDE_FIELD_GRU && (!p->Wr || !p->br)) return fail(NCDE_ERR_INVALID, "GRU field: NULL Wr/br");
+    int d = p->field_input == NCDE_INPUT_MATMUL ? p->hidden : p->hidden + p->channels;
     for (int l = 0; l < p->n_layers; ++l) {
         if (p->layer_in[l] != d) return fail(NCDE_ERR_INVALID, "layer %d: in=%d does not chain from %d", l, p->layer_in[l], d);
         if (p->layer_out[l] < 1) return fail(NCDE_ERR_INVALID, "layer %d: out=%d", l, p->layer_out[l]);
@@ -69,6 +87,11 @@ int generic_supported(const NcdeProblem* p, const Layout& y, int pass) {
 
 // pick the kernel family: 1 = fast (shape-specialised), 2 = tiled (batch-tiled, large hidden), 0 = generic, <0 = error
 int select_family(const NcdeProblem* p, const Layout& y, int pass) {
+    if (y.variant) {   // gated fields / evaluate / derivative inputs: their own kernels on the generic structure
+        if ((p->flags & NCDE_FLAG_FORCE_FAST) || !ncde_variant_supported(p, pass))
+            return fail(NCDE_ERR_UNSUPPORTED, "vector-field variant outside what ncde_variant.hip covers (pass %d)", pass);
+        return 3;
+    }
     const bool fast_ok = ncde_fast_supported(p, pass);
     if (p->flags & NCDE_FLAG_FORCE_FAST) {
         if (!fast_ok) return fail(NCDE_ERR_UNSUPPORTED, "no shape-specialised kernel for this problem (pass %d)", pass);
@@ -94,6 +117,11 @@ int launch_forward(const NcdeProblem* p, const Layout& y, int family, float* out
         if (rc != NCDE_OK) return fail(rc, "fast forward launch failed");
         return NCDE_OK;
     }
+    if (family == 3) {
+        const int rc = ncde_variant_forward(p, out, stages, st);
+        if (rc != NCDE_OK) return fail(rc, "variant forward launch failed");
+        return NCDE_OK;
+    }
     if (family == 2) {
         const int rc = ncde_tiled_forward(p, out, stages, ws, ws_bytes, st);
         if (rc != NCDE_OK) return fail(rc, "tiled forward launch failed");
@@ -115,6 +143,12 @@ int launch_adjoint(const NcdeProblem* p, const Layout& y, int family, const floa
     if (family == 1) {
         const int rc = ncde_fast_adjoint(p, src, grad_out, g, ws, ws_bytes, st, main_kernel_only, discrete);
         if (rc != NCDE_OK) return fail(rc, "fast adjoint launch failed");
+        return NCDE_OK;
+    }
+    if (family == 3) {
+        const int rc = ncde_variant_adjoint(p, src, grad_out, g, ws, st, main_kernel_only, discrete);
+        if (rc == NCDE_ERR_INVALID) return fail(rc, "NcdeGrads: NULL destination for a parameter gradient");
+        if (rc != NCDE_OK) return fail(rc, "variant adjoint launch failed");
         return NCDE_OK;
     }
     if (family == 2) {
@@ -144,41 +178,62 @@ int ncde_version(void) { return NCDE_ABI_VERSION; }
 const char* ncde_last_error_string(void) { return g_err; }
 
 int ncde_num_outputs(const NcdeProblem* p) {
-    const int rc = validate(p);
+    NcdeProblem q_;
+    int rc = normalize(p, &q_);
+    if (rc != NCDE_OK) return rc;
+    p = &q_;
+    rc = validate(p);
     if (rc != NCDE_OK) return rc;
     return p->output == NCDE_OUT_KNOTS ? p->n_knots : 2;
 }
 
 int64_t ncde_workspace_bytes(const NcdeProblem* p, int pass) {
-    const int rc = validate(p);
+    NcdeProblem q_;
+    int rc = normalize(p, &q_);
+    if (rc != NCDE_OK) return rc;
+    p = &q_;
+    rc = validate(p);
     if (rc != NCDE_OK) return rc;
     const Layout y = make_layout(p);
     const int fam = select_family(p, y, pass);
     if (fam < 0) return fam;
     if (fam == 1) return ncde_fast_workspace_bytes(p, pass);
     if (fam == 2) return ncde_tiled_workspace_bytes(p, pass);
+    if (fam == 3) return ncde_variant_workspace_bytes(p, pass);
     if (pass == 0) return 256;
     return (int64_t)sizeof(float) * (int64_t)y.n_wg * (int64_t)y.theta_size + 256;
 }
 
 int64_t ncde_stage_record_bytes(const NcdeProblem* p) {
-    const int rc = validate(p);
+    NcdeProblem q_;
+    int rc = normalize(p, &q_);
+    if (rc != NCDE_OK) return rc;
+    p = &q_;
+    rc = validate(p);
     if (rc != NCDE_OK) return rc;
     const int S = p->method == NCDE_RK4_38 ? 4 : (p->method == NCDE_MIDPOINT ? 2 : 1);
     return (int64_t)sizeof(float) * (int64_t)(p->n_knots - 1) * S * (int64_t)p->batch * p->hidden;
 }
 
 const char* ncde_kernel_name(const NcdeProblem* p, int pass) {
+    NcdeProblem q_;
+    if (normalize(p, &q_) != NCDE_OK) return nullptr;
+    p = &q_;
     if (validate(p) != NCDE_OK) return nullptr;
     const Layout y = make_layout(p);
     const int fam = select_family(p, y, pass);
     if (fam < 0) return nullptr;
     if (fam == 2) return ncde_tiled_kernel_name(p, pass);
+    if (fam == 3) return pass == 0 ? "ncde_fwd_variant" : (pass == 1 ? "ncde_adj_variant" : "ncde_adj_variant<discrete>");
     return fam == 1 ? ncde_fast_kernel_name(p, pass) : (pass == 0 ? "ncde_fwd_generic" : (pass == 1 ? "ncde_adj_generic" : "ncde_adj_generic<discrete>"));
 }
 
 int ncde_forward(const NcdeProblem* p, float* out, void* workspace, size_t workspace_bytes, void* stream) {
-    int rc = validate(p);
+    NcdeProblem q_;
+    int rc = normalize(p, &q_);
+    if (rc != NCDE_OK) return rc;
+    p = &q_;
+    rc = validate(p);
     if (rc != NCDE_OK) return rc;
     if (!out) return fail(NCDE_ERR_INVALID, "out is NULL");
     const Layout y = make_layout(p);
@@ -190,7 +245,11 @@ int ncde_forward(const NcdeProblem* p, float* out, void* workspace, size_t works
 }
 
 int ncde_forward_record(const NcdeProblem* p, float* out, float* stages, void* workspace, size_t workspace_bytes, void* stream) {
-    int rc = validate(p);
+    NcdeProblem q_;
+    int rc = normalize(p, &q_);
+    if (rc != NCDE_OK) return rc;
+    p = &q_;
+    rc = validate(p);
     if (rc != NCDE_OK) return rc;
     if (!out || !stages) return fail(NCDE_ERR_INVALID, "out/stages is NULL");
     if (p->flags & NCDE_FLAG_DEBUG_PROFILE) return fail(NCDE_ERR_UNSUPPORTED, "no instrumented recording forward");
@@ -204,7 +263,11 @@ int ncde_forward_record(const NcdeProblem* p, float* out, float* stages, void* w
 
 int ncde_backward(const NcdeProblem* p, const float* stages, const float* grad_out, const NcdeGrads* grads, void* workspace,
                   size_t workspace_bytes, void* stream) {
-    int rc = validate(p);
+    NcdeProblem q_;
+    int rc = normalize(p, &q_);
+    if (rc != NCDE_OK) return rc;
+    p = &q_;
+    rc = validate(p);
     if (rc != NCDE_OK) return rc;
     if (!stages || !grad_out || !grads || !grads->grad_z0) return fail(NCDE_ERR_INVALID, "NULL stages/grad_out/grads");
     const Layout y = make_layout(p);
@@ -217,7 +280,11 @@ int ncde_backward(const NcdeProblem* p, const float* stages, const float* grad_o
 
 int ncde_adjoint(const NcdeProblem* p, const float* z_out, const float* grad_out, const NcdeGrads* grads, void* workspace,
                  size_t workspace_bytes, void* stream) {
-    int rc = validate(p);
+    NcdeProblem q_;
+    int rc = normalize(p, &q_);
+    if (rc != NCDE_OK) return rc;
+    p = &q_;
+    rc = validate(p);
     if (rc != NCDE_OK) return rc;
     if (!z_out || !grad_out || !grads || !grads->grad_z0) return fail(NCDE_ERR_INVALID, "NULL z_out/grad_out/grads");
     const Layout y = make_layout(p);
@@ -230,7 +297,11 @@ int ncde_adjoint(const NcdeProblem* p, const float* z_out, const float* grad_out
 
 int ncde_time_kernel(const NcdeProblem* p, int pass, float* out, const float* grad_out, const NcdeGrads* grads, void* workspace,
                      size_t workspace_bytes, void* stream, int iters, float* ms_per_launch) {
-    int rc = validate(p);
+    NcdeProblem q_;
+    int rc = normalize(p, &q_);
+    if (rc != NCDE_OK) return rc;
+    p = &q_;
+    rc = validate(p);
     if (rc != NCDE_OK) return rc;
     if (iters < 1 || !ms_per_launch) return fail(NCDE_ERR_INVALID, "iters < 1 or NULL result");
     if (pass < 0 || pass > 2) return fail(NCDE_ERR_INVALID, "pass %d outside {0, 1, 2}", pass);

@@ -38,6 +38,15 @@ struct KArgs {
     float* recC;      // w * cotangent  [stage][sample tile][H][16]
     float* recD;      // dX/dt          [stage][sample tile][C/4][16][4]
     int gstride;      // floats per workgroup partial in gpart (hidden-layer parameters only)
+    // vector-field variants (generic family only): gated heads, reset net, evaluate / derivative input modes
+    int field_kind, field_input;
+    int d0;           // width of the field input u: H (matmul) or H + C
+    int rows;         // rows of the heads: H*C (matmul) or H
+    const float* Wg;
+    const float* bg;
+    const float* Wr;
+    const float* br;
+    int gWg_off, gbg_off, gWr_off, gbr_off;
 };
 
 __device__ __forceinline__ int ru4(int x) { return (x + 3) & ~3; }

@@ -502,9 +502,9 @@ extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_adj_generic(KArgs
 // ------------------------------------------------------------------------------------------------
 struct ReduceSegs {
     int n;
-    int off[2 * NCDE_MAX_LAYERS + 2];
-    int len[2 * NCDE_MAX_LAYERS + 2];
-    float* dst[2 * NCDE_MAX_LAYERS + 2];
+    int off[2 * NCDE_MAX_LAYERS + 6];
+    int len[2 * NCDE_MAX_LAYERS + 6];
+    float* dst[2 * NCDE_MAX_LAYERS + 6];
 };
 
 extern "C" __global__ __launch_bounds__(256) void ncde_reduce_partials(const float* __restrict__ gpart, int n_part,

@@ -9,9 +9,9 @@
 
 struct ReduceSegs {
     int n;
-    int off[2 * NCDE_MAX_LAYERS + 2];
-    int len[2 * NCDE_MAX_LAYERS + 2];
-    float* dst[2 * NCDE_MAX_LAYERS + 2];
+    int off[2 * NCDE_MAX_LAYERS + 6];
+    int len[2 * NCDE_MAX_LAYERS + 6];
+    float* dst[2 * NCDE_MAX_LAYERS + 6];
 };
 extern "C" __global__ void ncde_reduce_partials(const float* gpart, int n_part, int theta_size, ReduceSegs segs);
 
@@ -23,6 +23,9 @@ struct Layout {
     int Hp, Cp, Dp, HS, DS, L;
     int theta_size;
     int gW_off[NCDE_MAX_LAYERS], gb_off[NCDE_MAX_LAYERS], gWo_off, gbo_off;
+    int gWg_off, gbg_off, gWr_off, gbr_off;
+    int d0, rows;          // field input width, head rows
+    bool variant;          // gated field or evaluate / derivative input (generic family only)
     int dlast;
     int n_wg;
     size_t lds_fwd, lds_adj;
@@ -34,7 +37,10 @@ inline Layout make_layout(const NcdeProblem* p) {
     y.L = p->n_layers;
     y.Hp = hru16(p->hidden);
     y.Cp = hru4(p->channels);
-    y.Dp = y.Hp;
+    y.variant = p->field_kind != NCDE_FIELD_ORIGINAL || p->field_input != NCDE_INPUT_MATMUL;
+    y.d0 = p->field_input == NCDE_INPUT_MATMUL ? p->hidden : p->hidden + p->channels;
+    y.rows = p->field_input == NCDE_INPUT_MATMUL ? p->hidden * p->channels : p->hidden;
+    y.Dp = std::max(y.Hp, hru16(y.d0));
     for (int l = 0; l < y.L; ++l) y.Dp = std::max(y.Dp, hru16(p->layer_out[l]));
     y.HS = y.Hp * 16;
     y.DS = y.Dp * 16;
@@ -51,8 +57,17 @@ inline Layout make_layout(const NcdeProblem* p) {
         if (prevB >= 0) y.gb_off[l] = y.gb_off[prevB];
         else { y.gb_off[l] = off; off += p->layer_out[l]; }
     }
-    y.gWo_off = off; off += p->hidden * p->channels * y.dlast;
-    y.gbo_off = off; off += p->hidden * p->channels;
+    y.gWo_off = off; off += y.rows * y.dlast;
+    y.gbo_off = off; off += y.rows;
+    y.gWg_off = y.gbg_off = y.gWr_off = y.gbr_off = 0;
+    if (p->field_kind != NCDE_FIELD_ORIGINAL) {
+        y.gWg_off = off; off += y.rows * y.dlast;
+        y.gbg_off = off; off += y.rows;
+    }
+    if (p->field_kind == NCDE_FIELD_GRU) {
+        y.gWr_off = off; off += y.d0 * y.d0;
+        y.gbr_off = off; off += y.d0;
+    }
     y.theta_size = off;
     y.n_wg = (p->batch + NCDE_TILE - 1) / NCDE_TILE;
     y.lds_fwd = sizeof(float) * (size_t)(5 * y.HS + 2 * y.DS + y.Cp * 16);
@@ -79,6 +94,9 @@ inline void fill_kargs(const NcdeProblem* p, const Layout& y, KArgs* a) {
     a->cs_b = p->coeffs_stride_b; a->cs_t = p->coeffs_stride_t;
     a->z0 = p->z0;
     a->gWo_off = y.gWo_off; a->gbo_off = y.gbo_off; a->theta_size = y.theta_size;
+    a->field_kind = p->field_kind; a->field_input = p->field_input; a->d0 = y.d0; a->rows = y.rows;
+    a->Wg = p->Wg; a->bg = p->bg; a->Wr = p->Wr; a->br = p->br;
+    a->gWg_off = y.gWg_off; a->gbg_off = y.gbg_off; a->gWr_off = y.gWr_off; a->gbr_off = y.gbr_off;
     a->gacc_in_lds = y.gacc_in_lds;
 }
 
@@ -96,8 +114,16 @@ inline int launch_reduce_partials(const NcdeProblem* p, const Layout& y, const N
         if (firstW) { segs.off[n] = y.gW_off[l]; segs.len[n] = p->layer_out[l] * p->layer_in[l]; segs.dst[n] = g->grad_layer_W[l]; ++n; }
         if (firstB) { segs.off[n] = y.gb_off[l]; segs.len[n] = p->layer_out[l]; segs.dst[n] = g->grad_layer_b[l]; ++n; }
     }
-    segs.off[n] = y.gWo_off; segs.len[n] = p->hidden * p->channels * y.dlast; segs.dst[n] = g->grad_Wo; ++n;
-    segs.off[n] = y.gbo_off; segs.len[n] = p->hidden * p->channels; segs.dst[n] = g->grad_bo; ++n;
+    segs.off[n] = y.gWo_off; segs.len[n] = y.rows * y.dlast; segs.dst[n] = g->grad_Wo; ++n;
+    segs.off[n] = y.gbo_off; segs.len[n] = y.rows; segs.dst[n] = g->grad_bo; ++n;
+    if (p->field_kind != NCDE_FIELD_ORIGINAL) {
+        segs.off[n] = y.gWg_off; segs.len[n] = y.rows * y.dlast; segs.dst[n] = g->grad_Wg; ++n;
+        segs.off[n] = y.gbg_off; segs.len[n] = y.rows; segs.dst[n] = g->grad_bg; ++n;
+    }
+    if (p->field_kind == NCDE_FIELD_GRU) {
+        segs.off[n] = y.gWr_off; segs.len[n] = y.d0 * y.d0; segs.dst[n] = g->grad_Wr; ++n;
+        segs.off[n] = y.gbr_off; segs.len[n] = y.d0; segs.dst[n] = g->grad_br; ++n;
+    }
     segs.n = n;
     for (int i = 0; i < n; ++i)
         if (!segs.dst[i]) return NCDE_ERR_INVALID;

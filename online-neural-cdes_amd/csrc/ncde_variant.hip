@@ -1,0 +1,676 @@
+// Vector-field VARIANTS of the reference on the generic 16-sample-tile structure:
+//   gated fields   src/ncde/vector_fields/gating.py:7-61      minimal: M = sigmoid(Wg hh + bg) * tanh(Wo hh + bo)
+//                                                             gru:     M = sigmoid(Wg net(u) + bg) * tanh(Wo net(rg * u) + bo),
+//                                                                      rg = sigmoid(Wr u + br)
+//   input modes    modules/torchcde/torchcde/solver.py:112-137 matmul:     u = z,             dz/dt = M[H,C] . dX/dt
+//                                                             evaluate:   u = [z, X(t)],     dz/dt = M[H]
+//                                                             derivative: u = [z, dX/dt(t)], dz/dt = M[H]
+// Same design as ncde_generic.hip (activations in LDS as [unit][sample], fp32 MFMA 16x16x4, weights streamed from L2,
+// the whole time loop inside the kernel, per-workgroup parameter-gradient partials); the head loop carries two
+// accumulators (tanh and sigmoid head), the inner net can run twice per stage (GRU), the field input has H + C rows
+// in the evaluate / derivative modes.  The continuous adjoint and the exact discrete backward share one kernel.
+#include "ncde_common.h"
+#include "ncde_host.h"
+#include "ncde_variant.h"
+
+#define VR_NW 4
+#define VR_THREADS (64 * VR_NW)
+#define VR_MAXJT 8  // last hidden width <= 128
+
+namespace {
+
+__device__ __forceinline__ float sigmoid_dev(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);  // exp(-x)
+    return __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// control input of the stage for the 16 samples of the tile -> CIN[c*16 + s]:
+// value = false: dX/dt(t) (interpolation_linear.py:231-234, interpolation_cubic.py:331-336)
+// value = true : X(t)     (interpolation_linear.py:221-229, interpolation_cubic.py:324-329)
+__device__ void vr_load_cin(const KArgs& a, int b0, int idx, float frac, bool value, float* CIN, int Cp, int tid) {
+    for (int e = tid; e < 16 * Cp; e += VR_THREADS) {
+        const int s = e / Cp, c = e - s * Cp;
+        const int b = b0 + s;
+        float v = 0.0f;
+        if (c < a.C && b < a.B) {
+            const float* p = a.coeffs + (long long)b * a.cs_b + (long long)idx * a.cs_t;
+            if (a.interp == NCDE_INTERP_LINEAR) {
+                const float d = p[a.cs_t + c] - p[c];
+                v = value ? p[c] + (frac * d) / 1.0f : d;
+            } else {
+                const float aa = p[c], bb = p[a.C + c], cc = p[2 * a.C + c], dd = p[3 * a.C + c];
+                if (value) {
+                    float inner = 0.5f * cc + (dd * frac) / 3.0f;
+                    inner = bb + inner * frac;
+                    v = aa + inner * frac;
+                } else {
+                    const float inner = cc + dd * frac;
+                    v = bb + inner * frac;
+                }
+            }
+        }
+        CIN[c * 16 + s] = v;
+    }
+}
+
+// out[n][s] = act(sum_k W[n][k] in[k][s] + bias[n]), n < ru16(N) (rows >= N come out as act(0) masked to 0)
+// ACT: 0 = relu, 1 = sigmoid
+template <int ACT>
+__device__ void vr_dense(const float* __restrict__ W, const float* __restrict__ bias, int N, int K, const float* in, float* out,
+                         int wave, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    const int ntiles = (N + 15) >> 4, nks = (K + 3) >> 2;
+    for (int t = wave; t < ntiles; t += VR_NW) {
+        const int rowA = 16 * t + li;
+        const bool rv = rowA < N;
+        const float* wrow = W + (long long)(rv ? rowA : 0) * K;
+        f32x4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * t + 4 * lk + r;
+            acc[r] = row < N ? bias[row] : 0.0f;
+        }
+#pragma unroll 4
+        for (int ks = 0; ks < nks; ++ks) {
+            const int k = 4 * ks + lk;
+            const float av = (rv && k < K) ? wrow[k] : 0.0f;
+            acc = mfma16(av, in[k * 16 + li], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * t + 4 * lk + r;
+            const float v = ACT == 0 ? fmaxf(acc[r], 0.0f) : sigmoid_dev(acc[r]);
+            out[row * 16 + li] = row < N ? v : 0.0f;
+        }
+    }
+}
+
+// x_1 .. x_L of the inner net for input `in`; all layers kept when X_all (adjoint), else ping-pong into A0/A1.
+// Returns the buffer holding x_L.
+__device__ const float* vr_net(const KArgs& a, const float* in, float* X, int DS, bool keep_all, int wave, int lane) {
+    for (int l = 0; l < a.n_layers; ++l) {
+        float* outb = keep_all ? X + l * DS : X + (l & 1) * DS;
+        vr_dense<0>(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane);
+        __syncthreads();
+        in = outb;
+    }
+    return in;
+}
+
+struct HeadTile {
+    int rowA;       // weight row this lane streams (A operand), -1 = none
+    int rowD[4];    // row of D register r, -1 = none
+    int hD[4];      // state index h of D register r
+};
+
+// tile q of the head: matmul -> (hb, cq) with rows (h = 4hb+g, c = 4cq+r); direct -> rows 16q .. 16q+15 = h
+__device__ __forceinline__ HeadTile vr_head_tile(const KArgs& a, int q, int ncq, int li, int lk, int& cq_out) {
+    HeadTile t;
+    if (a.field_input == NCDE_INPUT_MATMUL) {
+        const int hb = q / ncq, cq = q - hb * ncq;
+        cq_out = cq;
+        const int hA = 4 * hb + (li >> 2), cA = 4 * cq + (li & 3), hD = 4 * hb + lk;
+        t.rowA = (hA < a.H && cA < a.C) ? hA * a.C + cA : -1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 4 * cq + r;
+            t.rowD[r] = (hD < a.H && c < a.C) ? hD * a.C + c : -1;
+            t.hD[r] = hD;
+        }
+    } else {
+        cq_out = 0;
+        t.rowA = 16 * q + li < a.H ? 16 * q + li : -1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int h = 16 * q + 4 * lk + r;
+            t.rowD[r] = h < a.H ? h : -1;
+            t.hD[r] = h;
+        }
+    }
+    return t;
+}
+
+__device__ __forceinline__ f32x4 vr_head_gemm(const float* __restrict__ W, const float* __restrict__ bias, const HeadTile& t, int K,
+                                              const float* in, int li, int lk) {
+    f32x4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = t.rowD[r] >= 0 ? bias[t.rowD[r]] : 0.0f;
+    const float* wrow = W + (long long)(t.rowA >= 0 ? t.rowA : 0) * K;
+    const int nks = (K + 3) >> 2;
+#pragma unroll 4
+    for (int ks = 0; ks < nks; ++ks) {
+        const int k = 4 * ks + lk;
+        const float av = (t.rowA >= 0 && k < K) ? wrow[k] : 0.0f;
+        acc = mfma16(av, in[k * 16 + li], acc);
+    }
+    return acc;
+}
+
+struct StageCombineV {
+    __device__ static __forceinline__ float apply(int method, int j, float k, float& y0, float& k1, float& k2, bool& last) {
+        last = false;
+        if (method == NCDE_RK4_38) {
+            if (j == 0) { k1 = k; return y0 + k * 0.333333343267440796f; }
+            if (j == 1) { k2 = k; return y0 + (k - k1 * 0.333333343267440796f); }
+            if (j == 2) { const float ys = y0 + ((k1 - k2) + k); k2 = k2 + k; return ys; }
+            last = true;
+            y0 = y0 + ((k1 + 3.0f * k2) + k) * 0.125f;
+            return y0;
+        }
+        if (method == NCDE_MIDPOINT) {
+            if (j == 0) return y0 + k * 0.5f;
+            last = true;
+            y0 = y0 + k;
+            return y0;
+        }
+        last = true;
+        y0 = y0 + k;
+        return y0;
+    }
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_fwd_variant(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int b0 = blockIdx.x * NCDE_TILE;
+    const int H = a.H, C = a.C, Hp = ru16(H), Cp = ru4(C), d0 = a.d0, L = a.n_layers;
+    int Dp = max(Hp, ru16(d0));
+    for (int l = 0; l < L; ++l) Dp = max(Dp, ru16(a.dout[l]));
+    const int HS = Hp * 16, DS = Dp * 16;
+    const bool matmul = a.field_input == NCDE_INPUT_MATMUL, gru = a.field_kind == NCDE_FIELD_GRU, gated = a.field_kind != NCDE_FIELD_ORIGINAL;
+    float* U = lds;              // field input [d0][16]: rows < H = stage state, rows H.. = control input
+    float* RU = U + DS;          // rg * u (gru)
+    float* RG = RU + DS;         // reset gate (gru)
+    float* XA = RG + DS;         // ping-pong activations, inner pass (2 buffers)
+    float* XB = XA + 2 * DS;     // ping-pong activations, reset pass (2 buffers)
+    float* Y0 = XB + 2 * DS;
+    float* K1 = Y0 + HS;
+    float* K2 = K1 + HS;
+    float* KO = K2 + HS;
+    float* CIN = KO + HS;        // [Cp][16]
+    const int total = 7 * DS + 4 * HS + Cp * 16;
+    for (int e = tid; e < total; e += VR_THREADS) lds[e] = 0.0f;
+    __syncthreads();
+    for (int e = tid; e < HS; e += VR_THREADS) {
+        const int h = e >> 4, s = e & 15, b = b0 + s;
+        if (h < H && b < a.B) {
+            const float v = a.z0[(long long)b * H + h];
+            Y0[e] = v;
+            U[e] = v;
+            a.out[((long long)b * a.n_out) * H + h] = v;
+        }
+    }
+    const int S = n_stages(a.method);
+    const int dlast = L ? a.dout[L - 1] : d0;
+    const int ncq = Cp >> 2, ngrp = matmul ? (Hp >> 2) : (Hp >> 4), per_grp = matmul ? ncq : 1;
+    for (int n = 0; n < a.T - 1; ++n) {
+        for (int j = 0; j < S; ++j) {
+            const float t = (float)n + stage_offset(a.method, j);
+            const int idx = piece_index(t, a.n_pieces);
+            vr_load_cin(a, b0, idx, t - (float)idx, a.field_input == NCDE_INPUT_EVALUATE, CIN, Cp, tid);
+            __syncthreads();
+            if (!matmul)
+                for (int e = tid; e < C * 16; e += VR_THREADS) U[H * 16 + e] = CIN[e];
+            if (a.stages) {
+                float* rec = a.stages + ((long long)(n * S + j) * a.B + b0) * H;
+                for (int e = tid; e < 16 * H; e += VR_THREADS) {
+                    const int s = e / H, h = e - s * H;
+                    if (b0 + s < a.B) rec[e] = U[h * 16 + s];
+                }
+            }
+            __syncthreads();
+            if (gru) {
+                vr_dense<1>(a.Wr, a.br, d0, d0, U, RG, wave, lane);
+                __syncthreads();
+                for (int e = tid; e < ru16(d0) * 16; e += VR_THREADS) RU[e] = RG[e] * U[e];
+                __syncthreads();
+            }
+            const float* xi = vr_net(a, U, XA, DS, false, wave, lane);
+            const float* xr = gru ? vr_net(a, RU, XB, DS, false, wave, lane) : xi;
+            // groups of head tiles: matmul -> one h-block (all its channel quads, contraction accumulated in a
+            // register); evaluate / derivative -> one 16-row tile
+            for (int grp = wave; grp < ngrp; grp += VR_NW) {
+                float ksum = 0.0f;
+                for (int qi = 0; qi < per_grp; ++qi) {
+                    int cq;
+                    const HeadTile ht = vr_head_tile(a, grp * per_grp + qi, ncq, li, lk, cq);
+                    const f32x4 pt = vr_head_gemm(a.Wo, a.bo, ht, dlast, xr, li, lk);
+                    f32x4 ps = pt;
+                    if (gated) ps = vr_head_gemm(a.Wg, a.bg, ht, dlast, xi, li, lk);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float m = tanh_dev(pt[r]);
+                        if (gated) m = sigmoid_dev(ps[r]) * m;
+                        if (matmul) ksum = fmaf(m, CIN[(4 * cq + r) * 16 + li], ksum);
+                        else if (ht.hD[r] < Hp) KO[ht.hD[r] * 16 + li] = ht.rowD[r] >= 0 ? m : 0.0f;
+                    }
+                }
+                if (matmul && 4 * grp + lk < Hp) KO[(4 * grp + lk) * 16 + li] = ksum;
+            }
+            __syncthreads();
+            for (int e = tid; e < HS; e += VR_THREADS) {
+                float y0 = Y0[e], k1 = K1[e], k2 = K2[e];
+                bool last;
+                const float ys = StageCombineV::apply(a.method, j, KO[e], y0, k1, k2, last);
+                U[e] = ys;
+                K1[e] = k1;
+                K2[e] = k2;
+                if (last) {
+                    Y0[e] = y0;
+                    const int h = e >> 4, s = e & 15, b = b0 + s;
+                    if (h < H && b < a.B) {
+                        if (a.output == NCDE_OUT_KNOTS) a.out[((long long)b * a.n_out + (n + 1)) * H + h] = y0;
+                        else if (n == a.T - 2) a.out[((long long)b * a.n_out + 1) * H + h] = y0;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// adjoint / exact discrete backward
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// gW[j][i] += w sum_s gpre[j][s] xin[i][s];  gb[j] += w sum_s gpre[j][s]      (samples are the K dim of the MFMA)
+__device__ void vr_dw_acc(const float* gpre, const float* xin, int N, int K, float w, float* gW, float* gb, int tid, int wave, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    for (int jj = tid; jj < N; jj += VR_THREADS) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) sum += gpre[jj * 16 + s];
+        gb[jj] += w * sum;
+    }
+    const int njt = (N + 15) >> 4, nit = (K + 15) >> 4;
+    for (int tt = wave; tt < njt * nit; tt += VR_NW) {
+        const int jt = tt / nit, it = tt - jt * nit;
+        f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) g = mfma16(gpre[(16 * jt + li) * 16 + 4 * ks + lk], xin[(16 * it + li) * 16 + 4 * ks + lk], g);
+        const int col = 16 * it + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * jt + 4 * lk + r;
+            if (row < N && col < K) gW[(long long)row * K + col] += w * g[r];
+        }
+    }
+}
+
+// out[i][s] (+)= sum_j W[j][i] gpre[j][s], i < ru16(K); optionally x relu'(mask[i][s])
+__device__ void vr_bwd_data(const float* __restrict__ W, int N, int K, const float* gpre, const float* mask, float* out, bool accumulate,
+                            int wave, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    const int nit = (K + 15) >> 4, nks = (N + 3) >> 2;
+    for (int it = wave; it < nit; it += VR_NW) {
+        const int col = 16 * it + li;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int ks = 0; ks < nks; ++ks) {
+            const int k = 4 * ks + lk;
+            const float av = (k < N && col < K) ? W[(long long)k * K + col] : 0.0f;
+            acc = mfma16(av, gpre[k * 16 + li], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * it + 4 * lk + r;
+            float v = acc[r];
+            if (mask) v = mask[row * 16 + li] > 0.0f ? v : 0.0f;
+            if (accumulate) v += out[row * 16 + li];
+            out[row * 16 + li] = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int b0 = blockIdx.x * NCDE_TILE;
+    const int H = a.H, C = a.C, Hp = ru16(H), Cp = ru4(C), d0 = a.d0, L = a.n_layers;
+    int Dp = max(Hp, ru16(d0));
+    for (int l = 0; l < L; ++l) Dp = max(Dp, ru16(a.dout[l]));
+    const int HS = Hp * 16, DS = Dp * 16;
+    const bool matmul = a.field_input == NCDE_INPUT_MATMUL, gru = a.field_kind == NCDE_FIELD_GRU, gated = a.field_kind != NCDE_FIELD_ORIGINAL;
+    float* U = lds;                  // field input (rows < H: y stage input)
+    float* RG = U + DS;
+    float* RU = RG + DS;
+    float* XI = RU + DS;             // [L] inner pass activations
+    float* XR = XI + L * DS;         // [L] reset pass activations (gru)
+    float* GA = XR + L * DS;         // dL/dpre ping
+    float* GB = GA + DS;             // pong
+    float* PW = GB + DS;             // [8] per-wave partials of dL/dx_L: 0..3 inner pass, 4..7 reset pass
+    float* DUI = PW + 8 * DS;        // cotangent of u
+    float* DUR = DUI + DS;           // cotangent of rg * u
+    float* AS = DUR + DS;            // stage cotangent [Hp][16]
+    float* Y0 = AS + HS;
+    float* A0 = Y0 + HS;
+    float* KY1 = A0 + HS;
+    float* KY2 = KY1 + HS;
+    float* KA1 = KY2 + HS;
+    float* KA2 = KA1 + HS;
+    float* KOY = KA2 + HS;
+    float* KOA = KOY + HS;
+    float* CIN = KOA + HS;
+    float* SC = CIN + Cp * 16;       // per-wave 16x17 transpose scratch
+    float* GL = SC + VR_NW * 16 * 17;
+    const int total = (15 + 2 * L) * DS + 9 * HS + Cp * 16 + VR_NW * 16 * 17 + (a.gacc_in_lds ? a.theta_size : 0);
+    for (int e = tid; e < total; e += VR_THREADS) lds[e] = 0.0f;
+    float* gacc = a.gacc_in_lds ? GL : a.gpart + (long long)blockIdx.x * a.theta_size;
+    if (!a.gacc_in_lds)
+        for (int e = tid; e < a.theta_size; e += VR_THREADS) gacc[e] = 0.0f;
+    __syncthreads();
+    const int last_row = a.n_out - 1;
+    const int S = n_stages(a.method);
+    const bool disc = a.discrete != 0;
+    for (int e = tid; e < HS; e += VR_THREADS) {
+        const int h = e >> 4, s = e & 15, b = b0 + s;
+        if (h < H && b < a.B) {
+            const long long o = ((long long)b * a.n_out + last_row) * H + h;
+            const float g = a.grad_out[o];
+            A0[e] = g;
+            if (disc) {
+                AS[e] = a.method == NCDE_RK4_38 ? g * 0.125f : g;
+            } else {
+                const float y = a.z_out[o];
+                Y0[e] = y; U[e] = y; AS[e] = g;
+            }
+        }
+    }
+    const int dlast = a.dout[L - 1];
+    const int ncq = Cp >> 2, ngrp = matmul ? (Hp >> 2) : (Hp >> 4), per_grp = matmul ? ncq : 1;
+    const int njt = (dlast + 15) >> 4;
+    float* sc = SC + wave * 16 * 17;
+    for (int n = a.T - 1; n >= 1; --n) {
+        for (int j = 0; j < S; ++j) {
+            const float t = disc ? (float)(n - 1) + stage_offset(a.method, S - 1 - j) : -(-(float)n + stage_offset(a.method, j));
+            const int idx = piece_index(t, a.n_pieces);
+            const float w = disc ? 1.0f : stage_weight(a.method, j);
+            vr_load_cin(a, b0, idx, t - (float)idx, a.field_input == NCDE_INPUT_EVALUATE, CIN, Cp, tid);
+            if (disc) {
+                const float* rec = a.stages + ((long long)((n - 1) * S + (S - 1 - j)) * a.B + b0) * H;
+                for (int e = tid; e < 16 * H; e += VR_THREADS) {
+                    const int s = e / H, h = e - s * H;
+                    U[h * 16 + s] = b0 + s < a.B ? rec[e] : 0.0f;
+                }
+            }
+            __syncthreads();
+            if (!matmul) {
+                for (int e = tid; e < C * 16; e += VR_THREADS) U[H * 16 + e] = CIN[e];
+                __syncthreads();
+            }
+            if (gru) {
+                vr_dense<1>(a.Wr, a.br, d0, d0, U, RG, wave, lane);
+                __syncthreads();
+                for (int e = tid; e < ru16(d0) * 16; e += VR_THREADS) RU[e] = RG[e] * U[e];
+                __syncthreads();
+            }
+            const float* xi = vr_net(a, U, XI, DS, true, wave, lane);
+            const float* xr = gru ? vr_net(a, RU, XR, DS, true, wave, lane) : xi;
+            // ---- heads: f, cotangents of the two pre-activations, head parameter gradients, partials of dL/dx_L ------
+            f32x4 accI[VR_MAXJT], accR[VR_MAXJT];
+#pragma unroll
+            for (int jt = 0; jt < VR_MAXJT; ++jt) accI[jt] = accR[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int grp = wave; grp < ngrp; grp += VR_NW) {
+                float ksum = 0.0f;
+                for (int qi = 0; qi < per_grp; ++qi) {
+                    int cq;
+                    const HeadTile ht = vr_head_tile(a, grp * per_grp + qi, ncq, li, lk, cq);
+                    const f32x4 pt = vr_head_gemm(a.Wo, a.bo, ht, dlast, xr, li, lk);
+                    f32x4 ps = pt;
+                    if (gated) ps = vr_head_gemm(a.Wg, a.bg, ht, dlast, xi, li, lk);
+                    float dPt[4], dPs[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float th = tanh_dev(pt[r]);
+                        const float sg = gated ? sigmoid_dev(ps[r]) : 1.0f;
+                        const float m = gated ? sg * th : th;
+                        float dm;
+                        if (matmul) {
+                            const float dx = CIN[(4 * cq + r) * 16 + li];
+                            ksum = fmaf(m, dx, ksum);
+                            dm = (ht.hD[r] < Hp ? AS[ht.hD[r] * 16 + li] : 0.0f) * dx;
+                        } else {
+                            if (ht.hD[r] < Hp) KOY[ht.hD[r] * 16 + li] = ht.rowD[r] >= 0 ? m : 0.0f;
+                            dm = ht.hD[r] < Hp ? AS[ht.hD[r] * 16 + li] : 0.0f;
+                        }
+                        if (ht.rowD[r] < 0) dm = 0.0f;
+                        dPt[r] = gated ? (dm * sg) * (1.0f - th * th) : dm * (1.0f - th * th);
+                        dPs[r] = gated ? (dm * th) * (sg * (1.0f - sg)) : 0.0f;
+                    }
+                    // dL/dx_L of the pass feeding each head: rows of the tile are the K dim (k-step r, k-sub lane>>4)
+#pragma unroll
+                    for (int jt = 0; jt < VR_MAXJT; ++jt) {
+                        if (jt < njt) {
+                            const int jcol = 16 * jt + li;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const bool ok = ht.rowD[r] >= 0 && jcol < dlast;
+                                const float avt = ok ? a.Wo[(long long)ht.rowD[r] * dlast + jcol] : 0.0f;
+                                if (gru) accR[jt] = mfma16(avt, dPt[r], accR[jt]);
+                                else accI[jt] = mfma16(avt, dPt[r], accI[jt]);
+                                if (gated) {
+                                    const float avs = ok ? a.Wg[(long long)ht.rowD[r] * dlast + jcol] : 0.0f;
+                                    accI[jt] = mfma16(avs, dPs[r], accI[jt]);
+                                }
+                            }
+                        }
+                    }
+                    if (w != 0.0f) {
+#pragma unroll
+                        for (int hd = 0; hd < 2; ++hd) {
+                            if (hd == 1 && !gated) break;
+                            const float* dP = hd == 0 ? dPt : dPs;
+                            const float* xl = hd == 0 ? xr : xi;
+                            float* gWh = gacc + (hd == 0 ? a.gWo_off : a.gWg_off);
+                            float* gbh = gacc + (hd == 0 ? a.gbo_off : a.gbg_off);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float sum = row16_sum(dP[r]);
+                                if (li == 0 && ht.rowD[r] >= 0) gbh[ht.rowD[r]] += w * sum;
+                            }
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) sc[(4 * lk + r) * 17 + li] = w * dP[r];
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            for (int jt = 0; jt < njt; ++jt) {
+                                f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                                for (int ks = 0; ks < 4; ++ks) g = mfma16(sc[li * 17 + 4 * ks + lk], xl[(16 * jt + li) * 16 + 4 * ks + lk], g);
+                                const int jcol = 16 * jt + li;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    if (ht.rowD[r] >= 0 && jcol < dlast) gWh[(long long)ht.rowD[r] * dlast + jcol] += g[r];
+                            }
+                        }
+                    }
+                }
+                if (matmul && 4 * grp + lk < Hp) KOY[(4 * grp + lk) * 16 + li] = ksum;
+            }
+            {
+                float* pi = PW + wave * DS;
+                float* pr = PW + (4 + wave) * DS;
+#pragma unroll
+                for (int jt = 0; jt < VR_MAXJT; ++jt)
+                    if (jt < njt) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            pi[(16 * jt + 4 * lk + r) * 16 + li] = accI[jt][r];
+                            if (gru) pr[(16 * jt + 4 * lk + r) * 16 + li] = accR[jt][r];
+                        }
+                    }
+            }
+            __syncthreads();
+            // ---- each pass of the inner net backwards (dW/db accumulate for both) -----------------------------------------
+            const int DL = ru16(dlast) * 16;
+            for (int pass = 0; pass < (gru ? 2 : 1); ++pass) {
+                const float* Xp = pass == 0 ? XI : XR;
+                const float* pw = PW + pass * 4 * DS;
+                const float* x0 = pass == 0 ? U : RU;
+                float* du = pass == 0 ? DUI : DUR;
+                const float* xl = Xp + (L - 1) * DS;
+                for (int e = tid; e < DL; e += VR_THREADS) {
+                    const float gsum = (pw[e] + pw[DS + e]) + (pw[2 * DS + e] + pw[3 * DS + e]);
+                    GA[e] = xl[e] > 0.0f ? gsum : 0.0f;
+                }
+                __syncthreads();
+                float* gpre = GA;
+                float* gx = GB;
+                for (int l = L - 1; l >= 0; --l) {
+                    const int N = a.dout[l], K = a.din[l];
+                    const float* xin = l == 0 ? x0 : Xp + (l - 1) * DS;
+                    if (w != 0.0f) vr_dw_acc(gpre, xin, N, K, w, gacc + a.gW_off[l], gacc + a.gb_off[l], tid, wave, lane);
+                    vr_bwd_data(a.W[l], N, K, gpre, l > 0 ? xin : nullptr, l == 0 ? du : gx, false, wave, lane);
+                    __syncthreads();
+                    float* tmp = gpre; gpre = gx; gx = tmp;
+                }
+            }
+            if (gru) {
+                // u enters directly and through rg * u: du += dru * rg;  cotangent of the reset pre-activation
+                for (int e = tid; e < ru16(d0) * 16; e += VR_THREADS) {
+                    const float rg = RG[e], u = U[e], dru = DUR[e];
+                    DUI[e] += dru * rg;
+                    GA[e] = (dru * u) * (rg * (1.0f - rg));
+                }
+                __syncthreads();
+                if (w != 0.0f) vr_dw_acc(GA, U, d0, d0, w, gacc + a.gWr_off, gacc + a.gbr_off, tid, wave, lane);
+                vr_bwd_data(a.Wr, d0, d0, GA, nullptr, DUI, true, wave, lane);
+                __syncthreads();
+            }
+            // ---- Butcher bookkeeping (KOA = dL/dy of the stage = the first H rows of du) -----------------------------------
+            for (int e = tid; e < HS; e += VR_THREADS) {
+                const int h = e >> 4, s = e & 15, b = b0 + s;
+                const bool valid = h < H && b < a.B;
+                const float d = h < H ? DUI[e] : 0.0f;
+                if (disc) {
+                    float a0 = A0[e];
+                    bool last = false;
+                    float next = 0.0f;
+                    if (a.method == NCDE_RK4_38) {
+                        const float c4 = a0 * 0.125f;
+                        if (j == 0) { KA1[e] = d; next = 3.0f * c4 + d; }
+                        else if (j == 1) { KA2[e] = d; next = (3.0f * c4 - KA1[e]) + d; }
+                        else if (j == 2) { KY1[e] = d; next = ((c4 + KA1[e]) - 0.333333343267440796f * KA2[e]) + 0.333333343267440796f * d; }
+                        else { a0 = (((a0 + KA1[e]) + KA2[e]) + KY1[e]) + d; last = true; }
+                    } else if (a.method == NCDE_MIDPOINT) {
+                        if (j == 0) { KA1[e] = d; next = 0.5f * d; }
+                        else { a0 = (a0 + KA1[e]) + d; last = true; }
+                    } else {
+                        a0 = a0 + d; last = true;
+                    }
+                    if (last) {
+                        if (a.output == NCDE_OUT_KNOTS || n == 1)
+                            a0 = a0 + (valid ? a.grad_out[((long long)b * a.n_out + (a.output == NCDE_OUT_KNOTS ? n - 1 : 0)) * H + h] : 0.0f);
+                        A0[e] = a0;
+                        next = a.method == NCDE_RK4_38 ? a0 * 0.125f : a0;
+                        if (n == 1 && valid) a.grad_z0[(long long)b * H + h] = a0;
+                    }
+                    AS[e] = next;
+                } else {
+                    float y0 = Y0[e], k1 = KY1[e], k2 = KY2[e];
+                    bool last;
+                    const float ys = StageCombineV::apply(a.method, j, -KOY[e], y0, k1, k2, last);
+                    U[e] = ys; KY1[e] = k1; KY2[e] = k2;
+                    float a0 = A0[e], q1 = KA1[e], q2 = KA2[e];
+                    const float as = StageCombineV::apply(a.method, j, d, a0, q1, q2, last);
+                    KA1[e] = q1; KA2[e] = q2;
+                    if (!last) {
+                        AS[e] = as;
+                    } else {
+                        if (a.output == NCDE_OUT_KNOTS) {
+                            const long long o = ((long long)b * a.n_out + (n - 1)) * H + h;
+                            y0 = valid ? a.z_out[o] : 0.0f;
+                            a0 = a0 + (valid ? a.grad_out[o] : 0.0f);
+                        } else if (n == 1) {
+                            a0 = a0 + (valid ? a.grad_out[((long long)b * a.n_out) * H + h] : 0.0f);
+                        }
+                        Y0[e] = y0; U[e] = y0; A0[e] = a0; AS[e] = a0;
+                        if (n == 1 && valid) a.grad_z0[(long long)b * H + h] = a0;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (a.gacc_in_lds) {
+        float* dst = a.gpart + (long long)blockIdx.x * a.theta_size;
+        for (int e = tid; e < a.theta_size; e += VR_THREADS) dst[e] = GL[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct VrPlan {
+    size_t lds_fwd, lds_adj;
+    int gacc_in_lds;
+};
+
+VrPlan vr_plan(const NcdeProblem* p, const Layout& y) {
+    VrPlan v{};
+    const size_t HS = (size_t)y.Hp * 16, DS = (size_t)y.Dp * 16, L = (size_t)p->n_layers;
+    v.lds_fwd = sizeof(float) * (7 * DS + 4 * HS + (size_t)y.Cp * 16);
+    const size_t adj = sizeof(float) * ((15 + 2 * L) * DS + 9 * HS + (size_t)y.Cp * 16 + VR_NW * 16 * 17);
+    v.gacc_in_lds = adj + sizeof(float) * (size_t)y.theta_size <= (size_t)kLdsLimit;
+    v.lds_adj = adj + (v.gacc_in_lds ? sizeof(float) * (size_t)y.theta_size : 0);
+    return v;
+}
+
+}  // namespace
+
+bool ncde_variant_supported(const NcdeProblem* p, int pass) {
+    const Layout y = make_layout(p);
+    if (p->n_layers < 1 || y.dlast > 16 * VR_MAXJT) return false;
+    const VrPlan v = vr_plan(p, y);
+    return pass == 0 ? v.lds_fwd <= (size_t)kLdsLimit : v.lds_adj <= (size_t)kLdsLimit;
+}
+
+int64_t ncde_variant_workspace_bytes(const NcdeProblem* p, int pass) {
+    if (!ncde_variant_supported(p, pass)) return NCDE_ERR_UNSUPPORTED;
+    if (pass == 0) return 256;
+    const Layout y = make_layout(p);
+    return (int64_t)sizeof(float) * (int64_t)y.n_wg * (int64_t)y.theta_size + 256;
+}
+
+int ncde_variant_forward(const NcdeProblem* p, float* out, float* stages, hipStream_t st) {
+    if (!ncde_variant_supported(p, 0)) return NCDE_ERR_UNSUPPORTED;
+    const Layout y = make_layout(p);
+    const VrPlan v = vr_plan(p, y);
+    KArgs a;
+    fill_kargs(p, y, &a);
+    a.out = out;
+    a.stages = stages;
+    if (hipFuncSetAttribute((const void*)ncde_fwd_variant, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds_fwd) != hipSuccess) return NCDE_ERR_HIP;
+    hipLaunchKernelGGL(ncde_fwd_variant, dim3(y.n_wg), dim3(VR_THREADS), v.lds_fwd, st, a);
+    return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
+}
+
+int ncde_variant_adjoint(const NcdeProblem* p, const float* src, const float* grad_out, const NcdeGrads* g, void* ws, hipStream_t st,
+                         bool main_kernel_only, bool discrete) {
+    if (!ncde_variant_supported(p, 1)) return NCDE_ERR_UNSUPPORTED;
+    const Layout y = make_layout(p);
+    const VrPlan v = vr_plan(p, y);
+    KArgs a;
+    fill_kargs(p, y, &a);
+    a.grad_out = grad_out; a.grad_z0 = g->grad_z0;
+    if (discrete) { a.stages = const_cast<float*>(src); a.discrete = 1; }
+    else a.z_out = src;
+    a.gpart = (float*)ws;
+    a.gacc_in_lds = v.gacc_in_lds;
+    if (hipFuncSetAttribute((const void*)ncde_adj_variant, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds_adj) != hipSuccess) return NCDE_ERR_HIP;
+    hipLaunchKernelGGL(ncde_adj_variant, dim3(y.n_wg), dim3(VR_THREADS), v.lds_adj, st, a);
+    if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
+    if (main_kernel_only) return NCDE_OK;
+    return launch_reduce_partials(p, y, g, (const float*)ws, y.n_wg, st);
+}

@@ -10,14 +10,14 @@ from torch import nn
 
 from .interpolation import LinearInterpolation, NaturalCubicSpline
 from .solver import cdeint
-from .vector_fields import OriginalVectorField
+from .vector_fields import GRUGatedVectorField, MinimalGatedVectorField, OriginalVectorField
 
 SPLINES = {
     "cubic": NaturalCubicSpline,
     "linear": LinearInterpolation,
     "rectilinear": LinearInterpolation,
 }
-VECTOR_FIELDS = {"original": OriginalVectorField}
+VECTOR_FIELDS = {"original": OriginalVectorField, "minimal": MinimalGatedVectorField, "gru": GRUGatedVectorField}
 
 
 class NeuralCDE(nn.Module):
@@ -54,7 +54,7 @@ class NeuralCDE(nn.Module):
         self.atol, self.rtol = 1e-5, 1e-3
         self.cdeint_options = {"step_size": 1}
         if vector_field not in VECTOR_FIELDS:
-            raise NotImplementedError("vector_field '%s' is not implemented (SURVEY.md §8f row 3)" % vector_field)
+            raise NotImplementedError("vector_field '%s' (sparse / low-rank) is outside the fused path" % vector_field)
         self.func = VECTOR_FIELDS[vector_field](input_dim=input_dim, hidden_dim=hidden_dim,
                                                 hidden_hidden_dim=hidden_hidden_dim, num_layers=num_layers,
                                                 sparsity=sparsity, vector_field_type=vector_field_type)

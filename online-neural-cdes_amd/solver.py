@@ -23,13 +23,24 @@ class FieldSpec:
     """What the fused kernels need to know about ``func``: the Linear+ReLU stack (entries may repeat
     the same Parameters = a shared layer) and the final Linear (+tanh, viewed [H, C])."""
 
-    def __init__(self, layers, Wo, bo):
+    def __init__(self, layers, Wo, bo, kind="original", mode="matmul", Wg=None, bg=None, Wr=None, br=None):
         self.layers = list(layers)
         self.Wo, self.bo = Wo, bo
+        # variants (src/ncde/vector_fields/gating.py; vector_field_type of solver.py:112-137)
+        self.kind, self.mode = kind, mode
+        self.Wg, self.bg, self.Wr, self.br = Wg, bg, Wr, br
+
+    def extra_params(self):
+        out = []
+        if self.kind == "gru":
+            out += [self.Wr, self.br]
+        if self.kind in ("minimal", "gru"):
+            out += [self.Wg, self.bg]
+        return out
 
     def unique_params(self):
         seen, out = set(), []
-        for p in [q for wb in self.layers for q in wb] + [self.Wo, self.bo]:
+        for p in [q for wb in self.layers for q in wb] + self.extra_params() + [self.Wo, self.bo]:
             if id(p) not in seen:
                 seen.add(id(p))
                 out.append(p)
@@ -82,8 +93,19 @@ def build_problem(coeffs, interp, z0, spec, method, output, flags=0):
         p.layer_W[i], p.layer_b[i] = w.data_ptr(), b.data_ptr()
     p.Wo, p.bo = spec.Wo.data_ptr(), spec.bo.data_ptr()
     d_last = spec.layers[-1][0].shape[0] if spec.layers else H
-    if tuple(spec.Wo.shape) != (H * p.channels, d_last):
-        raise ValueError("final layer must be [H*C, d_last] = [%d, %d], got %s" % (H * p.channels, d_last, tuple(spec.Wo.shape)))
+    rows = H * p.channels if spec.mode == "matmul" else H
+    if tuple(spec.Wo.shape) != (rows, d_last):
+        raise ValueError("final layer must be [%d, %d], got %s" % (rows, d_last, tuple(spec.Wo.shape)))
+    p.field_kind, p.field_input = _lib.FIELD_KIND[spec.kind], _lib.FIELD_INPUT[spec.mode]
+    if spec.kind != "original":
+        if tuple(spec.Wg.shape) != (rows, d_last):
+            raise ValueError("sigmoid head must be [%d, %d], got %s" % (rows, d_last, tuple(spec.Wg.shape)))
+        p.Wg, p.bg = spec.Wg.data_ptr(), spec.bg.data_ptr()
+    if spec.kind == "gru":
+        d0 = H if spec.mode == "matmul" else H + p.channels
+        if tuple(spec.Wr.shape) != (d0, d0):
+            raise ValueError("reset net must be [%d, %d], got %s" % (d0, d0, tuple(spec.Wr.shape)))
+        p.Wr, p.br = spec.Wr.data_ptr(), spec.br.data_ptr()
     p.coeffs = coeffs.data_ptr()
     p.coeffs_stride_b, p.coeffs_stride_t = coeffs.stride(0), coeffs.stride(1)
     p.z0 = z0.data_ptr()
@@ -159,6 +181,10 @@ class _FusedCdeint(torch.autograd.Function):
         for i, (w, b) in enumerate(spec.layers):
             g.grad_layer_W[i], g.grad_layer_b[i] = gbuf[id(w)].data_ptr(), gbuf[id(b)].data_ptr()
         g.grad_Wo, g.grad_bo = gbuf[id(spec.Wo)].data_ptr(), gbuf[id(spec.bo)].data_ptr()
+        if spec.kind != "original":
+            g.grad_Wg, g.grad_bg = gbuf[id(spec.Wg)].data_ptr(), gbuf[id(spec.bg)].data_ptr()
+        if spec.kind == "gru":
+            g.grad_Wr, g.grad_br = gbuf[id(spec.Wr)].data_ptr(), gbuf[id(spec.br)].data_ptr()
         with torch.cuda.device(dev):
             if ctx.recorded:
                 ws = _workspace(p, 2, dev)
@@ -202,8 +228,6 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
         raise ValueError('Invalid method "{}". Must be one of {}'.format(method, '{"' + '", "'.join(_ALL_METHODS) + '"}.'))
     if method not in _FIXED_METHODS:
         raise NotImplementedError("method '%s': only the fixed-step solvers %s run on the fused path" % (method, _FIXED_METHODS))
-    if vector_field_type != "matmul":
-        raise NotImplementedError("vector_field_type='%s' is not fused yet (only 'matmul')" % vector_field_type)
     if not isinstance(X, (LinearInterpolation, NaturalCubicSpline)):
         raise NotImplementedError("X must be ncde_amd.LinearInterpolation or ncde_amd.NaturalCubicSpline")
     if not X._default_grid:
@@ -228,6 +252,8 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
     if coeffs.shape[0] != z0.shape[0]:
         raise ValueError("batch of X (%d) != batch of z0 (%d)" % (coeffs.shape[0], z0.shape[0]))
     spec = _field_spec(func)
+    if spec.mode != vector_field_type:
+        raise ValueError("vector_field_type='%s' but func was built for '%s'" % (vector_field_type, spec.mode))
     uniq = spec.unique_params()
     for q in uniq:
         _check_tensor(q, "a vector-field parameter")

@@ -9,15 +9,23 @@ from ncde_amd import _lib
 class CaseField(torch.nn.Module):
     """Vector field built from a case's parameter dict; repeated (W, b) names share one Parameter."""
 
-    def __init__(self, params, layers, device):
+    def __init__(self, params, layers, device, kind="original", mode="matmul"):
         super().__init__()
         self.p = torch.nn.ParameterDict({k: torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(v)).to(device))
                                          for k, v in params.items()})
         self.layer_names = layers
+        self.kind, self.mode = kind, mode
         self.nfe = 0
 
     def fused_spec(self):
-        return ncde_amd.FieldSpec([(self.p[w], self.p[b]) for w, b in self.layer_names], self.p["Wo"], self.p["bo"])
+        g = lambda k: self.p[k] if k in self.p else None   # noqa: E731
+        return ncde_amd.FieldSpec([(self.p[w], self.p[b]) for w, b in self.layer_names], self.p["Wo"], self.p["bo"],
+                                  self.kind, self.mode, g("Wg"), g("bg"), g("Wr"), g("br"))
+
+
+def case_field(case, device):
+    m = case["meta"]
+    return CaseField(case["params"], case["layers"], device, m.get("field_kind", "original"), m.get("field_mode", "matmul"))
 
 
 def run_case(case, flags=_lib.FLAG_AUTO, device="cuda", need_grads=True, adjoint=True):
@@ -25,11 +33,11 @@ def run_case(case, flags=_lib.FLAG_AUTO, device="cuda", need_grads=True, adjoint
     m = case["meta"]
     coeffs = torch.from_numpy(case["coeffs"]).to(device)
     X = (ncde_amd.LinearInterpolation if m["kind"] == "linear" else ncde_amd.NaturalCubicSpline)(coeffs)
-    func = CaseField(case["params"], case["layers"], device)
+    func = case_field(case, device)
     z0 = torch.from_numpy(case["z0"]).to(device).requires_grad_(True)
     t = X.grid_points if m["sequence"] else X.interval
-    out = ncde_amd.cdeint(X, func, z0, t, adjoint=adjoint, method=m["method"], options={"step_size": 1},
-                          kernel_flags=flags)
+    out = ncde_amd.cdeint(X, func, z0, t, adjoint=adjoint, vector_field_type=func.mode, method=m["method"],
+                          options={"step_size": 1}, kernel_flags=flags)
     res = {"z_out": out.detach().cpu().numpy(), "nfe_fwd": func.nfe, "kernels": kernel_names(case, flags, device)}
     if need_grads:
         gout = torch.from_numpy(case["expect"]["grad_out"]).to(device)
@@ -49,7 +57,7 @@ def run_adjoint_direct(case, z_out, flags=_lib.FLAG_AUTO, device="cuda", stages=
     from ncde_amd import solver
     m = case["meta"]
     coeffs = torch.from_numpy(case["coeffs"]).to(device)
-    func = CaseField(case["params"], case["layers"], device)
+    func = case_field(case, device)
     spec = func.fused_spec()
     z_out = torch.from_numpy(np.ascontiguousarray(z_out)).to(device)
     gout = torch.from_numpy(case["expect"]["grad_out"]).to(device).contiguous()
@@ -64,6 +72,10 @@ def run_adjoint_direct(case, z_out, flags=_lib.FLAG_AUTO, device="cuda", stages=
     for i, (w, b) in enumerate(spec.layers):
         g.grad_layer_W[i], g.grad_layer_b[i] = gbuf[id(w)].data_ptr(), gbuf[id(b)].data_ptr()
     g.grad_Wo, g.grad_bo = gbuf[id(spec.Wo)].data_ptr(), gbuf[id(spec.bo)].data_ptr()
+    if spec.kind != "original":
+        g.grad_Wg, g.grad_bg = gbuf[id(spec.Wg)].data_ptr(), gbuf[id(spec.bg)].data_ptr()
+    if spec.kind == "gru":
+        g.grad_Wr, g.grad_br = gbuf[id(spec.Wr)].data_ptr(), gbuf[id(spec.br)].data_ptr()
     if stages is not None:
         rec = torch.from_numpy(np.ascontiguousarray(stages)).to(device)
         assert rec.numel() * 4 == _lib.lib().ncde_stage_record_bytes(ctypes.byref(p))
@@ -86,7 +98,7 @@ def kernel_names(case, flags=_lib.FLAG_AUTO, device="cuda"):
     from ncde_amd import solver
     m = case["meta"]
     coeffs = torch.from_numpy(case["coeffs"]).to(device)
-    func = CaseField(case["params"], case["layers"], device)
+    func = case_field(case, device)
     z0 = torch.from_numpy(case["z0"]).to(device)
     p = solver.build_problem(coeffs, m["kind"], z0, func.fused_spec(), m["method"],
                              _lib.OUT_KNOTS if m["sequence"] else _lib.OUT_INTERVAL, flags)

@@ -70,6 +70,70 @@ def test_auto_dispatch_matches_reference_golden(name, gpu_lib):
     _check_case(name, FLAGS["auto"])
 
 
+@pytest.mark.parametrize("name", gu.VARIANT_CASES)
+def test_field_variants_match_reference_golden(name, gpu_lib):
+    """Gated vector fields (minimal, GRU) and the evaluate / derivative input modes (goldens g9):
+    forward, continuous adjoint and exact discrete backward through ncde_fwd_variant / ncde_adj_variant."""
+    import gpu_util
+    import ncde_oracle as orc
+    case = gu.load_case(name)
+    m, ex = case["meta"], case["expect"]
+    res = gpu_util.run_case(case)
+    assert res["kernels"] == ("ncde_fwd_variant", "ncde_adj_variant", "ncde_adj_variant<discrete>"), res["kernels"]
+    assert gu.relerr(res["z_out"], ex["z_out"]) <= TIGHT_Z
+    for k, e in _grad_errors(case, res).items():
+        assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), ("end-to-end", k, e)
+    iso = gpu_util.run_adjoint_direct(case, ex["z_out"])
+    for k, e in _grad_errors(case, iso).items():
+        assert e <= TIGHT_G, ("adjoint kernel on reference z_out", k, e)
+    resd = gpu_util.run_case(case, adjoint=False)
+    for k, e in _grad_errors(case, resd, "bp_").items():
+        assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), ("discrete end-to-end", k, e)
+    rec = orc.stage_record(orc.Control(case["coeffs"], m["kind"]), gu.oracle_field(case), case["z0"], m["method"]).numpy()
+    isod = gpu_util.run_adjoint_direct(case, ex["z_out"], stages=rec)
+    for k, e in _grad_errors(case, isod, "bp_").items():
+        assert e <= TIGHT_G, ("backward kernel on the oracle's stage record", k, e)
+
+
+@pytest.mark.parametrize("vf,vft", [("gru", "evaluate"), ("minimal", "matmul"), ("original", "derivative")])
+def test_neuralcde_module_with_field_variants(vf, vft, gpu_lib):
+    """NeuralCDE(vector_field=..., vector_field_type=...) end to end (same constructor arguments as the reference,
+    src/ncde/ncde.py:42-61) against the oracle evaluated with the module's own parameters."""
+    import ncde_amd
+    import ncde_oracle as orc
+    B, L, C, H, HH, nl, OUT = 9, 6, 5, 16, 24, 3, 2
+    coeffs = gu.data.make_rectilinear_coeffs(B, L, C - 1, missing=0.3, seed=51)
+    torch.manual_seed(3)
+    model = ncde_amd.NeuralCDE(C, H, OUT, hidden_hidden_dim=HH, num_layers=nl, interpolation="rectilinear", vector_field=vf,
+                               vector_field_type=vft, adjoint=False, solver="rk4", return_sequences=True).cuda()
+    x = torch.from_numpy(coeffs).cuda()
+    out = model(x)
+    w = torch.from_numpy(gu.data.normal(5, out.numel(), stream=2).reshape(out.shape).astype(np.float32)).cuda()
+    (out * w).sum().backward()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    p = {"W0": sd["func.net_to_hh.0.weight"], "b0": sd["func.net_to_hh.0.bias"], "W1": sd["func.net_to_hh.2.weight"], "b1": sd["func.net_to_hh.2.bias"]}
+    head = "func.tanh_output_layer.0" if vf == "original" else "func.tanh_net.0"
+    p["Wo"], p["bo"] = sd[head + ".weight"], sd[head + ".bias"]
+    if vf != "original":
+        p["Wg"], p["bg"] = sd["func.sigmoid_net.0.weight"], sd["func.sigmoid_net.0.bias"]
+    if vf == "gru":
+        p["Wr"], p["br"] = sd["func.reset_net.0.weight"], sd["func.reset_net.0.bias"]
+    field = orc.Field.variant(p, H, C, nl, vf, vft)
+    ctl = orc.Control(coeffs, "linear")
+    z0 = torch.from_numpy(coeffs[:, 0]) @ sd["initial_linear.weight"].t() + sd["initial_linear.bias"]
+    z = orc.solve_forward(ctl, field, z0, "rk4", True)
+    ref = (z @ sd["final_linear.weight"].t() + sd["final_linear.bias"])[:, ::2]
+    assert out.shape == ref.shape and gu.relerr(out.detach().cpu(), ref) <= TIGHT_Z
+    gz = torch.zeros_like(z)
+    gz[:, ::2] = w.cpu() @ sd["final_linear.weight"]
+    dz0, gp = orc.solve_discrete_backward(ctl, field, z0, gz, "rk4", True)
+    got = {id(q): q.grad.cpu() for q in model.func.parameters()}
+    for q, g in zip(model.func.fused_spec().unique_params(), gp):
+        assert gu.relerr(got[id(q)], g) <= E2E_G
+    assert gu.relerr(model.initial_linear.weight.grad.cpu(), dz0.t() @ torch.from_numpy(coeffs[:, 0])) <= E2E_G
+    assert model.nfe == 4 * (2 * L - 2)
+
+
 @pytest.mark.parametrize("flags", ["generic", "auto"])
 @pytest.mark.parametrize("name", gu.SOLVE_CASES)
 def test_discrete_backward_matches_reference_golden(name, flags, gpu_lib):

@@ -41,9 +41,30 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 
 def test_struct_layout_matches_header():
-    # 9 int32 + n_layers + 2*8 int32, 2*8 pointers, 3 pointers, 2 int64, 1 pointer (with natural alignment)
-    assert ctypes.sizeof(_lib.NcdeProblem) == 4 * 10 + 4 * 16 + 8 * 16 + 8 * 3 + 8 * 2 + 8
-    assert ctypes.sizeof(_lib.NcdeGrads) == 8 * (1 + 16 + 2)
+    # 9 int32 + n_layers + 2*8 int32, 2*8 pointers, 3 pointers, 2 int64, 1 pointer (with natural alignment);
+    # ABI version 2 appends 2 int32 + 4 pointers (gated fields / input modes) -- a version-1 struct is the prefix
+    v1 = 4 * 10 + 4 * 16 + 8 * 16 + 8 * 3 + 8 * 2 + 8
+    assert _lib.NcdeProblem.field_kind.offset == v1
+    assert ctypes.sizeof(_lib.NcdeProblem) == v1 + 4 * 2 + 8 * 4
+    assert ctypes.sizeof(_lib.NcdeGrads) == 8 * (1 + 16 + 2 + 4)
+
+
+def test_version1_structs_are_still_accepted():
+    """A caller built against the version-1 header passes the shorter struct; the library must not read past it."""
+    lib = ncde_amd.lib()
+    p = _problem()
+    p.abi_version = 1
+    p.field_kind, p.field_input = 7, 9            # garbage where a version-1 struct simply ends
+    assert lib.ncde_num_outputs(ctypes.byref(p)) == 2
+    assert (lib.ncde_kernel_name(ctypes.byref(p), 0) or b"").startswith(b"ncde_fwd_fast")
+    p.abi_version = 2
+    assert lib.ncde_num_outputs(ctypes.byref(p)) == -1 and b"field_kind" in lib.ncde_last_error_string()
+    p.field_kind, p.field_input = 0, 5
+    assert lib.ncde_num_outputs(ctypes.byref(p)) == -1 and b"vector_field_type" in lib.ncde_last_error_string()
+    p.field_kind, p.field_input = 1, 0
+    assert lib.ncde_num_outputs(ctypes.byref(p)) == -1 and b"Wg" in lib.ncde_last_error_string()
+    p.Wg, p.bg = 0x6000, 0x6100
+    assert lib.ncde_kernel_name(ctypes.byref(p), 1) == b"ncde_adj_variant"
 
 
 def test_validation_and_error_strings_without_gpu():
