@@ -173,7 +173,10 @@ def main():
     labels = (torch.from_numpy(ncde_amd.data.uniform01(7, B_total, stream=5)[lo:lo + B_local]) > 0.5).float().to(dev).unsqueeze(1)
     model, fw, rw = make_model(c, dev)
     bucket = D.FlatGradAllReduce(model.parameters())
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    try:     # single-kernel Adam: ~0.5 ms less launch overhead per step than the foreach implementation
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    except (TypeError, RuntimeError):
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     loss_fn = torch.nn.BCEWithLogitsLoss()
 
     def step():

@@ -44,20 +44,27 @@ class FlatGradAllReduce:
     rank's loss is the mean over its own equally sized shard.
     """
 
-    def __init__(self, params, average=True):
+    def __init__(self, params, average=True, single=None):
         self.params = [p for p in params if p.requires_grad]
         self.average = average
+        # single process: no bucket aliasing at all (autograd assigns fresh .grad tensors: no zero fill, no accumulate kernels)
+        self.single = (not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)) if single is None else single
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        # point every .grad into the bucket so backward writes land there without a pack step
-        off = 0
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        if not self.single:
+            # point every .grad into the bucket so backward writes land there without a pack step
+            off = 0
+            for p in self.params:
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
 
     def zero(self):
-        self.flat.zero_()
+        if self.single:      # one process: nothing to exchange -- let autograd assign fresh .grad tensors (no zero fill,
+            for p in self.params:   # no accumulate kernels)
+                p.grad = None
+        else:
+            self.flat.zero_()
 
     def reduce(self):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
@@ -73,6 +80,12 @@ class FlatGradAllReduce:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             if self.average:
                 self.flat.div_(dist.get_world_size())
+        return self.flat
+
+    def gathered(self):
+        """The flat gradient as one tensor (the bucket itself in the multi-process case; packed on demand otherwise)."""
+        if self.single:
+            return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params])
         return self.flat
 
 

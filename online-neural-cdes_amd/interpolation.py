@@ -20,13 +20,29 @@ def _tag(t, kind, owner):
     return t
 
 
+_GRID_CACHE = {}   # (n_knots, dtype, device) -> (t, [t0, t_last]): the default integer grid is built once, not per forward
+
+
+def _default_grid(n_knots, like):
+    key = (n_knots, like.dtype, like.device)
+    hit = _GRID_CACHE.get(key)
+    if hit is None:
+        t = torch.linspace(0, n_knots - 1, n_knots, dtype=like.dtype, device=like.device)
+        hit = (t, torch.stack([t[0], t[-1]]))
+        if len(_GRID_CACHE) > 64:
+            _GRID_CACHE.clear()
+        _GRID_CACHE[key] = hit
+    return hit
+
+
 class _ControlBase(torch.nn.Module):
     interp_name = None
 
     def _setup_t(self, t, n_knots, like):
         self._default_grid = t is None
+        self._interval = None
         if t is None:
-            t = torch.linspace(0, n_knots - 1, n_knots, dtype=like.dtype, device=like.device)
+            t, self._interval = _default_grid(n_knots, like)
         self.register_buffer("_t", t)
 
     @property
@@ -35,7 +51,13 @@ class _ControlBase(torch.nn.Module):
 
     @property
     def interval(self):
-        return _tag(torch.stack([self._t[0], self._t[-1]]), "interval", self)
+        iv = self._interval if self._interval is not None else torch.stack([self._t[0], self._t[-1]])
+        return _tag(iv, "interval", self)
+
+    def _at_first_knot(self, t):
+        """X(t) at t = first knot of the default grid is the first coefficient row itself (fractional part 0): no
+        bucketize / gather kernels for the ``h0 = Linear(X(0))`` of every forward (ncde.py:170-198)."""
+        return self._default_grid and isinstance(t, (int, float)) and t == 0
 
     def _interpret_t(self, t, n_pieces):
         t = torch.as_tensor(t, dtype=self._t.dtype, device=self._t.device)
@@ -70,6 +92,8 @@ class LinearInterpolation(_ControlBase):
         return self._coeffs.size(-1)
 
     def evaluate(self, t):
+        if self._at_first_knot(t):
+            return self._coeffs[..., 0, :]
         frac, index = self._interpret_t(t, self._coeffs.size(-2) - 1)
         prev_c = self._coeffs[..., index, :]
         next_c = self._coeffs[..., index + 1, :]
@@ -114,6 +138,8 @@ class NaturalCubicSpline(_ControlBase):
         return row[..., :c], row[..., c:2 * c], row[..., 2 * c:3 * c], row[..., 3 * c:]
 
     def evaluate(self, t):
+        if self._at_first_knot(t):
+            return self._coeffs[..., 0, :self._channels]
         frac, index = self._interpret_t(t, self._coeffs.size(-2))
         frac = frac.unsqueeze(-1)
         a, b, two_c, three_d = self._parts(index)

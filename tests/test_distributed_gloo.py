@@ -47,7 +47,7 @@ def _worker(rank, world, port, out_dir):
     for _ in range(3):
         D.train_step(model, bucket, opt, x, y, loss_fn)
     flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
-    torch.save({"params": flat, "grad": bucket.flat.clone()}, os.path.join(out_dir, "rank%d.pt" % rank))
+    torch.save({"params": flat, "grad": bucket.gathered().clone()}, os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -68,7 +68,7 @@ def test_two_rank_data_parallel_matches_single_process(tmp_path):
         D.train_step(model, bucket, opt, x, y, torch.nn.BCEWithLogitsLoss())
     flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     assert torch.allclose(flat, r0["params"], rtol=1e-5, atol=1e-6)
-    assert torch.allclose(bucket.flat, r0["grad"], rtol=1e-4, atol=1e-6)
+    assert torch.allclose(bucket.gathered(), r0["grad"], rtol=1e-4, atol=1e-6)
 
 
 def test_shard_bounds_tile_the_batch():
@@ -82,7 +82,7 @@ def test_shard_bounds_tile_the_batch():
 
 def test_bucket_aliases_parameter_grads():
     model = _make_model()
-    bucket = D.FlatGradAllReduce(model.parameters())
+    bucket = D.FlatGradAllReduce(model.parameters(), single=False)      # the multi-process layout, exercised in one process
     x, y = _data(0, 16)
     torch.nn.functional.mse_loss(model(x), y).backward()
     off = 0
