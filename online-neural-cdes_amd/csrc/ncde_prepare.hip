@@ -17,60 +17,236 @@ namespace {
 // linear knots with missing values: leading gap <- first observation, trailing gap <- last observation,
 // interior gaps <- linear interpolation between the neighbours, all-NaN series <- 0.
 // rect >= 0: rectilinear preparation first (forward fill, every row twice, time channel advanced one slot).
+// One series (one sample, one channel); xs / os are strided views (global memory or an LDS copy).
+// mode 0: linear knots, NaN filled (L rows out);  1: rectilinear value channel (2L-1 rows out);  2: rectilinear time channel
+__device__ void linear_series(const float* xs, long long sx, float* os, long long so, int L, int mode) {
+    if (mode == 2) {  // time channel: t_0, t_1, t_1, t_2, t_2, ... (advanced by one slot)
+        const int T = 2 * L - 1;
+        for (int i = 0; i < L; ++i) {
+            const float v = xs[i * sx];
+            if (i > 0) os[(2 * i - 1) * so] = v;
+            if (2 * i < T) os[(2 * i) * so] = v;
+        }
+        return;
+    }
+    if (mode == 1) {  // forward fill; a leading gap takes the first observation (0 if there is none)
+        const int T = 2 * L - 1;
+        float first = 0.0f;
+        for (int i = 0; i < L; ++i) {
+            const float v = xs[i * sx];
+            if (!isnan(v)) { first = v; break; }
+        }
+        float last = first;
+        for (int i = 0; i < L; ++i) {
+            const float v = xs[i * sx];
+            if (!isnan(v)) last = v;
+            os[(2 * i) * so] = last;
+            if (2 * i + 1 < T) os[(2 * i + 1) * so] = last;
+        }
+        return;
+    }
+    int prev = -1;  // index of the last observation seen
+    float prev_v = 0.0f;
+    for (int i = 0; i < L; ++i) {
+        const float v = xs[i * sx];
+        if (isnan(v)) continue;
+        if (prev < 0) {
+            for (int k = 0; k < i; ++k) os[k * so] = v;
+        } else {
+            for (int k = prev + 1; k < i; ++k) {
+                const float ratio = ((float)k - (float)prev) / ((float)i - (float)prev);
+                os[k * so] = prev_v + ratio * (v - prev_v);
+            }
+        }
+        os[i * so] = v;
+        prev = i;
+        prev_v = v;
+    }
+    if (prev < 0) {
+        for (int k = 0; k < L; ++k) os[k * so] = 0.0f;
+    } else {
+        for (int k = prev + 1; k < L; ++k) os[k * so] = prev_v;
+    }
+}
+
+// v1: one thread per series straight on global memory (any size; coalescing limited to C*4-byte runs)
 __global__ __launch_bounds__(256) void ncde_linear_coeffs_kernel(const float* __restrict__ x, int B, int L, int C, int rect,
                                                                   float* __restrict__ out) {
     const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (tid >= (long long)B * C) return;
     const int b = (int)(tid / C), c = (int)(tid - (long long)b * C);
-    const float* xs = x + (long long)b * L * C + c;
-    if (rect >= 0) {
-        const int T = 2 * L - 1;
-        float* os = out + (long long)b * T * C + c;
-        if (c == rect) {  // time channel: t_0, t_1, t_1, t_2, t_2, ... (advanced by one slot)
-            for (int i = 0; i < L; ++i) {
-                const float v = xs[(long long)i * C];
-                if (i > 0) os[(long long)(2 * i - 1) * C] = v;
-                if (2 * i < T) os[(long long)(2 * i) * C] = v;
-            }
-            return;
-        }
-        // value channels: forward fill; a leading gap takes the first observation (0 if there is none)
-        float first = 0.0f;
-        for (int i = 0; i < L; ++i) {
-            const float v = xs[(long long)i * C];
-            if (!isnan(v)) { first = v; break; }
-        }
-        float last = first;
-        for (int i = 0; i < L; ++i) {
-            const float v = xs[(long long)i * C];
-            if (!isnan(v)) last = v;
-            os[(long long)(2 * i) * C] = last;
-            if (2 * i + 1 < T) os[(long long)(2 * i + 1) * C] = last;
-        }
-        return;
+    const int T = rect >= 0 ? 2 * L - 1 : L;
+    linear_series(x + (long long)b * L * C + c, C, out + (long long)b * T * C + c, C, L, rect < 0 ? 0 : (c == rect ? 2 : 1));
+}
+
+// v2: one workgroup per sample, the whole [L][C] series staged in LDS: fully coalesced loads and stores, and the
+// per-channel fills as WAVE SCANS along time (lane <-> time step): index of the last observation at or before i
+// (inclusive prefix max) and of the next one at or after i (suffix min), 64 time steps per scan, carried across chunks.
+// The arithmetic per element is exactly linear_series()'s, so the result is bit-identical to v1.
+__device__ __forceinline__ int wave_prefix_max(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d, 64);
+        if (lane >= d) v = max(v, o);
     }
-    float* os = out + (long long)b * L * C + c;
-    int prev = -1;  // index of the last observation seen
-    float prev_v = 0.0f;
-    for (int i = 0; i < L; ++i) {
-        const float v = xs[(long long)i * C];
-        if (isnan(v)) continue;
-        if (prev < 0) {
-            for (int k = 0; k < i; ++k) os[(long long)k * C] = v;
-        } else {
-            for (int k = prev + 1; k < i; ++k) {
-                const float ratio = ((float)k - (float)prev) / ((float)i - (float)prev);
-                os[(long long)k * C] = prev_v + ratio * (v - prev_v);
-            }
-        }
-        os[(long long)i * C] = v;
-        prev = i;
-        prev_v = v;
+    return v;
+}
+__device__ __forceinline__ int wave_suffix_min(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_down(v, d, 64);
+        if (lane + d < 64) v = min(v, o);
     }
-    if (prev < 0) {
-        for (int k = 0; k < L; ++k) os[(long long)k * C] = 0.0f;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void ncde_linear_coeffs_lds_kernel(const float* __restrict__ x, int B, int L, int C, int rect,
+                                                                     float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int T = rect >= 0 ? 2 * L - 1 : L;
+    float* xin = sm;                                   // [L][C] raw
+    int* prv = reinterpret_cast<int*>(sm + L * C);     // [L][C] index of the last observation <= i (-1: none)
+    int* nxt = prv + L * C;                            // [L][C] index of the next observation >= i (L: none)   (linear fill only)
+    const float* src = x + (long long)b * L * C;
+    if (((L * C) & 3) == 0 && ((((long long)b * L * C) & 3) == 0)) {
+        for (int e = tid; e < (L * C) >> 2; e += 256) reinterpret_cast<float4*>(xin)[e] = reinterpret_cast<const float4*>(src)[e];
     } else {
-        for (int k = prev + 1; k < L; ++k) os[(long long)k * C] = prev_v;
+        for (int e = tid; e < L * C; e += 256) xin[e] = src[e];
+    }
+    __syncthreads();
+    // scans along time, thread <-> (time chunk k, channel c): a short serial pass over the chunk, then the carry from the
+    // nearest earlier (later) chunk that holds an observation
+    {
+        const int nch = C <= 256 ? (256 / C < 64 ? 256 / C : 64) : 1;       // chunks per channel
+        const int cl = (L + nch - 1) / nch;                                 // time steps per chunk
+        int* car = nxt + (rect < 0 ? L * C : 0);                            // [nch][C] chunk summaries (behind the index arrays)
+        const int k = tid / C, c = tid - k * C;
+        const bool act = C <= 256 && k < nch;
+        const int i0 = k * cl, i1 = min(L, i0 + cl);
+        for (int cc = act ? c : C; cc < C; cc += 256) {
+            int last = -1;
+            for (int i = i0; i < i1; ++i) {
+                if (!isnan(xin[i * C + cc])) last = i;
+                prv[i * C + cc] = last;
+            }
+            car[k * C + cc] = last;
+        }
+        __syncthreads();
+        for (int cc = act ? c : C; cc < C; cc += 256) {
+            int cin = -1;
+            for (int kk = k - 1; kk >= 0 && cin < 0; --kk) cin = car[kk * C + cc];
+            for (int i = i0; i < i1 && prv[i * C + cc] < 0; ++i) prv[i * C + cc] = cin;
+        }
+        if (rect < 0) {
+            __syncthreads();
+            for (int cc = act ? c : C; cc < C; cc += 256) {
+                int next = L;
+                for (int i = i1 - 1; i >= i0; --i) {
+                    if (!isnan(xin[i * C + cc])) next = i;
+                    nxt[i * C + cc] = next;
+                }
+                car[k * C + cc] = next;
+            }
+            __syncthreads();
+            for (int cc = act ? c : C; cc < C; cc += 256) {
+                int cin = L;
+                for (int kk = k + 1; kk < nch && cin >= L; ++kk) cin = car[kk * C + cc];
+                for (int i = i1 - 1; i >= i0 && nxt[i * C + cc] >= L; --i) nxt[i * C + cc] = cin;
+            }
+        }
+    }
+    __syncthreads();
+    float* dst = out + (long long)b * T * C;
+    // output: thread <-> (row offset, channel), rows strided by the rows one pass covers: no division in the loops,
+    // consecutive threads write consecutive addresses
+    const int rp = 256 / C > 0 ? 256 / C : 1;
+    const int r0 = tid / C, c = tid - r0 * C;
+    const bool active = C <= 256 ? r0 < rp : true;
+    if (rect >= 0 && (C & 3) == 0 && C <= 1024 && ((((long long)b * T * C) & 3) == 0)) {
+        // 16-byte stores: thread <-> (row offset, channel quad)
+        const int CQ = C >> 2, rp4 = 256 / CQ > 0 ? 256 / CQ : 1;
+        const int q0 = tid / CQ, cq = tid - q0 * CQ;
+        if (q0 < rp4) {
+            int first[4] = {-2, -2, -2, -2};
+            for (int t = q0; t < T; t += rp4) {
+                float4 v4;
+                float* vv = reinterpret_cast<float*>(&v4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cc = 4 * cq + u;
+                    if (cc == rect) {
+                        vv[u] = xin[((t + 1) >> 1) * C + cc];
+                    } else {
+                        int p = prv[(t >> 1) * C + cc];
+                        if (p < 0) {
+                            if (first[u] == -2) {
+                                first[u] = -1;
+                                if (prv[(L - 1) * C + cc] >= 0) {
+                                    int lo = 0, hi = L - 1;
+                                    while (lo < hi) {
+                                        const int mid = (lo + hi) >> 1;
+                                        if (prv[mid * C + cc] >= 0) hi = mid; else lo = mid + 1;
+                                    }
+                                    first[u] = lo;
+                                }
+                            }
+                            p = first[u];
+                        }
+                        vv[u] = p >= 0 ? xin[p * C + cc] : 0.0f;
+                    }
+                }
+                *reinterpret_cast<float4*>(dst + t * C + 4 * cq) = v4;
+            }
+        }
+    } else if (rect >= 0) {
+        // value channels = forward fill of row t/2 (leading gap: the first observation, 0 if none);
+        // time channel advanced by one slot: row (t+1)/2
+        int first = -2;                                 // first observation of this channel, found lazily (-1: none)
+        for (int cc = c; cc < C && active; cc += 256) {
+            for (int t = r0; t < T; t += rp) {
+                float v;
+                if (cc == rect) {
+                    v = xin[((t + 1) >> 1) * C + cc];
+                } else {
+                    int p = prv[(t >> 1) * C + cc];
+                    if (p < 0) {
+                        if (first == -2) {              // smallest j with prv[j] >= 0 (prv is monotone in j)
+                            first = -1;
+                            if (prv[(L - 1) * C + cc] >= 0) {
+                                int lo = 0, hi = L - 1;
+                                while (lo < hi) {
+                                    const int mid = (lo + hi) >> 1;
+                                    if (prv[mid * C + cc] >= 0) hi = mid; else lo = mid + 1;
+                                }
+                                first = lo;
+                            }
+                        }
+                        p = first;
+                    }
+                    v = p >= 0 ? xin[p * C + cc] : 0.0f;
+                }
+                dst[t * C + cc] = v;
+            }
+            first = -2;
+        }
+    } else {
+        for (int cc = c; cc < C && active; cc += 256) {
+            for (int i = r0; i < L; i += rp) {
+                const int e = i * C + cc;
+                const int p = prv[e], q = nxt[e];
+                float v;
+                if (p == i) v = xin[e];
+                else if (p < 0) v = q < L ? xin[q * C + cc] : 0.0f;                // leading gap / no observation
+                else if (q >= L) v = xin[p * C + cc];                              // trailing gap
+                else {
+                    const float pv = xin[p * C + cc], qv = xin[q * C + cc];
+                    const float ratio = ((float)i - (float)p) / ((float)q - (float)p);
+                    v = pv + ratio * (qv - pv);
+                }
+                dst[e] = v;
+            }
+        }
     }
 }
 
@@ -243,8 +419,17 @@ int64_t ncde_prepare_workspace_bytes(int kind, int B, int L, int C) {
 int ncde_prepare_linear(const float* x, int B, int L, int C, int rectilinear_time_index, float* out, void* stream) {
     if (!x || !out || B < 1 || L < 2 || C < 1 || rectilinear_time_index >= C) return NCDE_ERR_INVALID;
     const long long n = (long long)B * C;
-    hipLaunchKernelGGL(ncde_linear_coeffs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, B, L, C,
-                       rectilinear_time_index < 0 ? -1 : rectilinear_time_index, out);
+    const int rect = rectilinear_time_index < 0 ? -1 : rectilinear_time_index;
+    const int T = rect >= 0 ? 2 * L - 1 : L;
+    (void)T;
+    const size_t lds = sizeof(float) * ((size_t)L * C * (rect >= 0 ? 2 : 3) + 64 * (size_t)C);
+    if (lds <= 64 * 1024 && C <= 256) {   // the series fits LDS: staged, coalesced, scan-parallel variant
+        if (hipFuncSetAttribute((const void*)ncde_linear_coeffs_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return NCDE_ERR_HIP;
+        hipLaunchKernelGGL(ncde_linear_coeffs_lds_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, x, B, L, C, rect, out);
+    } else {
+        hipLaunchKernelGGL(ncde_linear_coeffs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, B, L, C, rect, out);
+    }
     return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
 }
 
