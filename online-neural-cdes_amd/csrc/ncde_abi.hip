@@ -92,6 +92,7 @@ int select_family(const NcdeProblem* p, const Layout& y, int pass) {
             return fail(NCDE_ERR_UNSUPPORTED, "vector-field variant outside what ncde_variant.hip covers (pass %d)", pass);
         return 3;
     }
+    if ((p->flags & NCDE_FLAG_FORCE_TILED) && ncde_tiled_supported(p, pass)) return 2;   // also ahead of a specialised kernel
     const bool fast_ok = ncde_fast_supported(p, pass);
     if (p->flags & NCDE_FLAG_FORCE_FAST) {
         if (!fast_ok) return fail(NCDE_ERR_UNSUPPORTED, "no shape-specialised kernel for this problem (pass %d)", pass);
