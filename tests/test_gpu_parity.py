@@ -405,6 +405,43 @@ def test_tiled_family_vs_oracle(shape, interp, method, seq, gpu_lib):
         assert e <= TIGHT_G, ("tiled discrete backward on the oracle's stage record", k, e)
 
 
+_SWEEP = [  # (B, L, C, H, HH, nl, interp, method, seq)  -- whatever family the dispatcher picks for each
+    (5, 4, 3, 7, 15, 1, "linear", "rk4", False),         # reference defaults: hidden_hidden_dim = 15 (odd widths: generic)
+    (33, 6, 6, 10, 15, 3, "cubic", "midpoint", True),
+    (19, 9, 8, 32, 32, 2, "linear", "euler", True),      # multiples of 16/4 without a specialised kernel: tiled
+    (40, 5, 12, 48, 16, 3, "cubic", "rk4", False),
+    (17, 7, 20, 32, 32, 4, "linear", "rk4", True),       # cfg2 dims but nl = 4: no fast adjoint instantiation
+    (70, 3, 4, 64, 64, 3, "linear", "midpoint", False),  # cfg4 dims, linear control
+    (16, 2, 16, 16, 128, 2, "linear", "rk4", False),     # a single step, wide hidden layers
+    (3, 12, 2, 16, 16, 1, "cubic", "euler", True),       # time + one channel
+]
+
+
+@pytest.mark.parametrize("cfg", _SWEEP, ids=lambda c: "B%d_L%d_C%d_H%d_HH%d_nl%d_%s_%s_%s" % (c[:6] + (c[6], c[7], "seq" if c[8] else "final")))
+def test_shape_sweep_every_family_vs_oracle(cfg, gpu_lib):
+    """Shapes the dispatcher routes to different kernel families (odd widths, no specialised instantiation, tiny and
+    wide layers, one channel): forward, continuous adjoint and exact discrete backward against the oracle, and the
+    dispatched family against the generic one."""
+    import gpu_util
+    B, L, C, H, HH, nl, interp, method, seq = cfg
+    case = _seeded_case(interp, method, seq, B=B, L=L, C=C, H=H, HH=HH, nl=nl, seed=500 + B)
+    ex = case["expect"]
+    res = gpu_util.run_case(case)
+    assert gu.relerr(res["z_out"], ex["z_out"]) <= TIGHT_Z, res["kernels"]
+    gen = gpu_util.run_case(case, flags=1, need_grads=False)
+    assert gu.relerr(res["z_out"], gen["z_out"]) <= TIGHT_Z
+    iso = gpu_util.run_adjoint_direct(case, ex["z_out"])
+    for k, e in _grad_errors(case, iso).items():
+        assert e <= TIGHT_G, ("adjoint", res["kernels"][1], k, e)
+    isod = gpu_util.run_adjoint_direct(case, ex["z_out"], stages=case["stage_record"])
+    for k, e in _grad_errors(case, isod, "bp_").items():
+        assert e <= TIGHT_G, ("discrete backward", res["kernels"][2], k, e)
+    resd = gpu_util.run_case(case, adjoint=False)
+    assert np.array_equal(resd["z_out"], res["z_out"])
+    for k, e in _grad_errors(case, resd, "bp_").items():
+        assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), ("discrete end-to-end", k, e)
+
+
 def test_gpu_coefficient_builders_match_reference(gpu_lib):
     """ncde_prepare_linear / ncde_prepare_cubic against the reference's builders
     (golden g8) -- bit-exact for the rectilinear preparation and the spline, 1e-6 for the NaN fill -- and at
