@@ -236,3 +236,16 @@ def test_gpu_coefficient_builders_refuse_cpu_tensors():
         ncde_amd.linear_interpolation_coeffs(torch.zeros(2, 5, 3))
     with pytest.raises(NotImplementedError):
         ncde_amd.natural_cubic_coeffs(torch.zeros(2, 5, 3))
+
+
+def test_temporal_loss_wrapper_masks_finished_series():
+    """Per-time-step labels with NaN after a series has ended (metrics.py:26-46)."""
+    preds = torch.arange(24, dtype=torch.float32).reshape(2, 4, 3).requires_grad_(True)
+    labels = torch.zeros(2, 4, 3)
+    labels[0, 2:] = float("nan")
+    loss = ncde_amd.TemporalLossWrapper(torch.nn.MSELoss())(preds, labels)
+    keep = torch.cat([preds[0, :2].reshape(-1), preds[1].reshape(-1)])
+    assert torch.allclose(loss, (keep ** 2).mean())
+    loss.backward()
+    assert float(preds.grad[0, 2:].abs().sum()) == 0.0 and float(preds.grad[1].abs().sum()) > 0
+    assert torch.allclose(ncde_amd.RMSELoss(eps=0.0)(torch.tensor([3.0, 4.0]), torch.zeros(2)), torch.tensor(12.5).sqrt())
