@@ -315,10 +315,12 @@ __device__ void cubic_series_missing(const float* xs, float* os, float* wb, floa
     }
 }
 
-__global__ __launch_bounds__(256) void ncde_cubic_coeffs_kernel(const float* __restrict__ x, int B, int L, int C,
+__global__ __launch_bounds__(64) void ncde_cubic_coeffs_kernel(const float* __restrict__ x, int B, int L, int C,
                                                                  float* __restrict__ out, float* __restrict__ ws,
                                                                  const float* __restrict__ diag_swept, float* __restrict__ ws_d) {
-    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+    // one wave per workgroup: the serial recurrences are latency-bound, so many small workgroups (all CUs, many waves in
+    // flight) beat few large ones -- 32768 series at cfg4 are only 128 workgroups of 256
+    const long long tid = (long long)blockIdx.x * 64 + threadIdx.x;
     if (tid >= (long long)B * C) return;
     const int b = (int)(tid / C), c = (int)(tid - (long long)b * C);
     const float* xs = x + (long long)b * L * C + c;
@@ -441,7 +443,7 @@ int ncde_prepare_cubic(const float* x, int B, int L, int C, float* out, void* wo
     float* diag = ws_d + (size_t)B * L * C;
     hipLaunchKernelGGL(ncde_cubic_diag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, L, diag);
     const long long n = (long long)B * C;
-    hipLaunchKernelGGL(ncde_cubic_coeffs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, B, L, C, out,
+    hipLaunchKernelGGL(ncde_cubic_coeffs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, x, B, L, C, out,
                        ws, diag, ws_d);
     return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
 }
