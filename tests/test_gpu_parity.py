@@ -473,3 +473,52 @@ def test_gpu_coefficient_builders_match_reference(gpu_lib):
     x4 = gu.data.synthetic_series(256, 182, 3, seed=1234)
     got = ncde_amd.natural_cubic_coeffs(torch.from_numpy(x4).cuda()).cpu().numpy()
     assert np.array_equal(got, gu.data.natural_cubic_coeffs(x4))
+
+
+def test_integration_md_stub_with_version1_struct(gpu_lib):
+    """The ctypes stub of INTEGRATION.md, verbatim in spirit: a caller that only knows the VERSION-1 struct (no trailing
+    field_kind .. br members) drives ncde_forward on a reference-shaped module and gets what cdeint returns."""
+    import ctypes
+    import ncde_amd
+    from ncde_amd import _lib
+
+    class NcdeProblemV1(ctypes.Structure):          # mirrors include/ncde_hip.h up to z0
+        _fields_ = [("abi_version", ctypes.c_int32), ("batch", ctypes.c_int32), ("n_knots", ctypes.c_int32),
+                    ("channels", ctypes.c_int32), ("hidden", ctypes.c_int32), ("interp", ctypes.c_int32),
+                    ("method", ctypes.c_int32), ("output", ctypes.c_int32), ("flags", ctypes.c_uint32),
+                    ("n_layers", ctypes.c_int32), ("layer_in", ctypes.c_int32 * 8), ("layer_out", ctypes.c_int32 * 8),
+                    ("layer_W", ctypes.c_void_p * 8), ("layer_b", ctypes.c_void_p * 8),
+                    ("Wo", ctypes.c_void_p), ("bo", ctypes.c_void_p), ("coeffs", ctypes.c_void_p),
+                    ("coeffs_stride_b", ctypes.c_int64), ("coeffs_stride_t", ctypes.c_int64), ("z0", ctypes.c_void_p)]
+
+    assert ctypes.sizeof(NcdeProblemV1) == _lib.NcdeProblem.field_kind.offset
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    B, L, C, H, HH, nl = 40, 9, 20, 32, 32, 3
+    coeffs = torch.from_numpy(gu.data.make_rectilinear_coeffs(B, L, C - 1, missing=0.3, seed=8)).cuda()
+    torch.manual_seed(1)
+    func = ncde_amd.OriginalVectorField(C, H, HH, nl).cuda()
+    z0 = torch.randn(B, H, device="cuda")
+    for every_knot in (False, True):
+        p = NcdeProblemV1(abi_version=1, batch=B, n_knots=coeffs.shape[1], channels=C, hidden=H, interp=0, method=2,
+                          output=int(every_knot), flags=0)
+        lins = [m for m in func.net_to_hh if isinstance(m, torch.nn.Linear)]
+        p.n_layers = len(lins)
+        for i, m in enumerate(lins):
+            p.layer_out[i], p.layer_in[i] = m.weight.shape
+            p.layer_W[i], p.layer_b[i] = m.weight.data_ptr(), m.bias.data_ptr()
+        out_lin = func.tanh_output_layer[0]
+        p.Wo, p.bo = out_lin.weight.data_ptr(), out_lin.bias.data_ptr()
+        p.coeffs, p.coeffs_stride_b, p.coeffs_stride_t = coeffs.data_ptr(), coeffs.stride(0), coeffs.stride(1)
+        p.z0 = z0.data_ptr()
+        lib.ncde_workspace_bytes.restype = ctypes.c_int64
+        ws = torch.empty(max(lib.ncde_workspace_bytes(ctypes.byref(p), 0), 256), dtype=torch.uint8, device="cuda")
+        n_out = coeffs.shape[1] if every_knot else 2
+        out = torch.empty(B, n_out, H, device="cuda")
+        rc = lib.ncde_forward(ctypes.byref(p), ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                              ctypes.c_size_t(ws.numel()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        X = ncde_amd.LinearInterpolation(coeffs)
+        with torch.no_grad():
+            ref = ncde_amd.cdeint(X, func, z0, X.grid_points if every_knot else X.interval, method="rk4", options={"step_size": 1})
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
