@@ -87,7 +87,9 @@ int generic_supported(const NcdeProblem* p, const Layout& y, int pass) {
 
 // pick the kernel family: 1 = fast (shape-specialised), 2 = tiled (batch-tiled, large hidden), 0 = generic, <0 = error
 int select_family(const NcdeProblem* p, const Layout& y, int pass) {
-    if (y.variant) {   // gated fields / evaluate / derivative inputs: their own kernels on the generic structure
+    if (y.variant) {   // gated fields / evaluate / derivative inputs: the batch-tiled family knows the minimal-gated field;
+                       // everything else runs on their own kernels on the generic structure
+        if (!(p->flags & (NCDE_FLAG_FORCE_GENERIC | NCDE_FLAG_FORCE_FAST)) && ncde_tiled_supported(p, pass) && ncde_tiled_preferred(p, pass)) return 2;
         if ((p->flags & NCDE_FLAG_FORCE_FAST) || !ncde_variant_supported(p, pass))
             return fail(NCDE_ERR_UNSUPPORTED, "vector-field variant outside what ncde_variant.hip covers (pass %d)", pass);
         return 3;

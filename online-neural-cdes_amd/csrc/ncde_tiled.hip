@@ -45,6 +45,10 @@ __device__ __forceinline__ void tl_load_dx(const KArgs& a, int b0, int idx, floa
     }
 }
 
+__device__ __forceinline__ float tl_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+
 // One weight panel = 16 rows x PK k-blocks of 16: PK 16-byte loads per lane, all in flight together.
 // PK is the largest of {8, 4, 2, 1} dividing K/16, so the panel loops carry no guards.
 template <int PK>
@@ -178,7 +182,22 @@ __device__ __forceinline__ void tl_output_pk(const KArgs& a, const float* in, co
 
 // Same, for the common case K = 16 PK (one panel = the whole tile row block): a straight-line loop body (no branches:
 // the waitcnt pass then keeps the next tile's loads in flight across the MFMAs), two named buffers, unrolled by two.
-template <int NS, int PK, int NWV>
+// one head tile as fetched: the 16-row weight panel(s) and the bias quad of this lane's D rows
+template <int PK, int GATED>
+struct TlTile {
+    Panel<PK> P;
+    f32x4 bias;
+};
+template <int PK>
+struct TlTile<PK, 1> {
+    Panel<PK> P;
+    f32x4 bias;
+    Panel<PK> G;       // sigmoid head
+    f32x4 biasg;
+};
+
+// GATED: the minimal-gated field (gating.py:7-32) -- a second head Wg, M = sigmoid(Wg x + bg) * tanh(Wo x + bo)
+template <int NS, int PK, int NWV, int GATED>
 __device__ __forceinline__ void tl_output_whole(const KArgs& a, const float* in, const float* DX, float* KO, int wave, int lane) {
     constexpr int NSP = NS * 16, dlast = 16 * PK;
     const int li = lane & 15, lk = lane >> 4;
@@ -186,16 +205,18 @@ __device__ __forceinline__ void tl_output_whole(const KArgs& a, const float* in,
     const int nhb_w = (nhb - wave + NWV - 1) / NWV;
     if (nhb_w <= 0) return;
     const int nq = nhb_w * ncq;
-    struct TileIn {
-        Panel<PK> P;
-        f32x4 bias;
-    };
+    using TileIn = TlTile<PK, GATED>;
     int fhi = 0, fcq = 0, fq = 0;
     auto fetch = [&]() {
         const int hb = wave + NWV * fhi;
         TileIn t;
-        t.P = tl_load_panel<PK>(a.Wo + (long long)((4 * hb + (li >> 2)) * C + 4 * fcq + (li & 3)) * dlast + 4 * lk, 0);
+        const long long woff = (long long)((4 * hb + (li >> 2)) * C + 4 * fcq + (li & 3)) * dlast + 4 * lk;
+        t.P = tl_load_panel<PK>(a.Wo + woff, 0);
         t.bias = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb + lk) * C + 4 * fcq);
+        if constexpr (GATED != 0) {
+            t.G = tl_load_panel<PK>(a.Wg + woff, 0);
+            t.biasg = *reinterpret_cast<const f32x4*>(a.bg + (4 * hb + lk) * C + 4 * fcq);
+        }
         const bool more = fq + 1 < nq, wrap = fcq + 1 == ncq;
         fq += more ? 1 : 0;
         fhi += (more && wrap) ? 1 : 0;
@@ -208,16 +229,25 @@ __device__ __forceinline__ void tl_output_whole(const KArgs& a, const float* in,
     for (int st = 0; st < NS; ++st) kacc[st] = 0.0f;
     auto step = [&](const TileIn& t) {
         const int hb = wave + NWV * chi;
-        f32x4 acc[NS];
+        f32x4 acc[NS], accg[NS];
 #pragma unroll
         for (int st = 0; st < NS; ++st) acc[st] = t.bias;
         tl_mma_panel<NS, PK>(t.P, in, 0, li, lk, acc);
+        if constexpr (GATED != 0) {
+#pragma unroll
+            for (int st = 0; st < NS; ++st) accg[st] = t.biasg;
+            tl_mma_panel<NS, PK>(t.G, in, 0, li, lk, accg);
+        }
 #pragma unroll
         for (int st = 0; st < NS; ++st) {
             const f32x4 dx = *reinterpret_cast<const f32x4*>(DX + (ccq * NSP + st * 16 + li) * 4);
             float kk = ccq == 0 ? 0.0f : kacc[st];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) kk = fmaf(tanh_dev(acc[st][r]), dx[r], kk);
+            for (int r = 0; r < 4; ++r) {
+                float m = tanh_dev(acc[st][r]);
+                if constexpr (GATED != 0) m = tl_sigmoid(accg[st][r]) * m;
+                kk = fmaf(m, dx[r], kk);
+            }
             kacc[st] = kk;
             KO[(hb * NSP + st * 16 + li) * 4 + lk] = kk;     // running sum; the last channel quad leaves the total
         }
@@ -240,7 +270,7 @@ __device__ __forceinline__ void tl_output_whole(const KArgs& a, const float* in,
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int NS, int NWV, int EM>
+template <int NS, int NWV, int EM, int GATED = 0>
 __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
     constexpr int NSP = NS * 16, NT = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -299,10 +329,10 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                 in = outb;
             }
             switch (nkb_o) {
-                case 8: tl_output_whole<NS, 8, NWV>(a, in, DX, KO, wave, lane); break;
-                case 4: tl_output_whole<NS, 4, NWV>(a, in, DX, KO, wave, lane); break;
-                case 2: tl_output_whole<NS, 2, NWV>(a, in, DX, KO, wave, lane); break;
-                case 1: tl_output_whole<NS, 1, NWV>(a, in, DX, KO, wave, lane); break;
+                case 8: tl_output_whole<NS, 8, NWV, GATED>(a, in, DX, KO, wave, lane); break;
+                case 4: tl_output_whole<NS, 4, NWV, GATED>(a, in, DX, KO, wave, lane); break;
+                case 2: tl_output_whole<NS, 2, NWV, GATED>(a, in, DX, KO, wave, lane); break;
+                case 1: tl_output_whole<NS, 1, NWV, GATED>(a, in, DX, KO, wave, lane); break;
                 default:
                     if (tl_panel_k(nkb_o) == 2) tl_output_pk<NS, 2, NWV>(a, in, DX, KO, dlast, wave, lane);
                     else tl_output_pk<NS, 1, NWV>(a, in, DX, KO, dlast, wave, lane);
@@ -359,15 +389,13 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
 namespace {
 
 template <int PK>
-struct WoTile {
-    Panel<PK> P;
-    f32x4 bias;
-};
+using WoTile = TlTile<PK, 0>;
 
 // RES = 1: the (at most two) output tiles of this wave are resident in registers (`res`), nothing is fetched.
-template <int PK, int NWV, int RES>
+template <int PK, int NWV, int RES, int GATED>
 __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, const float* AS, const float* DX, float* KOY,
                                               float* scr, int wave, int lane, const WoTile<PK>* res) {
+    static_assert(!(RES != 0 && GATED != 0), "resident weights are built for the original field only");
     constexpr int NSP = 16, SCS = 16 * PK + 4;
     const int li = lane & 15, lk = lane >> 4;
     const int C = a.C, nhb = a.H >> 2, ncq = C >> 2, dlast = 16 * PK;
@@ -376,13 +404,18 @@ __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, c
     for (int jt = 0; jt < PK; ++jt) accJ[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nhb_w = (nhb - wave + NWV - 1) / NWV;
     const int nq = nhb_w > 0 ? nhb_w * ncq : 0;
-    using TileIn = WoTile<PK>;
+    using TileIn = TlTile<PK, GATED>;
     int fhi = 0, fcq = 0, fq = 0;
     auto fetch = [&]() {
         const int hb = wave + NWV * fhi;
         TileIn t;
-        t.P = tl_load_panel<PK>(a.Wo + (long long)((4 * hb + (li >> 2)) * C + 4 * fcq + (li & 3)) * dlast + 4 * lk, 0);
+        const long long woff = (long long)((4 * hb + (li >> 2)) * C + 4 * fcq + (li & 3)) * dlast + 4 * lk;
+        t.P = tl_load_panel<PK>(a.Wo + woff, 0);
         t.bias = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb + lk) * C + 4 * fcq);
+        if constexpr (GATED != 0) {
+            t.G = tl_load_panel<PK>(a.Wg + woff, 0);
+            t.biasg = *reinterpret_cast<const f32x4*>(a.bg + (4 * hb + lk) * C + 4 * fcq);
+        }
         const bool more = fq + 1 < nq, wrap = fcq + 1 == ncq;
         fq += more ? 1 : 0;
         fhi += (more && wrap) ? 1 : 0;
@@ -401,13 +434,26 @@ __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, c
         tl_mma_panel<1, PK>(t.P, xL, 0, li, lk, acc);
         const float aval = AS[(hb * NSP + li) * 4 + lk];
         const f32x4 dx = *reinterpret_cast<const f32x4*>(DX + (cq * NSP + li) * 4);
-        float dP[4];
+        float dP[4], dPg[4];
         float kk = cq == 0 ? 0.0f : kacc;
+        f32x4 accg[1];
+        if constexpr (GATED != 0) {
+            accg[0] = t.biasg;
+            tl_mma_panel<1, PK>(t.G, xL, 0, li, lk, accg);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float m = tanh_dev(acc[0][r]);
-            kk = fmaf(m, dx[r], kk);
-            dP[r] = (aval * dx[r]) * (1.0f - m * m);
+            const float th = tanh_dev(acc[0][r]);
+            const float dm = aval * dx[r];
+            if constexpr (GATED != 0) {
+                const float sg = tl_sigmoid(accg[0][r]);
+                kk = fmaf(sg * th, dx[r], kk);
+                dP[r] = (dm * sg) * (1.0f - th * th);
+                dPg[r] = (dm * th) * (sg * (1.0f - sg));
+            } else {
+                kk = fmaf(th, dx[r], kk);
+                dP[r] = dm * (1.0f - th * th);
+            }
         }
         kacc = kk;
         KOY[(hb * NSP + li) * 4 + lk] = kk;      // running sum; the last channel quad leaves the total
@@ -416,6 +462,14 @@ __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, c
         for (int jt = 0; jt < PK; ++jt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) accJ[jt] = mfma16(scr[(4 * lk + r) * SCS + 16 * jt + li], dP[r], accJ[jt]);
+        if constexpr (GATED != 0) {     // ... + sum_u Wg[u][j] dPg[u][s], through the same scratch
+#pragma unroll
+            for (int i = 0; i < PK; ++i) *reinterpret_cast<f32x4*>(scr + li * SCS + 16 * i + 4 * lk) = t.G.v[i];
+#pragma unroll
+            for (int jt = 0; jt < PK; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accJ[jt] = mfma16(scr[(4 * lk + r) * SCS + 16 * jt + li], dPg[r], accJ[jt]);
+        }
         const bool wrap = ccq + 1 == ncq;
         chi += wrap ? 1 : 0;
         ccq = wrap ? 0 : ccq + 1;
@@ -495,7 +549,7 @@ __device__ __forceinline__ void tl_dw_acc(const float* gpre, const float* xin, i
 // tiles): every weight fragment a wave needs -- its forward row tile and its transposed tile of the (at most two)
 // hidden matrices, its (at most two) output tiles -- is loaded ONCE and stays in registers, so no phase of a stage
 // waits on an L2 round trip (cfg4: 11.3 -> see DESIGN.md).
-template <int PK, int NWV, int RES = 0>
+template <int PK, int NWV, int RES = 0, int GATED = 0>
 __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     constexpr int NT = 64 * NWV, TL_EADJ = RES ? (16 * 16 * PK + NT - 1) / NT : 2048 / NT;
     constexpr int TL_DWT = RES ? (PK * PK + NWV - 1) / NWV : 64 / NWV;   // hidden dW tiles per wave and weight slot
@@ -683,7 +737,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                 in = outb;
             }
             // ---- output layer: f, dP, per-wave partial of dL/dx_L -----------------------------------------------------
-            tl_output_vjp<PK, NWV, RES>(a, in, AS, DX, KOY, scr, wave, lane, wo);
+            tl_output_vjp<PK, NWV, RES, GATED>(a, in, AS, DX, KOY, scr, wave, lane, wo);
             // ---- records for pass B (x_L twice, weighted cotangent, dX/dt) --------------------------------------------
             {
                 const long long tile = (long long)sc * n_st + blockIdx.x;
@@ -865,7 +919,9 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
 // grid = (H*C/16 row tiles, parts); one WAVE = one 16-row tile of Wo x one 1/(4*parts) slice of the sample
 // tiles, for ALL stages: P = Wo_tile x_L + bo is recomputed (PK*4 MFMAs), dP = cot (x) dX (1 - tanh^2 P), and
 // dWo_tile += dP x_L^T (PK*4 MFMAs, samples are the K dim; dP transposed through a 16x17 LDS patch).
-template <int PK>
+// HEAD 0: the original field (tanh head).  Minimal-gated field: HEAD 1 = gradient of the tanh head (Wo, bo), HEAD 2 = of the
+// sigmoid head (Wg, bg); either run recomputes both pre-activations (M = sigmoid(Pg) * tanh(Pt)), accumulates one.
+template <int PK, int HEAD = 0>
 __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_st, float* gpartB) {
     __shared__ float patch[4][16 * 17];
     __shared__ __attribute__((aligned(16))) float red[4][PK * 256 + 64];
@@ -875,8 +931,15 @@ __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_s
     const int C = a.C, H = a.H, ncq = C >> 2, dlast = 16 * PK;
     const int tile = blockIdx.x, hb = tile / ncq, cq = tile - hb * ncq;
     const int part = blockIdx.y * 4 + wave, nparts = gridDim.y * 4;
-    const Panel<PK> Wp = tl_load_panel<PK>(a.Wo + (long long)((4 * hb + (li >> 2)) * C + 4 * cq + (li & 3)) * dlast + 4 * lk, 0);
+    const long long woff = (long long)((4 * hb + (li >> 2)) * C + 4 * cq + (li & 3)) * dlast + 4 * lk;
+    const Panel<PK> Wp = tl_load_panel<PK>(a.Wo + woff, 0);
     const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb + lk) * C + 4 * cq);
+    Panel<PK> Wq;        // sigmoid head (gated field)
+    f32x4 bq;
+    if constexpr (HEAD != 0) {
+        Wq = tl_load_panel<PK>(a.Wg + woff, 0);
+        bq = *reinterpret_cast<const f32x4*>(a.bg + (4 * hb + lk) * C + 4 * cq);
+    }
     f32x4 gW[PK];
     float gb[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -909,10 +972,25 @@ __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_s
         for (int i = 0; i < PK; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = mfma16(Wp.v[i][e], f.xa[i][e], acc);
+        f32x4 accq;
+        if constexpr (HEAD != 0) {
+            accq = bq;
+#pragma unroll
+            for (int i = 0; i < PK; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) accq = mfma16(Wq.v[i][e], f.xa[i][e], accq);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float m = tanh_dev(acc[r]);
-            const float dp = (f.cot * f.dx[r]) * (1.0f - m * m);
+            const float dm = f.cot * f.dx[r];
+            float dp;
+            if constexpr (HEAD == 0) {
+                dp = dm * (1.0f - m * m);
+            } else {
+                const float sg = tl_sigmoid(accq[r]);
+                dp = HEAD == 1 ? (dm * sg) * (1.0f - m * m) : (dm * m) * (sg * (1.0f - sg));
+            }
             gb[r] += dp;
             pt[(4 * lk + r) * 17 + li] = dp;
         }
@@ -1049,7 +1127,7 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
     const int row_tiles = p->hidden * p->channels / 16;
     t.parts = 1;
     while (t.parts < 64 && row_tiles * 4 * t.parts < 4096 && 4 * t.parts * 2 <= t.n_st) t.parts *= 2;
-    t.gpartB = off; off += (long long)t.parts * t.theta_o;
+    t.gpartB = off; off += (long long)t.parts * t.theta_o * (p->field_kind == NCDE_FIELD_MINIMAL ? 2 : 1);
     t.total = off + 64;
     return t;
 }
@@ -1059,6 +1137,13 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
 bool ncde_tiled_supported(const NcdeProblem* p, int pass) {
     if (p->n_layers < 1 || p->hidden % 16 || p->channels % 4) return false;
     auto aligned = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    // field variants: the minimal-gated field with the matmul input (a second head on the same activations)
+    if (p->field_input != NCDE_INPUT_MATMUL) return false;
+    if (p->field_kind == NCDE_FIELD_GRU) return false;
+    if (p->field_kind == NCDE_FIELD_MINIMAL) {
+        const int nkb = p->layer_out[p->n_layers - 1] / 16;
+        if (!aligned(p->Wg) || !aligned(p->bg) || !(nkb == 1 || nkb == 2 || nkb == 4 || nkb == 8)) return false;
+    }
     for (int l = 0; l < p->n_layers; ++l)
         if (p->layer_out[l] % 16 || p->layer_in[l] % 16 || !aligned(p->layer_W[l]) || !aligned(p->layer_b[l])) return false;
     if (!aligned(p->Wo) || !aligned(p->bo)) return false;
@@ -1076,9 +1161,11 @@ bool ncde_tiled_preferred(const NcdeProblem* p, int pass) {
 
 const char* ncde_tiled_kernel_name(const NcdeProblem* p, int pass) {
     if (!ncde_tiled_supported(p, pass)) return nullptr;
-    if (pass == 1) return "ncde_adj_tiled+ncde_dwo_tiled";
-    if (pass == 2) return "ncde_adj_tiled<discrete>+ncde_dwo_tiled";
+    const bool gated = p->field_kind == NCDE_FIELD_MINIMAL;
+    if (pass == 1) return gated ? "ncde_adj_tiled<gated>+ncde_dwo_tiled" : "ncde_adj_tiled+ncde_dwo_tiled";
+    if (pass == 2) return gated ? "ncde_adj_tiled<gated,discrete>+ncde_dwo_tiled" : "ncde_adj_tiled<discrete>+ncde_dwo_tiled";
     const int ns = tiled_fwd_ns(p);
+    if (gated) return ns == 4 ? "ncde_fwd_tiled<NS4,gated>" : (ns == 2 ? "ncde_fwd_tiled<NS2,gated>" : "ncde_fwd_tiled<NS1,gated>");
     return ns == 4 ? "ncde_fwd_tiled<NS4>" : (ns == 2 ? "ncde_fwd_tiled<NS2>" : "ncde_fwd_tiled<NS1>");
 }
 
@@ -1103,6 +1190,8 @@ int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws
     void (*fn)(KArgs) = ns == 4 ? (small ? ncde_fwd_tiled<4, TL_NW, 4> : ncde_fwd_tiled<4, TL_NW, 16>)
                                 : (ns == 2 ? (small ? ncde_fwd_tiled<2, TL_NW, 4> : ncde_fwd_tiled<2, TL_NW, 16>)
                                            : (small ? ncde_fwd_tiled<1, TL_NW, 4> : ncde_fwd_tiled<1, TL_NW, 16>));
+    if (p->field_kind == NCDE_FIELD_MINIMAL)
+        fn = ns == 4 ? ncde_fwd_tiled<4, TL_NW, 16, 1> : (ns == 2 ? ncde_fwd_tiled<2, TL_NW, 16, 1> : ncde_fwd_tiled<1, TL_NW, 16, 1>);
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NCDE_ERR_HIP;
     const int nwg = (p->batch + ns * 16 - 1) / (ns * 16);
     hipLaunchKernelGGL(fn, dim3(nwg), dim3(TL_THREADS), lds, st, a);
@@ -1126,13 +1215,20 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     a.gstride = t.gstride;
     const int pk = tiled_adj_pk(p);
     // small square models: every weight fragment register-resident (see ncde_adj_tiled)
-    bool res = pk <= 4 && p->hidden == 16 * pk && p->hidden * p->channels / 16 <= 2 * TL_ADJ_NW;
+    const bool gated = p->field_kind == NCDE_FIELD_MINIMAL;
+    bool res = !gated && pk <= 4 && p->hidden == 16 * pk && p->hidden * p->channels / 16 <= 2 * TL_ADJ_NW;
     for (int l = 0; l < p->n_layers; ++l) res = res && p->layer_out[l] == 16 * pk && p->layer_in[l] == 16 * pk;
     void (*fa)(KArgs) = pk == 8 ? ncde_adj_tiled<8, TL_ADJ_NW>
                                 : (pk == 4 ? (res ? ncde_adj_tiled<4, TL_ADJ_NW, 1> : ncde_adj_tiled<4, TL_ADJ_NW>)
                                            : (pk == 2 ? (res ? ncde_adj_tiled<2, TL_ADJ_NW, 1> : ncde_adj_tiled<2, TL_ADJ_NW>)
                                                       : (res ? ncde_adj_tiled<1, TL_ADJ_NW, 1> : ncde_adj_tiled<1, TL_ADJ_NW>)));
     void (*fb)(KArgs, int, int, float*) = pk == 8 ? ncde_dwo_tiled<8> : (pk == 4 ? ncde_dwo_tiled<4> : (pk == 2 ? ncde_dwo_tiled<2> : ncde_dwo_tiled<1>));
+    void (*fb2)(KArgs, int, int, float*) = nullptr;
+    if (gated) {
+        fa = pk == 8 ? ncde_adj_tiled<8, TL_ADJ_NW, 0, 1> : (pk == 4 ? ncde_adj_tiled<4, TL_ADJ_NW, 0, 1> : (pk == 2 ? ncde_adj_tiled<2, TL_ADJ_NW, 0, 1> : ncde_adj_tiled<1, TL_ADJ_NW, 0, 1>));
+        fb = pk == 8 ? ncde_dwo_tiled<8, 1> : (pk == 4 ? ncde_dwo_tiled<4, 1> : (pk == 2 ? ncde_dwo_tiled<2, 1> : ncde_dwo_tiled<1, 1>));
+        fb2 = pk == 8 ? ncde_dwo_tiled<8, 2> : (pk == 4 ? ncde_dwo_tiled<4, 2> : (pk == 2 ? ncde_dwo_tiled<2, 2> : ncde_dwo_tiled<1, 2>));
+    }
     const size_t lds = tiled_adj_lds(p);
     if (hipFuncSetAttribute((const void*)fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NCDE_ERR_HIP;
     hipLaunchKernelGGL(fa, dim3(t.n_st), dim3(64 * TL_ADJ_NW), lds, st, a);
@@ -1140,6 +1236,11 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     float* gB = w + t.gpartB;
     hipLaunchKernelGGL(fb, dim3(p->hidden * p->channels / 16, t.parts), dim3(256), 0, st, a, t.n_sc, t.n_st, gB);
     if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
+    float* gB2 = gB + (long long)t.parts * t.theta_o;
+    if (fb2) {
+        hipLaunchKernelGGL(fb2, dim3(p->hidden * p->channels / 16, t.parts), dim3(256), 0, st, a, t.n_sc, t.n_st, gB2);
+        if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
+    }
     if (main_kernel_only) return NCDE_OK;
     // deterministic reductions: hidden-layer partials of the sweep, then the part-group partials of pass B
     ReduceSegs segs{};
@@ -1162,5 +1263,11 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     so.off[0] = 0; so.len[0] = wo_sz; so.dst[0] = g->grad_Wo;
     so.off[1] = wo_sz; so.len[1] = p->hidden * p->channels; so.dst[1] = g->grad_bo;
     hipLaunchKernelGGL(ncde_reduce_partials, dim3(((int)t.theta_o + 255) / 256), dim3(256), 0, st, (const float*)gB, t.parts, (int)t.theta_o, so);
+    if (fb2) {
+        if (!g->grad_Wg || !g->grad_bg) return NCDE_ERR_INVALID;
+        so.dst[0] = g->grad_Wg;
+        so.dst[1] = g->grad_bg;
+        hipLaunchKernelGGL(ncde_reduce_partials, dim3(((int)t.theta_o + 255) / 256), dim3(256), 0, st, (const float*)gB2, t.parts, (int)t.theta_o, so);
+    }
     return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
 }

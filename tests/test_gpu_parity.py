@@ -289,7 +289,7 @@ def test_module_level_matches_reference(gpu_lib):
         assert model.nfe == int(f[vname + "__nfe"]), vname
 
 
-def _seeded_case(interp, method, seq, B, L, C, H, HH, nl, seed):
+def _seeded_case(interp, method, seq, B, L, C, H, HH, nl, seed, kind="original"):
     """A fresh case (inputs from the deterministic generator, expectation from the oracle)."""
     import torch as _t
     import ncde_oracle as orc
@@ -299,12 +299,16 @@ def _seeded_case(interp, method, seq, B, L, C, H, HH, nl, seed):
     else:
         coeffs = gu.data.make_rectilinear_coeffs(B, L, C - 1, missing=0.3, seed=seed)
         x0 = coeffs[:, 0]
-    p = gu.data.make_field_weights(H, HH, C, seed=seed + 1)
+    p = gu.data.make_field_weights(H, HH, C, seed=seed + 1) if kind == "original" else \
+        gu.data.make_variant_weights(H, HH, C, seed=seed + 1, kind=kind, mode="matmul")
     rw = gu.data.make_readin_weights(H, C, 1, seed=seed + 1)
     z0 = (x0 @ rw["Wi"].T + rw["bi"]).astype(np.float32)
     layers = [("W0", "b0")] + [("W1", "b1")] * (nl - 1)
-    names = ["W0", "b0"] + (["W1", "b1"] if nl > 1 else []) + ["Wo", "bo"]
-    case = {"meta": {"kind": interp, "method": method, "sequence": seq, "param_names": names,
+    names = ["W0", "b0"] + (["W1", "b1"] if nl > 1 else []) + (["Wr", "br"] if kind == "gru" else []) + \
+        (["Wg", "bg"] if kind != "original" else []) + ["Wo", "bo"]
+    if nl == 1:
+        p = {k: v for k, v in p.items() if k not in ("W1", "b1")}
+    case = {"meta": {"kind": interp, "method": method, "sequence": seq, "param_names": names, "field_kind": kind, "field_mode": "matmul",
                      "dims": {"C": C, "H": H, "HH": HH, "nl": nl}, "field": "original"},
             "coeffs": coeffs, "z0": z0, "params": p, "layers": layers, "H": H, "C": C}
     field = gu.oracle_field(case)
@@ -403,6 +407,37 @@ def test_tiled_family_vs_oracle(shape, interp, method, seq, gpu_lib):
     isod = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=FT, stages=case["stage_record"])
     for k, e in _grad_errors(case, isod, "bp_").items():
         assert e <= TIGHT_G, ("tiled discrete backward on the oracle's stage record", k, e)
+
+
+@pytest.mark.parametrize("shape", [(8, 32, 32, 2), (20, 32, 32, 3), (4, 64, 64, 3), (80, 128, 128, 2)])
+@pytest.mark.parametrize("interp,method,seq", [("linear", "rk4", False), ("cubic", "midpoint", True)])
+def test_tiled_minimal_gated_vs_oracle(shape, interp, method, seq, gpu_lib):
+    """The minimal-gated field on the batch-tiled family (second head in the forward, in the sweep's VJP, and one
+    gradient pass per head): forward, continuous adjoint and exact discrete backward against the oracle, and against the
+    variant kernels on the generic structure."""
+    import gpu_util
+    C, H, HH, nl = shape
+    case = _seeded_case(interp, method, seq, B=37, L=6, C=C, H=H, HH=HH, nl=nl, seed=700 + C, kind="minimal")
+    ex = case["expect"]
+    res = gpu_util.run_case(case)
+    assert res["kernels"][0].startswith("ncde_fwd_tiled") and "gated" in res["kernels"][0], res["kernels"]
+    assert "gated" in res["kernels"][1] and "gated" in res["kernels"][2], res["kernels"]
+    assert gu.relerr(res["z_out"], ex["z_out"]) <= TIGHT_Z
+    gen = gpu_util.run_case(case, flags=1, need_grads=False)
+    assert gen["kernels"][0] == "ncde_fwd_variant" and gu.relerr(gen["z_out"], ex["z_out"]) <= TIGHT_Z
+    for flag in (0x1000, 0x2000, 0x4000):
+        rn = gpu_util.run_case(case, flags=flag, need_grads=False)
+        assert gu.relerr(rn["z_out"], ex["z_out"]) <= TIGHT_Z, (flag, rn["kernels"])
+    iso = gpu_util.run_adjoint_direct(case, ex["z_out"])
+    for k, e in _grad_errors(case, iso).items():
+        assert e <= TIGHT_G, ("gated tiled adjoint", k, e)
+    again = gpu_util.run_adjoint_direct(case, ex["z_out"])
+    assert all(np.array_equal(again["grads"][k], iso["grads"][k]) for k in iso["grads"])
+    isod = gpu_util.run_adjoint_direct(case, ex["z_out"], stages=case["stage_record"])
+    for k, e in _grad_errors(case, isod, "bp_").items():
+        assert e <= TIGHT_G, ("gated tiled discrete backward", k, e)
+    for k, e in _grad_errors(case, res).items():
+        assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), ("end-to-end", k, e)
 
 
 _SWEEP = [  # (B, L, C, H, HH, nl, interp, method, seq)  -- whatever family the dispatcher picks for each
