@@ -10,6 +10,9 @@ forward solve (fused kernel) + loss + continuous-adjoint backward (fused kernel)
 all-reduce of the flat gradient] + Adam update, on BASELINE.json configs[1]/[2] (B=4096 per GPU, 200 raw
 observations -> 399 rectilinear knots, 20 channels incl. time, H=HH=32, nl=3, RK4-3/8, step 1).
 `value` = sample-steps/s = (samples processed by all ranks) * (T-1) / time, fp32 throughout.
+The headline line is WEAK scaling (B=4096 per GPU, the sharding rule of the task statement); for N>1 the same run also
+times the north-star's STRONG-scaling workload (global B=4096 sharded over the N ranks) and reports it under "strong".
+Inputs: raw synthetic series (ncde_amd.data) turned into coefficients by the GPU builders (csrc/ncde_prepare.hip).
 """
 import argparse
 import ctypes
@@ -49,12 +52,16 @@ def bytes_forward_per_sample_step(c):
     return (12 if c["interpolation"] == "cubic" else 4) * c["C"]
 
 
-def make_inputs(c, B, offset):
+def make_inputs(c, B, offset, dev):
+    """Deterministic raw series [B, L, C] (host generator, shardable by `offset`) -> control-path coefficients on `dev`
+    by the product's own GPU builders (bit-identical to the reference's builders, tests/golden/g8)."""
+    x = ncde_amd.data.synthetic_series(B, c["L"], c["C"] - 1, missing=c["missing"], seed=1234, batch_offset=offset)
+    x = torch.from_numpy(x).to(dev)
     if c["interpolation"] == "rectilinear":
-        return ncde_amd.data.make_rectilinear_coeffs(B, c["L"], c["C"] - 1, missing=c["missing"], seed=1234, batch_offset=offset)
+        return ncde_amd.linear_interpolation_coeffs(x, rectilinear=0)
     if c["interpolation"] == "cubic":
-        return ncde_amd.data.make_cubic_coeffs(B, c["L"], c["C"] - 1, seed=1234, batch_offset=offset)
-    return ncde_amd.data.make_linear_coeffs(B, c["L"], c["C"] - 1, seed=1234, batch_offset=offset)
+        return ncde_amd.natural_cubic_coeffs(x)
+    return x
 
 
 def make_model(c, device):
@@ -122,9 +129,12 @@ def cpu_baseline(c, fw, rw, sample_B):
     """The oracle (torch-CPU restatement of the reference op sequence, pinned to the reference by
     oracle/gen_golden.py) timed on this host's cores: forward + adjoint on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import coeff_oracle
     import ncde_oracle as orc
     torch.set_num_threads(host_cores())
-    coeffs = make_inputs(c, sample_B, 0)
+    x = ncde_amd.data.synthetic_series(sample_B, c["L"], c["C"] - 1, missing=c["missing"], seed=1234)
+    coeffs = coeff_oracle.natural_cubic_coeffs(x) if c["interpolation"] == "cubic" else \
+        (coeff_oracle.rectilinear_prep(x, 0) if c["interpolation"] == "rectilinear" else x)
     kind = "cubic" if c["interpolation"] == "cubic" else "linear"
     field = orc.Field.original(fw, c["H"], c["C"], c["nl"])
     ctl = orc.Control(coeffs, kind)
@@ -142,15 +152,76 @@ def cpu_baseline(c, fw, rw, sample_B):
                       % (sample_B, ctl.n_knots, t2 - t0, steps / (t1 - t0))}
 
 
+class Workload:
+    """One rank's shard of a configuration: inputs resident in HBM, model, bucket, optimizer."""
+
+    def __init__(self, c, B_local, B_total, lo, dev):
+        self.c, self.B_local, self.B_total = c, B_local, B_total
+        self.coeffs = make_inputs(c, B_local, lo, dev)
+        self.T = self.coeffs.shape[1] + (1 if c["interpolation"] == "cubic" else 0)
+        self.labels = (torch.from_numpy(ncde_amd.data.uniform01(7, B_total, stream=5)[lo:lo + B_local]) > 0.5).float().to(dev).unsqueeze(1)
+        self.model, self.fw, self.rw = make_model(c, dev)
+        self.bucket = D.FlatGradAllReduce(self.model.parameters())
+        try:     # single-kernel Adam: ~0.5 ms less launch overhead per step than the foreach implementation
+            self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, fused=True)
+        except (TypeError, RuntimeError):
+            self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3)
+        self.loss_fn = torch.nn.BCEWithLogitsLoss()
+
+    def step(self):
+        return D.train_step(self.model, self.bucket, self.opt, self.coeffs, self.labels, self.loss_fn)
+
+    def timed(self, steps, warmup, world, dev):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks (seconds)."""
+        for _ in range(warmup):
+            self.step()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = self.step()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        assert torch.isfinite(loss).item(), "training diverged"
+        return float(tmax.item()), float(loss)
+
+
+def pmc_traffic(name, config, B_local):
+    """HBM bytes per launch of kernel `name` from the committed rocprofv3 PMC summary (bench.py cannot run the profiler on
+    itself) -- only if that summary was taken on exactly the kernel sources this library is built from (fingerprint) and
+    on this workload; otherwise None."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_%s_summary.json" % config)
+    try:
+        with open(path) as fh:
+            pmc = json.load(fh)
+    except (OSError, ValueError):
+        return None, None
+    meta = pmc.get("_meta", {})
+    if meta.get("source_fingerprint") != _lib.source_fingerprint() or meta.get("batch") != B_local:
+        return None, None
+    for key, rec_ in pmc.items():
+        if key.startswith("ncde_") and name.startswith(key) and "hbm_read_MB_per_launch_corrected_x2" in rec_:
+            return round((rec_["hbm_read_MB_per_launch_corrected_x2"] + rec_.get("hbm_write_MB_per_launch", 0.0)) * 1e6), os.path.relpath(path, ROOT)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
-    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="which workload the headline `value` is quoted on; with N>1 the other one is timed too")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU (weak) / global (strong) batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the forward-only / adjoint=False / other-scaling legs")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     args = ap.parse_args()
 
@@ -161,65 +232,52 @@ def main():
     dev = torch.device("cuda", local_rank)
     D.init_process_group("nccl")
     c = dict(CONFIGS[args.config])
-    if args.scaling == "weak":
-        B_local = args.batch or c["B"]
-        B_total, lo = B_local * world, rank * B_local
-    else:
+
+    def shard(scaling):
+        if scaling == "weak":
+            B_local = args.batch or c["B"]
+            return B_local, B_local * world, rank * B_local
         B_total = args.batch or c["B"]
         lo, hi = D.shard_bounds(B_total, rank, world)
-        B_local = hi - lo
-    coeffs = torch.from_numpy(make_inputs(c, B_local, lo)).to(dev)
-    T = coeffs.shape[1] + (1 if c["interpolation"] == "cubic" else 0)
-    labels = (torch.from_numpy(ncde_amd.data.uniform01(7, B_total, stream=5)[lo:lo + B_local]) > 0.5).float().to(dev).unsqueeze(1)
-    model, fw, rw = make_model(c, dev)
-    bucket = D.FlatGradAllReduce(model.parameters())
-    try:     # single-kernel Adam: ~0.5 ms less launch overhead per step than the foreach implementation
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
-    except (TypeError, RuntimeError):
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    loss_fn = torch.nn.BCEWithLogitsLoss()
+        # equal shards: the averaged all-reduce of per-shard mean-loss gradients is then the global-mean gradient
+        assert B_total % world == 0, "strong scaling needs a global batch divisible by the number of ranks"
+        return hi - lo, B_total, lo
 
-    def step():
-        return D.train_step(model, bucket, opt, coeffs, labels, loss_fn)
+    B_local, B_total, lo = shard(args.scaling)
+    w = Workload(c, B_local, B_total, lo, dev)
+    model, coeffs, T = w.model, w.coeffs, w.T
+    dt, loss = w.timed(args.steps, args.warmup, world, dev)
 
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax.item())
-    assert torch.isfinite(loss).item(), "training diverged"
-
-    # forward-only throughput (inference), same inputs
-    with torch.no_grad():
-        model(coeffs)
-        torch.cuda.synchronize()
-        tf0 = time.perf_counter()
-        for _ in range(args.steps):
+    tf = td = None
+    other = None
+    if not args.no_extras:
+        # forward-only throughput (inference), same inputs
+        with torch.no_grad():
             model(coeffs)
+            torch.cuda.synchronize()
+            tf0 = time.perf_counter()
+            for _ in range(args.steps):
+                model(coeffs)
+            torch.cuda.synchronize()
+            tf = (time.perf_counter() - tf0) / args.steps
+        # adjoint=False training step (recording forward + exact discrete backward), reported beside the headline
+        model.adjoint = False
+        w.step()
         torch.cuda.synchronize()
-        tf = (time.perf_counter() - tf0) / args.steps
-
-    # adjoint=False training step (recording forward + exact discrete backward), reported beside the headline
-    model.adjoint = False
-    step()
-    torch.cuda.synchronize()
-    td0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    td = (time.perf_counter() - td0) / args.steps
-    model.adjoint = True
+        td0 = time.perf_counter()
+        for _ in range(args.steps):
+            w.step()
+        torch.cuda.synchronize()
+        td = (time.perf_counter() - td0) / args.steps
+        model.adjoint = True
+        if world > 1:      # the other scaling mode, same contract (barrier + synchronize, max over ranks)
+            oname = "strong" if args.scaling == "weak" else "weak"
+            oB_local, oB_total, olo = shard(oname)
+            ow = Workload(c, oB_local, oB_total, olo, dev)
+            odt, _ = ow.timed(args.steps, args.warmup, world, dev)
+            other = {"scaling": oname, "value": oB_total * (ow.T - 1) * args.steps / odt, "unit": "sample-steps/s",
+                     "ms_per_step": odt / args.steps * 1e3, "global_batch": oB_total, "batch_per_gpu": oB_local}
+            del ow
 
     if rank == 0:
         ms_fwd, ms_adj, names = time_kernels(model, c, coeffs)
@@ -228,27 +286,17 @@ def main():
         f_adj = 3 * f_fwd     # stage recompute + VJP wrt z + VJP wrt theta
         by_fwd = bytes_forward_per_sample_step(c)
 
-        pmc = {}
-        try:    # HBM bytes per launch measured with rocprofv3 PMC passes (committed summary; bench.py cannot run the profiler)
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_cfg2_summary.json")) as fh:
-                pmc = json.load(fh)
-        except (OSError, ValueError):
-            pass
-
-        def traffic_of(name):
-            key = "ncde_fwd_fast_bf3" if "fwd_fast_bf3" in name else ("ncde_adj_fast3" if "adj_fast3" in name else None)
-            rec_ = pmc.get(key) if (key and args.config == "cfg2" and B_local == 4096) else None
-            if not rec_ or "hbm_read_MB_per_launch_corrected_x2" not in rec_:
-                return None
-            return round((rec_["hbm_read_MB_per_launch_corrected_x2"] + rec_.get("hbm_write_MB_per_launch", 0.0)) * 1e6)
-
         def roof(ms, flops, nbytes, name):
             tf_s = flops * steps_per_launch / (ms * 1e-3) / 1e12
-            return {"bound": "mfma", "kernel": name, "achieved": round(tf_s, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf_s / PEAK_FP32_TFLOPS, 4), "traffic": traffic_of(name), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_pmc_cfg2_summary.json)",
-                    "algorithmic_bytes_per_launch": nbytes * steps_per_launch, "ms_per_launch": round(ms, 4),
-                    "hbm_algorithmic_GBs": round(nbytes * steps_per_launch / (ms * 1e-3) / 1e9, 2),
-                    "hbm_frac": round(nbytes * steps_per_launch / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6)}
+            traffic, src = pmc_traffic(name, args.config, B_local)
+            r = {"bound": "mfma", "kernel": name, "achieved": round(tf_s, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(tf_s / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                 "algorithmic_bytes_per_launch": nbytes * steps_per_launch, "ms_per_launch": round(ms, 4),
+                 "hbm_algorithmic_GBs": round(nbytes * steps_per_launch / (ms * 1e-3) / 1e9, 2),
+                 "hbm_frac": round(nbytes * steps_per_launch / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6)}
+            if traffic is not None:
+                r["traffic_unit"] = "bytes/launch (rocprofv3 PMC passes on these kernel sources, %s)" % src
+            return r
 
         rec = {
             "metric": "solved integration steps/sec (fwd+adjoint)",
@@ -265,15 +313,20 @@ def main():
                                    % (args.config, c["interpolation"], c["solver"], B_local, B_total, c["L"], T, c["C"], c["H"],
                                       c["nl"], "RCCL grad all-reduce + " if world > 1 else ""),
                        "global_batch": B_total, "seq_len": c["L"], "parallelism": "dp%d" % world},
-            "forward_only_value": B_local * (T - 1) / tf, "forward_only_ms": tf * 1e3,
-            "adjoint_false_value": B_local * (T - 1) / td, "adjoint_false_ms_per_step": td * 1e3,
-            "adjoint_false_note": "same step with NeuralCDE(adjoint=False): recording forward + exact discrete backward (per rank, no barrier)",
             "roofline": roof(ms_adj, f_adj, by_fwd, names[1]),
             "roofline_forward": roof(ms_fwd, f_fwd, by_fwd, names[0]),
-            "loss": float(loss),
+            "loss": loss,
         }
+        if tf is not None:
+            rec.update({"forward_only_value": B_local * (T - 1) / tf, "forward_only_ms": tf * 1e3,
+                        "adjoint_false_value": B_local * (T - 1) / td, "adjoint_false_ms_per_step": td * 1e3,
+                        "adjoint_false_note": "same step with NeuralCDE(adjoint=False): recording forward + exact discrete backward (per rank, no barrier)"})
+        if world == 1:     # one GPU: the weak and the strong workload coincide (global batch = per-GPU batch)
+            rec["strong" if args.scaling == "weak" else "weak"] = {"value": rec["value"], "ms_per_step": rec["ms_per_step"], "global_batch": B_total, "batch_per_gpu": B_local, "note": "identical to the headline at n_gpus=1"}
+        elif other is not None:
+            rec[other["scaling"]] = other
         if not args.no_cpu_baseline and world == 1:
-            rec["cpu_baseline"] = cpu_baseline(c, fw, rw, args.cpu_sample)
+            rec["cpu_baseline"] = cpu_baseline(c, w.fw, w.rw, args.cpu_sample)
             rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
         print(json.dumps(rec))
     if world > 1:

@@ -81,6 +81,22 @@ class NcdeError(RuntimeError):
     pass
 
 
+def source_fingerprint():
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, include/ncde_hip.h) the library is built from: ties a
+    committed rocprofv3 counter summary (tools/pmc_summary.py records it) to the kernels bench.py is timing."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h")))
+    files.append(os.path.join(os.path.dirname(here), "include", "ncde_hip.h"))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def lib():
     """Load (once) and return the ctypes handle; raises if the HIP extension is not built."""
     global _LIB

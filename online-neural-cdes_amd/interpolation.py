@@ -6,6 +6,8 @@ They keep the reference's constructor, ``grid_points``, ``interval``, ``evaluate
 ``cdeint`` the fused HIP kernels read the raw coefficient tensor and evaluate dX/dt on chip, so
 the ``[B, T-1, C]`` derivative tensor the reference materialises in its constructor is never built.
 """
+import weakref
+
 import torch
 
 
@@ -16,7 +18,7 @@ class _Tagged(torch.Tensor):
 def _tag(t, kind, owner):
     t = t.as_subclass(_Tagged)
     t._ncde_kind = kind
-    t._ncde_owner = id(owner)
+    t._ncde_owner = weakref.ref(owner)
     return t
 
 

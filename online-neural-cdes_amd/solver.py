@@ -58,7 +58,8 @@ def _field_spec(func):
 def _time_mode(X, t):
     """-> _lib.OUT_INTERVAL / OUT_KNOTS.  Tagged tensors from X.interval / X.grid_points avoid a device sync."""
     kind = getattr(t, "_ncde_kind", None)
-    if kind is not None and getattr(t, "_ncde_owner", None) == id(X):
+    owner = getattr(t, "_ncde_owner", None)      # a weakref: a recycled id() of a dead control can never match
+    if kind is not None and owner is not None and owner() is X and t.numel() == (X.n_knots if kind == "knots" else 2):
         return _lib.OUT_KNOTS if kind == "knots" else _lib.OUT_INTERVAL
     tv = torch.as_tensor(t).detach().cpu().double()
     assert tv.dim() == 1, "t must be one dimensional"
@@ -162,6 +163,7 @@ class _FusedCdeint(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable     # the kernels are not themselves differentiable: no create_graph
     def backward(ctx, grad_out):
         cfg = ctx.cfg
         if ctx.recorded:
@@ -198,8 +200,9 @@ class _FusedCdeint(torch.autograd.Function):
         if not ctx.recorded and cfg["func"] is not None and hasattr(cfg["func"], "nfe"):
             cfg["func"].nfe += cfg["nfe_per_solve"]   # the adjoint sweep re-evaluates f (base.py:90); autograd does not
         grads = []
+        keep = cfg["adjoint_param_ids"]     # adjoint_params of odeint_adjoint (adjoint.py:176-183): others get no gradient
         for q, needs in zip(params, ctx.needs_input_grad[3:]):
-            grads.append(gbuf[id(q)] if needs else None)
+            grads.append(gbuf[id(q)] if needs and (keep is None or id(q) in keep) else None)
         return (grad_z0 if ctx.needs_input_grad[0] else None, None, None, *grads)
 
 
@@ -235,13 +238,26 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
     step = options.pop("step_size", None)
     if step is None or float(step) != 1.0:
         raise NotImplementedError("options={'step_size': 1} is required (the reference's NeuralCDE setting, ncde.py:130-134)")
-    options.pop("perturb", None)
+    if options.pop("perturb", False):
+        warnings.warn("cdeint: options['perturb'] is ignored by the fused fixed-step kernels (stage times are exact knots/fractions)")
     for k in options:
         warnings.warn("cdeint: Unexpected arguments {}".format({k: options[k]}))
     if not torch.is_tensor(z0):
         raise NotImplementedError("tuple-valued z0 is outside the fused path")
     if z0.dim() != 2:
         raise NotImplementedError("z0 must be [batch, hidden]")
+    ap = set(id(q) for q in adjoint_params) if adjoint_params is not None else None
+    for buffer in X.buffers():
+        if not buffer.requires_grad:
+            continue
+        if adjoint and (ap is None or id(buffer) not in ap):       # the reference's warning (solver.py:207-221)
+            warnings.warn("One of the inputs to the control path X requires gradients but is not listed in "
+                          "`options['adjoint_params']`. It will not receive a gradient when using the adjoint method.")
+        else:
+            # adjoint=False tapes the solve in the reference, so the path's coefficients (and whatever produced them)
+            # would receive gradients; the fused backward has no dL/dcoeffs -- refuse rather than drop it silently
+            raise NotImplementedError("cdeint: gradients with respect to the control path's coefficients are not "
+                                      "implemented on the fused path; detach() the coefficients")
     coeffs = X.fused_coeffs
     if coeffs.dim() != 3:
         raise NotImplementedError("coeffs must be [batch, time, channels]")
@@ -259,17 +275,15 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
         _check_tensor(q, "a vector-field parameter")
         if not q.is_contiguous():
             raise NotImplementedError("vector-field parameters must be contiguous")
-    if adjoint:
-        ap = set(id(q) for q in adjoint_params) if adjoint_params is not None else set()
-        for buffer in X.buffers():
-            if buffer.requires_grad and id(buffer) not in ap:
-                warnings.warn("One of the inputs to the control path X requires gradients but is not listed in "
-                              "`options['adjoint_params']`. It will not receive a gradient when using the adjoint method.")
+    if adjoint and ap is not None:
+        ap = ap & set(id(q) for q in uniq)
+    else:
+        ap = None
     output = _time_mode(X, t)
     stages = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
     nfe = stages * (X.n_knots - 1)
     cfg = {"spec": spec, "interp": X.interp_name, "method": method, "output": output, "flags": flags,
-           "adjoint": bool(adjoint), "func": func, "nfe_per_solve": nfe}
+           "adjoint": bool(adjoint), "func": func, "nfe_per_solve": nfe, "adjoint_param_ids": ap}
     out = _FusedCdeint.apply(z0, coeffs.detach(), cfg, *uniq)
     if hasattr(func, "nfe"):
         func.nfe += nfe

@@ -39,7 +39,7 @@ from src.ncde.vector_fields.gating import GRUGatedVectorField as RefGRU, Minimal
 import ncde_amd  # noqa: E402
 import ncde_oracle as orc  # noqa: E402
 
-data = ncde_amd.data
+import coeff_oracle as data  # noqa: E402  (workload generators + the numpy restatement of the coefficient builders)
 GOLD = os.path.join(ROOT, "tests", "golden")
 os.makedirs(GOLD, exist_ok=True)
 torch.set_num_threads(8)

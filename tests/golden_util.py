@@ -4,9 +4,7 @@ import os
 
 import numpy as np
 
-import ncde_amd
-
-data = ncde_amd.data
+import coeff_oracle as data  # noqa: F401  workload generators (ncde_amd.data) + numpy restatement of the coefficient builders
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 SOLVE_CASES = [

@@ -1,0 +1,98 @@
+"""Data-parallel training with the REAL model on one GPU: two processes, both on cuda:0, `gloo` backend (the
+collective's transport does not matter here; what is exercised is `FlatGradAllReduce(single=False)` -- `.grad` aliased
+into the flat bucket -- against `_FusedCdeint.backward`, which returns fresh gradient tensors that autograd must
+accumulate into those views, followed by identical Adam updates).  The same code runs under RCCL with one GPU per rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import golden_util as gu
+import ncde_amd
+from ncde_amd import distributed as D
+
+pytestmark = pytest.mark.gpu
+
+B, L, C, H, HH, NL, OUT = 64, 12, 20, 32, 32, 3, 1
+STEPS = 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _make_model(adjoint, seq):
+    torch.manual_seed(0)
+    return ncde_amd.NeuralCDE(C, H, OUT, hidden_hidden_dim=HH, num_layers=NL, interpolation="rectilinear", adjoint=adjoint,
+                              solver="rk4", return_sequences=seq).cuda()
+
+
+def _data(lo, hi, seq):
+    x = gu.data.make_rectilinear_coeffs(B, L, C - 1, missing=0.3, seed=21)
+    n = L if seq else 1
+    y = (ncde_amd.data.uniform01(3, B * n, stream=2) > 0.5).astype(np.float32).reshape(B, n, 1)
+    if not seq:
+        y = y[:, 0]
+    return torch.from_numpy(x[lo:hi]).cuda(), torch.from_numpy(y[lo:hi]).cuda()
+
+
+def _train(model, x, y):
+    bucket = D.FlatGradAllReduce(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+    first = None
+    for _ in range(STEPS):
+        D.train_step(model, bucket, opt, x, y, loss_fn)
+        if first is None:
+            first = bucket.gathered().detach().clone().cpu()      # gradient at the common initial parameters
+    torch.cuda.synchronize()
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+    return flat, first, bucket
+
+
+def _worker(rank, world, port, out_dir, adjoint, seq):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    r, _, w = D.init_process_group("gloo")
+    assert (r, w) == (rank, world)
+    lo, hi = D.shard_bounds(B, rank, world)
+    x, y = _data(lo, hi, seq)
+    model = _make_model(adjoint, seq)
+    flat, grad, bucket = _train(model, x, y)
+    assert not bucket.single
+    off = 0
+    for p in model.parameters():        # backward accumulated straight into the bucket: the views were never replaced
+        assert p.grad.data_ptr() == bucket.flat[off:off + p.numel()].data_ptr()
+        off += p.numel()
+    torch.save({"params": flat, "grad": grad}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("adjoint,seq", [(True, False), (False, True)])
+def test_two_rank_neuralcde_data_parallel_on_one_gpu(adjoint, seq, tmp_path, gpu_lib):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), adjoint, seq), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    assert torch.equal(r0["params"], r1["params"])           # replicas stay bit-identical
+    assert torch.equal(r0["grad"], r1["grad"])
+    # a single process on the full batch: mean loss over 64 samples == average of the two 32-sample mean-loss gradients
+    x, y = _data(0, B, seq)
+    flat, grad, _ = _train(_make_model(adjoint, seq), x, y)
+    scale = float(grad.abs().max())
+    eg = float((grad - r0["grad"]).abs().max()) / scale
+    ep = float((flat - r0["params"]).abs().max())
+    print("dp vs single process: first-step gradient %.2e (rel. to max), parameters after %d Adam steps %.2e (abs)" % (eg, STEPS, ep))
+    assert eg <= 1e-5, eg        # summation order only (32 + 32 samples vs 64 in one launch)
+    # Adam divides by sqrt(v): an element whose gradient is small by cancellation turns fp32 summation noise into an update
+    # difference of up to ~lr * (relative error of that element); lr = 1e-2, 3 steps
+    assert ep <= 1e-3, ep

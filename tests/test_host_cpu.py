@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+import golden_util as gu
 import ncde_amd
 from ncde_amd import _lib, solver
 
@@ -111,8 +112,8 @@ def test_kernel_family_selection():
 
 def test_control_paths_match_oracle_control():
     import ncde_oracle as orc
-    lin = ncde_amd.data.make_rectilinear_coeffs(3, 6, 4, missing=0.3, seed=5)
-    cub = ncde_amd.data.make_cubic_coeffs(3, 7, 3, seed=6)
+    lin = gu.data.make_rectilinear_coeffs(3, 6, 4, missing=0.3, seed=5)
+    cub = gu.data.make_cubic_coeffs(3, 7, 3, seed=6)
     for coeffs, cls, kind in ((lin, ncde_amd.LinearInterpolation, "linear"), (cub, ncde_amd.NaturalCubicSpline, "cubic")):
         X, ctl = cls(torch.from_numpy(coeffs)), orc.Control(coeffs, kind)
         assert X.n_knots == ctl.n_knots and X.channels == ctl.channels
@@ -131,16 +132,16 @@ def test_rectilinear_preparation_known_answer():
                   [[0.2, nan], [0.3, 2.0], [0.3, nan]]], dtype=np.float32)
     want = np.array([[[0.1, 0.4], [0.2, 0.4], [0.2, 0.4], [0.9, 0.4], [0.9, 1.1]],
                      [[0.2, 2.0], [0.3, 2.0], [0.3, 2.0], [0.3, 2.0], [0.3, 2.0]]], dtype=np.float32)
-    got = ncde_amd.data.linear_interpolation_coeffs(x, rectilinear=0)
+    got = gu.data.linear_interpolation_coeffs(x, rectilinear=0)
     assert np.array_equal(got, want)
-    assert np.array_equal(ncde_amd.data.linear_interpolation_coeffs(x[:, :, ::-1].copy(), rectilinear=1), want[:, :, ::-1])
+    assert np.array_equal(gu.data.linear_interpolation_coeffs(x[:, :, ::-1].copy(), rectilinear=1), want[:, :, ::-1])
     bad = x.copy()
     bad[0, 1, 0] = nan
     with pytest.raises(AssertionError):
-        ncde_amd.data.linear_interpolation_coeffs(bad, rectilinear=0)
+        gu.data.linear_interpolation_coeffs(bad, rectilinear=0)
     # interior gaps are filled linearly, all-NaN channels become 0
     y = np.array([[[0.0, nan], [nan, nan], [2.0, nan]]], dtype=np.float32)
-    assert np.array_equal(ncde_amd.data.linear_interpolation_coeffs(y), np.array([[[0, 0], [1, 0], [2, 0]]], np.float32))
+    assert np.array_equal(gu.data.linear_interpolation_coeffs(y), np.array([[[0, 0], [1, 0], [2, 0]]], np.float32))
 
 
 def test_natural_cubic_reproduces_linear_data_and_interpolates_knots():
@@ -148,22 +149,22 @@ def test_natural_cubic_reproduces_linear_data_and_interpolates_knots():
     L, C = 9, 3
     t = np.arange(L, dtype=np.float32)[:, None]
     x = (t * np.array([0.5, -1.25, 2.0], np.float32) + np.array([1.0, 0.0, -3.0], np.float32))[None]
-    X = ncde_amd.NaturalCubicSpline(torch.from_numpy(ncde_amd.data.natural_cubic_coeffs(x)))
+    X = ncde_amd.NaturalCubicSpline(torch.from_numpy(gu.data.natural_cubic_coeffs(x)))
     for tv in (0.0, 0.3, 4.0, 6.75, 8.0):
         assert torch.allclose(X.derivative(torch.tensor(tv)), torch.tensor([[0.5, -1.25, 2.0]]), atol=1e-4)
         assert torch.allclose(X.evaluate(torch.tensor(tv)), torch.from_numpy(x[:, 0] + tv * np.array([0.5, -1.25, 2.0], np.float32)), atol=1e-4)
     y = ncde_amd.data.synthetic_series(2, 12, 2, seed=3)
-    Y = ncde_amd.NaturalCubicSpline(torch.from_numpy(ncde_amd.data.natural_cubic_coeffs(y)))
+    Y = ncde_amd.NaturalCubicSpline(torch.from_numpy(gu.data.natural_cubic_coeffs(y)))
     for k in range(12):
         assert torch.allclose(Y.evaluate(torch.tensor(float(k))), torch.from_numpy(y[:, k]), atol=1e-5)
 
 
 def test_generator_is_deterministic_and_shardable():
-    a = ncde_amd.data.make_rectilinear_coeffs(8, 10, 3, missing=0.3, seed=1234)
-    b = ncde_amd.data.make_rectilinear_coeffs(8, 10, 3, missing=0.3, seed=1234)
+    a = gu.data.make_rectilinear_coeffs(8, 10, 3, missing=0.3, seed=1234)
+    b = gu.data.make_rectilinear_coeffs(8, 10, 3, missing=0.3, seed=1234)
     assert np.array_equal(a, b) and not np.isnan(a).any()
-    lo = ncde_amd.data.make_rectilinear_coeffs(4, 10, 3, missing=0.3, seed=1234, batch_offset=0)
-    hi = ncde_amd.data.make_rectilinear_coeffs(4, 10, 3, missing=0.3, seed=1234, batch_offset=4)
+    lo = gu.data.make_rectilinear_coeffs(4, 10, 3, missing=0.3, seed=1234, batch_offset=0)
+    hi = gu.data.make_rectilinear_coeffs(4, 10, 3, missing=0.3, seed=1234, batch_offset=4)
     assert np.array_equal(np.concatenate([lo, hi]), a)     # rank shards tile the global batch exactly
     assert a.shape == (8, 19, 4) and np.all(np.diff(a[:, :, 0], axis=1) >= 0)
 
@@ -210,6 +211,46 @@ def test_no_cpu_fallback_product_path_fails_loudly_on_cpu_tensors():
         ncde_amd.NeuralCDE(3, 4, 1, solver="dopri5")
 
 
+def test_control_path_gradients_are_refused_not_dropped():
+    """adjoint=False tapes the solve in the reference, so coefficients that require grad would receive one; the fused
+    backward has no dL/dcoeffs: refuse.  adjoint=True: the reference's warning (torchcde/solver.py:207-221), and an
+    explicit request through adjoint_params is refused as well.  perturb=True is not silently swallowed."""
+    import warnings
+    c = torch.zeros(2, 5, 3, requires_grad=True)
+    X = ncde_amd.LinearInterpolation(c)
+    f = ncde_amd.OriginalVectorField(3, 4, 8, 2)
+    z0 = torch.zeros(2, 4)
+    kw = dict(method="rk4", options={"step_size": 1})
+    with pytest.raises(NotImplementedError, match="coefficients"):
+        ncde_amd.cdeint(X, f, z0, X.interval, adjoint=False, **kw)
+    with pytest.raises(NotImplementedError, match="coefficients"):
+        ncde_amd.cdeint(X, f, z0, X.interval, adjoint=True, adjoint_params=tuple(f.parameters()) + (c,), **kw)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        with pytest.raises(NotImplementedError, match="GPU"):       # past the warning, stops at the CPU tensors
+            ncde_amd.cdeint(X, f, z0, X.interval, adjoint=True, **kw)
+        assert any("requires gradients" in str(x.message) for x in w)
+    Xd = ncde_amd.LinearInterpolation(torch.zeros(2, 5, 3))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        with pytest.raises(NotImplementedError, match="GPU"):
+            ncde_amd.cdeint(Xd, f, z0, Xd.interval, method="rk4", options={"step_size": 1, "perturb": True})
+        assert any("perturb" in str(x.message) for x in w)
+
+
+def test_tagged_times_do_not_outlive_their_control():
+    """X.interval / X.grid_points carry a weak reference to their control: a tensor kept from another (or a dead) control
+    is re-validated by value instead of being trusted."""
+    X = ncde_amd.LinearInterpolation(torch.zeros(2, 5, 3))
+    Y = ncde_amd.LinearInterpolation(torch.zeros(2, 9, 3))
+    with pytest.raises(NotImplementedError):
+        solver._time_mode(X, Y.grid_points)          # 9 knots of another control
+    kept = Y.interval
+    del Y
+    with pytest.raises(NotImplementedError):
+        solver._time_mode(X, kept)
+
+
 def test_time_mode_detection():
     X = ncde_amd.LinearInterpolation(torch.zeros(2, 5, 3))
     assert solver._time_mode(X, X.interval) == _lib.OUT_INTERVAL
@@ -226,11 +267,11 @@ def test_host_coefficient_mirrors_match_reference_golden():
     """data.py's numpy builders against outputs of the reference's torchcde builders (golden g8)."""
     import golden_util as gu
     f = np.load(os.path.join(gu.GOLD, "g8_coeffs.npz"))
-    assert gu.relerr(ncde_amd.data.linear_interpolation_coeffs(f["x_missing"]), f["linear"]) <= 1e-6
-    assert np.array_equal(ncde_amd.data.linear_interpolation_coeffs(f["x_missing"], rectilinear=0), f["rectilinear"])
-    assert np.array_equal(ncde_amd.data.natural_cubic_coeffs(f["x_clean"]), f["cubic"])
-    assert np.array_equal(ncde_amd.data.natural_cubic_coeffs(f["x_clean"][:, :2]), f["cubic_len2"])
-    assert np.array_equal(ncde_amd.data.natural_cubic_coeffs(f["x_missing"]), f["cubic_missing"])   # NaN = missing values
+    assert gu.relerr(gu.data.linear_interpolation_coeffs(f["x_missing"]), f["linear"]) <= 1e-6
+    assert np.array_equal(gu.data.linear_interpolation_coeffs(f["x_missing"], rectilinear=0), f["rectilinear"])
+    assert np.array_equal(gu.data.natural_cubic_coeffs(f["x_clean"]), f["cubic"])
+    assert np.array_equal(gu.data.natural_cubic_coeffs(f["x_clean"][:, :2]), f["cubic_len2"])
+    assert np.array_equal(gu.data.natural_cubic_coeffs(f["x_missing"]), f["cubic_missing"])   # NaN = missing values
 
 
 def test_gpu_coefficient_builders_refuse_cpu_tensors():
@@ -240,14 +281,22 @@ def test_gpu_coefficient_builders_refuse_cpu_tensors():
         ncde_amd.natural_cubic_coeffs(torch.zeros(2, 5, 3))
 
 
-def test_temporal_loss_wrapper_masks_finished_series():
-    """Per-time-step labels with NaN after a series has ended (metrics.py:26-46)."""
-    preds = torch.arange(24, dtype=torch.float32).reshape(2, 4, 3).requires_grad_(True)
-    labels = torch.zeros(2, 4, 3)
+def test_masked_temporal_loss_ignores_finished_series():
+    """Per-time-step labels with NaN after a series has ended (the reference's masking rule, metrics.py:26-46): the
+    sync-free weighted formulation equals the loss over the gathered valid positions, and masked positions get no gradient."""
+    preds = (torch.arange(24, dtype=torch.float32).reshape(2, 4, 3) / 7 - 1).requires_grad_(True)
+    labels = (torch.arange(24, dtype=torch.float32).reshape(2, 4, 3) % 2)
     labels[0, 2:] = float("nan")
-    loss = ncde_amd.TemporalLossWrapper(torch.nn.MSELoss())(preds, labels)
-    keep = torch.cat([preds[0, :2].reshape(-1), preds[1].reshape(-1)])
-    assert torch.allclose(loss, (keep ** 2).mean())
-    loss.backward()
-    assert float(preds.grad[0, 2:].abs().sum()) == 0.0 and float(preds.grad[1].abs().sum()) > 0
-    assert torch.allclose(ncde_amd.RMSELoss(eps=0.0)(torch.tensor([3.0, 4.0]), torch.zeros(2)), torch.tensor(12.5).sqrt())
+    keep_p = torch.cat([preds[0, :2].reshape(-1), preds[1].reshape(-1)])
+    keep_y = torch.cat([labels[0, :2].reshape(-1), labels[1].reshape(-1)])
+    for kind, ref in (("mse", torch.nn.functional.mse_loss), ("l1", torch.nn.functional.l1_loss),
+                      ("bce_logits", torch.nn.functional.binary_cross_entropy_with_logits)):
+        loss = ncde_amd.MaskedTemporalLoss(kind)(preds, labels)
+        assert torch.allclose(loss, ref(keep_p, keep_y)), kind
+        g, = torch.autograd.grad(loss, preds)
+        assert float(g[0, 2:].abs().sum()) == 0.0 and float(g[1].abs().sum()) > 0 and torch.isfinite(g).all()
+    rm = ncde_amd.MaskedTemporalLoss("rmse", eps=0.0)(preds, labels)
+    assert torch.allclose(rm, torch.nn.functional.mse_loss(keep_p, keep_y).sqrt())
+    assert float(ncde_amd.masked_mean(preds, torch.full_like(labels, float("nan")))) == 0.0
+    with pytest.raises(ValueError):
+        ncde_amd.MaskedTemporalLoss("hinge")

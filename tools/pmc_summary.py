@@ -1,12 +1,18 @@
 """Summarise rocprofv3 --pmc passes (counter_collection.csv files under a directory) per kernel:
-    python tools/pmc_summary.py <dir> <out.json>
+    python tools/pmc_summary.py <dir> <out.json> [--config cfg2 --batch 4096 --note "..."]
 FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1024 B per the counter definition; FETCH_SIZE of wide coalesced reads
-is doubled (MI355X_MICROARCH.md, HBM section).  GRBM_GUI_ACTIVE in the CSV is the sum over the 8 XCDs."""
-import csv, glob, json, os, sys
+is doubled (MI355X_MICROARCH.md, HBM section).  GRBM_GUI_ACTIVE in the CSV is the sum over the 8 XCDs.
+The summary records the fingerprint of the kernel sources it was taken on (`_meta.source_fingerprint`): bench.py reports
+`roofline.traffic` from it only while the library it times is built from exactly those sources."""
+import argparse, csv, glob, json, os, sys
 from collections import defaultdict
-root, out = sys.argv[1], sys.argv[2]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ap = argparse.ArgumentParser()
+ap.add_argument("root"); ap.add_argument("out")
+ap.add_argument("--config", default="cfg2"); ap.add_argument("--batch", type=int, default=4096); ap.add_argument("--note", default="")
+a = ap.parse_args()
 acc = defaultdict(lambda: defaultdict(list))
-for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+for f in glob.glob(os.path.join(a.root, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
         if "ncde_" not in name:
@@ -23,6 +29,12 @@ for k, cs in acc.items():
         d["hbm_write_MB_per_launch"] = d["WRITE_SIZE"] * 1024 / 1e6
     if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
         d["MfmaUtil_pct"] = 100.0 * d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8 * 256 * 4)
+    if "SQ_ACTIVE_INST_VALU" in d and "SQ_WAVE_CYCLES" in d:
+        d["VALU_active_frac_of_wave_cycles"] = d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"]
+    if "SQ_WAIT_INST_ANY" in d and "SQ_WAVE_CYCLES" in d:
+        d["wait_frac_of_wave_cycles"] = d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"]
     res[k] = d
-json.dump(res, open(out, "w"), indent=1)
+from ncde_amd import _lib  # noqa: E402
+res["_meta"] = {"source_fingerprint": _lib.source_fingerprint(), "config": a.config, "batch": a.batch, "note": a.note}
+json.dump(res, open(a.out, "w"), indent=1)
 print(json.dumps(res, indent=1))
