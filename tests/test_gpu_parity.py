@@ -190,11 +190,16 @@ def _cfg2_case(B):
             "H": 32, "C": 20, "expect": {"grad_out": gout}}, names
 
 
-# Full-length (T = 399, 398 steps = 1592 stages) tolerances for the BENCHMARKED cfg2/cfg3 kernels, measured on MI355X
-# (tools/parity_report.py prints them):  the kernels in isolation -- fed the oracle's own z_T / stage record -- stay in the
-# fp32 round-off class (continuous adjoint re-integrates y backwards over 398 steps; split-bf16 chain vs the oracle's
-# addmm order), so the guard is CFG2_ISO; end to end the forward's 5e-7 difference in z_T is amplified by the sweep.
-CFG2_ISO_G, CFG2_E2E_G = 2e-4, 1e-3
+# Full-length (T = 399, 398 steps = 1592 stages) tolerances for the BENCHMARKED cfg2/cfg3 kernels.  Measured on MI355X
+# (this test prints them): against the oracle on the 32-sample sub-batch every gradient -- continuous adjoint (y re-integrated
+# backwards over 398 steps) and exact discrete backward, kernel in isolation and end to end -- is within 1.1e-5
+# (dz0 3e-7, W0/W1 5e-6, Wo 1.1e-5, biases 2e-6): the fp32 round-off class of the split-bf16 chain vs the oracle's addmm
+# order, no drift worth a looser bound.  Guard: 5e-5.  Over all 4096 samples a last-bit difference in z flips a ReLU mask
+# for a handful of samples (fp32 behaviour of the model, see _check_case), which moves THAT sample's dL/dz0 at the 1e-3
+# level: the full-batch check is therefore per sample (99 % within 5e-5, none beyond 2e-2) and, for the parameter
+# gradients (sums over the batch), 2e-4.
+CFG2_ISO_G = CFG2_E2E_G = 5e-5
+CFG2_FULL_BATCH_G = 2e-4
 
 
 def test_full_size_cfg2_adjoint_and_discrete_backward_vs_oracle(gpu_lib):
@@ -246,9 +251,13 @@ def test_full_size_cfg2_adjoint_and_discrete_backward_vs_oracle(gpu_lib):
     zb = orc.solve_forward(ctlb, fieldb, big["z0"], "rk4", False)
     assert gu.relerr(rb["z_out"], zb) <= TIGHT_Z
     dz0b, gpb = orc.solve_adjoint(ctlb, fieldb, zb, big["expect"]["grad_out"], "rk4", False)
-    assert gu.relerr(rb["dz0"], dz0b) <= CFG2_E2E_G
-    for pname, g in zip(names, gpb):
-        assert gu.relerr(rb["grads"][pname], g) <= CFG2_E2E_G, (pname, gu.relerr(rb["grads"][pname], g))
+    per = np.abs(rb["dz0"] - dz0b.numpy()).max(1) / np.abs(dz0b.numpy()).max()
+    full = {pname: gu.relerr(rb["grads"][pname], g) for pname, g in zip(names, gpb)}
+    print("cfg2 full batch: dz0 per-sample rel err median %.2e, p99 %.2e, max %.2e (%d of %d samples > 5e-5);" %
+          (np.median(per), np.quantile(per, 0.99), per.max(), int((per > 5e-5).sum()), B), {k: "%.2e" % v for k, v in full.items()})
+    assert np.quantile(per, 0.99) <= 5e-5 and per.max() <= 2e-2, (np.quantile(per, 0.99), per.max())
+    for pname, e in full.items():
+        assert e <= CFG2_FULL_BATCH_G, (pname, e)
 
 
 @pytest.mark.parametrize("cfg", ["cfg4", "cfg5"])
