@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define NCDE_ABI_VERSION 2 /* version-1 structs (without the trailing field_kind .. br members) are still accepted */
+#define NCDE_ABI_VERSION 3 /* version-1 structs (no trailing field_kind .. br members) and version-2 structs (no trailing
+                              time_plan .. members) are still accepted */
 #define NCDE_MAX_LAYERS 8
 
 typedef enum NcdeStatus {
@@ -48,8 +49,9 @@ typedef enum NcdeInterp { NCDE_INTERP_LINEAR = 0, NCDE_INTERP_CUBIC = 1 } NcdeIn
 typedef enum NcdeMethod { NCDE_EULER = 0, NCDE_MIDPOINT = 1, NCDE_RK4_38 = 2 } NcdeMethod;
 
 /* which times the solution is reported at: t = X.interval (2 outputs: z(0), z(T-1)) or
- * t = X.grid_points (every knot), the two cases src/ncde/ncde.py:219-225 uses. */
-typedef enum NcdeOutput { NCDE_OUT_INTERVAL = 0, NCDE_OUT_KNOTS = 1 } NcdeOutput;
+ * t = X.grid_points (every knot), the two cases src/ncde/ncde.py:219-225 uses on the default grid with step_size 1;
+ * NCDE_OUT_TIMES = the general time axis (any increasing t, any step_size, user knot grids): needs a time plan. */
+typedef enum NcdeOutput { NCDE_OUT_INTERVAL = 0, NCDE_OUT_KNOTS = 1, NCDE_OUT_TIMES = 2 } NcdeOutput;
 
 /* kernel family selection (ncde_forward/ncde_adjoint `flags`) */
 #define NCDE_FLAG_AUTO 0u
@@ -116,6 +118,15 @@ typedef struct NcdeProblem {
     const float* bg;
     const float* Wr;
     const float* br;
+
+    /* ---- ABI version 3: general time axis (read only when abi_version >= 3 and output == NCDE_OUT_TIMES) ----
+     * time_plan: DEVICE copy of the buffer ncde_time_plan_build() filled on the host; the three counts are the ones it
+     * returned in NcdeTimePlanInfo.  The solution then has n_t_out rows per sample (row 0 = z0 = z(t[0])). */
+    const void* time_plan;
+    int32_t n_t_out;
+    int32_t n_steps_fwd;
+    int32_t n_steps_adj;
+    int32_t reserved_;
 } NcdeProblem;
 
 typedef enum NcdeFieldKind { NCDE_FIELD_ORIGINAL = 0, NCDE_FIELD_MINIMAL = 1, NCDE_FIELD_GRU = 2 } NcdeFieldKind;
@@ -135,6 +146,33 @@ typedef struct NcdeGrads {
     float* grad_Wr;
     float* grad_br;
 } NcdeGrads;
+
+/* General time axis of torchdiffeq's fixed-grid solvers, replacing
+ *   the grid built from options['step_size']                     torchdiffeq/_impl/solvers.py:78-87
+ *   the output pick / linear interpolation between grid states    solvers.py:103-117, 166-172
+ *   user knot grids of the control path                           torchcde/interpolation_linear.py:186-202, interpolation_cubic.py:283-305
+ *   one reverse solve per output interval on its own grid         torchdiffeq/_impl/adjoint.py:116-133
+ * The caller describes the axis with HOST arrays; ncde_time_plan_build() (pure CPU code, exact torch arithmetic in the
+ * dtype of t) turns it into a small table the kernels walk.  Copy the table to the device, point NcdeProblem.time_plan
+ * at it, set output = NCDE_OUT_TIMES and the three counts from NcdeTimePlanInfo. */
+typedef struct NcdeTimeSpec {
+    int32_t n_t;          /* number of output times (>= 2); t[0] is where the solve starts (z0 = z(t[0])) */
+    int32_t time_is_f64;  /* 0: the caller's t tensor is fp32 (grid arithmetic in fp32, as torch does); 1: fp64 */
+    const double* t;      /* HOST, n_t strictly increasing values */
+    double step_size;     /* options['step_size'] > 0 */
+    const double* knots;  /* HOST, the n_knots knot times X was built on, or NULL = default integer grid 0..T-1 */
+} NcdeTimeSpec;
+
+typedef struct NcdeTimePlanInfo {
+    int32_t n_t_out;      /* = n_t */
+    int32_t n_steps_fwd;  /* solver steps of the forward solve */
+    int32_t n_steps_adj;  /* solver steps of all reverse solves of the continuous adjoint */
+    int32_t stages;       /* stages per step of the method */
+    int64_t bytes;        /* size of the plan */
+} NcdeTimePlanInfo;
+
+/* host_buffer == NULL: only fills *info (sizes).  Uses p->method, p->n_knots. */
+int ncde_time_plan_build(const NcdeProblem* p, const NcdeTimeSpec* ts, void* host_buffer, size_t bytes, NcdeTimePlanInfo* info);
 
 int ncde_version(void);
 const char* ncde_last_error_string(void);

@@ -6,12 +6,12 @@ raises.  Build it with ``python __graft_entry__.py`` (or ``make -C online-neural
 import ctypes
 import os
 
-NCDE_ABI_VERSION = 2
+NCDE_ABI_VERSION = 3
 NCDE_MAX_LAYERS = 8
 
 INTERP = {"linear": 0, "cubic": 1}
 METHOD = {"euler": 0, "midpoint": 1, "rk4": 2}
-OUT_INTERVAL, OUT_KNOTS = 0, 1
+OUT_INTERVAL, OUT_KNOTS, OUT_TIMES = 0, 1, 2
 FIELD_KIND = {"original": 0, "minimal": 1, "gru": 2}
 FIELD_INPUT = {"matmul": 0, "evaluate": 1, "derivative": 2}
 FLAG_AUTO, FLAG_FORCE_GENERIC, FLAG_FORCE_FAST, FLAG_FP32_MFMA, FLAG_ADJOINT_V1, FLAG_ADJOINT_V2 = 0, 1, 2, 4, 8, 16
@@ -49,6 +49,32 @@ class NcdeProblem(ctypes.Structure):
         ("bg", _c_float_p),
         ("Wr", _c_float_p),
         ("br", _c_float_p),
+        # ABI version 3: general time axis
+        ("time_plan", ctypes.c_void_p),
+        ("n_t_out", ctypes.c_int32),
+        ("n_steps_fwd", ctypes.c_int32),
+        ("n_steps_adj", ctypes.c_int32),
+        ("reserved_", ctypes.c_int32),
+    ]
+
+
+class NcdeTimeSpec(ctypes.Structure):
+    _fields_ = [
+        ("n_t", ctypes.c_int32),
+        ("time_is_f64", ctypes.c_int32),
+        ("t", ctypes.POINTER(ctypes.c_double)),
+        ("step_size", ctypes.c_double),
+        ("knots", ctypes.POINTER(ctypes.c_double)),
+    ]
+
+
+class NcdeTimePlanInfo(ctypes.Structure):
+    _fields_ = [
+        ("n_t_out", ctypes.c_int32),
+        ("n_steps_fwd", ctypes.c_int32),
+        ("n_steps_adj", ctypes.c_int32),
+        ("stages", ctypes.c_int32),
+        ("bytes", ctypes.c_int64),
     ]
 
 
@@ -71,6 +97,7 @@ EXPORTS = (
     "ncde_kernel_name", "ncde_forward", "ncde_adjoint", "ncde_time_kernel",
     "ncde_prepare_workspace_bytes", "ncde_prepare_linear", "ncde_prepare_cubic",
     "ncde_stage_record_bytes", "ncde_forward_record", "ncde_backward",
+    "ncde_time_plan_build",
 )
 
 _LIB = None
@@ -137,6 +164,8 @@ def lib():
     h.ncde_prepare_linear.restype = ctypes.c_int
     h.ncde_prepare_cubic.argtypes = [vp, i32, i32, i32, vp, vp, sz, vp]
     h.ncde_prepare_cubic.restype = ctypes.c_int
+    h.ncde_time_plan_build.argtypes = [P, ctypes.POINTER(NcdeTimeSpec), vp, sz, ctypes.POINTER(NcdeTimePlanInfo)]
+    h.ncde_time_plan_build.restype = ctypes.c_int
     if h.ncde_version() != NCDE_ABI_VERSION:
         raise NcdeError("libncde_hip.so ABI %d != binding %d" % (h.ncde_version(), NCDE_ABI_VERSION))
     _LIB = h

@@ -12,6 +12,7 @@
 #include "ncde_fast.h"
 #include "ncde_host.h"
 #include "ncde_tiled.h"
+#include "ncde_timeplan.h"
 #include "ncde_variant.h"
 
 extern "C" __global__ void ncde_fwd_generic(KArgs a);
@@ -39,10 +40,12 @@ int fail(int code, const char* fmt, ...) {
 // field_kind .. br members), which reads as the original field with the matmul input.
 int normalize(const NcdeProblem* in, NcdeProblem* out) {
     if (!in) return fail(NCDE_ERR_INVALID, "problem is NULL");
-    if (in->abi_version != 1 && in->abi_version != NCDE_ABI_VERSION)
-        return fail(NCDE_ERR_INVALID, "abi_version %d not in {1, %d}", in->abi_version, NCDE_ABI_VERSION);
+    if (in->abi_version < 1 || in->abi_version > NCDE_ABI_VERSION)
+        return fail(NCDE_ERR_INVALID, "abi_version %d not in [1, %d]", in->abi_version, NCDE_ABI_VERSION);
     memset(out, 0, sizeof(*out));
-    memcpy(out, in, in->abi_version >= 2 ? sizeof(NcdeProblem) : offsetof(NcdeProblem, field_kind));
+    // version 1 ends before field_kind, version 2 before time_plan: the missing tail reads as zeros (original field, matmul
+    // input, default time axis)
+    memcpy(out, in, in->abi_version >= 3 ? sizeof(NcdeProblem) : (in->abi_version == 2 ? offsetof(NcdeProblem, time_plan) : offsetof(NcdeProblem, field_kind)));
     out->abi_version = NCDE_ABI_VERSION;
     return NCDE_OK;
 }
@@ -54,7 +57,13 @@ int validate(const NcdeProblem* p) {
     if (p->interp != NCDE_INTERP_LINEAR && p->interp != NCDE_INTERP_CUBIC) return fail(NCDE_ERR_INVALID, "unknown interp %d", p->interp);
     if (p->method != NCDE_EULER && p->method != NCDE_MIDPOINT && p->method != NCDE_RK4_38)
         return fail(NCDE_ERR_INVALID, "Invalid method %d. Must be one of {euler, midpoint, rk4}", p->method);
-    if (p->output != NCDE_OUT_INTERVAL && p->output != NCDE_OUT_KNOTS) return fail(NCDE_ERR_INVALID, "unknown output mode %d", p->output);
+    if (p->output != NCDE_OUT_INTERVAL && p->output != NCDE_OUT_KNOTS && p->output != NCDE_OUT_TIMES) return fail(NCDE_ERR_INVALID, "unknown output mode %d", p->output);
+    if (p->output == NCDE_OUT_TIMES) {
+        if (!p->time_plan) return fail(NCDE_ERR_INVALID, "output = NCDE_OUT_TIMES needs a time plan (ncde_time_plan_build)");
+        if (p->n_t_out < 2 || p->n_steps_fwd < 1 || p->n_steps_adj < 1) return fail(NCDE_ERR_INVALID, "time plan counts: n_t_out %d, n_steps_fwd %d, n_steps_adj %d", p->n_t_out, p->n_steps_fwd, p->n_steps_adj);
+    } else if (p->time_plan) {
+        return fail(NCDE_ERR_INVALID, "a time plan is only read with output = NCDE_OUT_TIMES");
+    }
     if (p->n_layers < 0 || p->n_layers > NCDE_MAX_LAYERS) return fail(NCDE_ERR_INVALID, "n_layers %d outside [0, %d]", p->n_layers, NCDE_MAX_LAYERS);
     if (p->field_kind < NCDE_FIELD_ORIGINAL || p->field_kind > NCDE_FIELD_GRU) return fail(NCDE_ERR_INVALID, "unknown field_kind %d", p->field_kind);
     if (p->field_input < NCDE_INPUT_MATMUL || p->field_input > NCDE_INPUT_DERIVATIVE)
@@ -87,6 +96,15 @@ int generic_supported(const NcdeProblem* p, const Layout& y, int pass) {
 
 // pick the kernel family: 1 = fast (shape-specialised), 2 = tiled (batch-tiled, large hidden), 0 = generic, <0 = error
 int select_family(const NcdeProblem* p, const Layout& y, int pass) {
+    if (p->output == NCDE_OUT_TIMES) {   // general time axis: the plan-driven generic / variant kernels
+        if (p->flags & (NCDE_FLAG_FORCE_FAST | NCDE_FLAG_FORCE_TILED)) return fail(NCDE_ERR_UNSUPPORTED, "the general time axis runs on the generic family only");
+        if (y.variant) {
+            if (!ncde_variant_supported(p, pass)) return fail(NCDE_ERR_UNSUPPORTED, "vector-field variant outside what ncde_variant.hip covers (pass %d)", pass);
+            return 3;
+        }
+        const int rc = generic_supported(p, y, pass);
+        return rc == NCDE_OK ? 0 : rc;
+    }
     if (y.variant) {   // gated fields / evaluate / derivative inputs: the batch-tiled family knows the minimal-gated field;
                        // everything else runs on their own kernels on the generic structure
         if (!(p->flags & (NCDE_FLAG_FORCE_GENERIC | NCDE_FLAG_FORCE_FAST)) && ncde_tiled_supported(p, pass) && ncde_tiled_preferred(p, pass)) return 2;
@@ -187,7 +205,19 @@ int ncde_num_outputs(const NcdeProblem* p) {
     p = &q_;
     rc = validate(p);
     if (rc != NCDE_OK) return rc;
-    return p->output == NCDE_OUT_KNOTS ? p->n_knots : 2;
+    return p->output == NCDE_OUT_TIMES ? p->n_t_out : (p->output == NCDE_OUT_KNOTS ? p->n_knots : 2);
+}
+
+int ncde_time_plan_build(const NcdeProblem* p, const NcdeTimeSpec* ts, void* host_buffer, size_t bytes, NcdeTimePlanInfo* info) {
+    NcdeProblem q_;
+    int rc = normalize(p, &q_);
+    if (rc != NCDE_OK) return rc;
+    if (q_.n_knots < 2) return fail(NCDE_ERR_INVALID, "Must have a time dimension of size at least 2 (n_knots=%d)", q_.n_knots);
+    if (q_.method != NCDE_EULER && q_.method != NCDE_MIDPOINT && q_.method != NCDE_RK4_38) return fail(NCDE_ERR_INVALID, "Invalid method %d", q_.method);
+    char msg[256] = "";
+    rc = ncde_time_plan_build_impl(&q_, ts, host_buffer, bytes, info, msg, sizeof(msg));
+    if (rc != NCDE_OK) return fail(rc, "%s", msg);
+    return NCDE_OK;
 }
 
 int64_t ncde_workspace_bytes(const NcdeProblem* p, int pass) {
@@ -215,7 +245,8 @@ int64_t ncde_stage_record_bytes(const NcdeProblem* p) {
     rc = validate(p);
     if (rc != NCDE_OK) return rc;
     const int S = p->method == NCDE_RK4_38 ? 4 : (p->method == NCDE_MIDPOINT ? 2 : 1);
-    return (int64_t)sizeof(float) * (int64_t)(p->n_knots - 1) * S * (int64_t)p->batch * p->hidden;
+    const int n_steps = p->output == NCDE_OUT_TIMES ? p->n_steps_fwd : p->n_knots - 1;
+    return (int64_t)sizeof(float) * (int64_t)n_steps * S * (int64_t)p->batch * p->hidden;
 }
 
 const char* ncde_kernel_name(const NcdeProblem* p, int pass) {

@@ -47,7 +47,36 @@ struct KArgs {
     const float* Wr;
     const float* br;
     int gWg_off, gbg_off, gWr_off, gbr_off;
+    // general time axis (generic / variant families): host-built time plan (ncde_plan.h), NULL = default integer grid, step 1
+    const int* plan;
+    int n_steps_fwd, n_steps_adj;
 };
+
+// ---- time plan (built on the host by ncde_time_plan_build, csrc/ncde_timeplan.hip; layout in 4-byte words) -------------
+//   header  [8]                     : magic, S, n_fwd, n_adj, n_out, off_fwd, off_out, off_adj
+//   forward step  [3 + 3S] x n_fwd  : dt (f32), first output row emitted after the step, number of such rows,
+//                                     S x { piece index (i32), t - knot[idx] (f32), knot[idx+1] - knot[idx] (f32) }
+//   output  [2] x n_out             : kind (0 = the step's y0, 1 = its y1, 2 = y0 + slope (y1 - y0)), slope (f32)
+//   adjoint step [3 + 3S] x n_adj   : dt in negated time (f32), output row to reset to after the step (or -1), pad,
+//                                     S x stage descriptors at the REAL time of the stage
+#define NCDE_PLAN_MAGIC 0x4e43504c
+#define NCDE_PLAN_HEADER 8
+struct StageDesc {
+    int idx;
+    float frac;   // t - knot[idx]
+    float kdt;    // knot[idx + 1] - knot[idx]  (1 on the default grid)
+};
+__host__ __device__ __forceinline__ int plan_step_words(int S) { return 3 + 3 * S; }
+__host__ __device__ __forceinline__ int plan_off_fwd() { return NCDE_PLAN_HEADER; }
+__host__ __device__ __forceinline__ int plan_off_out(int S, int n_fwd) { return NCDE_PLAN_HEADER + n_fwd * plan_step_words(S); }
+__host__ __device__ __forceinline__ int plan_off_adj(int S, int n_fwd, int n_out) { return plan_off_out(S, n_fwd) + 2 * n_out; }
+__device__ __forceinline__ StageDesc plan_stage(const int* step, int j) {
+    StageDesc d;
+    d.idx = step[3 + 3 * j];
+    d.frac = __int_as_float(step[4 + 3 * j]);
+    d.kdt = __int_as_float(step[5 + 3 * j]);
+    return d;
+}
 
 __device__ __forceinline__ int ru4(int x) { return (x + 3) & ~3; }
 __device__ __forceinline__ int ru16(int x) { return (x + 15) & ~15; }
@@ -111,3 +140,54 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += __shfl_xor(v, 1, 64);
     return v;
 }
+
+struct StageCombine {
+    // Butcher bookkeeping on one state array set (Y0, K1, K2) given the fresh stage derivative k and the step dt, in the
+    // operation order of fixed_grid.py:6-29 / rk_common.py:106-114 (dt = 1 on the default grid: the products are exact).
+    // Returns the next stage input (or the new state after the last stage); `last` tells which.
+    __device__ static __forceinline__ float apply(int method, int j, float k, float dt, float& y0, float& k1, float& k2, bool& last) {
+        last = false;
+        if (method == NCDE_RK4_38) {
+            if (j == 0) { k1 = k; return y0 + (dt * k) * 0.333333343267440796f; }
+            if (j == 1) { k2 = k; return y0 + dt * (k - k1 * 0.333333343267440796f); }
+            if (j == 2) { const float ys = y0 + dt * ((k1 - k2) + k); k2 = k2 + k; return ys; }
+            last = true;
+            y0 = y0 + (((k1 + 3.0f * k2) + k) * dt) * 0.125f;
+            return y0;
+        }
+        if (method == NCDE_MIDPOINT) {
+            if (j == 0) return y0 + k * (0.5f * dt);
+            last = true;
+            y0 = y0 + dt * k;
+            return y0;
+        }
+        last = true;
+        y0 = y0 + dt * k;
+        return y0;
+    }
+};
+
+// stage descriptor of stage j of forward step n on the default integer grid with step 1
+__device__ __forceinline__ StageDesc default_stage(int method, float t, int n_pieces) {
+    StageDesc d;
+    d.idx = piece_index(t, n_pieces);
+    d.frac = t - (float)d.idx;
+    d.kdt = 1.0f;
+    return d;
+}
+
+// Exact discrete backward on a planned time axis: cotangent that the outputs emitted after forward step `pstep` send to
+// that step's y1 (part = 1) or y0 (part = 0) -- the transpose of the output pick / interpolation of solvers.py:108-116, 166-172.
+__device__ __forceinline__ float plan_out_cotangent(const KArgs& a, const int* pstep, const int* pout, int part, long long brow, int h) {
+    float acc = 0.0f;
+    const int q0 = pstep[1], q1 = q0 + pstep[2];
+    for (int q = q0; q < q1; ++q) {
+        const int kind = pout[2 * q];
+        const float slope = __int_as_float(pout[2 * q + 1]);
+        const float g = a.grad_out[(brow + q) * a.H + h];
+        if (part == 1) acc += kind == 1 ? g : (kind == 2 ? slope * g : 0.0f);
+        else acc += kind == 0 ? g : (kind == 2 ? g - slope * g : 0.0f);
+    }
+    return acc;
+}
+

@@ -24,7 +24,9 @@ namespace {
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // dX/dt(t) for the 16 samples of the tile -> DX[c*16 + s]  (rows c >= C and samples >= B are zero)
-__device__ void load_dx(const KArgs& a, int b0, int idx, float frac, float* DX, int Cp, int tid) {
+__device__ void load_dx(const KArgs& a, int b0, const StageDesc& sd, float* DX, int Cp, int tid) {
+    const int idx = sd.idx;
+    const float frac = sd.frac;
     for (int e = tid; e < 16 * Cp; e += GEN_THREADS) {
         const int s = e / Cp, c = e - s * Cp;
         const int b = b0 + s;
@@ -33,6 +35,7 @@ __device__ void load_dx(const KArgs& a, int b0, int idx, float frac, float* DX, 
             const float* p = a.coeffs + (long long)b * a.cs_b + (long long)idx * a.cs_t;
             if (a.interp == NCDE_INTERP_LINEAR) {
                 v = p[a.cs_t + c] - p[c];
+                if (sd.kdt != 1.0f) v = v / sd.kdt;   // user knot grid: (c[i+1]-c[i]) / (t[i+1]-t[i]), interpolation_linear.py:198
             } else {
                 const float bb = p[a.C + c], cc = p[2 * a.C + c], dd = p[3 * a.C + c];
                 const float inner = cc + dd * frac;
@@ -68,31 +71,6 @@ __device__ void dense_relu(const float* __restrict__ W, const float* __restrict_
         for (int r = 0; r < 4; ++r) out[(16 * t + 4 * lk + r) * 16 + li] = fmaxf(acc[r], 0.0f);
     }
 }
-
-struct StageCombine {
-    // Butcher bookkeeping on one state array set (Y0, K1, K2) given the fresh stage derivative k.
-    // Returns the next stage input (or the new state after the last stage); `last` tells which.
-    __device__ static __forceinline__ float apply(int method, int j, float k, float& y0, float& k1, float& k2, bool& last) {
-        last = false;
-        if (method == NCDE_RK4_38) {
-            if (j == 0) { k1 = k; return y0 + k * 0.333333343267440796f; }
-            if (j == 1) { k2 = k; return y0 + (k - k1 * 0.333333343267440796f); }
-            if (j == 2) { const float ys = y0 + ((k1 - k2) + k); k2 = k2 + k; return ys; }
-            last = true;
-            y0 = y0 + ((k1 + 3.0f * k2) + k) * 0.125f;
-            return y0;
-        }
-        if (method == NCDE_MIDPOINT) {
-            if (j == 0) return y0 + k * 0.5f;
-            last = true;
-            y0 = y0 + k;
-            return y0;
-        }
-        last = true;
-        y0 = y0 + k;
-        return y0;
-    }
-};
 
 }  // namespace
 
@@ -132,13 +110,17 @@ extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_fwd_generic(KArgs
     const int dlast = a.n_layers ? a.dout[a.n_layers - 1] : H;
     const int nks_o = (dlast + 3) >> 2, nhb = Hp >> 2, ncq = Cp >> 2;
     int cur_idx = -1;
-    for (int n = 0; n < a.T - 1; ++n) {
+    const bool planned = a.plan != nullptr;
+    const int n_steps = planned ? a.n_steps_fwd : a.T - 1;
+    const int* pout = planned ? a.plan + plan_off_out(S, a.n_steps_fwd) : nullptr;
+    for (int n = 0; n < n_steps; ++n) {
+        const int* pstep = planned ? a.plan + plan_off_fwd() + n * plan_step_words(S) : nullptr;
+        const float dt = planned ? __int_as_float(pstep[0]) : 1.0f;
         for (int j = 0; j < S; ++j) {
-            const float t = (float)n + stage_offset(a.method, j);
-            const int idx = piece_index(t, a.n_pieces);
-            if (a.interp != NCDE_INTERP_LINEAR || idx != cur_idx) {
-                load_dx(a, b0, idx, t - (float)idx, DX, Cp, tid);
-                cur_idx = idx;
+            const StageDesc sd = planned ? plan_stage(pstep, j) : default_stage(a.method, (float)n + stage_offset(a.method, j), a.n_pieces);
+            if (a.interp != NCDE_INTERP_LINEAR || sd.idx != cur_idx) {
+                load_dx(a, b0, sd, DX, Cp, tid);
+                cur_idx = sd.idx;
             }
             __syncthreads();
             if (a.stages) {  // record the stage input for the exact discrete backward
@@ -183,8 +165,9 @@ extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_fwd_generic(KArgs
             __syncthreads();
             for (int e = tid; e < HS; e += GEN_THREADS) {
                 float y0 = Y0[e], k1 = K1[e], k2 = K2[e];
+                const float yprev = y0;
                 bool last;
-                const float ys = StageCombine::apply(a.method, j, KO[e], y0, k1, k2, last);
+                const float ys = StageCombine::apply(a.method, j, KO[e], dt, y0, k1, k2, last);
                 YS[e] = ys;
                 K1[e] = k1;
                 K2[e] = k2;
@@ -192,7 +175,15 @@ extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_fwd_generic(KArgs
                     Y0[e] = y0;
                     const int h = e >> 4, s = e & 15, b = b0 + s;
                     if (h < H && b < a.B) {
-                        if (a.output == NCDE_OUT_KNOTS) a.out[((long long)b * a.n_out + (n + 1)) * H + h] = y0;
+                        if (planned) {   // outputs this step brackets: y1 itself at a grid hit, else linear interpolation (solvers.py:166-172)
+                            const int q0 = pstep[1], q1 = q0 + pstep[2];
+                            for (int q = q0; q < q1; ++q) {
+                                const int kind = pout[2 * q];
+                                const float slope = __int_as_float(pout[2 * q + 1]);
+                                const float v = kind == 1 ? y0 : (kind == 0 ? yprev : yprev + slope * (y0 - yprev));
+                                a.out[((long long)b * a.n_out + q) * H + h] = v;
+                            }
+                        } else if (a.output == NCDE_OUT_KNOTS) a.out[((long long)b * a.n_out + (n + 1)) * H + h] = y0;
                         else if (n == a.T - 2) a.out[((long long)b * a.n_out + 1) * H + h] = y0;
                     }
                 }
@@ -240,14 +231,22 @@ extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_adj_generic(KArgs
     const int last_row = a.n_out - 1;
     const int S = n_stages(a.method);
     const bool disc = a.discrete != 0;
+    const bool planned = a.plan != nullptr;
+    const int pw_ = plan_step_words(S);
+    const int* pfwd = planned ? a.plan + plan_off_fwd() : nullptr;
+    const int* pout = planned ? a.plan + plan_off_out(S, a.n_steps_fwd) : nullptr;
+    const int* padj = planned ? a.plan + plan_off_adj(S, a.n_steps_fwd, a.n_out) : nullptr;
+    const int n_rsteps = planned ? (disc ? a.n_steps_fwd : a.n_steps_adj) : a.T - 1;
     for (int e = tid; e < HS; e += GEN_THREADS) {
         const int h = e >> 4, s = e & 15, b = b0 + s;
         if (h < H && b < a.B) {
             const long long o = ((long long)b * a.n_out + last_row) * H + h;
-            const float g = a.grad_out[o];
+            float g = a.grad_out[o];
+            if (planned && disc) g = plan_out_cotangent(a, pfwd + (a.n_steps_fwd - 1) * pw_, pout, 1, (long long)b * a.n_out, h);
             A0[e] = g;
-            if (disc) {
-                AS[e] = a.method == NCDE_RK4_38 ? g * 0.125f : g;   // cotangent of the last stage's k
+            if (disc) {   // cotangent of the last stage's k: rk4 (a dt)/8, midpoint / euler dt a
+                const float dtl = planned ? __int_as_float(pfwd[(a.n_steps_fwd - 1) * pw_]) : 1.0f;
+                AS[e] = a.method == NCDE_RK4_38 ? (g * dtl) * 0.125f : dtl * g;
             } else {
                 const float y = a.z_out[o];
                 Y0[e] = y; YS[e] = y; AS[e] = g;
@@ -257,16 +256,24 @@ extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_adj_generic(KArgs
     const int dlast = L ? a.dout[L - 1] : H;
     const int nks_o = (dlast + 3) >> 2, nhb = Hp >> 2, ncq = Cp >> 2, njt = (dlast + 15) >> 4;
     float* sc = SC + wave * 16 * 17;
-    for (int n = a.T - 1; n >= 1; --n) {  // reverse step: knot n -> n-1, negated time s: -n -> -(n-1)
+    for (int rstep = 0; rstep < n_rsteps; ++rstep) {
+        // default grid: reverse step knot n -> n-1 (negated time s: -n -> -(n-1)); m = the forward step being transposed
+        const int n = a.T - 1 - rstep, m = n_rsteps - 1 - rstep;
+        const int* pstep = planned ? (disc ? pfwd + m * pw_ : padj + rstep * pw_) : nullptr;
+        const float dt = planned ? __int_as_float(pstep[0]) : 1.0f;
         for (int j = 0; j < S; ++j) {
-            const float s0 = -(float)n;
-            // discrete mode walks the stages of forward step n-1 -> n backwards, at their forward times
-            const float t = disc ? (float)(n - 1) + stage_offset(a.method, S - 1 - j) : -(s0 + stage_offset(a.method, j));
-            const int idx = piece_index(t, a.n_pieces);
-            const float w = disc ? 1.0f : stage_weight(a.method, j);
-            load_dx(a, b0, idx, t - (float)idx, DX, Cp, tid);
+            StageDesc sd;
+            if (planned) {
+                sd = plan_stage(pstep, disc ? S - 1 - j : j);
+            } else {
+                const float s0 = -(float)n;
+                // discrete mode walks the stages of forward step n-1 -> n backwards, at their forward times
+                sd = default_stage(a.method, disc ? (float)(n - 1) + stage_offset(a.method, S - 1 - j) : -(s0 + stage_offset(a.method, j)), a.n_pieces);
+            }
+            const float w = disc ? 1.0f : stage_weight(a.method, j) * dt;
+            load_dx(a, b0, sd, DX, Cp, tid);
             if (disc) {
-                const float* rec = a.stages + ((long long)((n - 1) * S + (S - 1 - j)) * a.B + b0) * H;
+                const float* rec = a.stages + ((long long)(m * S + (S - 1 - j)) * a.B + b0) * H;
                 for (int e = tid; e < 16 * H; e += GEN_THREADS) {
                     const int s = e / H, h = e - s * H;
                     YS[h * 16 + s] = b0 + s < a.B ? rec[e] : 0.0f;
@@ -431,20 +438,22 @@ extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_adj_generic(KArgs
             }
             if (disc) {
                 // ---- transpose of the Butcher step: KOA = dL/dY_stage; next cotangent / new a ----------------
-                // RK4 (3/8): c4 = a/8; c3 = 3 c4 + d4; c2 = 3 c4 - d4 + d3; c1 = c4 + d4 - d3/3 + d2/3; a += d4+d3+d2+d1
+                // RK4 (3/8): c4 = a dt/8; c3 = 3 c4 + dt d4; c2 = 3 c4 - dt d4 + dt d3; c1 = c4 + dt d4 - dt/3 d3 + dt/3 d2;
+                // a += d4+d3+d2+d1
                 for (int e = tid; e < HS; e += GEN_THREADS) {
                     const float d = KOA[e];
                     float a0 = A0[e];
                     bool last = false;
                     float next = 0.0f;
                     if (a.method == NCDE_RK4_38) {
-                        const float c4 = a0 * 0.125f;
-                        if (j == 0) { KA1[e] = d; next = 3.0f * c4 + d; }
-                        else if (j == 1) { KA2[e] = d; next = (3.0f * c4 - KA1[e]) + d; }
-                        else if (j == 2) { KY1[e] = d; next = ((c4 + KA1[e]) - 0.333333343267440796f * KA2[e]) + 0.333333343267440796f * d; }
+                        const float c4 = (a0 * dt) * 0.125f;
+                        const float dt3 = dt * 0.333333343267440796f;
+                        if (j == 0) { KA1[e] = d; next = 3.0f * c4 + dt * d; }
+                        else if (j == 1) { KA2[e] = d; next = (3.0f * c4 - dt * KA1[e]) + dt * d; }
+                        else if (j == 2) { KY1[e] = d; next = ((c4 + dt * KA1[e]) - dt3 * KA2[e]) + dt3 * d; }
                         else { a0 = (((a0 + KA1[e]) + KA2[e]) + KY1[e]) + d; last = true; }
                     } else if (a.method == NCDE_MIDPOINT) {
-                        if (j == 0) { KA1[e] = d; next = 0.5f * d; }
+                        if (j == 0) { KA1[e] = d; next = (0.5f * dt) * d; }
                         else { a0 = (a0 + KA1[e]) + d; last = true; }
                     } else {
                         a0 = a0 + d; last = true;
@@ -452,11 +461,21 @@ extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_adj_generic(KArgs
                     if (last) {
                         const int h = e >> 4, s = e & 15, b = b0 + s;
                         const bool valid = h < H && b < a.B;
-                        if (a.output == NCDE_OUT_KNOTS || n == 1)
+                        float dtp = 1.0f;   // dt of the forward step transposed next
+                        if (planned) {
+                            if (valid) {
+                                const long long brow = (long long)b * a.n_out;
+                                a0 = a0 + plan_out_cotangent(a, pstep, pout, 0, brow, h);
+                                if (m > 0) a0 = a0 + plan_out_cotangent(a, pstep - pw_, pout, 1, brow, h);
+                                else a0 = a0 + a.grad_out[brow * H + h];      // row 0 of the solution is z0 itself
+                            }
+                            if (m > 0) dtp = __int_as_float(pstep[-pw_]);
+                        } else if (a.output == NCDE_OUT_KNOTS || n == 1) {
                             a0 = a0 + (valid ? a.grad_out[((long long)b * a.n_out + (a.output == NCDE_OUT_KNOTS ? n - 1 : 0)) * H + h] : 0.0f);
+                        }
                         A0[e] = a0;
-                        next = a.method == NCDE_RK4_38 ? a0 * 0.125f : a0;
-                        if (n == 1 && valid) a.grad_z0[(long long)b * H + h] = a0;
+                        next = a.method == NCDE_RK4_38 ? (a0 * dtp) * 0.125f : dtp * a0;
+                        if (m == 0 && valid) a.grad_z0[(long long)b * H + h] = a0;
                     }
                     AS[e] = next;
                 }
@@ -467,17 +486,24 @@ extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_adj_generic(KArgs
             for (int e = tid; e < HS; e += GEN_THREADS) {
                 float y0 = Y0[e], k1 = KY1[e], k2 = KY2[e];
                 bool last;
-                const float ys = StageCombine::apply(a.method, j, -KOY[e], y0, k1, k2, last);
+                const float ys = StageCombine::apply(a.method, j, -KOY[e], dt, y0, k1, k2, last);
                 YS[e] = ys; KY1[e] = k1; KY2[e] = k2;
                 float a0 = A0[e], q1 = KA1[e], q2 = KA2[e];
-                const float as = StageCombine::apply(a.method, j, KOA[e], a0, q1, q2, last);
+                const float as = StageCombine::apply(a.method, j, KOA[e], dt, a0, q1, q2, last);
                 KA1[e] = q1; KA2[e] = q2;
                 if (!last) {
                     AS[e] = as;
                 } else {
                     const int h = e >> 4, s = e & 15, b = b0 + s;
                     const bool valid = h < H && b < a.B;
-                    if (a.output == NCDE_OUT_KNOTS) {  // reset y to the stored value, add dL/dz at this knot
+                    if (planned) {   // end of one reverse solve t[i] -> t[i-1]: reset y to the stored z(t[i-1]), a += dL/dz(t[i-1])
+                        const int row = pstep[1];
+                        if (row >= 0) {
+                            const long long o = ((long long)b * a.n_out + row) * H + h;
+                            y0 = valid ? a.z_out[o] : 0.0f;
+                            a0 = a0 + (valid ? a.grad_out[o] : 0.0f);
+                        }
+                    } else if (a.output == NCDE_OUT_KNOTS) {  // reset y to the stored value, add dL/dz at this knot
                         const long long o = ((long long)b * a.n_out + (n - 1)) * H + h;
                         y0 = valid ? a.z_out[o] : 0.0f;
                         a0 = a0 + (valid ? a.grad_out[o] : 0.0f);
@@ -485,7 +511,7 @@ extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_adj_generic(KArgs
                         a0 = a0 + (valid ? a.grad_out[((long long)b * a.n_out) * H + h] : 0.0f);
                     }
                     Y0[e] = y0; YS[e] = y0; A0[e] = a0; AS[e] = a0;
-                    if (n == 1 && valid) a.grad_z0[(long long)b * H + h] = a0;
+                    if (rstep == n_rsteps - 1 && valid) a.grad_z0[(long long)b * H + h] = a0;
                 }
             }
             __syncthreads();

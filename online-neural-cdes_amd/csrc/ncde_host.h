@@ -84,7 +84,12 @@ inline void fill_kargs(const NcdeProblem* p, const Layout& y, KArgs* a) {
     a->B = p->batch; a->T = p->n_knots; a->C = p->channels; a->H = p->hidden;
     a->interp = p->interp; a->method = p->method; a->output = p->output; a->n_layers = p->n_layers;
     a->n_pieces = p->n_knots - 1;
-    a->n_out = p->output == NCDE_OUT_KNOTS ? p->n_knots : 2;
+    a->n_out = p->output == NCDE_OUT_TIMES ? p->n_t_out : (p->output == NCDE_OUT_KNOTS ? p->n_knots : 2);
+    if (p->output == NCDE_OUT_TIMES) {
+        a->plan = (const int*)p->time_plan;
+        a->n_steps_fwd = p->n_steps_fwd;
+        a->n_steps_adj = p->n_steps_adj;
+    }
     for (int l = 0; l < p->n_layers; ++l) {
         a->din[l] = p->layer_in[l]; a->dout[l] = p->layer_out[l];
         a->W[l] = p->layer_W[l]; a->b[l] = p->layer_b[l];

@@ -27,7 +27,9 @@ __device__ __forceinline__ float sigmoid_dev(float x) {
 // control input of the stage for the 16 samples of the tile -> CIN[c*16 + s]:
 // value = false: dX/dt(t) (interpolation_linear.py:231-234, interpolation_cubic.py:331-336)
 // value = true : X(t)     (interpolation_linear.py:221-229, interpolation_cubic.py:324-329)
-__device__ void vr_load_cin(const KArgs& a, int b0, int idx, float frac, bool value, float* CIN, int Cp, int tid) {
+__device__ void vr_load_cin(const KArgs& a, int b0, const StageDesc& sd, bool value, float* CIN, int Cp, int tid) {
+    const int idx = sd.idx;
+    const float frac = sd.frac, kdt = sd.kdt;
     for (int e = tid; e < 16 * Cp; e += VR_THREADS) {
         const int s = e / Cp, c = e - s * Cp;
         const int b = b0 + s;
@@ -36,7 +38,7 @@ __device__ void vr_load_cin(const KArgs& a, int b0, int idx, float frac, bool va
             const float* p = a.coeffs + (long long)b * a.cs_b + (long long)idx * a.cs_t;
             if (a.interp == NCDE_INTERP_LINEAR) {
                 const float d = p[a.cs_t + c] - p[c];
-                v = value ? p[c] + (frac * d) / 1.0f : d;
+                v = value ? p[c] + (frac * d) / kdt : (kdt != 1.0f ? d / kdt : d);
             } else {
                 const float aa = p[c], bb = p[a.C + c], cc = p[2 * a.C + c], dd = p[3 * a.C + c];
                 if (value) {
@@ -146,29 +148,6 @@ __device__ __forceinline__ f32x4 vr_head_gemm(const float* __restrict__ W, const
     return acc;
 }
 
-struct StageCombineV {
-    __device__ static __forceinline__ float apply(int method, int j, float k, float& y0, float& k1, float& k2, bool& last) {
-        last = false;
-        if (method == NCDE_RK4_38) {
-            if (j == 0) { k1 = k; return y0 + k * 0.333333343267440796f; }
-            if (j == 1) { k2 = k; return y0 + (k - k1 * 0.333333343267440796f); }
-            if (j == 2) { const float ys = y0 + ((k1 - k2) + k); k2 = k2 + k; return ys; }
-            last = true;
-            y0 = y0 + ((k1 + 3.0f * k2) + k) * 0.125f;
-            return y0;
-        }
-        if (method == NCDE_MIDPOINT) {
-            if (j == 0) return y0 + k * 0.5f;
-            last = true;
-            y0 = y0 + k;
-            return y0;
-        }
-        last = true;
-        y0 = y0 + k;
-        return y0;
-    }
-};
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -209,11 +188,15 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_fwd_variant(KArgs 
     const int S = n_stages(a.method);
     const int dlast = L ? a.dout[L - 1] : d0;
     const int ncq = Cp >> 2, ngrp = matmul ? (Hp >> 2) : (Hp >> 4), per_grp = matmul ? ncq : 1;
-    for (int n = 0; n < a.T - 1; ++n) {
+    const bool planned = a.plan != nullptr;
+    const int n_steps = planned ? a.n_steps_fwd : a.T - 1;
+    const int* pout = planned ? a.plan + plan_off_out(S, a.n_steps_fwd) : nullptr;
+    for (int n = 0; n < n_steps; ++n) {
+        const int* pstep = planned ? a.plan + plan_off_fwd() + n * plan_step_words(S) : nullptr;
+        const float dt = planned ? __int_as_float(pstep[0]) : 1.0f;
         for (int j = 0; j < S; ++j) {
-            const float t = (float)n + stage_offset(a.method, j);
-            const int idx = piece_index(t, a.n_pieces);
-            vr_load_cin(a, b0, idx, t - (float)idx, a.field_input == NCDE_INPUT_EVALUATE, CIN, Cp, tid);
+            const StageDesc sd = planned ? plan_stage(pstep, j) : default_stage(a.method, (float)n + stage_offset(a.method, j), a.n_pieces);
+            vr_load_cin(a, b0, sd, a.field_input == NCDE_INPUT_EVALUATE, CIN, Cp, tid);
             __syncthreads();
             if (!matmul)
                 for (int e = tid; e < C * 16; e += VR_THREADS) U[H * 16 + e] = CIN[e];
@@ -256,8 +239,9 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_fwd_variant(KArgs 
             __syncthreads();
             for (int e = tid; e < HS; e += VR_THREADS) {
                 float y0 = Y0[e], k1 = K1[e], k2 = K2[e];
+                const float yprev = y0;
                 bool last;
-                const float ys = StageCombineV::apply(a.method, j, KO[e], y0, k1, k2, last);
+                const float ys = StageCombine::apply(a.method, j, KO[e], dt, y0, k1, k2, last);
                 U[e] = ys;
                 K1[e] = k1;
                 K2[e] = k2;
@@ -265,7 +249,14 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_fwd_variant(KArgs 
                     Y0[e] = y0;
                     const int h = e >> 4, s = e & 15, b = b0 + s;
                     if (h < H && b < a.B) {
-                        if (a.output == NCDE_OUT_KNOTS) a.out[((long long)b * a.n_out + (n + 1)) * H + h] = y0;
+                        if (planned) {
+                            const int q0 = pstep[1], q1 = q0 + pstep[2];
+                            for (int q = q0; q < q1; ++q) {
+                                const int kind = pout[2 * q];
+                                const float slope = __int_as_float(pout[2 * q + 1]);
+                                a.out[((long long)b * a.n_out + q) * H + h] = kind == 1 ? y0 : (kind == 0 ? yprev : yprev + slope * (y0 - yprev));
+                            }
+                        } else if (a.output == NCDE_OUT_KNOTS) a.out[((long long)b * a.n_out + (n + 1)) * H + h] = y0;
                         else if (n == a.T - 2) a.out[((long long)b * a.n_out + 1) * H + h] = y0;
                     }
                 }
@@ -372,14 +363,22 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
     const int last_row = a.n_out - 1;
     const int S = n_stages(a.method);
     const bool disc = a.discrete != 0;
+    const bool planned = a.plan != nullptr;
+    const int pw_ = plan_step_words(S);
+    const int* pfwd = planned ? a.plan + plan_off_fwd() : nullptr;
+    const int* pout = planned ? a.plan + plan_off_out(S, a.n_steps_fwd) : nullptr;
+    const int* padj = planned ? a.plan + plan_off_adj(S, a.n_steps_fwd, a.n_out) : nullptr;
+    const int n_rsteps = planned ? (disc ? a.n_steps_fwd : a.n_steps_adj) : a.T - 1;
     for (int e = tid; e < HS; e += VR_THREADS) {
         const int h = e >> 4, s = e & 15, b = b0 + s;
         if (h < H && b < a.B) {
             const long long o = ((long long)b * a.n_out + last_row) * H + h;
-            const float g = a.grad_out[o];
+            float g = a.grad_out[o];
+            if (planned && disc) g = plan_out_cotangent(a, pfwd + (a.n_steps_fwd - 1) * pw_, pout, 1, (long long)b * a.n_out, h);
             A0[e] = g;
             if (disc) {
-                AS[e] = a.method == NCDE_RK4_38 ? g * 0.125f : g;
+                const float dtl = planned ? __int_as_float(pfwd[(a.n_steps_fwd - 1) * pw_]) : 1.0f;
+                AS[e] = a.method == NCDE_RK4_38 ? (g * dtl) * 0.125f : dtl * g;
             } else {
                 const float y = a.z_out[o];
                 Y0[e] = y; U[e] = y; AS[e] = g;
@@ -390,14 +389,18 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
     const int ncq = Cp >> 2, ngrp = matmul ? (Hp >> 2) : (Hp >> 4), per_grp = matmul ? ncq : 1;
     const int njt = (dlast + 15) >> 4;
     float* sc = SC + wave * 16 * 17;
-    for (int n = a.T - 1; n >= 1; --n) {
+    for (int rstep = 0; rstep < n_rsteps; ++rstep) {
+        const int n = a.T - 1 - rstep, m = n_rsteps - 1 - rstep;   // default grid: reverse step n -> n-1; m = forward step transposed
+        const int* pstep = planned ? (disc ? pfwd + m * pw_ : padj + rstep * pw_) : nullptr;
+        const float dt = planned ? __int_as_float(pstep[0]) : 1.0f;
         for (int j = 0; j < S; ++j) {
-            const float t = disc ? (float)(n - 1) + stage_offset(a.method, S - 1 - j) : -(-(float)n + stage_offset(a.method, j));
-            const int idx = piece_index(t, a.n_pieces);
-            const float w = disc ? 1.0f : stage_weight(a.method, j);
-            vr_load_cin(a, b0, idx, t - (float)idx, a.field_input == NCDE_INPUT_EVALUATE, CIN, Cp, tid);
+            StageDesc sd;
+            if (planned) sd = plan_stage(pstep, disc ? S - 1 - j : j);
+            else sd = default_stage(a.method, disc ? (float)(n - 1) + stage_offset(a.method, S - 1 - j) : -(-(float)n + stage_offset(a.method, j)), a.n_pieces);
+            const float w = disc ? 1.0f : stage_weight(a.method, j) * dt;
+            vr_load_cin(a, b0, sd, a.field_input == NCDE_INPUT_EVALUATE, CIN, Cp, tid);
             if (disc) {
-                const float* rec = a.stages + ((long long)((n - 1) * S + (S - 1 - j)) * a.B + b0) * H;
+                const float* rec = a.stages + ((long long)(m * S + (S - 1 - j)) * a.B + b0) * H;
                 for (int e = tid; e < 16 * H; e += VR_THREADS) {
                     const int s = e / H, h = e - s * H;
                     U[h * 16 + s] = b0 + s < a.B ? rec[e] : 0.0f;
@@ -556,37 +559,55 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
                     bool last = false;
                     float next = 0.0f;
                     if (a.method == NCDE_RK4_38) {
-                        const float c4 = a0 * 0.125f;
-                        if (j == 0) { KA1[e] = d; next = 3.0f * c4 + d; }
-                        else if (j == 1) { KA2[e] = d; next = (3.0f * c4 - KA1[e]) + d; }
-                        else if (j == 2) { KY1[e] = d; next = ((c4 + KA1[e]) - 0.333333343267440796f * KA2[e]) + 0.333333343267440796f * d; }
+                        const float c4 = (a0 * dt) * 0.125f;
+                        const float dt3 = dt * 0.333333343267440796f;
+                        if (j == 0) { KA1[e] = d; next = 3.0f * c4 + dt * d; }
+                        else if (j == 1) { KA2[e] = d; next = (3.0f * c4 - dt * KA1[e]) + dt * d; }
+                        else if (j == 2) { KY1[e] = d; next = ((c4 + dt * KA1[e]) - dt3 * KA2[e]) + dt3 * d; }
                         else { a0 = (((a0 + KA1[e]) + KA2[e]) + KY1[e]) + d; last = true; }
                     } else if (a.method == NCDE_MIDPOINT) {
-                        if (j == 0) { KA1[e] = d; next = 0.5f * d; }
+                        if (j == 0) { KA1[e] = d; next = (0.5f * dt) * d; }
                         else { a0 = (a0 + KA1[e]) + d; last = true; }
                     } else {
                         a0 = a0 + d; last = true;
                     }
                     if (last) {
-                        if (a.output == NCDE_OUT_KNOTS || n == 1)
+                        float dtp = 1.0f;
+                        if (planned) {
+                            if (valid) {
+                                const long long brow = (long long)b * a.n_out;
+                                a0 = a0 + plan_out_cotangent(a, pstep, pout, 0, brow, h);
+                                if (m > 0) a0 = a0 + plan_out_cotangent(a, pstep - pw_, pout, 1, brow, h);
+                                else a0 = a0 + a.grad_out[brow * H + h];
+                            }
+                            if (m > 0) dtp = __int_as_float(pstep[-pw_]);
+                        } else if (a.output == NCDE_OUT_KNOTS || n == 1) {
                             a0 = a0 + (valid ? a.grad_out[((long long)b * a.n_out + (a.output == NCDE_OUT_KNOTS ? n - 1 : 0)) * H + h] : 0.0f);
+                        }
                         A0[e] = a0;
-                        next = a.method == NCDE_RK4_38 ? a0 * 0.125f : a0;
-                        if (n == 1 && valid) a.grad_z0[(long long)b * H + h] = a0;
+                        next = a.method == NCDE_RK4_38 ? (a0 * dtp) * 0.125f : dtp * a0;
+                        if (m == 0 && valid) a.grad_z0[(long long)b * H + h] = a0;
                     }
                     AS[e] = next;
                 } else {
                     float y0 = Y0[e], k1 = KY1[e], k2 = KY2[e];
                     bool last;
-                    const float ys = StageCombineV::apply(a.method, j, -KOY[e], y0, k1, k2, last);
+                    const float ys = StageCombine::apply(a.method, j, -KOY[e], dt, y0, k1, k2, last);
                     U[e] = ys; KY1[e] = k1; KY2[e] = k2;
                     float a0 = A0[e], q1 = KA1[e], q2 = KA2[e];
-                    const float as = StageCombineV::apply(a.method, j, d, a0, q1, q2, last);
+                    const float as = StageCombine::apply(a.method, j, d, dt, a0, q1, q2, last);
                     KA1[e] = q1; KA2[e] = q2;
                     if (!last) {
                         AS[e] = as;
                     } else {
-                        if (a.output == NCDE_OUT_KNOTS) {
+                        if (planned) {
+                            const int row = pstep[1];
+                            if (row >= 0) {
+                                const long long o = ((long long)b * a.n_out + row) * H + h;
+                                y0 = valid ? a.z_out[o] : 0.0f;
+                                a0 = a0 + (valid ? a.grad_out[o] : 0.0f);
+                            }
+                        } else if (a.output == NCDE_OUT_KNOTS) {
                             const long long o = ((long long)b * a.n_out + (n - 1)) * H + h;
                             y0 = valid ? a.z_out[o] : 0.0f;
                             a0 = a0 + (valid ? a.grad_out[o] : 0.0f);
@@ -594,7 +615,7 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
                             a0 = a0 + (valid ? a.grad_out[((long long)b * a.n_out) * H + h] : 0.0f);
                         }
                         Y0[e] = y0; U[e] = y0; A0[e] = a0; AS[e] = a0;
-                        if (n == 1 && valid) a.grad_z0[(long long)b * H + h] = a0;
+                        if (rstep == n_rsteps - 1 && valid) a.grad_z0[(long long)b * H + h] = a0;
                     }
                 }
             }

@@ -9,6 +9,7 @@ outside the fused path raises NotImplementedError naming the reason.
 import ctypes
 import warnings
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -65,14 +66,51 @@ def _time_mode(X, t):
     assert tv.dim() == 1, "t must be one dimensional"
     assert (tv[1:] > tv[:-1]).all(), "t must be strictly increasing or decreasing"  # misc.py:336-343
     n = X.n_knots
-    if tv.numel() == n and torch.equal(tv, torch.arange(n, dtype=torch.double)):
-        return _lib.OUT_KNOTS
-    if tv.numel() == 2 and tv[0] == 0 and tv[1] == n - 1:
-        return _lib.OUT_INTERVAL
-    raise NotImplementedError("cdeint: t must be X.interval or X.grid_points on the fused path")
+    if X._default_grid:
+        if tv.numel() == n and torch.equal(tv, torch.arange(n, dtype=torch.double)):
+            return _lib.OUT_KNOTS
+        if tv.numel() == 2 and tv[0] == 0 and tv[1] == n - 1:
+            return _lib.OUT_INTERVAL
+    return None     # any other increasing t: the general time axis (time plan)
 
 
-def build_problem(coeffs, interp, z0, spec, method, output, flags=0):
+_PLAN_CACHE = {}    # (method, step, t bytes, t dtype, knot bytes, n_knots, device) -> (device plan, info)
+
+
+def _time_plan(X, t, method, step, device):
+    """Build (once per distinct time axis) the table the plan-driven kernels walk: ncde_time_plan_build evaluates the
+    reference's grid / stage-time / knot-index arithmetic on the host (solvers.py:78-87, 103-117; one device sync for t)."""
+    tt = torch.as_tensor(t).detach()
+    f64 = tt.dtype == torch.float64
+    tv = np.ascontiguousarray(tt.cpu().double().numpy())
+    kn = None if X._default_grid else np.ascontiguousarray(X._t.detach().cpu().double().numpy())
+    key = (method, float(step), tv.tobytes(), f64, None if kn is None else kn.tobytes(), X.n_knots, str(device))
+    hit = _PLAN_CACHE.get(key)
+    if hit is not None:
+        return hit
+    p = _lib.NcdeProblem()
+    p.abi_version, p.n_knots, p.method = _lib.NCDE_ABI_VERSION, X.n_knots, _lib.METHOD[method]
+    dp = ctypes.POINTER(ctypes.c_double)
+    ts = _lib.NcdeTimeSpec(n_t=len(tv), time_is_f64=int(f64), t=tv.ctypes.data_as(dp), step_size=float(step),
+                           knots=None if kn is None else kn.ctypes.data_as(dp))
+    info = _lib.NcdeTimePlanInfo()
+    lib = _lib.lib()
+    rc = lib.ncde_time_plan_build(ctypes.byref(p), ctypes.byref(ts), None, 0, ctypes.byref(info))
+    if rc == -1:
+        raise AssertionError(lib.ncde_last_error_string().decode())       # misc.py:336-343 asserts on a non-monotone t
+    _lib.check(rc, "ncde_time_plan_build")
+    buf = np.zeros(info.bytes // 4, dtype=np.int32)
+    _lib.check(lib.ncde_time_plan_build(ctypes.byref(p), ctypes.byref(ts), buf.ctypes.data, buf.nbytes, ctypes.byref(info)),
+               "ncde_time_plan_build")
+    plan = torch.from_numpy(buf).to(device)
+    hit = (plan, (info.n_t_out, info.n_steps_fwd, info.n_steps_adj))
+    if len(_PLAN_CACHE) > 64:
+        _PLAN_CACHE.clear()
+    _PLAN_CACHE[key] = hit
+    return hit
+
+
+def build_problem(coeffs, interp, z0, spec, method, output, flags=0, plan=None):
     """Fill an NcdeProblem from torch tensors (all must stay alive while the call is in flight)."""
     p = _lib.NcdeProblem()
     p.abi_version = _lib.NCDE_ABI_VERSION
@@ -110,6 +148,10 @@ def build_problem(coeffs, interp, z0, spec, method, output, flags=0):
     p.coeffs = coeffs.data_ptr()
     p.coeffs_stride_b, p.coeffs_stride_t = coeffs.stride(0), coeffs.stride(1)
     p.z0 = z0.data_ptr()
+    if plan is not None:          # general time axis: (device table, (n_t_out, n_steps_fwd, n_steps_adj))
+        p.output = _lib.OUT_TIMES
+        p.time_plan = plan[0].data_ptr()
+        p.n_t_out, p.n_steps_fwd, p.n_steps_adj = plan[1]
     return p
 
 
@@ -137,8 +179,11 @@ class _FusedCdeint(torch.autograd.Function):
     def forward(ctx, z0, coeffs, cfg, *params):
         spec = cfg["spec"]
         z0c = z0.detach().contiguous()
-        p = build_problem(coeffs, cfg["interp"], z0c, spec, cfg["method"], cfg["output"], cfg["flags"])
-        n_out = coeffs.shape[1] + (1 if cfg["interp"] == "cubic" else 0) if cfg["output"] == _lib.OUT_KNOTS else 2
+        p = build_problem(coeffs, cfg["interp"], z0c, spec, cfg["method"], cfg["output"], cfg["flags"], cfg["plan"])
+        if cfg["plan"] is not None:
+            n_out = cfg["plan"][1][0]
+        else:
+            n_out = coeffs.shape[1] + (1 if cfg["interp"] == "cubic" else 0) if cfg["output"] == _lib.OUT_KNOTS else 2
         out = torch.empty(z0.shape[0], n_out, z0.shape[1], dtype=torch.float32, device=z0.device)
         record = (not cfg["adjoint"]) and any(ctx.needs_input_grad)
         stages = None
@@ -174,7 +219,7 @@ class _FusedCdeint(torch.autograd.Function):
         dev = out.device
         grad_out = grad_out.contiguous().float()
         z0 = out[:, 0]     # only its shape matters here: the backward kernels never read z0 (row 0 of `out` is a valid pointer)
-        p = build_problem(coeffs, cfg["interp"], z0, spec, cfg["method"], cfg["output"], cfg["flags"])
+        p = build_problem(coeffs, cfg["interp"], z0, spec, cfg["method"], cfg["output"], cfg["flags"], cfg["plan"])
         uniq = spec.unique_params()
         gbuf = {id(q): torch.empty_like(q, memory_format=torch.contiguous_format) for q in uniq}
         g = _lib.NcdeGrads()
@@ -198,7 +243,7 @@ class _FusedCdeint(torch.autograd.Function):
                                              ws.data_ptr(), ws.numel(), _stream_ptr())
         _lib.check(rc, "ncde_backward" if ctx.recorded else "ncde_adjoint")
         if not ctx.recorded and cfg["func"] is not None and hasattr(cfg["func"], "nfe"):
-            cfg["func"].nfe += cfg["nfe_per_solve"]   # the adjoint sweep re-evaluates f (base.py:90); autograd does not
+            cfg["func"].nfe += cfg["nfe_adjoint"]   # the adjoint sweep re-evaluates f (base.py:90); autograd does not
         grads = []
         keep = cfg["adjoint_param_ids"]     # adjoint_params of odeint_adjoint (adjoint.py:176-183): others get no gradient
         for q, needs in zip(params, ctx.needs_input_grad[3:]):
@@ -209,10 +254,11 @@ class _FusedCdeint(torch.autograd.Function):
 def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
     r"""Solve ``z_t = z_{t_0} + \int f(z_s) dX_s``; returns ``[batch, len(t), hidden]`` like the reference.
 
-    Same arguments as ``torchcde.cdeint`` (solver.py:140).  Fused path requirements: X a
-    LinearInterpolation / NaturalCubicSpline on its default integer grid, ``func`` exposing
-    ``fused_spec()``, ``method`` in {euler, midpoint, rk4} with ``options={'step_size': 1}``,
-    ``vector_field_type='matmul'``, fp32 CUDA tensors, ``t`` = X.interval or X.grid_points.
+    Same arguments as ``torchcde.cdeint`` (solver.py:140).  Requirements: X a LinearInterpolation /
+    NaturalCubicSpline (default integer grid or a user knot grid), ``func`` exposing ``fused_spec()``, ``method`` in
+    {euler, midpoint, rk4} with ``options={'step_size': h}``, fp32 CUDA tensors, ``t`` any increasing times.
+    The reference's NeuralCDE setting -- default grid, step 1, t = X.interval or X.grid_points -- runs on the
+    shape-specialised / batch-tiled kernels; any other time axis on the plan-driven generic kernels.
     """
     if vector_field_type not in ("matmul", "evaluate", "derivative"):
         raise ValueError("vector_field_type string not recognised")
@@ -233,19 +279,25 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
         raise NotImplementedError("method '%s': only the fixed-step solvers %s run on the fused path" % (method, _FIXED_METHODS))
     if not isinstance(X, (LinearInterpolation, NaturalCubicSpline)):
         raise NotImplementedError("X must be ncde_amd.LinearInterpolation or ncde_amd.NaturalCubicSpline")
-    if not X._default_grid:
-        raise NotImplementedError("controls with a user-supplied knot grid t are outside the fused path")
     step = options.pop("step_size", None)
-    if step is None or float(step) != 1.0:
-        raise NotImplementedError("options={'step_size': 1} is required (the reference's NeuralCDE setting, ncde.py:130-134)")
+    if "grid_constructor" in options:
+        raise NotImplementedError("options['grid_constructor'] is outside the fused path; give options={'step_size': h}")
+    if step is None:
+        raise NotImplementedError("options={'step_size': h} is required on the fused path (without it torchdiffeq steps "
+                                  "from output time to output time, solvers.py:69-71)")
+    if torch.is_tensor(step):
+        step = step.item()
+    if not float(step) > 0.0:
+        raise ValueError("step_size must be positive")
     if options.pop("perturb", False):
         warnings.warn("cdeint: options['perturb'] is ignored by the fused fixed-step kernels (stage times are exact knots/fractions)")
     for k in options:
         warnings.warn("cdeint: Unexpected arguments {}".format({k: options[k]}))
     if not torch.is_tensor(z0):
         raise NotImplementedError("tuple-valued z0 is outside the fused path")
-    if z0.dim() != 2:
-        raise NotImplementedError("z0 must be [batch, hidden]")
+    batch_shape = z0.shape[:-1]          # any number of batch dimensions, as the reference allows (flattened for the kernels)
+    if z0.dim() < 1:
+        raise ValueError("z0 must have a hidden dimension")
     ap = set(id(q) for q in adjoint_params) if adjoint_params is not None else None
     for buffer in X.buffers():
         if not buffer.requires_grad:
@@ -259,10 +311,13 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
             raise NotImplementedError("cdeint: gradients with respect to the control path's coefficients are not "
                                       "implemented on the fused path; detach() the coefficients")
     coeffs = X.fused_coeffs
-    if coeffs.dim() != 3:
-        raise NotImplementedError("coeffs must be [batch, time, channels]")
+    if coeffs.dim() < 2 or tuple(coeffs.shape[:-2]) != tuple(batch_shape):
+        raise ValueError("batch dimensions of X %s != batch dimensions of z0 %s" % (tuple(coeffs.shape[:-2]), tuple(batch_shape)))
     _check_tensor(z0, "z0")
     _check_tensor(coeffs, "coeffs")
+    if len(batch_shape) != 1:
+        z0 = z0.reshape(-1, z0.shape[-1])
+        coeffs = coeffs.reshape(-1, coeffs.shape[-2], coeffs.shape[-1])
     if coeffs.stride(2) != 1:
         coeffs = coeffs.contiguous()
     if coeffs.shape[0] != z0.shape[0]:
@@ -279,12 +334,22 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
         ap = ap & set(id(q) for q in uniq)
     else:
         ap = None
-    output = _time_mode(X, t)
+    output = _time_mode(X, t) if float(step) == 1.0 else None
     stages = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
-    nfe = stages * (X.n_knots - 1)
-    cfg = {"spec": spec, "interp": X.interp_name, "method": method, "output": output, "flags": flags,
-           "adjoint": bool(adjoint), "func": func, "nfe_per_solve": nfe, "adjoint_param_ids": ap}
+    plan = None
+    if output is None:
+        tq = torch.as_tensor(t)
+        assert tq.dim() == 1, "t must be one dimensional"
+        plan = _time_plan(X, tq, method, step, z0.device)
+        output = _lib.OUT_TIMES
+        nfe, nfe_adj = stages * plan[1][1], stages * plan[1][2]
+    else:
+        nfe = nfe_adj = stages * (X.n_knots - 1)
+    cfg = {"spec": spec, "interp": X.interp_name, "method": method, "output": output, "flags": flags, "plan": plan,
+           "adjoint": bool(adjoint), "func": func, "nfe_per_solve": nfe, "nfe_adjoint": nfe_adj, "adjoint_param_ids": ap}
     out = _FusedCdeint.apply(z0, coeffs.detach(), cfg, *uniq)
     if hasattr(func, "nfe"):
         func.nfe += nfe
+    if len(batch_shape) != 1:
+        out = out.reshape(*batch_shape, out.shape[-2], out.shape[-1])
     return out

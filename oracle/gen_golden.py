@@ -274,7 +274,86 @@ def gen_g8():
                         x_clean=xc, cubic=cub_ref, cubic_len2=cub2_ref, cubic_missing=cubm_ref)
 
 
+def gen_g11():
+    """The rest of the cdeint call surface: arbitrary increasing output times (linearly interpolated
+    between grid states, solvers.py:103-117, 166-172), step_size != 1 (solvers.py:78-87), user knot grids
+    (interpolation_linear.py:186-202, interpolation_cubic.py:283-305).  adjoint=True and adjoint=False gradients."""
+    report = []
+    B, L, C, H, HH, nl = 10, 9, 5, 16, 24, 3
+    p = data.make_field_weights(H, HH, C, seed=6)
+    rw = data.make_readin_weights(H, C, 1, seed=6)
+    names = ["W0", "b0", "W1", "b1", "Wo", "bo"]
+    x = data.synthetic_series(B, L, C - 1, missing=0.0, seed=61)
+    knots = np.cumsum(0.4 + 1.2 * data.uniform01(7, L, stream=9)).astype(np.float32)      # irregular, increasing
+    knots -= knots[0] - np.float32(0.25)
+    cases = [
+        # name, interp, knots (None = default grid), method, step_size, output times
+        ("g11_times_rk4_half", "linear", None, "rk4", 0.5, np.array([0.3, 1.0, 2.75, 3.1, 6.5, 7.0], np.float32)),
+        ("g11_times_midpoint_third", "cubic", None, "midpoint", 1.0 / 3.0, np.array([0.0, 2.2, 5.0, 8.0], np.float32)),
+        ("g11_knots_rk4", "linear", knots, "rk4", 0.7, np.array([knots[0], knots[3], 0.5 * (knots[4] + knots[5]), knots[-1]], np.float32)),
+        ("g11_knots_cubic_euler", "cubic", knots, "euler", 0.25, knots.copy()),
+        ("g11_knots_interval_rk4", "cubic", knots, "rk4", 1.0, np.array([knots[0], knots[-1]], np.float32)),
+        # fp64 output times with an fp32 state: the grid arithmetic runs in fp64, the control path sees fp32 stage times
+        ("g11_times_f64_rk4", "linear", None, "rk4", 0.3, np.array([0.1, 0.7, 2.3, 5.9, 7.25], np.float64)),
+    ]
+    for name, interp, kn, method, step, tout in cases:
+        xt = torch.from_numpy(x)
+        tk = None if kn is None else torch.from_numpy(kn)
+        if interp == "linear":
+            coeffs = torchcde.linear_interpolation_coeffs(xt, t=tk)
+            X = torchcde.LinearInterpolation(coeffs, t=tk)
+        else:
+            coeffs = torchcde.natural_cubic_coeffs(xt, t=tk)
+            X = torchcde.NaturalCubicSpline(coeffs, t=tk)
+        coeffs_np = coeffs.numpy().copy()
+        z0 = z0_from(x[:, 0], rw)
+        func = ref_field_original(p, C, H, HH, nl)
+        ofield = orc.Field.original(p, H, C, nl)
+        t = torch.from_numpy(tout)
+        gout = grad_out_like((B, len(tout), H), seed=13)
+        res = {}
+        for adj in (True, False):
+            z0t = torch.from_numpy(z0).clone().requires_grad_(True)
+            for q in func.parameters():
+                q.grad = None
+            func.nfe = 0
+            out = torchcde.cdeint(X, func, z0t, t, adjoint=adj, method=method, options={"step_size": step})
+            (out * torch.from_numpy(gout)).sum().backward()
+            res[adj] = (out.detach(), z0t.grad.detach(), [q.grad.detach().clone() for q in func.parameters()], func.nfe)
+        ctl = orc.Control(coeffs_np, interp, t=kn)
+        nfe = [0]
+        z_or = orc.solve_forward_times(ctl, ofield, z0, tout, method, step, nfe=nfe)
+        dz0_or, gp_or = orc.solve_adjoint_times(ctl, ofield, tout, z_or, gout, method, step, nfe=nfe)
+        dz0_ob, gp_ob = orc.solve_discrete_backward_times(ctl, ofield, z0, tout, gout, method, step)
+        z_ref, dz0_ref, gp_ref, nfe_ref = res[True]
+        _, dz0_bp, gp_bp, _ = res[False]
+        e = {"z": relerr(z_or, z_ref), "dz0": relerr(dz0_or, dz0_ref), "dtheta": max(relerr(a, b) for a, b in zip(gp_or, gp_ref)),
+             "bp_dz0": relerr(dz0_ob, dz0_bp), "bp_dtheta": max(relerr(a, b) for a, b in zip(gp_ob, gp_bp))}
+        print(f"{name:28s} oracle-vs-ref: " + " ".join(f"{k} {v:.2e}" for k, v in e.items()), "nfe", nfe[0], nfe_ref)
+        assert nfe[0] == nfe_ref
+        assert e["z"] <= 2e-6 and max(e["dz0"], e["dtheta"], e["bp_dz0"], e["bp_dtheta"]) <= 2e-5, "oracle does not reproduce the reference"
+        rec = {"z_out": z_ref.numpy(), "dz0": dz0_ref.numpy(), "grad_out": gout, "bp_dz0": dz0_bp.numpy(), "coeffs": coeffs_np, "z0": z0,
+               "t_out": tout, "x": x}
+        if kn is not None:
+            rec["knots"] = kn
+        for n, g, gb in zip(names, gp_ref, gp_bp):
+            rec["d" + n], rec["bp_d" + n] = g.numpy(), gb.numpy()
+        for k, v in p.items():
+            rec["p_" + k] = v
+        meta = {"name": name, "kind": interp, "method": method, "step_size": step, "field": "original", "nfe": nfe_ref,
+                "dims": {"C": C, "H": H, "HH": HH, "nl": nl}, "param_names": names, "oracle_vs_ref": e, "user_knots": kn is not None,
+                "t_dtype": str(tout.dtype)}
+        rec["meta"] = np.array(json.dumps(meta))
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+        report.append(meta)
+    with open(os.path.join(GOLD, "MANIFEST_times.json"), "w") as f:
+        json.dump(report, f, indent=1)
+
+
 def main():
+    if "--only-g11" in sys.argv:
+        gen_g11()
+        return
     if "--only-g9" in sys.argv:
         gen_g9()
         return
@@ -383,6 +462,7 @@ def main():
 
     gen_g8()
     gen_g9()
+    gen_g11()
 
     # ---- G5: full-size cfg2 forward z_T (inputs regenerated by tests from the generator) ---------
     if "--no-full" not in sys.argv:

@@ -183,18 +183,16 @@ class Field:
 
 
 class Control:
-    """Control path on the default integer knot grid. kind in {'linear', 'cubic'} ('rectilinear' data
-    uses 'linear' evaluation, src/ncde/ncde.py:12-15)."""
+    """Control path. kind in {'linear', 'cubic'} ('rectilinear' data uses 'linear' evaluation, src/ncde/ncde.py:12-15).
+    ``t`` = the knot grid the coefficients were built on (None = the default integer grid linspace(0, T-1, T),
+    interpolation_linear.py:195-196 / interpolation_cubic.py:291-292)."""
 
-    def __init__(self, coeffs, kind):
+    def __init__(self, coeffs, kind, t=None):
         self.kind = kind
         coeffs = torch.as_tensor(coeffs)
         self.coeffs = coeffs
         if kind == "linear":
             self.n_pieces = coeffs.shape[-2] - 1
-            # (c[1:]-c[:-1]) / (t[1:]-t[:-1]) with unit knot spacing (interpolation_linear.py:198)
-            t = torch.linspace(0, coeffs.shape[-2] - 1, coeffs.shape[-2], dtype=coeffs.dtype)
-            self.derivs = (coeffs[..., 1:, :] - coeffs[..., :-1, :]) / (t[1:] - t[:-1]).unsqueeze(-1)
             self.channels = coeffs.shape[-1]
         elif kind == "cubic":
             self.n_pieces = coeffs.shape[-2]
@@ -205,23 +203,34 @@ class Control:
         else:
             raise ValueError(kind)
         self.n_knots = self.n_pieces + 1
+        self.default_grid = t is None
+        if t is None:
+            t = torch.linspace(0, self.n_knots - 1, self.n_knots, dtype=coeffs.dtype)
+        self.t = torch.as_tensor(t, dtype=coeffs.dtype)
+        assert self.t.shape == (self.n_knots,)
+        if kind == "linear":
+            # (c[1:]-c[:-1]) / (t[1:]-t[:-1])  (interpolation_linear.py:198)
+            self.derivs = (coeffs[..., 1:, :] - coeffs[..., :-1, :]) / (self.t[1:] - self.t[:-1]).unsqueeze(-1)
 
     def x0(self):
         return self.coeffs[..., 0, :] if self.kind == "linear" else self.a[..., 0, :]
 
     def piece(self, t):
-        """bucketize(t, knots, right=False) - 1, clamped: the LEFT piece at an exact knot."""
-        tv = float(t)
-        idx = int(math.ceil(tv)) - 1
+        """bucketize(t, knots, right=False) - 1, clamped: the LEFT piece at an exact knot
+        (interpolation_linear.py:212-219, interpolation_cubic.py:315-322)."""
+        if self.default_grid:
+            idx = int(math.ceil(float(t))) - 1
+        else:
+            idx = int(torch.bucketize(torch.as_tensor(t, dtype=self.t.dtype), self.t)) - 1
         return max(0, min(idx, self.n_pieces - 1))
 
     def evaluate(self, t):
         """X(t) (interpolation_linear.py:221-229, interpolation_cubic.py:324-329)."""
         idx = self.piece(t)
-        frac = t - _f32(idx)
+        frac = t - self.t[idx]
         if self.kind == "linear":
             prev, nxt = self.coeffs[..., idx, :], self.coeffs[..., idx + 1, :]
-            diff_t = _f32(idx + 1) - _f32(idx)
+            diff_t = self.t[idx + 1] - self.t[idx]
             return prev + frac * (nxt - prev) / diff_t
         inner = 0.5 * self.two_c[..., idx, :] + self.three_d[..., idx, :] * frac / 3
         inner = self.b[..., idx, :] + inner * frac
@@ -235,7 +244,7 @@ class Control:
         idx = self.piece(t)
         if self.kind == "linear":
             return self.derivs[..., idx, :]
-        frac = t - _f32(idx)
+        frac = t - self.t[idx]
         inner = self.two_c[..., idx, :] + self.three_d[..., idx, :] * frac
         return self.b[..., idx, :] + inner * frac
 
@@ -419,3 +428,259 @@ def solve_discrete_backward(control, field, z0, grad_out, method="rk4", sequence
             a = a + grad_out[:, n]
     a = a + grad_out[:, 0]           # row 0 of the solution is z0 itself
     return a, g
+
+
+# ======================================================================================================================
+# General time axis: any increasing output times t, any step_size, user knot grids (the rest of the cdeint call surface).
+# Restates  solvers.py:78-87 (grid from step_size), :94-119 (loop + output pick), :166-172 (linear interpolation of the
+# output between the two bracketing grid states)  and  adjoint.py:116-133 (one reverse solve per output interval, each
+# with its OWN grid starting at t[i]).  All time arithmetic in the dtype of ``t`` (fp32 here), exactly as torch does it.
+# ======================================================================================================================
+def fixed_time_grid(t, step_size):
+    """solvers.py:78-87: arange(0, ceil((t[-1]-t[0])/step + 1)) * step + t[0], last entry := t[-1]."""
+    t = torch.as_tensor(t)
+    start, end = t[0], t[-1]
+    niters = torch.ceil((end - start) / step_size + 1).item()
+    grid = torch.arange(0, niters, dtype=t.dtype) * step_size + start
+    grid[-1] = t[-1]
+    return grid
+
+
+def _linear_interp(t0, t1, y0, y1, t):
+    if t == t0:
+        return y0
+    if t == t1:
+        return y1
+    slope = (t - t0) / (t1 - t0)
+    return y0 + slope * (y1 - y0)
+
+
+def solve_forward_times(control, field, z0, t, method="rk4", step_size=1.0, nfe=None):
+    """z at the times t (increasing, t[0] = start of the solve) -> [B, len(t), H]."""
+    stage_plan(method)
+    z0 = torch.as_tensor(z0)
+    t = torch.as_tensor(t)
+    if not t.is_floating_point():
+        t = t.to(z0.dtype)
+    grid = fixed_time_grid(t, step_size)      # in the dtype of t (fp32 or fp64), as torch does
+    assert grid[0] == t[0] and grid[-1] == t[-1]
+
+    def fn(tt, state):
+        if nfe is not None:
+            nfe[0] += 1
+        return (field.g(state[0], control.field_input(tt.to(z0.dtype), field.mode)),)     # misc.py:181: t.to(y.dtype)
+
+    sol = [z0]
+    j = 1
+    y0 = z0
+    for t0, t1 in zip(grid[:-1], grid[1:]):
+        y1 = _step(fn, method, t0, t1 - t0, t1, (y0,))[0]
+        while j < len(t) and t1 >= t[j]:
+            sol.append(_linear_interp(t0, t1, y0, y1, t[j]))
+            j += 1
+        y0 = y1
+    return torch.stack(sol, dim=1)
+
+
+def solve_adjoint_times(control, field, t, z_out, grad_out, method="rk4", step_size=1.0, nfe=None):
+    """Continuous adjoint for arbitrary output times: for i = len(t)-1 .. 1 one reverse solve from t[i] to t[i-1] on its
+    own grid in negated time (adjoint.py:116-133, misc.py:262-271), y reset to the stored z_out[i-1], a += grad_out[i-1]."""
+    stage_plan(method)
+    z_out = torch.as_tensor(z_out)
+    grad_out = torch.as_tensor(grad_out)
+    t = torch.as_tensor(t)
+    if not t.is_floating_point():
+        t = t.to(z_out.dtype)
+    params = field.unique_params()
+
+    def fn(s, state):
+        if nfe is not None:
+            nfe[0] += 1
+        y, a = state[0], state[1]
+        tt = -(s.to(y.dtype))
+        dx = control.field_input(tt, field.mode)
+        f, saved = field.g(y, dx, save=True)
+        vjp_y, vjp_p = field.g_vjp(saved, dx, -a)
+        return (-f, -vjp_y) + tuple(-v for v in vjp_p)
+
+    y = z_out[:, -1]
+    a = grad_out[:, -1].clone()
+    g = tuple(torch.zeros_like(p) for p in params)
+    for i in range(len(t) - 1, 0, -1):
+        grid = fixed_time_grid(-t[i - 1:i + 1].flip(0), step_size)
+        state = (y, a) + g
+        for s0, s1 in zip(grid[:-1], grid[1:]):
+            state = _step(fn, method, s0, s1 - s0, s1, state)
+        a, g = state[1], tuple(state[2:])
+        y = z_out[:, i - 1]
+        a = a + grad_out[:, i - 1]
+    return a, list(g)
+
+
+def _forward_stages_times(control, field, z0, t, method, step_size):
+    z0 = torch.as_tensor(z0)
+    t = torch.as_tensor(t)
+    if not t.is_floating_point():
+        t = t.to(z0.dtype)
+    grid = fixed_time_grid(t, step_size)
+    steps = []
+    y = z0
+    _inp = control.field_input
+
+    class _C:      # the control path sees the stage time cast to the state dtype (misc.py:181)
+        @staticmethod
+        def field_input(tt, mode):
+            return _inp(tt.to(z0.dtype), mode)
+    control = _C
+    for t0, t1 in zip(grid[:-1], grid[1:]):
+        dt = t1 - t0
+        if method == "euler":
+            ts, Ys = [t0], [y]
+            y1 = y + dt * field.g(y, control.field_input(t0, field.mode))
+        elif method == "midpoint":
+            half = 0.5 * dt
+            k1 = field.g(y, control.field_input(t0, field.mode))
+            ym = y + k1 * half
+            ts, Ys = [t0, t0 + half], [y, ym]
+            y1 = y + dt * field.g(ym, control.field_input(t0 + half, field.mode))
+        else:
+            k1 = field.g(y, control.field_input(t0, field.mode))
+            y2 = y + dt * k1 * _ONE_THIRD
+            k2 = field.g(y2, control.field_input(t0 + dt * _ONE_THIRD, field.mode))
+            y3 = y + dt * (k2 - k1 * _ONE_THIRD)
+            k3 = field.g(y3, control.field_input(t0 + dt * _TWO_THIRDS, field.mode))
+            y4 = y + dt * (k1 - k2 + k3)
+            k4 = field.g(y4, control.field_input(t1, field.mode))
+            ts, Ys = [t0, t0 + dt * _ONE_THIRD, t0 + dt * _TWO_THIRDS, t1], [y, y2, y3, y4]
+            y1 = y + (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
+        steps.append((ts, Ys, dt, t0, t1))
+        y = y1
+    return grid, steps
+
+
+def stage_record_times(control, field, z0, t, method="rk4", step_size=1.0):
+    _, steps = _forward_stages_times(control, field, z0, t, method, step_size)
+    return torch.stack([Y for _, Ys, _, _, _ in steps for Y in Ys], dim=0)
+
+
+def solve_discrete_backward_times(control, field, z0, t, grad_out, method="rk4", step_size=1.0):
+    """Exact gradient of the discretised solve for arbitrary output times (autograd through solvers.py:94-119 incl. the
+    linear interpolation of the outputs, :166-172).  grad_out: [B, len(t), H]."""
+    grad_out = torch.as_tensor(grad_out)
+    t = torch.as_tensor(t)
+    if not t.is_floating_point():
+        t = t.to(grad_out.dtype)
+    params = field.unique_params()
+    grid, steps = _forward_stages_times(control, field, z0, t, method, step_size)
+    # which outputs each step emits (solvers.py:108-116)
+    emits = [[] for _ in steps]
+    j = 1
+    for n, (_, _, _, t0, t1) in enumerate(steps):
+        while j < len(t) and t1 >= t[j]:
+            emits[n].append(j)
+            j += 1
+    g = [torch.zeros_like(p) for p in params]
+
+    def pull(tt, Y, ck):
+        dx = control.field_input(tt.to(Y.dtype), field.mode)
+        _, saved = field.g(Y, dx, save=True)
+        dY, dp = field.g_vjp(saved, dx, ck.to(Y.dtype))
+        for i, v in enumerate(dp):
+            g[i] = g[i] + v
+        return dY
+
+    a = torch.zeros_like(grad_out[:, 0])      # cotangent of the state after the step being transposed
+    for n in range(len(steps) - 1, -1, -1):
+        ts, Ys, dt, t0, t1 = steps[n]
+        a_y0 = torch.zeros_like(a)
+        for jj in emits[n]:
+            gj = grad_out[:, jj]
+            if t[jj] == t0:
+                a_y0 = a_y0 + gj
+            elif t[jj] == t1:
+                a = a + gj
+            else:
+                slope = (t[jj] - t0) / (t1 - t0)
+                a = a + slope * gj
+                a_y0 = a_y0 + (gj - slope * gj)
+        if method == "euler":
+            a = a + pull(ts[0], Ys[0], dt * a)
+        elif method == "midpoint":
+            dYm = pull(ts[1], Ys[1], dt * a)
+            dY1 = pull(ts[0], Ys[0], (0.5 * dt) * dYm)
+            a = a + dYm + dY1
+        else:
+            ck4 = a * dt * 0.125
+            dY4 = pull(ts[3], Ys[3], ck4)
+            ck3 = 3 * ck4 + dt * dY4
+            dY3 = pull(ts[2], Ys[2], ck3)
+            ck2 = 3 * ck4 - dt * dY4 + dt * dY3
+            dY2 = pull(ts[1], Ys[1], ck2)
+            ck1 = ck4 + dt * dY4 - (dt * _ONE_THIRD) * dY3 + (dt * _ONE_THIRD) * dY2
+            dY1 = pull(ts[0], Ys[0], ck1)
+            a = a + dY4 + dY3 + dY2 + dY1
+        a = a + a_y0
+    a = a + grad_out[:, 0]
+    return a, g
+
+
+def time_plan_words(control, t, method, step_size):
+    """The time plan of csrc/ncde_timeplan.hip (layout: csrc/ncde_common.h) restated with torch's own arithmetic: the
+    checker for the C++ builder (bit for bit).  t: 1-D tensor (fp32 or fp64: the grid arithmetic runs in its dtype)."""
+    import numpy as np
+    t = torch.as_tensor(t)
+    S = {"rk4": 4, "midpoint": 2, "euler": 1}[method]
+    pw = 3 + 3 * S
+    f32 = torch.float32
+
+    def stage_words(tt):
+        tt = tt.to(f32)
+        idx = control.piece(tt)
+        frac = tt - control.t[idx]
+        kdt = control.t[idx + 1] - control.t[idx]
+        return [np.int32(idx), np.float32(frac).view(np.int32), np.float32(kdt).view(np.int32)]
+
+    def step_words(t0, t1, neg):
+        dt = t1 - t0
+        if method == "rk4":
+            ts = [t0, t0 + dt * _ONE_THIRD, t0 + dt * _TWO_THIRDS, t1]
+        elif method == "midpoint":
+            ts = [t0, t0 + 0.5 * dt]
+        else:
+            ts = [t0]
+        out = []
+        for x in ts:
+            out += stage_words(-x if neg else x)
+        return np.float32(dt.to(f32)).view(np.int32), out
+
+    grid = fixed_time_grid(t, step_size)
+    n_fwd, nt = len(grid) - 1, len(t)
+    fwd, outs = [], [np.int32(0), np.int32(0)]
+    j = 1
+    for t0, t1 in zip(grid[:-1], grid[1:]):
+        dtw, sw = step_words(t0, t1, False)
+        first, cnt = j, 0
+        while j < nt and t1 >= t[j]:
+            if t[j] == t0:
+                outs += [np.int32(0), np.int32(0)]
+            elif t[j] == t1:
+                outs += [np.int32(1), np.int32(0)]
+            else:
+                slope = (t[j] - t0) / (t1 - t0)
+                outs += [np.int32(2), np.float32(slope.to(f32)).view(np.int32)]
+            j += 1
+            cnt += 1
+        fwd += [dtw, np.int32(first), np.int32(cnt)] + sw
+    adj = []
+    n_adj = 0
+    for i in range(nt - 1, 0, -1):
+        g = fixed_time_grid(-t[i - 1:i + 1].flip(0), step_size)
+        for q, (s0, s1) in enumerate(zip(g[:-1], g[1:])):
+            dtw, sw = step_words(s0, s1, True)
+            adj += [dtw, np.int32(i - 1 if q == len(g) - 2 else -1), np.int32(0)] + sw
+            n_adj += 1
+    off_fwd = 8
+    off_out = off_fwd + n_fwd * pw
+    off_adj = off_out + 2 * nt
+    head = [np.int32(0x4e43504c), S, n_fwd, n_adj, nt, off_fwd, off_out, off_adj]
+    return np.array([np.int32(x) for x in head + fwd + outs + adj], dtype=np.int32), n_fwd, n_adj

@@ -104,3 +104,22 @@ def kernel_names(case, flags=_lib.FLAG_AUTO, device="cuda"):
                              _lib.OUT_KNOTS if m["sequence"] else _lib.OUT_INTERVAL, flags)
     lib = _lib.lib()
     return tuple((lib.ncde_kernel_name(ctypes.byref(p), k) or b"?").decode() for k in (0, 1, 2))
+
+
+def run_times_case(f, meta, adjoint=True, flags=_lib.FLAG_AUTO, device="cuda", kind="original", mode="matmul", params=None):
+    """A general-time-axis case (golden g11 layout: coeffs, [knots], t_out, z0, p_*, grad_out) through cdeint."""
+    coeffs = torch.from_numpy(f["coeffs"]).to(device)
+    kn = torch.from_numpy(f["knots"]).to(device) if "knots" in f else None
+    X = (ncde_amd.LinearInterpolation if meta["kind"] == "linear" else ncde_amd.NaturalCubicSpline)(coeffs, t=kn)
+    params = params if params is not None else {k[2:]: f[k] for k in f if k.startswith("p_")}
+    nl = meta["dims"]["nl"]
+    func = CaseField(params, [("W0", "b0")] + [("W1", "b1")] * (nl - 1), device, kind, mode)
+    z0 = torch.from_numpy(f["z0"]).to(device).requires_grad_(True)
+    t = torch.from_numpy(f["t_out"]).to(device)
+    out = ncde_amd.cdeint(X, func, z0, t, adjoint=adjoint, vector_field_type=mode, method=meta["method"],
+                          options={"step_size": meta["step_size"]}, kernel_flags=flags)
+    nfe_fwd = func.nfe
+    (out * torch.from_numpy(f["grad_out"]).to(device)).sum().backward()
+    torch.cuda.synchronize()
+    return {"z_out": out.detach().cpu().numpy(), "dz0": z0.grad.cpu().numpy(), "nfe": func.nfe, "nfe_fwd": nfe_fwd,
+            "grads": {k: v.grad.cpu().numpy() for k, v in func.p.items() if v.grad is not None}}

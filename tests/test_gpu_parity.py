@@ -196,10 +196,11 @@ def _cfg2_case(B):
 # (dz0 3e-7, W0/W1 5e-6, Wo 1.1e-5, biases 2e-6): the fp32 round-off class of the split-bf16 chain vs the oracle's addmm
 # order, no drift worth a looser bound.  Guard: 5e-5.  Over all 4096 samples a last-bit difference in z flips a ReLU mask
 # for a handful of samples (fp32 behaviour of the model, see _check_case), which moves THAT sample's dL/dz0 at the 1e-3
-# level: the full-batch check is therefore per sample (99 % within 5e-5, none beyond 2e-2) and, for the parameter
-# gradients (sums over the batch), 2e-4.
+# level (measured: 25 of 4096 samples beyond 5e-5, median 7e-8, p99 7e-6, worst 1.3e-3): the full-batch check is therefore
+# per sample (99 % within 5e-5, none beyond 2e-2), and the parameter gradients -- sums over the batch that include those
+# samples -- are held to the documented 1e-3 (measured: W0 6.0e-4, b0 5.2e-4, W1 1.8e-4, Wo 7.9e-5).
 CFG2_ISO_G = CFG2_E2E_G = 5e-5
-CFG2_FULL_BATCH_G = 2e-4
+CFG2_FULL_BATCH_G = TOL_DTHETA
 
 
 def test_full_size_cfg2_adjoint_and_discrete_backward_vs_oracle(gpu_lib):
@@ -625,6 +626,126 @@ def test_gpu_coefficient_builders_match_reference(gpu_lib):
     x4 = gu.data.synthetic_series(256, 182, 3, seed=1234)
     got = ncde_amd.natural_cubic_coeffs(torch.from_numpy(x4).cuda()).cpu().numpy()
     assert np.array_equal(got, gu.data.natural_cubic_coeffs(x4))
+
+
+TIMES_CASES = ["g11_times_rk4_half", "g11_times_midpoint_third", "g11_knots_rk4", "g11_knots_cubic_euler",
+               "g11_knots_interval_rk4", "g11_times_f64_rk4"]
+
+
+@pytest.mark.parametrize("name", TIMES_CASES)
+def test_general_time_axis_matches_reference_golden(name, gpu_lib):
+    """The rest of the cdeint call surface (goldens g11, produced by the imported reference): arbitrary increasing output
+    times (outputs linearly interpolated between grid states, solvers.py:103-117, 166-172), step_size != 1
+    (solvers.py:78-87), user knot grids, fp64 times -- forward, continuous adjoint (one reverse solve per output
+    interval, adjoint.py:116-133) and the exact discrete backward, through the plan-driven generic kernels."""
+    import json
+    import os
+    import gpu_util
+    f = dict(np.load(os.path.join(gu.GOLD, name + ".npz")))
+    m = json.loads(str(f["meta"]))
+    res = gpu_util.run_times_case(f, m, adjoint=True)
+    assert res["z_out"].shape == f["z_out"].shape
+    assert gu.relerr(res["z_out"], f["z_out"]) <= TIGHT_Z
+    assert gu.relerr(res["dz0"], f["dz0"]) <= E2E_G
+    for pname in m["param_names"]:
+        assert gu.relerr(res["grads"][pname], f["d" + pname]) <= E2E_G, pname
+    assert res["nfe"] == m["nfe"]                      # the reference's own counter on the same axis (base.py:90)
+    resd = gpu_util.run_times_case(f, m, adjoint=False)
+    assert np.array_equal(resd["z_out"], res["z_out"])
+    assert gu.relerr(resd["dz0"], f["bp_dz0"]) <= E2E_G
+    for pname in m["param_names"]:
+        assert gu.relerr(resd["grads"][pname], f["bp_d" + pname]) <= E2E_G, pname
+
+
+@pytest.mark.parametrize("kind,mode,interp,method,step", [("gru", "evaluate", "cubic", "rk4", 0.5), ("minimal", "matmul", "linear", "midpoint", 0.4),
+                                                         ("original", "derivative", "linear", "euler", 0.25)])
+def test_general_time_axis_field_variants_vs_oracle(kind, mode, interp, method, step, gpu_lib):
+    """Gated fields / evaluate / derivative inputs on a general time axis (user knots, off-grid outputs) against the oracle
+    (whose general-time functions are pinned to the reference on g11 and whose variant fields are pinned on g9)."""
+    import os
+    import gpu_util
+    import ncde_oracle as orc
+    f = dict(np.load(os.path.join(gu.GOLD, "g11_knots_rk4.npz" if interp == "linear" else "g11_knots_cubic_euler.npz")))
+    C, H, HH, nl = 5, 16, 24, 3
+    p = gu.data.make_variant_weights(H, HH, C, seed=17, kind=kind, mode=mode)
+    kn = f["knots"]
+    tout = np.array([kn[0], 0.5 * (kn[1] + kn[2]), kn[4], kn[-1] - 0.125], np.float32)
+    meta = {"kind": interp, "method": method, "step_size": step, "dims": {"nl": nl}}
+    field = orc.Field.variant(p, H, C, nl, kind, mode)
+    ctl = orc.Control(f["coeffs"], interp, t=kn)
+    z = orc.solve_forward_times(ctl, field, f["z0"], tout, method, step)
+    gout = (gu.data.normal(23, z.numel(), stream=1).reshape(z.shape) / 2.0).astype(np.float32)
+    dz0, gp = orc.solve_adjoint_times(ctl, field, tout, z, gout, method, step)
+    bdz0, bgp = orc.solve_discrete_backward_times(ctl, field, f["z0"], tout, gout, method, step)
+    g = dict(f, t_out=tout, grad_out=gout)
+    names = [n for n in ("W0", "b0", "W1", "b1", "Wr", "br", "Wg", "bg", "Wo", "bo") if n in p]
+    res = gpu_util.run_times_case(g, meta, adjoint=True, kind=kind, mode=mode, params=p)
+    assert gu.relerr(res["z_out"], z) <= TIGHT_Z
+    assert gu.relerr(res["dz0"], dz0) <= E2E_G
+    for n_, g_ in zip(names, gp):
+        assert gu.relerr(res["grads"][n_], g_) <= E2E_G, n_
+    resd = gpu_util.run_times_case(g, meta, adjoint=False, kind=kind, mode=mode, params=p)
+    assert gu.relerr(resd["dz0"], bdz0) <= E2E_G
+    for n_, g_ in zip(names, bgp):
+        assert gu.relerr(resd["grads"][n_], g_) <= E2E_G, n_
+
+
+def test_default_axis_through_the_time_plan_equals_the_default_kernels(gpu_lib):
+    """The same solve requested as explicit times (t = arange(T) as a plain tensor with step 1 is recognised as the default
+    axis; step 0.5 is not) -- a plan whose steps are the integer grid must reproduce the default-path generic kernels bit
+    for bit, forward and both backward modes (the plan only replaces WHERE the times come from)."""
+    import gpu_util
+    from ncde_amd import solver
+    case = gu.load_case("g2_rect_rk4_seq")
+    base = gpu_util.run_case(case, flags=1)
+    based = gpu_util.run_case(case, flags=1, adjoint=False)
+    coeffs = torch.from_numpy(case["coeffs"]).cuda()
+    X = ncde_amd_mod().LinearInterpolation(coeffs)
+    T = coeffs.shape[1]
+    plan = solver._time_plan(X, torch.arange(T, dtype=torch.float32), "rk4", 1.0, coeffs.device)
+    assert plan[1] == (T, T - 1, T - 1)
+    for adjoint, want in ((True, base), (False, based)):
+        func = gpu_util.case_field(case, "cuda")
+        z0 = torch.from_numpy(case["z0"]).cuda().requires_grad_(True)
+        cfg = {"spec": func.fused_spec(), "interp": "linear", "method": "rk4", "output": 2, "flags": 0, "plan": plan, "adjoint": adjoint,
+               "func": None, "nfe_per_solve": 0, "nfe_adjoint": 0, "adjoint_param_ids": None}
+        out = solver._FusedCdeint.apply(z0, coeffs, cfg, *func.fused_spec().unique_params())
+        (out * torch.from_numpy(case["expect"]["grad_out"]).cuda()).sum().backward()
+        assert np.array_equal(out.detach().cpu().numpy(), want["z_out"])
+        assert np.array_equal(z0.grad.cpu().numpy(), want["dz0"])
+        for k, v in func.p.items():
+            assert np.array_equal(v.grad.cpu().numpy(), want["grads"][k]), k
+
+
+def ncde_amd_mod():
+    import ncde_amd
+    return ncde_amd
+
+
+def test_reference_cdeint_shape_test_ported(gpu_lib):
+    """Port of the reference's own cdeint test (/root/reference/modules/torchcde/test/test_cdeint.py:5-41, rk4 branch):
+    random batch dimensions (0..2), natural cubic spline of random values, random fp64 output times inside the interval,
+    step_size = 1/num_points; the vector field is an OriginalVectorField (arbitrary Python fields are outside the fused
+    path).  Checks the output shape as the reference does, plus finiteness and z(t[0]) = z0."""
+    import ncde_amd
+    gen = torch.Generator().manual_seed(0)
+    ri = lambda lo, hi: int(torch.randint(low=lo, high=hi, size=(1,), generator=gen).item())     # noqa: E731
+    for _ in range(10):
+        num_points, num_channels, num_hidden = ri(5, 100), ri(1, 3), ri(1, 5)
+        batch_dims = [ri(1, 3) for _ in range(ri(0, 3))]
+        values = torch.rand(*batch_dims, num_points, num_channels, generator=gen).cuda()
+        coeffs = ncde_amd.natural_cubic_coeffs(values)
+        spline = ncde_amd.NaturalCubicSpline(coeffs)
+        torch.manual_seed(1)
+        f = ncde_amd.OriginalVectorField(num_channels, num_hidden, 7, 2).cuda()
+        z0 = torch.rand(*batch_dims, num_hidden, generator=gen).cuda()
+        num_out_times = ri(2, 10)
+        start, end = spline.interval
+        out_times = torch.rand(num_out_times, dtype=torch.float64, generator=gen).sort().values.cuda() * (end - start) + start
+        out = ncde_amd.cdeint(spline, f, z0, out_times, method="rk4", options={"step_size": 1.0 / num_points}, rtol=1e-4, atol=1e-6)
+        assert out.shape == (*batch_dims, num_out_times, num_hidden)
+        assert torch.isfinite(out).all()
+        assert torch.equal(out[..., 0, :], z0)
 
 
 def test_integration_md_stub_with_version1_struct(gpu_lib):

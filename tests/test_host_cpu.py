@@ -43,10 +43,13 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     # 9 int32 + n_layers + 2*8 int32, 2*8 pointers, 3 pointers, 2 int64, 1 pointer (with natural alignment);
-    # ABI version 2 appends 2 int32 + 4 pointers (gated fields / input modes) -- a version-1 struct is the prefix
+    # ABI version 2 appends 2 int32 + 4 pointers (gated fields / input modes), version 3 one pointer + 4 int32 (general time
+    # axis) -- every older struct is a prefix of the newer one
     v1 = 4 * 10 + 4 * 16 + 8 * 16 + 8 * 3 + 8 * 2 + 8
     assert _lib.NcdeProblem.field_kind.offset == v1
-    assert ctypes.sizeof(_lib.NcdeProblem) == v1 + 4 * 2 + 8 * 4
+    assert _lib.NcdeProblem.time_plan.offset == v1 + 4 * 2 + 8 * 4
+    assert ctypes.sizeof(_lib.NcdeProblem) == v1 + 4 * 2 + 8 * 4 + 8 + 4 * 4
+    assert ctypes.sizeof(_lib.NcdeTimeSpec) == 4 * 2 + 8 * 3 and ctypes.sizeof(_lib.NcdeTimePlanInfo) == 4 * 4 + 8
     assert ctypes.sizeof(_lib.NcdeGrads) == 8 * (1 + 16 + 2 + 4)
 
 
@@ -68,6 +71,13 @@ def test_version1_structs_are_still_accepted():
     assert lib.ncde_kernel_name(ctypes.byref(p), 1) == b"ncde_adj_tiled<gated>+ncde_dwo_tiled"      # minimal gating: tiled family
     p.field_kind, p.Wr, p.br = 2, 0x7000, 0x7100
     assert lib.ncde_kernel_name(ctypes.byref(p), 1) == b"ncde_adj_variant"                           # GRU: variant kernels
+    # a version-2 caller's struct ends before time_plan: garbage there must not be read
+    q = _problem()
+    q.abi_version = 2
+    q.time_plan, q.n_t_out = 0xdead, -5
+    assert lib.ncde_num_outputs(ctypes.byref(q)) == 2
+    q.abi_version = 3
+    assert lib.ncde_num_outputs(ctypes.byref(q)) == -1 and b"time plan" in lib.ncde_last_error_string()
 
 
 def test_validation_and_error_strings_without_gpu():
@@ -195,6 +205,8 @@ def test_cdeint_argument_errors_mirror_the_reference():
         ncde_amd.cdeint(X, f, z0, X.interval)                       # the reference's default is adaptive dopri5
     with pytest.raises(NotImplementedError, match="step_size"):
         ncde_amd.cdeint(X, f, z0, X.interval, method="rk4")
+    with pytest.raises(ValueError, match="positive"):
+        ncde_amd.cdeint(X, f, z0, X.interval, method="rk4", options={"step_size": -1})
     with pytest.raises(NotImplementedError, match="fused_spec"):
         solver._field_spec(torch.nn.Linear(4, 12))      # arbitrary Python vector fields are refused, not emulated
 
@@ -243,12 +255,80 @@ def test_tagged_times_do_not_outlive_their_control():
     is re-validated by value instead of being trusted."""
     X = ncde_amd.LinearInterpolation(torch.zeros(2, 5, 3))
     Y = ncde_amd.LinearInterpolation(torch.zeros(2, 9, 3))
-    with pytest.raises(NotImplementedError):
-        solver._time_mode(X, Y.grid_points)          # 9 knots of another control
+    assert solver._time_mode(X, Y.grid_points) is None          # 9 knots of another control: not X's grid_points
     kept = Y.interval
     del Y
-    with pytest.raises(NotImplementedError):
-        solver._time_mode(X, kept)
+    assert solver._time_mode(X, kept) is None                   # [0, 8] is not X's interval [0, 4]
+
+
+def _c_time_plan(n_knots, method, t, step, knots=None):
+    p = _lib.NcdeProblem()
+    p.abi_version, p.n_knots, p.method = _lib.NCDE_ABI_VERSION, n_knots, _lib.METHOD[method]
+    f64 = np.asarray(t).dtype == np.float64
+    td = np.ascontiguousarray(np.asarray(t, dtype=np.float64))
+    kd = None if knots is None else np.ascontiguousarray(np.asarray(knots, dtype=np.float64))
+    dp = ctypes.POINTER(ctypes.c_double)
+    ts = _lib.NcdeTimeSpec(n_t=len(td), time_is_f64=int(f64), t=td.ctypes.data_as(dp), step_size=step,
+                           knots=None if kd is None else kd.ctypes.data_as(dp))
+    info = _lib.NcdeTimePlanInfo()
+    lib = ncde_amd.lib()
+    rc = lib.ncde_time_plan_build(ctypes.byref(p), ctypes.byref(ts), None, 0, ctypes.byref(info))
+    if rc != 0:
+        return rc, None, info
+    buf = np.zeros(info.bytes // 4, dtype=np.int32)
+    rc = lib.ncde_time_plan_build(ctypes.byref(p), ctypes.byref(ts), buf.ctypes.data, buf.nbytes, ctypes.byref(info))
+    return rc, buf, info
+
+
+def test_time_plan_builder_reproduces_torch_time_arithmetic():
+    """ncde_time_plan_build (host C++) against the oracle's restatement in torch's own arithmetic -- the time grid of
+    solvers.py:78-87, the stage times, the knot index / fraction of interpolation_linear.py:212-219, the output
+    interpolation weights and the per-interval reverse grids of adjoint.py:116-133 -- bit for bit, on the time axes of the
+    reference-generated goldens g11 (fp32 and fp64 times, user knot grids) and on the default axis."""
+    import json
+    import ncde_oracle as orc
+    for name in ("g11_times_rk4_half", "g11_times_midpoint_third", "g11_knots_rk4", "g11_knots_cubic_euler",
+                 "g11_knots_interval_rk4", "g11_times_f64_rk4"):
+        f = np.load(os.path.join(gu.GOLD, name + ".npz"))
+        m = json.loads(str(f["meta"]))
+        kn = f["knots"] if "knots" in f.files else None
+        ctl = orc.Control(f["coeffs"], m["kind"], t=kn)
+        want, n_fwd, n_adj = orc.time_plan_words(ctl, torch.from_numpy(f["t_out"]), m["method"], m["step_size"])
+        rc, got, info = _c_time_plan(ctl.n_knots, m["method"], f["t_out"], m["step_size"], kn)
+        assert rc == 0 and np.array_equal(got, want), name
+        assert (info.n_steps_fwd, info.n_steps_adj, info.n_t_out) == (n_fwd, n_adj, len(f["t_out"]))
+        S = {"rk4": 4, "midpoint": 2, "euler": 1}[m["method"]]
+        assert m["nfe"] == S * (n_fwd + n_adj)          # the reference's own nfe counter (base.py:90) on the same axis
+    # the default axis (knots of a 7-knot path, step 1): the plan is what the specialised kernels hard-code
+    ctl = orc.Control(np.zeros((1, 7, 2), np.float32), "linear")
+    for t in (torch.arange(7.0), torch.tensor([0.0, 6.0])):
+        want, n_fwd, n_adj = orc.time_plan_words(ctl, t, "rk4", 1.0)
+        rc, got, info = _c_time_plan(7, "rk4", t.numpy(), 1.0)
+        assert rc == 0 and np.array_equal(got, want) and n_fwd == n_adj == 6
+        idx = got[8:8 + 6 * 15].reshape(6, 15)[:, 3::3]
+        assert np.array_equal(idx, np.array([[max(n - 1, 0), n, n, n] for n in range(6)]))     # SURVEY.md §3.1 knot-index rule
+    # errors: non-monotone t, non-positive step (misc.py:336-343 asserts; here NCDE_ERR_INVALID + message)
+    rc, _, _ = _c_time_plan(7, "rk4", np.array([0.0, 2.0, 1.0], np.float32), 1.0)
+    assert rc == -1 and b"increasing" in ncde_amd.lib().ncde_last_error_string()
+    rc, _, _ = _c_time_plan(7, "rk4", np.array([0.0, 2.0], np.float32), 0.0)
+    assert rc == -1 and b"step_size" in ncde_amd.lib().ncde_last_error_string()
+    rc, _, _ = _c_time_plan(3, "rk4", np.array([0.0, 2.0], np.float32), 1.0, knots=[0.0, 1.0, 1.0])
+    assert rc == -1 and b"knot" in ncde_amd.lib().ncde_last_error_string()
+
+
+def test_general_time_axis_dispatches_to_the_generic_family():
+    lib = ncde_amd.lib()
+    p = _problem()                       # cfg2 shape: specialised kernels on the default axis ...
+    assert (lib.ncde_kernel_name(ctypes.byref(p), 0) or b"").startswith(b"ncde_fwd_fast")
+    p.output, p.time_plan, p.n_t_out, p.n_steps_fwd, p.n_steps_adj = _lib.OUT_TIMES, 0x9000, 5, 12, 14
+    assert lib.ncde_kernel_name(ctypes.byref(p), 0) == b"ncde_fwd_generic"        # ... plan-driven generic kernels otherwise
+    assert lib.ncde_kernel_name(ctypes.byref(p), 1) == b"ncde_adj_generic"
+    assert lib.ncde_num_outputs(ctypes.byref(p)) == 5
+    assert lib.ncde_stage_record_bytes(ctypes.byref(p)) == 4 * 12 * 4 * 32 * 32      # bytes: steps x stages x B x H
+    p.flags = _lib.FLAG_FORCE_FAST
+    assert lib.ncde_workspace_bytes(ctypes.byref(p), 0) == -2
+    p.flags, p.n_steps_fwd = 0, 0
+    assert lib.ncde_num_outputs(ctypes.byref(p)) == -1
 
 
 def test_time_mode_detection():
@@ -259,8 +339,9 @@ def test_time_mode_detection():
     assert solver._time_mode(X, torch.arange(5.0)) == _lib.OUT_KNOTS
     with pytest.raises(AssertionError):
         solver._time_mode(X, torch.tensor([0.0, 2.0, 1.0]))
-    with pytest.raises(NotImplementedError):
-        solver._time_mode(X, torch.tensor([0.0, 2.5]))
+    assert solver._time_mode(X, torch.tensor([0.0, 2.5])) is None        # -> general time axis (time plan)
+    Xk = ncde_amd.LinearInterpolation(torch.zeros(2, 5, 3), t=torch.tensor([0.0, 1.0, 2.0, 3.0, 4.5]))
+    assert solver._time_mode(Xk, torch.tensor([0.0, 4.0])) is None       # user knot grid: always the plan
 
 
 def test_host_coefficient_mirrors_match_reference_golden():
