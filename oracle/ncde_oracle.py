@@ -248,6 +248,16 @@ class Control:
         inner = self.two_c[..., idx, :] + self.three_d[..., idx, :] * frac
         return self.b[..., idx, :] + inner * frac
 
+    def second_derivative(self, t):
+        """d/dt of derivative(t): zero for a piecewise-linear path (the knot index carries no gradient), two_c + 2 three_d
+        frac for the cubic spline -- what autograd sends to t in adjoint.py:95-98 (the vjp_t component of the state)."""
+        idx = self.piece(t)
+        if self.kind == "linear":
+            return torch.zeros_like(self.derivs[..., idx, :])
+        frac = t - self.t[idx]
+        inner = self.two_c[..., idx, :] + self.three_d[..., idx, :] * frac
+        return inner + self.three_d[..., idx, :] * frac
+
 
 def stage_plan(method):
     if method not in ("rk4", "midpoint", "euler"):
@@ -684,3 +694,262 @@ def time_plan_words(control, t, method, step_size):
     off_adj = off_out + 2 * nt
     head = [np.int32(0x4e43504c), S, n_fwd, n_adj, nt, off_fwd, off_out, off_adj]
     return np.array([np.int32(x) for x in head + fwd + outs + adj], dtype=np.int32), n_fwd, n_adj
+
+
+# ======================================================================================================================
+# Adaptive Dormand-Prince 5(4) ("dopri5"): NeuralCDE(solver="dopri5") (src/ncde/ncde.py:129-134, options {"min_step": 0.5})
+# and the toy's default method (experiments/sim_bm_toy_example.py:54-57).  Restates, on FLAT state vectors as the reference
+# does (misc.py:131-139, 204-214):
+#   tableau, mid-point weights          torchdiffeq/_impl/dopri5.py:5-36
+#   one RK step + error estimate        rk_common.py:41-86        (stage times in the STATE dtype, state matmul over stages)
+#   step control                        rk_common.py:216-305      (time in fp64; accept iff ratio <= 1, min/max step overrides)
+#   initial step, error ratio, next dt  misc.py:33-103
+#   dense output                        interp.py:4-61, rk_common.py:307-313, 198-205
+#   stage time perturbation             misc.py:168-191 (alpha = 1 stages are evaluated just BEFORE t1)
+#   ONE error norm for the whole batch  misc.py:18-19 (rms over every element of the state)
+#   adjoint: one adaptive reverse solve per output interval over (vjp_t, y, a, g_theta) with the mixed norm
+#                                       adjoint.py:37-145, 235-247
+# ======================================================================================================================
+_DP_ALPHA = torch.tensor([1 / 5, 3 / 10, 4 / 5, 8 / 9, 1., 1.], dtype=torch.float64)
+_DP_BETA = [
+    torch.tensor([1 / 5], dtype=torch.float64),
+    torch.tensor([3 / 40, 9 / 40], dtype=torch.float64),
+    torch.tensor([44 / 45, -56 / 15, 32 / 9], dtype=torch.float64),
+    torch.tensor([19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729], dtype=torch.float64),
+    torch.tensor([9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656], dtype=torch.float64),
+    torch.tensor([35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84], dtype=torch.float64),
+]
+_DP_C_ERROR = torch.tensor([35 / 384 - 1951 / 21600, 0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720,
+                            -2187 / 6784 - -12231 / 42400, 11 / 84 - 649 / 6300, -1. / 60.], dtype=torch.float64)
+_DP_C_MID = torch.tensor([6025192743 / 30085553152 / 2, 0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+                          187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2], dtype=torch.float64)
+
+
+def _rms(x):
+    return x.pow(2).mean().sqrt()
+
+
+class Dopri5:
+    """RKAdaptiveStepsizeODESolver specialised to the Dormand-Prince tableau, on a flat state.
+    ``func(t, y, perturb)``: t a 0-dim tensor ALREADY in the state dtype; perturb in {0: none, -1: just before t}."""
+
+    def __init__(self, func, y0, rtol, atol, norm=_rms, min_step=0.0, max_step=float("inf"), first_step=None, safety=0.9,
+                 ifactor=10.0, dfactor=0.2, max_num_steps=2 ** 31 - 1):
+        f64 = torch.float64
+        self.func, self.y0, self.norm = func, y0, norm
+        self.rtol, self.atol = torch.as_tensor(rtol, dtype=f64), torch.as_tensor(atol, dtype=f64)
+        self.min_step, self.max_step = torch.as_tensor(min_step, dtype=f64), torch.as_tensor(max_step, dtype=f64)
+        self.first_step = None if first_step is None else torch.as_tensor(first_step, dtype=f64)
+        self.safety, self.ifactor, self.dfactor = (torch.as_tensor(v, dtype=f64) for v in (safety, ifactor, dfactor))
+        self.max_num_steps = max_num_steps
+        dt_ = y0.dtype
+        self.alpha = _DP_ALPHA.to(dt_)
+        self.beta = [b.to(dt_) for b in _DP_BETA]
+        self.c_error, self.mid = _DP_C_ERROR.to(dt_), _DP_C_MID.to(dt_)
+        self.n_accept = self.n_reject = 0
+        self.trace = []        # (t0, dt, accepted, error_ratio) per attempt
+
+    def _f(self, t, y, perturb=0):
+        t = t.to(y.dtype)
+        if perturb < 0:
+            t = torch.nextafter(t, torch.tensor(-math.inf))
+        return self.func(t, y)
+
+    def _select_initial_step(self, t0, f0):
+        y0 = self.y0
+        dtype = y0.dtype
+        t0 = t0.to(dtype)
+        scale = self.atol + torch.abs(y0) * self.rtol
+        d0, d1 = self.norm(y0 / scale), self.norm(f0 / scale)
+        if d0 < 1e-5 or d1 < 1e-5:
+            h0 = torch.tensor(1e-6, dtype=dtype)
+        else:
+            h0 = 0.01 * d0 / d1
+        y1 = y0 + h0 * f0
+        f1 = self._f(t0 + h0, y1)
+        d2 = self.norm((f1 - f0) / scale) / h0
+        if d1 <= 1e-15 and d2 <= 1e-15:
+            h1 = torch.max(torch.tensor(1e-6, dtype=dtype), h0 * 1e-3)
+        else:
+            h1 = (0.01 / max(d1, d2)) ** (1. / float(4 + 1))
+        return torch.min(100 * h0, h1).to(torch.float64)
+
+    def _rk_step(self, y0, f0, t0, dt, t1):
+        t0, dt, t1 = t0.to(y0.dtype), dt.to(y0.dtype), t1.to(y0.dtype)
+        k = torch.empty(*f0.shape, 7, dtype=y0.dtype)
+        k[..., 0] = f0
+        for i, (alpha_i, beta_i) in enumerate(zip(self.alpha, self.beta)):
+            if alpha_i == 1.:
+                ti, perturb = t1, -1
+            else:
+                ti, perturb = t0 + alpha_i * dt, 0
+            yi = y0 + k[..., :i + 1].matmul(beta_i * dt).view_as(f0)
+            k[..., i + 1] = self._f(ti, yi, perturb)
+        y1 = yi                                 # c_sol = (beta[-1], 0): the last stage input IS the solution
+        return y1, k[..., -1], k.matmul(dt * self.c_error), k
+
+    def _optimal_step_size(self, last_step, error_ratio):
+        if error_ratio == 0:
+            return last_step * self.ifactor
+        dfactor = self.dfactor
+        if error_ratio < 1:
+            dfactor = torch.ones((), dtype=last_step.dtype)
+        error_ratio = error_ratio.type_as(last_step)
+        exponent = torch.tensor(5, dtype=last_step.dtype).reciprocal()
+        factor = torch.min(self.ifactor, torch.max(self.safety / error_ratio ** exponent, dfactor))
+        return last_step * factor
+
+    def _adaptive_step(self, st):
+        y0, f0, _, t0, dt, interp = st
+        t1 = t0 + dt
+        assert t0 + dt > t0, "underflow in dt {}".format(dt.item())
+        assert torch.isfinite(y0).all(), "non-finite values in state `y`"
+        y1, f1, y1_error, k = self._rk_step(y0, f0, t0, dt, t1)
+        error_tol = self.atol + self.rtol * torch.max(y0.abs(), y1.abs())
+        error_ratio = self.norm(y1_error / error_tol)
+        accept = bool(error_ratio <= 1)
+        if dt > self.max_step:
+            accept = False
+        if dt <= self.min_step:
+            accept = True
+        self.trace.append((float(t0), float(dt), accept, float(error_ratio)))
+        if accept:
+            self.n_accept += 1
+            dtf = dt.type_as(y0)
+            y_mid = y0 + k.matmul(dtf * self.mid).view_as(y0)
+            fa, fb = k[..., 0], k[..., -1]
+            a = 2 * dtf * (fb - fa) - 8 * (y1 + y0) + 16 * y_mid
+            b = dtf * (5 * fa - 3 * fb) + 18 * y0 + 14 * y1 - 32 * y_mid
+            c = dtf * (fb - 4 * fa) - 11 * y0 - 5 * y1 + 16 * y_mid
+            interp = [y0, dtf * fa, c, b, a]
+            t_next, y_next, f_next = t1, y1, f1
+        else:
+            self.n_reject += 1
+            t_next, y_next, f_next = t0, y0, f0
+        dt_next = self._optimal_step_size(dt, error_ratio).clamp(self.min_step, self.max_step)
+        return (y_next, f_next, t0, t_next, dt_next, interp)
+
+    def integrate(self, t):
+        t = torch.as_tensor(t).to(torch.float64)
+        sol = [self.y0]
+        f0 = self._f(t[0], self.y0)
+        first = self._select_initial_step(t[0], f0) if self.first_step is None else self.first_step
+        st = (self.y0, f0, t[0], t[0], first, [self.y0] * 5)
+        for i in range(1, len(t)):
+            n = 0
+            while t[i] > st[3]:
+                assert n < self.max_num_steps, "max_num_steps exceeded"
+                st = self._adaptive_step(st)
+                n += 1
+            coeffs, t0, t1 = st[5], st[2], st[3]
+            assert (t0 <= t[i]) & (t[i] <= t1)
+            x = ((t[i] - t0) / (t1 - t0)).to(coeffs[0].dtype)
+            total = coeffs[0] + x * coeffs[1]
+            xp = x
+            for cf in coeffs[2:]:
+                xp = xp * x
+                total = total + xp * cf
+            sol.append(total)
+        return torch.stack(sol, dim=0)
+
+
+def dopri5_forward(control, field, z0, t, rtol, atol, options=None, stats=None):
+    """cdeint(..., method='dopri5') forward: z at the times t -> [B, len(t), H]; stats gets nfe / accepted / rejected."""
+    z0 = torch.as_tensor(z0)
+    nfe = [0]
+
+    def func(tt, y):
+        nfe[0] += 1
+        return field.g(y, control.field_input(tt, field.mode))
+
+    sv = Dopri5(func, z0, rtol, atol, **(options or {}))
+    sol = sv.integrate(t)
+    if stats is not None:
+        stats.update(nfe=nfe[0], accepted=sv.n_accept, rejected=sv.n_reject, trace=sv.trace)
+    return sol.permute(1, 0, 2).contiguous()
+
+
+def dopri5_adjoint(control, field, t, z_out, grad_out, rtol, atol, options=None, stats=None, vjp="hand"):
+    """Continuous adjoint with the adaptive solver (adjoint.py:37-145): per output interval a fresh dopri5 solve of the
+    flat augmented state [vjp_t, y, a, g_theta...] in negated time, mixed norm max(|t|, rms(y), rms(a), max_p rms(g_p)).
+
+    vjp = "hand": the hand-written VJPs used everywhere else in this oracle.  vjp = "autograd": the stage VJP through
+    torch.autograd.grad as adjoint.py:95-98 does -- same values up to summation order, but an ADAPTIVE solve amplifies
+    last-bit differences into different step sequences (steps cluster at the kinks of a piecewise-linear control, where a
+    1e-7 change of dt moves a stage across a knot), so gen_golden.py pins the step-control logic with "autograd" (step
+    sequence identical to the reference, gradients bit-level) and the hand VJPs at solver-tolerance level."""
+    z_out, grad_out = torch.as_tensor(z_out), torch.as_tensor(grad_out)
+    t = torch.as_tensor(t).to(torch.float64)
+    params = field.unique_params()
+    B, H = z_out.shape[0], z_out.shape[2]
+    sizes = [1, B * H, B * H] + [p.numel() for p in params]
+    nfe = [0]
+    acc = {"accepted": 0, "rejected": 0, "trace": []}
+
+    def unpack(v):
+        out, o = [], 0
+        for n in sizes:
+            out.append(v[o:o + n])
+            o += n
+        return out
+
+    def norm(v):
+        parts = unpack(v)
+        return max([parts[0].abs().max(), _rms(parts[1]), _rms(parts[2])] + [max([_rms(q) for q in parts[3:]])])
+
+    def func(s, v):                      # _ReverseFunc(mul = -1) around augmented_dynamics evaluated at -s
+        nfe[0] += 1
+        parts = unpack(v)
+        y, a = parts[1].view(B, H), parts[2].view(B, H)
+        tt = -s
+        dx = control.field_input(tt, field.mode)
+        if vjp == "autograd":
+            with torch.enable_grad():
+                yg = y.detach().requires_grad_(True)
+                tg = tt.detach().requires_grad_(True)
+                for q in params:
+                    q.requires_grad_(True)
+                f = field.g(yg, control.field_input(tg, field.mode))
+                vjp_t, vjp_y, *vjp_p = torch.autograd.grad(f, (tg, yg) + tuple(params), -a, allow_unused=True)
+                for q in params:
+                    q.requires_grad_(False)
+            f = f.detach()
+            vjp_p = [torch.zeros_like(q) if gq is None else gq for q, gq in zip(params, vjp_p)]
+            vjp_t = torch.zeros(1, dtype=v.dtype) if vjp_t is None else vjp_t.reshape(1)
+        else:
+            f, saved = field.g(y, dx, save=True)
+            vjp_y, vjp_p = field.g_vjp(saved, dx, -a)
+            # vjp_t: adjoint.py:75-98 calls func with a time tensor that (through the in-place requires_grad_ on the detached
+            # alias) DOES require grad, so the cubic spline's dependence on t lands in the first state component and, via
+            # |vjp_t|, in the error norm.  matmul mode: (-a)^T M d2X/dt2 summed over the batch.
+            if control.kind == "cubic":
+                if field.mode != "matmul":
+                    raise NotImplementedError("hand vjp_t only for the matmul input")
+                m = saved["th"] if field.kind == "original" else saved["sg"] * saved["th"]
+                ddx = ((-a).unsqueeze(-1) * m.view(-1, field.H, field.C)).sum(1)
+                vjp_t = (ddx * control.second_derivative(tt)).sum().reshape(1)
+            else:
+                vjp_t = torch.zeros(1, dtype=v.dtype)
+        flat = torch.cat([vjp_t, f.reshape(-1), vjp_y.reshape(-1)] + [q.reshape(-1) for q in vjp_p])
+        return -1.0 * flat
+
+    y = z_out[:, -1]
+    a = grad_out[:, -1].clone()
+    g = [torch.zeros_like(p) for p in params]
+    vt = torch.zeros(1, dtype=y.dtype)       # vjp_t: carried across the output intervals like a and g (adjoint.py:131)
+    for i in range(len(t) - 1, 0, -1):
+        v0 = torch.cat([vt, y.reshape(-1), a.reshape(-1)] + [q.reshape(-1) for q in g])
+        sv = Dopri5(func, v0, rtol, atol, norm=norm, **(options or {}))
+        v1 = sv.integrate(-t[i - 1:i + 1].flip(0))[1]
+        acc["accepted"] += sv.n_accept
+        acc["rejected"] += sv.n_reject
+        acc["trace"] += sv.trace
+        parts = unpack(v1)
+        vt = parts[0]
+        a = parts[2].view(B, H)
+        g = [q.view_as(p) for q, p in zip(parts[3:], params)]
+        y = z_out[:, i - 1]
+        a = a + grad_out[:, i - 1]
+    if stats is not None:
+        stats.update(nfe=nfe[0], **acc)
+    return a, g
