@@ -1,0 +1,827 @@
+// Adaptive Dormand-Prince 5(4) ("dopri5") for the Neural-CDE path: NeuralCDE(solver="dopri5") (src/ncde/ncde.py:129-134) and
+// the default method of cdeint (experiments/sim_bm_toy_example.py:54-57).  Restates, relative to
+// /root/reference/modules/torchdiffeq/torchdiffeq/_impl:
+//   dopri5.py:5-36            tableau, mid-point weights
+//   rk_common.py:41-86        one step + embedded error estimate (stage times in the STATE dtype; alpha = 1 stages just before t1)
+//   rk_common.py:216-305      step control: fp64 time, accept iff error ratio <= 1, min_step / max_step overrides
+//   misc.py:33-103            initial step, error ratio, next step size
+//   interp.py:4-61            4th-order dense output at the requested times (steps are NOT clipped to output times)
+//   misc.py:18-19             ONE rms norm over the whole batch state: every sample takes the same steps
+//   adjoint.py:37-145, 235-247  one adaptive reverse solve per output interval over (vjp_t, y, a, g_theta), mixed norm
+//
+// Why this is not the persistent per-tile loop of the fixed-step kernels: accept / reject is a property of the WHOLE batch
+// (one error norm), so every attempt needs a grid-wide reduction before anybody may move on.  The solve is therefore a
+// sequence of small launches per attempt -- six stage launches (one workgroup per 16-sample tile, the generic family's
+// stage code), a controller (one workgroup: norms, accept / reject, next dt, stage descriptors of the next attempt, all
+// time arithmetic in fp64 on the device) and a commit (dense output, state roll) -- with the state resident in HBM
+// between launches.  The host only counts rounds: it enqueues a batch of rounds (kernels of finished solves exit at
+// once) and looks at the controller's phase word between batches -- the trip count is data dependent, exactly as the
+// reference's Python `while next_t > self.rk_state.t1` is.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "ncde_adaptive.h"
+#include "ncde_generic_stage.h"
+#include "ncde_host.h"
+
+namespace {
+
+enum { DP_INIT0 = 0, DP_INIT1 = 1, DP_STEP = 2, DP_DONE = 3 };
+constexpr int DP_MAXSEG = 2 * NCDE_MAX_LAYERS + 8;
+
+struct DpCtrl {
+    double t0, dt, t1;      // solver time (forward: t; adjoint: s = -t): current time, attempted step, t0 + dt
+    double t_goal;          // adjoint: end of the current output interval in solver time
+    double h0d;
+    int phase, accepted_now, finish_now;
+    int j_out, j_begin, j_end;       // forward: next output row; rows emitted by the step just accepted
+    int interval;                    // adjoint: solving t[interval] -> t[interval - 1]
+    int row_now;                     // adjoint commit: output row the finished interval ends at
+    int n_attempts, n_accept, n_reject, nfe, steps_this_solve, error;
+    float h0, dtf, dtf_commit, x_end;
+    StageDesc st[7];                 // st[0]: the f0 / probe evaluation; st[1..6]: stages 2..7 of the attempt
+};
+
+struct DpArgs {
+    KArgs a;
+    DpCtrl* ctrl;
+    int adj, n_wg, n_t, n_knots, theta1;   // theta1 = theta_size + 1 (the vjp_t slot)
+    const double* t_out;     // [n_t] device
+    const float* knots;      // [n_knots] device or NULL
+    float* XOUT;             // [n_t] dense-output abscissae of the accepted step
+    float* Y0;  float* YC;  float* KY;      // [B][H], [B][H], [7][B][H]
+    float* A0;  float* AC;  float* KA;      // adjoint: the a part
+    float* GP;               // [n_wg][theta1] per-workgroup stage partials
+    float* KT;               // [7][theta1] reduced parameter-part stage derivatives (incl. vjp_t)
+    float* G0T; float* GCT;  // [theta1] current / candidate parameter part
+    double* PN;              // [n_wg][4] per-workgroup partial sums of squares
+    float* out;              // forward: [B][n_t][H]
+    const float* z_out;      // adjoint
+    const float* grad_out;
+    double rtol, atol, min_step, max_step, first_step, safety, ifactor, dfactor;
+    int max_num_steps;
+    int nseg, seg_off[DP_MAXSEG], seg_len[DP_MAXSEG];
+    int lds_words_fwd, lds_words_adj, gacc_in_lds;
+};
+
+__device__ const float kAlpha[6] = {(float)(1.0 / 5), (float)(3.0 / 10), (float)(4.0 / 5), (float)(8.0 / 9), 1.0f, 1.0f};
+__device__ const float kBeta[6][6] = {
+    {(float)(1.0 / 5), 0, 0, 0, 0, 0},
+    {(float)(3.0 / 40), (float)(9.0 / 40), 0, 0, 0, 0},
+    {(float)(44.0 / 45), (float)(-56.0 / 15), (float)(32.0 / 9), 0, 0, 0},
+    {(float)(19372.0 / 6561), (float)(-25360.0 / 2187), (float)(64448.0 / 6561), (float)(-212.0 / 729), 0, 0},
+    {(float)(9017.0 / 3168), (float)(-355.0 / 33), (float)(46732.0 / 5247), (float)(49.0 / 176), (float)(-5103.0 / 18656), 0},
+    {(float)(35.0 / 384), 0.0f, (float)(500.0 / 1113), (float)(125.0 / 192), (float)(-2187.0 / 6784), (float)(11.0 / 84)}};
+__device__ const float kCErr[7] = {(float)(35.0 / 384 - 1951.0 / 21600), 0.0f, (float)(500.0 / 1113 - 22642.0 / 50085),
+                                   (float)(125.0 / 192 - 451.0 / 720), (float)(-2187.0 / 6784 - -12231.0 / 42400),
+                                   (float)(11.0 / 84 - 649.0 / 6300), (float)(-1.0 / 60.0)};
+__device__ const float kMid[7] = {(float)(6025192743.0 / 30085553152.0 / 2), 0.0f, (float)(51252292925.0 / 65400821598.0 / 2),
+                                  (float)(-2691868925.0 / 45128329728.0 / 2), (float)(187940372067.0 / 1594534317056.0 / 2),
+                                  (float)(-1776094331.0 / 19743644256.0 / 2), (float)(11237099.0 / 235043384.0 / 2)};
+
+// bucketize(t, knots, right=False) - 1 clamped, fraction and knot spacing (interpolation_linear.py:212-219)
+__device__ StageDesc dp_stage_desc(float t, const float* knots, int n_knots) {
+    StageDesc d;
+    if (!knots) {
+        d.idx = piece_index(t, n_knots - 1);
+        d.frac = t - (float)d.idx;
+        d.kdt = 1.0f;
+        return d;
+    }
+    int lo = 0, hi = n_knots;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (knots[mid] < t) lo = mid + 1;
+        else hi = mid;
+    }
+    int idx = lo - 1;
+    idx = idx < 0 ? 0 : (idx > n_knots - 2 ? n_knots - 2 : idx);
+    d.idx = idx;
+    d.frac = t - knots[idx];
+    d.kdt = knots[idx + 1] - knots[idx];
+    return d;
+}
+
+// stage descriptors of one attempt [t0, t0 + dt] (rk_common.py:61-73): stage times in fp32; the two alpha = 1 stages sit
+// one ulp before t1 (misc.py:183-188).  neg: solver time is the negated real time (adjoint).
+__device__ void dp_plan_attempt(DpCtrl* c, const DpArgs& d) {
+    c->t1 = c->t0 + c->dt;
+    const float t0f = (float)c->t0, dtf = (float)c->dt, t1f = (float)c->t1;
+    c->dtf = dtf;
+    for (int i = 0; i < 6; ++i) {
+        float ti;
+        if (kAlpha[i] == 1.0f) ti = nextafterf(t1f, -INFINITY);
+        else ti = t0f + kAlpha[i] * dtf;
+        c->st[i + 1] = dp_stage_desc(d.adj ? -ti : ti, d.knots, d.n_knots);
+    }
+}
+
+__device__ __forceinline__ float dp_poly(float y0, float y1, float ym, float f0, float f1, float dt, float x) {
+    // interp.py:4-61: fit on (y0, y1, y_mid, f0, f1), evaluate at x in [0, 1]
+    const float a = 2.0f * dt * (f1 - f0) - 8.0f * (y1 + y0) + 16.0f * ym;
+    const float b = dt * (5.0f * f0 - 3.0f * f1) + 18.0f * y0 + 14.0f * y1 - 32.0f * ym;
+    const float c = dt * (f1 - 4.0f * f0) - 11.0f * y0 - 5.0f * y1 + 16.0f * ym;
+    const float dd = dt * f0;
+    float total = y0 + x * dd;
+    float xp = x;
+    xp = xp * x; total = total + xp * c;
+    xp = xp * x; total = total + xp * b;
+    xp = xp * x; total = total + xp * a;
+    return total;
+}
+
+// second derivative of the cubic spline for the tile -> D2X[c*16 + s] (the t-dependence autograd sends to vjp_t)
+__device__ void dp_load_d2x(const KArgs& a, int b0, const StageDesc& sd, float* D2X, int Cp, int tid) {
+    for (int e = tid; e < 16 * Cp; e += GEN_THREADS) {
+        const int s = e / Cp, c = e - s * Cp;
+        const int b = b0 + s;
+        float v = 0.0f;
+        if (c < a.C && b < a.B) {
+            const float* p = a.coeffs + (long long)b * a.cs_b + (long long)sd.idx * a.cs_t;
+            const float cc = p[2 * a.C + c], dd = p[3 * a.C + c];
+            const float inner = cc + dd * sd.frac;
+            v = inner + dd * sd.frac;
+        }
+        D2X[c * 16 + s] = v;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// init: state <- initial condition, controller <- start of the (first) solve
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(256) void ncde_dp_init(DpArgs d) {
+    const long long n = (long long)d.a.B * d.a.H;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int H = d.a.H;
+    if (gid < n) {
+        const int b = (int)(gid / H), h = (int)(gid - (long long)b * H);
+        if (!d.adj) {
+            const float v = d.a.z0[gid];
+            d.Y0[gid] = v;
+            d.out[((long long)b * d.n_t) * H + h] = v;
+        } else {
+            const long long o = ((long long)b * d.n_t + (d.n_t - 1)) * H + h;
+            d.Y0[gid] = d.z_out[o];
+            d.A0[gid] = d.grad_out[o];
+        }
+    }
+    if (d.adj)
+        for (long long e = gid; e < d.theta1; e += (long long)gridDim.x * 256) d.G0T[e] = 0.0f;
+    if (gid == 0) {
+        DpCtrl* c = d.ctrl;
+        memset(c, 0, sizeof(DpCtrl));
+        c->phase = DP_INIT0;
+        c->j_out = 1;
+        if (!d.adj) {
+            c->t0 = d.t_out[0];
+        } else {
+            c->interval = d.n_t - 1;
+            c->t0 = -d.t_out[d.n_t - 1];
+            c->t_goal = -d.t_out[d.n_t - 2];
+        }
+        c->t1 = c->t0;
+        c->st[0] = dp_stage_desc(d.adj ? -(float)c->t0 : (float)c->t0, d.knots, d.n_knots);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// one stage evaluation for every 16-sample tile
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_dp_stage(DpArgs d, int slot) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const DpCtrl* c = d.ctrl;
+    const int phase = c->phase;
+    if (phase == DP_DONE || c->error != 0 || (phase != DP_STEP && slot != 1)) return;
+    const KArgs& a = d.a;
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x * NCDE_TILE;
+    const int H = a.H, Hp = ru16(H), Cp = ru4(a.C), L = a.n_layers;
+    int Dp = Hp;
+    for (int l = 0; l < L; ++l) Dp = max(Dp, ru16(a.dout[l]));
+    const int HS = Hp * 16, DS = Dp * 16;
+    const float dtf = c->dtf, h0 = c->h0;
+    const StageDesc sd = c->st[phase == DP_STEP ? slot : 0];
+    const long long BH = (long long)a.B * H;
+    // stage index in the K planes: INIT0 -> plane 0 (f0), INIT1 -> plane 1 (probe, scratch), STEP -> plane `slot`
+    const int plane = phase == DP_INIT0 ? 0 : (phase == DP_INIT1 ? 1 : slot);
+    const float rtolf = (float)d.rtol, atolf = (float)d.atol;
+    double sum0 = 0.0, sum1 = 0.0, sum2 = 0.0, sum3 = 0.0;   // per-thread partial sums of squares (y / a parts)
+
+    if (!d.adj) {
+        float* YS = lds;
+        float* ACT0 = YS + HS;
+        float* ACT1 = ACT0 + DS;
+        float* KO = ACT1 + DS;
+        float* DX = KO + HS;
+        for (int e = tid; e < HS + 2 * DS + HS + Cp * 16; e += GEN_THREADS) lds[e] = 0.0f;
+        __syncthreads();
+        for (int e = tid; e < HS; e += GEN_THREADS) {
+            const int h = e >> 4, s = e & 15, b = b0 + s;
+            if (h < H && b < a.B) {
+                const long long g = (long long)b * H + h;
+                float y = d.Y0[g];
+                if (phase == DP_INIT1) y = y + h0 * d.KY[g];
+                else if (phase == DP_STEP) {
+                    float acc = 0.0f;
+                    for (int j = 0; j < slot; ++j) acc += d.KY[j * BH + g] * (kBeta[slot - 1][j] * dtf);
+                    y = y + acc;
+                }
+                YS[e] = y;
+            }
+        }
+        load_dx(a, b0, sd, DX, Cp, tid);
+        __syncthreads();
+        gen_stage_forward(a, YS, ACT0, ACT1, DX, KO, Hp, Cp, tid);
+        for (int e = tid; e < HS; e += GEN_THREADS) {
+            const int h = e >> 4, s = e & 15, b = b0 + s;
+            if (h < H && b < a.B) {
+                const long long g = (long long)b * H + h;
+                const float k = KO[e];
+                d.KY[plane * BH + g] = k;
+                if (phase == DP_INIT0) {
+                    const float y0 = d.Y0[g];
+                    const float scale = atolf + fabsf(y0) * rtolf;
+                    const float q0 = y0 / scale, q1 = k / scale;
+                    sum0 += (double)q0 * q0;
+                    sum1 += (double)q1 * q1;
+                } else if (phase == DP_INIT1) {
+                    const float y0 = d.Y0[g];
+                    const float scale = atolf + fabsf(y0) * rtolf;
+                    const float q = (k - d.KY[g]) / scale;
+                    sum0 += (double)q * q;
+                } else if (slot == 6) {
+                    const float y0 = d.Y0[g], y1 = YS[e];
+                    d.YC[g] = y1;     // c_sol = (beta[-1], 0): the input of the last stage IS the solution (rk_common.py:76-80)
+                    float err = 0.0f;
+                    for (int j = 0; j < 6; ++j) err += d.KY[j * BH + g] * (dtf * kCErr[j]);
+                    err += k * (dtf * kCErr[6]);
+                    const float tol = atolf + rtolf * fmaxf(fabsf(y0), fabsf(y1));
+                    const float q = err / tol;
+                    sum0 += (double)q * q;
+                }
+            }
+        }
+    } else {
+        float* YS = lds;
+        float* AS = YS + HS;
+        float* KOY = AS + HS;
+        float* KOA = KOY + HS;
+        float* X = KOA + HS;
+        float* G0 = X + (L > 0 ? L : 1) * DS;
+        float* G1 = G0 + DS;
+        float* PW2 = G1 + DS;
+        float* DX = PW2 + 2 * DS;
+        float* D2X = DX + Cp * 16;
+        float* SC = D2X + Cp * 16;
+        float* GL = SC + GEN_NW * 16 * 17;
+        const int total = 4 * HS + ((L > 0 ? L : 1) + 4) * DS + 2 * Cp * 16 + GEN_NW * 16 * 17 + (d.gacc_in_lds ? d.theta1 : 0);
+        for (int e = tid; e < total; e += GEN_THREADS) lds[e] = 0.0f;
+        float* gacc = d.gacc_in_lds ? GL : d.GP + (long long)blockIdx.x * d.theta1;
+        if (!d.gacc_in_lds)
+            for (int e = tid; e < d.theta1; e += GEN_THREADS) gacc[e] = 0.0f;
+        __syncthreads();
+        for (int e = tid; e < HS; e += GEN_THREADS) {
+            const int h = e >> 4, s = e & 15, b = b0 + s;
+            if (h < H && b < a.B) {
+                const long long g = (long long)b * H + h;
+                float y = d.Y0[g], av = d.A0[g];
+                if (phase == DP_INIT1) {
+                    y = y + h0 * d.KY[g];
+                    av = av + h0 * d.KA[g];
+                } else if (phase == DP_STEP) {
+                    float accy = 0.0f, acca = 0.0f;
+                    for (int j = 0; j < slot; ++j) {
+                        const float bj = kBeta[slot - 1][j] * dtf;
+                        accy += d.KY[j * BH + g] * bj;
+                        acca += d.KA[j * BH + g] * bj;
+                    }
+                    y = y + accy;
+                    av = av + acca;
+                }
+                YS[e] = y;
+                AS[e] = av;
+            }
+        }
+        load_dx(a, b0, sd, DX, Cp, tid);
+        const bool cubic = a.interp == NCDE_INTERP_CUBIC;
+        if (cubic) dp_load_d2x(a, b0, sd, D2X, Cp, tid);
+        __syncthreads();
+        gen_stage_vjp(a, YS, AS, DX, cubic ? D2X : nullptr, X, G0, G1, PW2, SC, KOY, KOA, gacc, 1.0f, Hp, Cp, DS, tid);
+        __syncthreads();
+        if (d.gacc_in_lds) {
+            float* dst = d.GP + (long long)blockIdx.x * d.theta1;
+            for (int e = tid; e < d.theta1; e += GEN_THREADS) dst[e] = GL[e];
+        }
+        for (int e = tid; e < HS; e += GEN_THREADS) {
+            const int h = e >> 4, s = e & 15, b = b0 + s;
+            if (h < H && b < a.B) {
+                const long long g = (long long)b * H + h;
+                const float ky = -KOY[e], ka = KOA[e];      // negated time: dy/ds = -f, da/ds = +a^T df/dy (misc.py:152-159)
+                d.KY[plane * BH + g] = ky;
+                d.KA[plane * BH + g] = ka;
+                const float y0 = d.Y0[g], a0 = d.A0[g];
+                if (phase == DP_INIT0) {
+                    const float sy = atolf + fabsf(y0) * rtolf, sa = atolf + fabsf(a0) * rtolf;
+                    const float q0 = y0 / sy, q1 = a0 / sa, q2 = ky / sy, q3 = ka / sa;
+                    sum0 += (double)q0 * q0; sum1 += (double)q1 * q1; sum2 += (double)q2 * q2; sum3 += (double)q3 * q3;
+                } else if (phase == DP_INIT1) {
+                    const float sy = atolf + fabsf(y0) * rtolf, sa = atolf + fabsf(a0) * rtolf;
+                    const float q0 = (ky - d.KY[g]) / sy, q1 = (ka - d.KA[g]) / sa;
+                    sum0 += (double)q0 * q0; sum1 += (double)q1 * q1;
+                } else if (slot == 6) {
+                    const float y1 = YS[e], a1 = AS[e];
+                    d.YC[g] = y1;
+                    d.AC[g] = a1;
+                    float ey = 0.0f, ea = 0.0f;
+                    for (int j = 0; j < 6; ++j) {
+                        const float cj = dtf * kCErr[j];
+                        ey += d.KY[j * BH + g] * cj;
+                        ea += d.KA[j * BH + g] * cj;
+                    }
+                    ey += ky * (dtf * kCErr[6]);
+                    ea += ka * (dtf * kCErr[6]);
+                    const float qy = ey / (atolf + rtolf * fmaxf(fabsf(y0), fabsf(y1)));
+                    const float qa = ea / (atolf + rtolf * fmaxf(fabsf(a0), fabsf(a1)));
+                    sum0 += (double)qy * qy; sum1 += (double)qa * qa;
+                }
+            }
+        }
+    }
+    // workgroup reduction of the partial sums -> PN[wg][0..3]
+    __shared__ double red[4][GEN_THREADS];
+    red[0][tid] = sum0; red[1][tid] = sum1; red[2][tid] = sum2; red[3][tid] = sum3;
+    __syncthreads();
+    for (int off = GEN_THREADS / 2; off > 0; off >>= 1) {
+        if (tid < off)
+            for (int q = 0; q < 4; ++q) red[q][tid] += red[q][tid + off];
+        __syncthreads();
+    }
+    if (tid < 4) d.PN[(long long)blockIdx.x * 4 + tid] = red[tid][0];
+}
+
+// parameter part of the stage derivative: deterministic sum of the per-workgroup partials (K4 of the fixed-step path)
+extern "C" __global__ __launch_bounds__(256) void ncde_dp_reduce_theta(DpArgs d, int slot) {
+    const DpCtrl* c = d.ctrl;
+    const int phase = c->phase;
+    if (phase == DP_DONE || c->error != 0 || (phase != DP_STEP && slot != 1)) return;
+    const int plane = phase == DP_INIT0 ? 0 : (phase == DP_INIT1 ? 1 : slot);
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= d.theta1) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 3 < d.n_wg; p += 4) {
+        s0 += d.GP[(long long)p * d.theta1 + k];
+        s1 += d.GP[(long long)(p + 1) * d.theta1 + k];
+        s2 += d.GP[(long long)(p + 2) * d.theta1 + k];
+        s3 += d.GP[(long long)(p + 3) * d.theta1 + k];
+    }
+    for (; p < d.n_wg; ++p) s0 += d.GP[(long long)p * d.theta1 + k];
+    d.KT[(long long)plane * d.theta1 + k] = (s0 + s1) + (s2 + s3);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// controller: one workgroup.  Norms over the whole batch, accept / reject, next step, phase transitions.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// block-wide sum of a double (256 threads); every thread gets the total
+__device__ double dp_block_sum(double v, double* sh) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    sh[tid] = v;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) sh[tid] += sh[tid + off];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+__device__ double dp_block_max(double v, double* sh) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    sh[tid] = v;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) sh[tid] = fmax(sh[tid], sh[tid + off]);
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// mixed norm of the parameter part (adjoint.py:239-242): max over parameter tensors of rms(v / scale), and |vjp_t| / scale.
+// which: 0 = state / scale(state), 1 = f0 / scale, 2 = (f1 - f0) / scale, 3 = err / tol (also writes the candidate GCT)
+__device__ double dp_theta_norm(const DpArgs& d, int which, float dtf, double* sh) {
+    const int tid = threadIdx.x;
+    const float rtolf = (float)d.rtol, atolf = (float)d.atol;
+    double best = 0.0;
+    for (int sg = 0; sg <= d.nseg; ++sg) {      // sg == nseg: the vjp_t slot (|.|, not rms)
+        const int off = sg < d.nseg ? d.seg_off[sg] : d.theta1 - 1;
+        const int len = sg < d.nseg ? d.seg_len[sg] : 1;
+        double acc = 0.0;
+        for (int e = tid; e < len; e += 256) {
+            const int k = off + e;
+            const float g0 = d.G0T[k];
+            float q;
+            if (which == 3) {
+                float inc = 0.0f, err = 0.0f;
+                for (int j = 0; j < 6; ++j) inc += d.KT[(long long)j * d.theta1 + k] * (kBeta[5][j] * dtf);
+                for (int j = 0; j < 7; ++j) err += d.KT[(long long)j * d.theta1 + k] * (dtf * kCErr[j]);
+                const float g1 = g0 + inc;
+                d.GCT[k] = g1;
+                q = err / (atolf + rtolf * fmaxf(fabsf(g0), fabsf(g1)));
+            } else {
+                const float scale = atolf + fabsf(g0) * rtolf;
+                const float k0 = d.KT[k];
+                q = which == 0 ? g0 / scale : (which == 1 ? k0 / scale : (d.KT[(long long)d.theta1 + k] - k0) / scale);
+            }
+            acc += (double)q * q;
+        }
+        const double tot = dp_block_sum(acc, sh);
+        const double nrm = sg < d.nseg ? sqrt(tot / (double)len) : sqrt(tot);
+        best = fmax(best, nrm);
+    }
+    return best;
+}
+
+}  // namespace
+
+extern "C" __global__ __launch_bounds__(256) void ncde_dp_control(DpArgs d) {
+    __shared__ double sh[256];
+    __shared__ int sh_accept, sh_finish;
+    __shared__ float sh_x;
+    DpCtrl* c = d.ctrl;
+    const int tid = threadIdx.x;
+    const int phase = c->phase;
+    if (phase == DP_DONE || c->error != 0) {
+        if (tid == 0) c->accepted_now = 0;
+        return;
+    }
+    // batch-wide sums of squares from the stage kernels
+    double p[4] = {0, 0, 0, 0};
+    for (int w = tid; w < d.n_wg; w += 256)
+        for (int q = 0; q < 4; ++q) p[q] += d.PN[(long long)w * 4 + q];
+    double tot[4];
+    for (int q = 0; q < 4; ++q) tot[q] = dp_block_sum(p[q], sh);
+    const double nel = (double)d.a.B * (double)d.a.H;
+    const float dtf = c->dtf;
+
+    if (phase == DP_INIT0) {
+        double d0 = sqrt(tot[0] / nel), d1 = sqrt(tot[d.adj ? 2 : 1] / nel);
+        if (d.adj) {
+            d0 = fmax(d0, sqrt(tot[1] / nel));
+            d1 = fmax(d1, sqrt(tot[3] / nel));
+            d0 = fmax(d0, dp_theta_norm(d, 0, dtf, sh));
+            d1 = fmax(d1, dp_theta_norm(d, 1, dtf, sh));
+        }
+        if (tid == 0) {
+            const float d0f = (float)d0, d1f = (float)d1;
+            c->nfe += 1;
+            c->h0d = d1;      // keep d1 for the second half of the rule
+            float h0;
+            if (d0f < 1e-5f || d1f < 1e-5f) h0 = 1e-6f;
+            else h0 = 0.01f * d0f / d1f;
+            c->h0 = h0;
+            if (d.first_step > 0.0) {      // options['first_step']: no probe evaluation (rk_common.py:160-164)
+                c->dt = d.first_step;
+                dp_plan_attempt(c, d);
+                c->phase = DP_STEP;
+            } else {
+                const float tp = (float)c->t0 + h0;
+                c->st[0] = dp_stage_desc(d.adj ? -tp : tp, d.knots, d.n_knots);
+                c->phase = DP_INIT1;
+            }
+            c->accepted_now = 0;
+        }
+        return;
+    }
+    if (phase == DP_INIT1) {
+        double s2 = sqrt(tot[0] / nel);
+        if (d.adj) {
+            s2 = fmax(s2, sqrt(tot[1] / nel));
+            s2 = fmax(s2, dp_theta_norm(d, 2, dtf, sh));
+        }
+        if (tid == 0) {
+            const float h0 = c->h0, d1f = (float)c->h0d;
+            const float d2f = (float)s2 / h0;
+            float h1;
+            if (d1f <= 1e-15f && d2f <= 1e-15f) h1 = fmaxf(1e-6f, h0 * 1e-3f);
+            else h1 = powf(0.01f / fmaxf(d1f, d2f), 1.0f / 5.0f);
+            c->nfe += 1;
+            c->dt = (double)fminf(100.0f * h0, h1);
+            dp_plan_attempt(c, d);
+            c->phase = DP_STEP;
+            c->accepted_now = 0;
+        }
+        return;
+    }
+    // ---- DP_STEP: error ratio of the attempt ---------------------------------------------------------------------
+    double ratio = sqrt(tot[0] / nel);
+    if (d.adj) {
+        ratio = fmax(ratio, sqrt(tot[1] / nel));
+        ratio = fmax(ratio, dp_theta_norm(d, 3, dtf, sh));
+    }
+    if (tid == 0) {
+        const float ratiof = (float)ratio;
+        const double dt = c->dt;
+        bool accept = ratiof <= 1.0f;
+        if (dt > d.max_step) accept = false;
+        if (dt <= d.min_step) accept = true;
+        if (!(ratio == ratio) || !(fabs(ratio) <= 1.79e308)) { c->error = 2; accept = false; }      // non-finite state
+        c->nfe += 6;
+        c->n_attempts += 1;
+        c->steps_this_solve += 1;
+        if (c->steps_this_solve > d.max_num_steps) c->error = 3;
+        // next step size (misc.py:84-97)
+        double dt_next;
+        if (ratiof == 0.0f) dt_next = dt * d.ifactor;
+        else {
+            const double dfac = ratiof < 1.0f ? 1.0 : d.dfactor;
+            const double factor = fmin(d.ifactor, fmax(d.safety / pow((double)ratiof, 0.2), dfac));
+            dt_next = dt * factor;
+        }
+        dt_next = fmin(fmax(dt_next, d.min_step), d.max_step);
+        int finish = 0;
+        c->dtf_commit = c->dtf;
+        if (accept) {
+            c->n_accept += 1;
+            const double t0 = c->t0, t1 = c->t1;
+            if (!d.adj) {
+                int j = c->j_out;
+                c->j_begin = j;
+                while (j < d.n_t && !(d.t_out[j] > t1)) {
+                    d.XOUT[j] = (float)((d.t_out[j] - t0) / (t1 - t0));
+                    ++j;
+                }
+                c->j_end = c->j_out = j;
+                if (j >= d.n_t) finish = 1;
+            } else if (!(c->t_goal > t1)) {
+                finish = 1;
+                sh_x = (float)((c->t_goal - t0) / (t1 - t0));
+                c->x_end = sh_x;
+                c->row_now = c->interval - 1;
+            }
+            c->t0 = t1;
+        } else {
+            c->n_reject += 1;
+        }
+        c->dt = dt_next;
+        if (!(c->t0 + c->dt > c->t0) && !finish && c->error == 0) c->error = 1;      // 'underflow in dt' (rk_common.py:232)
+        c->accepted_now = accept ? 1 : 0;
+        c->finish_now = finish;
+        sh_accept = accept ? 1 : 0;
+        sh_finish = finish;
+        if (finish) {
+            if (!d.adj || c->interval == 1) {
+                c->phase = DP_DONE;
+            } else {       // next output interval: a fresh solve (new f0, new initial step), adjoint.py:116-130
+                c->interval -= 1;
+                c->t0 = -d.t_out[c->interval];
+                c->t_goal = -d.t_out[c->interval - 1];
+                c->t1 = c->t0;
+                c->steps_this_solve = 0;
+                c->st[0] = dp_stage_desc(-(float)c->t0, d.knots, d.n_knots);
+                c->phase = DP_INIT0;
+            }
+        } else {
+            dp_plan_attempt(c, d);
+        }
+    }
+    __syncthreads();
+    if (d.adj && sh_accept) {      // roll the parameter part (every thread): candidate, or the dense output at the interval end
+        const float x = sh_x, dtc = c->dtf_commit;
+        for (int k = tid; k < d.theta1; k += 256) {
+            float g1 = d.GCT[k];
+            if (sh_finish) {
+                const float g0 = d.G0T[k];
+                float gm = 0.0f;
+                for (int j = 0; j < 7; ++j) gm += d.KT[(long long)j * d.theta1 + k] * (dtc * kMid[j]);
+                gm = g0 + gm;
+                g1 = dp_poly(g0, g1, gm, d.KT[k], d.KT[6LL * d.theta1 + k], dtc, x);
+            }
+            d.G0T[k] = g1;
+            d.KT[k] = d.KT[6LL * d.theta1 + k];      // FSAL (unused after a finished interval: INIT0 recomputes plane 0)
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// commit of an accepted step: dense output at the requested times, state roll, FSAL
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(256) void ncde_dp_commit(DpArgs d) {
+    const DpCtrl* c = d.ctrl;
+    if (!c->accepted_now) return;
+    const long long n = (long long)d.a.B * d.a.H;
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n) return;
+    const int H = d.a.H;
+    const int b = (int)(g / H), h = (int)(g - (long long)b * H);
+    const float dtc = c->dtf_commit;
+    const float y0 = d.Y0[g], y1 = d.YC[g];
+    const float f0 = d.KY[g], f1 = d.KY[6 * n + g];
+    if (!d.adj) {
+        if (c->j_end > c->j_begin) {
+            float ym = 0.0f;
+            for (int j = 0; j < 7; ++j) ym += d.KY[j * n + g] * (dtc * kMid[j]);
+            ym = y0 + ym;
+            for (int j = c->j_begin; j < c->j_end; ++j) d.out[((long long)b * d.n_t + j) * H + h] = dp_poly(y0, y1, ym, f0, f1, dtc, d.XOUT[j]);
+        }
+        d.Y0[g] = y1;
+        d.KY[g] = f1;
+        return;
+    }
+    const float a0 = d.A0[g], a1 = d.AC[g];
+    const float fa0 = d.KA[g], fa1 = d.KA[6 * n + g];
+    if (c->finish_now) {      // adjoint.py:131-133: a at the interval end (dense output), y reset to the stored solution
+        float am = 0.0f;
+        for (int j = 0; j < 7; ++j) am += d.KA[j * n + g] * (dtc * kMid[j]);
+        am = a0 + am;
+        const long long o = ((long long)b * d.n_t + c->row_now) * H + h;
+        d.A0[g] = dp_poly(a0, a1, am, fa0, fa1, dtc, c->x_end) + d.grad_out[o];
+        d.Y0[g] = d.z_out[o];
+    } else {
+        d.Y0[g] = y1;
+        d.A0[g] = a1;
+        d.KY[g] = f1;
+        d.KA[g] = fa1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct DpPlan {
+    size_t off_ctrl, off_t, off_knots, off_xout, off_y0, off_yc, off_ky, off_a0, off_ac, off_ka, off_gp, off_kt, off_g0t, off_gct, off_pn;
+    size_t total;
+    int theta1, n_wg;
+};
+
+size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+DpPlan dp_plan(const NcdeProblem* p, const Layout& y, int n_t, bool adj) {
+    DpPlan w{};
+    size_t o = 0;
+    const size_t BH = (size_t)p->batch * p->hidden;
+    w.theta1 = y.theta_size + 1;
+    w.n_wg = y.n_wg;
+    auto take = [&](size_t bytes) { const size_t at = o; o = al256(o + bytes); return at; };
+    w.off_ctrl = take(sizeof(DpCtrl));
+    w.off_t = take(sizeof(double) * n_t);
+    w.off_knots = take(sizeof(float) * p->n_knots);
+    w.off_xout = take(sizeof(float) * n_t);
+    w.off_y0 = take(4 * BH);
+    w.off_yc = take(4 * BH);
+    w.off_ky = take(4 * 7 * BH);
+    w.off_pn = take(sizeof(double) * 4 * w.n_wg);
+    if (adj) {
+        w.off_a0 = take(4 * BH);
+        w.off_ac = take(4 * BH);
+        w.off_ka = take(4 * 7 * BH);
+        w.off_gp = take(4 * (size_t)w.n_wg * w.theta1);
+        w.off_kt = take(4 * 7 * (size_t)w.theta1);
+        w.off_g0t = take(4 * (size_t)w.theta1);
+        w.off_gct = take(4 * (size_t)w.theta1);
+    }
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+
+int64_t ncde_dp_workspace_bytes(const NcdeProblem* p, int n_t, int adj) {
+    const Layout y = make_layout(p);
+    return (int64_t)dp_plan(p, y, n_t, adj != 0).total;
+}
+
+bool ncde_dp_supported(const NcdeProblem* p, int adj, char* why, size_t n) {
+    const Layout y = make_layout(p);
+    if (y.variant) { snprintf(why, n, "dopri5 runs the original field with the matmul input only"); return false; }
+    if (!adj && y.lds_fwd > (size_t)kLdsLimit) { snprintf(why, n, "dopri5 forward needs %zu B of LDS", y.lds_fwd); return false; }
+    if (adj) {
+        const size_t base = sizeof(float) * (size_t)(4 * y.HS + ((y.L > 0 ? y.L : 1) + 4) * y.DS + 2 * y.Cp * 16 + 4 * 16 * 17) + 4 * 256 * sizeof(double);
+        if (base > (size_t)kLdsLimit) { snprintf(why, n, "dopri5 adjoint needs %zu B of LDS", base); return false; }
+        if (y.dlast > 128) { snprintf(why, n, "dopri5 adjoint supports a last hidden width <= 128 (got %d)", y.dlast); return false; }
+    }
+    return true;
+}
+
+// Runs the solve to completion (this call synchronises: the number of attempts is data dependent).
+int ncde_dp_solve(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* op, int adj, float* out, const float* z_out,
+                  const float* grad_out, const NcdeGrads* g, void* ws, size_t ws_bytes, hipStream_t st, NcdeAdaptiveStats* stats,
+                  char* err, size_t errn) {
+    const Layout y = make_layout(p);
+    const int n_t = ts->n_t;
+    const DpPlan w = dp_plan(p, y, n_t, adj != 0);
+    if (ws_bytes < w.total) { snprintf(err, errn, "workspace %zu B < %zu B", ws_bytes, w.total); return NCDE_ERR_WORKSPACE; }
+    for (int i = 1; i < n_t; ++i)
+        if (!(ts->t[i] > ts->t[i - 1])) { snprintf(err, errn, "t must be strictly increasing (decreasing output times are outside the fused path)"); return NCDE_ERR_INVALID; }
+    char* base = (char*)ws;
+    DpArgs d;
+    memset(&d, 0, sizeof(d));
+    fill_kargs(p, y, &d.a);
+    d.a.n_out = n_t;
+    d.ctrl = (DpCtrl*)(base + w.off_ctrl);
+    d.adj = adj; d.n_wg = w.n_wg; d.n_t = n_t; d.n_knots = p->n_knots; d.theta1 = w.theta1;
+    d.t_out = (const double*)(base + w.off_t);
+    d.knots = ts->knots ? (const float*)(base + w.off_knots) : nullptr;
+    d.XOUT = (float*)(base + w.off_xout);
+    d.Y0 = (float*)(base + w.off_y0); d.YC = (float*)(base + w.off_yc); d.KY = (float*)(base + w.off_ky);
+    d.PN = (double*)(base + w.off_pn);
+    if (adj) {
+        d.A0 = (float*)(base + w.off_a0); d.AC = (float*)(base + w.off_ac); d.KA = (float*)(base + w.off_ka);
+        d.GP = (float*)(base + w.off_gp); d.KT = (float*)(base + w.off_kt);
+        d.G0T = (float*)(base + w.off_g0t); d.GCT = (float*)(base + w.off_gct);
+    }
+    d.out = out; d.z_out = z_out; d.grad_out = grad_out;
+    d.rtol = op->rtol; d.atol = op->atol; d.min_step = op->min_step; d.max_step = op->max_step > 0.0 ? op->max_step : INFINITY;
+    d.first_step = op->first_step;
+    d.safety = op->safety > 0.0 ? op->safety : 0.9;
+    d.ifactor = op->ifactor > 0.0 ? op->ifactor : 10.0;
+    d.dfactor = op->dfactor > 0.0 ? op->dfactor : 0.2;
+    d.max_num_steps = op->max_num_steps > 0 ? op->max_num_steps : 2147483647;
+    // parameter tensors = segments of the flat gradient layout (one rms each in the mixed norm)
+    {
+        int n = 0;
+        for (int l = 0; l < p->n_layers; ++l) {
+            bool firstW = true, firstB = true;
+            for (int q = 0; q < l; ++q) {
+                if (p->layer_W[q] == p->layer_W[l]) firstW = false;
+                if (p->layer_b[q] == p->layer_b[l]) firstB = false;
+            }
+            if (firstW) { d.seg_off[n] = y.gW_off[l]; d.seg_len[n] = p->layer_out[l] * p->layer_in[l]; ++n; }
+            if (firstB) { d.seg_off[n] = y.gb_off[l]; d.seg_len[n] = p->layer_out[l]; ++n; }
+        }
+        d.seg_off[n] = y.gWo_off; d.seg_len[n] = y.rows * y.dlast; ++n;
+        d.seg_off[n] = y.gbo_off; d.seg_len[n] = y.rows; ++n;
+        d.nseg = n;
+    }
+    // LDS plans
+    const size_t lds_fwd = sizeof(float) * (size_t)(2 * y.HS + 2 * y.DS + y.Cp * 16);
+    size_t lds_adj = sizeof(float) * (size_t)(4 * y.HS + ((y.L > 0 ? y.L : 1) + 4) * y.DS + 2 * y.Cp * 16 + 4 * 16 * 17);
+    const size_t red_bytes = 4 * 256 * sizeof(double);
+    d.gacc_in_lds = adj && lds_adj + sizeof(float) * (size_t)w.theta1 + red_bytes <= (size_t)kLdsLimit;
+    if (d.gacc_in_lds) lds_adj += sizeof(float) * (size_t)w.theta1;
+    const size_t lds = adj ? lds_adj : lds_fwd;
+
+#define DP_TRY(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) { snprintf(err, errn, "%s failed: %s", #expr, hipGetErrorString(e_)); return NCDE_ERR_HIP; } \
+    } while (0)
+
+    DP_TRY(hipMemcpyAsync(base + w.off_t, ts->t, sizeof(double) * n_t, hipMemcpyHostToDevice, st));
+    std::vector<float> kf;
+    if (ts->knots) {
+        kf.resize(p->n_knots);
+        for (int i = 0; i < p->n_knots; ++i) kf[i] = (float)ts->knots[i];
+        DP_TRY(hipMemcpyAsync(base + w.off_knots, kf.data(), sizeof(float) * p->n_knots, hipMemcpyHostToDevice, st));
+        DP_TRY(hipStreamSynchronize(st));      // kf is a local: the copy must have left it before we go on
+    }
+    const long long BH = (long long)p->batch * p->hidden;
+    const int egrid = (int)((BH + 255) / 256);
+    const int tgrid = (w.theta1 + 255) / 256;
+    DP_TRY(hipFuncSetAttribute((const void*)ncde_dp_stage, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ncde_dp_init, dim3(egrid), dim3(256), 0, st, d);
+    DP_TRY(hipGetLastError());
+    DpCtrl hc;
+    const int rounds_per_sync = 16;
+    for (long long guard = 0; guard < (1LL << 40); ++guard) {
+        for (int r = 0; r < rounds_per_sync; ++r) {
+            for (int slot = 1; slot <= 6; ++slot) {
+                hipLaunchKernelGGL(ncde_dp_stage, dim3(w.n_wg), dim3(GEN_THREADS), lds, st, d, slot);
+                if (adj) hipLaunchKernelGGL(ncde_dp_reduce_theta, dim3(tgrid), dim3(256), 0, st, d, slot);
+            }
+            hipLaunchKernelGGL(ncde_dp_control, dim3(1), dim3(256), 0, st, d);
+            hipLaunchKernelGGL(ncde_dp_commit, dim3(egrid), dim3(256), 0, st, d);
+        }
+        DP_TRY(hipGetLastError());
+        DP_TRY(hipMemcpyAsync(&hc, d.ctrl, sizeof(DpCtrl), hipMemcpyDeviceToHost, st));
+        DP_TRY(hipStreamSynchronize(st));
+        if (hc.error != 0 || hc.phase == DP_DONE) break;
+    }
+    if (stats) {
+        stats->nfe = hc.nfe; stats->n_accepted = hc.n_accept; stats->n_rejected = hc.n_reject;
+    }
+    if (hc.error == 1) { snprintf(err, errn, "underflow in dt %g", hc.dt); return NCDE_ERR_INVALID; }
+    if (hc.error == 2) { snprintf(err, errn, "non-finite values in state `y`"); return NCDE_ERR_INVALID; }
+    if (hc.error == 3) { snprintf(err, errn, "max_num_steps exceeded (%d)", d.max_num_steps); return NCDE_ERR_INVALID; }
+    if (adj) {
+        // dL/dz0 = a at the start time; dL/dtheta = the parameter part, scattered into the caller's buffers
+        DP_TRY(hipMemcpyAsync(g->grad_z0, d.A0, sizeof(float) * BH, hipMemcpyDeviceToDevice, st));
+        const int rc = launch_reduce_partials(p, y, g, d.G0T, 1, st);      // one "partial" of theta_size floats: a pure scatter
+        if (rc != NCDE_OK) { snprintf(err, errn, "NcdeGrads: NULL destination for a parameter gradient"); return rc; }
+    }
+    return NCDE_OK;
+#undef DP_TRY
+}
