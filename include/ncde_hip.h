@@ -174,6 +174,39 @@ typedef struct NcdeTimePlanInfo {
 /* host_buffer == NULL: only fills *info (sizes).  Uses p->method, p->n_knots. */
 int ncde_time_plan_build(const NcdeProblem* p, const NcdeTimeSpec* ts, void* host_buffer, size_t bytes, NcdeTimePlanInfo* info);
 
+/* ---- adaptive Dormand-Prince 5(4): method='dopri5' of torchdiffeq (the default method of cdeint; NeuralCDE(solver="dopri5")
+ * passes options {'min_step': 0.5}, src/ncde/ncde.py:130-134).  Replaces Dopri5Solver / RKAdaptiveStepsizeODESolver
+ * (torchdiffeq/_impl/dopri5.py:5-36, rk_common.py:117-313, misc.py:33-103, interp.py) and, for the backward pass, the
+ * per-interval adaptive solves of OdeintAdjointMethod.backward over (vjp_t, y, a, g_theta) with the mixed error norm
+ * (adjoint.py:37-145, 235-247).  The error norm is over the WHOLE batch (one accept / reject per attempt), the time is kept
+ * in fp64 on the device.  These two calls DO synchronise the stream (the number of attempts is data dependent).
+ * p->method and p->output are ignored; the solution has ts->n_t rows per sample (row 0 = z0 = z(t[0])); ts->step_size is
+ * ignored.  Original field with the matmul input only. */
+typedef struct NcdeAdaptiveOptions {
+    double rtol, atol;      /* cdeint defaults: 1e-4, 1e-6 (torchcde/solver.py:193-196) */
+    double min_step;        /* options['min_step'], default 0 */
+    double max_step;        /* options['max_step'], 0 = infinity */
+    double first_step;      /* options['first_step'], 0 = select automatically (misc.py:33-74) */
+    double safety, ifactor, dfactor; /* 0 = the reference's defaults 0.9, 10, 0.2 */
+    int32_t max_num_steps;  /* 0 = 2^31 - 1 */
+    int32_t trace_capacity; /* diagnostics: number of attempts `trace` has room for (0 = none) */
+    double* trace;          /* HOST buffer of trace_capacity x 4 doubles, filled after the solve with one row per attempt:
+                               t0, dt, accepted (0/1), error ratio -- the step sequence, for comparison with the reference's */
+} NcdeAdaptiveOptions;
+
+typedef struct NcdeAdaptiveStats {
+    int32_t nfe;            /* vector-field evaluations, as the reference's func.nfe counts them (base.py:90) */
+    int32_t n_accepted, n_rejected;
+    int32_t reserved_;
+} NcdeAdaptiveStats;
+
+int64_t ncde_dopri5_workspace_bytes(const NcdeProblem* p, const NcdeTimeSpec* ts, int pass /* 0 forward, 1 adjoint */);
+int ncde_dopri5_forward(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt, float* out, void* workspace,
+                        size_t workspace_bytes, void* stream, NcdeAdaptiveStats* stats);
+int ncde_dopri5_adjoint(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt, const float* z_out,
+                        const float* grad_out, const NcdeGrads* grads, void* workspace, size_t workspace_bytes, void* stream,
+                        NcdeAdaptiveStats* stats);
+
 int ncde_version(void);
 const char* ncde_last_error_string(void);
 

@@ -78,6 +78,15 @@ class NcdeTimePlanInfo(ctypes.Structure):
     ]
 
 
+class NcdeAdaptiveOptions(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_double) for n in ("rtol", "atol", "min_step", "max_step", "first_step", "safety", "ifactor", "dfactor")] + \
+               [("max_num_steps", ctypes.c_int32), ("trace_capacity", ctypes.c_int32), ("trace", ctypes.POINTER(ctypes.c_double))]
+
+
+class NcdeAdaptiveStats(ctypes.Structure):
+    _fields_ = [("nfe", ctypes.c_int32), ("n_accepted", ctypes.c_int32), ("n_rejected", ctypes.c_int32), ("reserved_", ctypes.c_int32)]
+
+
 class NcdeGrads(ctypes.Structure):
     _fields_ = [
         ("grad_z0", _c_float_p),
@@ -97,7 +106,7 @@ EXPORTS = (
     "ncde_kernel_name", "ncde_forward", "ncde_adjoint", "ncde_time_kernel",
     "ncde_prepare_workspace_bytes", "ncde_prepare_linear", "ncde_prepare_cubic",
     "ncde_stage_record_bytes", "ncde_forward_record", "ncde_backward",
-    "ncde_time_plan_build",
+    "ncde_time_plan_build", "ncde_dopri5_workspace_bytes", "ncde_dopri5_forward", "ncde_dopri5_adjoint",
 )
 
 _LIB = None
@@ -166,6 +175,13 @@ def lib():
     h.ncde_prepare_cubic.restype = ctypes.c_int
     h.ncde_time_plan_build.argtypes = [P, ctypes.POINTER(NcdeTimeSpec), vp, sz, ctypes.POINTER(NcdeTimePlanInfo)]
     h.ncde_time_plan_build.restype = ctypes.c_int
+    TS, AO, AS = ctypes.POINTER(NcdeTimeSpec), ctypes.POINTER(NcdeAdaptiveOptions), ctypes.POINTER(NcdeAdaptiveStats)
+    h.ncde_dopri5_workspace_bytes.argtypes = [P, TS, ctypes.c_int]
+    h.ncde_dopri5_workspace_bytes.restype = ctypes.c_int64
+    h.ncde_dopri5_forward.argtypes = [P, TS, AO, vp, vp, sz, vp, AS]
+    h.ncde_dopri5_forward.restype = ctypes.c_int
+    h.ncde_dopri5_adjoint.argtypes = [P, TS, AO, vp, vp, G, vp, sz, vp, AS]
+    h.ncde_dopri5_adjoint.restype = ctypes.c_int
     if h.ncde_version() != NCDE_ABI_VERSION:
         raise NcdeError("libncde_hip.so ABI %d != binding %d" % (h.ncde_version(), NCDE_ABI_VERSION))
     _LIB = h

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 
+#include "ncde_adaptive.h"
 #include "ncde_common.h"
 #include "ncde_fast.h"
 #include "ncde_host.h"
@@ -206,6 +207,60 @@ int ncde_num_outputs(const NcdeProblem* p) {
     rc = validate(p);
     if (rc != NCDE_OK) return rc;
     return p->output == NCDE_OUT_TIMES ? p->n_t_out : (p->output == NCDE_OUT_KNOTS ? p->n_knots : 2);
+}
+
+namespace {
+// common front end of the dopri5 calls: the problem is validated as a default-axis one (method / output are not used)
+int dopri5_prepare(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt, int adj, NcdeProblem* q) {
+    int rc = normalize(p, q);
+    if (rc != NCDE_OK) return rc;
+    q->method = NCDE_RK4_38;
+    q->output = NCDE_OUT_INTERVAL;
+    q->time_plan = nullptr;
+    rc = validate(q);
+    if (rc != NCDE_OK) return rc;
+    if (!ts || !ts->t || ts->n_t < 2) return fail(NCDE_ERR_INVALID, "time spec: need >= 2 output times");
+    if (opt && (!(opt->rtol > 0.0) || !(opt->atol >= 0.0))) return fail(NCDE_ERR_INVALID, "rtol must be > 0 and atol >= 0");
+    char why[200] = "";
+    if (!ncde_dp_supported(q, adj, why, sizeof(why))) return fail(NCDE_ERR_UNSUPPORTED, "%s", why);
+    return NCDE_OK;
+}
+}  // namespace
+
+int64_t ncde_dopri5_workspace_bytes(const NcdeProblem* p, const NcdeTimeSpec* ts, int pass) {
+    NcdeProblem q_;
+    NcdeAdaptiveOptions o{};
+    o.rtol = 1e-4;
+    const int rc = dopri5_prepare(p, ts, &o, pass != 0, &q_);
+    if (rc != NCDE_OK) return rc;
+    return ncde_dp_workspace_bytes(&q_, ts->n_t, pass != 0);
+}
+
+int ncde_dopri5_forward(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt, float* out, void* workspace,
+                        size_t workspace_bytes, void* stream, NcdeAdaptiveStats* stats) {
+    NcdeProblem q_;
+    if (!opt) return fail(NCDE_ERR_INVALID, "options are NULL");
+    int rc = dopri5_prepare(p, ts, opt, 0, &q_);
+    if (rc != NCDE_OK) return rc;
+    if (!out || !workspace) return fail(NCDE_ERR_INVALID, "out / workspace is NULL");
+    char msg[256] = "";
+    rc = ncde_dp_solve(&q_, ts, opt, 0, out, nullptr, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream, stats, msg, sizeof(msg));
+    if (rc != NCDE_OK) return fail(rc, "%s", msg);
+    return NCDE_OK;
+}
+
+int ncde_dopri5_adjoint(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt, const float* z_out,
+                        const float* grad_out, const NcdeGrads* grads, void* workspace, size_t workspace_bytes, void* stream,
+                        NcdeAdaptiveStats* stats) {
+    NcdeProblem q_;
+    if (!opt) return fail(NCDE_ERR_INVALID, "options are NULL");
+    int rc = dopri5_prepare(p, ts, opt, 1, &q_);
+    if (rc != NCDE_OK) return rc;
+    if (!z_out || !grad_out || !grads || !grads->grad_z0 || !workspace) return fail(NCDE_ERR_INVALID, "NULL z_out/grad_out/grads/workspace");
+    char msg[256] = "";
+    rc = ncde_dp_solve(&q_, ts, opt, 1, nullptr, z_out, grad_out, grads, workspace, workspace_bytes, (hipStream_t)stream, stats, msg, sizeof(msg));
+    if (rc != NCDE_OK) return fail(rc, "%s", msg);
+    return NCDE_OK;
 }
 
 int ncde_time_plan_build(const NcdeProblem* p, const NcdeTimeSpec* ts, void* host_buffer, size_t bytes, NcdeTimePlanInfo* info) {

@@ -1,0 +1,14 @@
+// Adaptive dopri5 (csrc/ncde_adaptive.hip); the public entry points are in include/ncde_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <vector>
+
+#include "ncde_hip.h"
+
+int64_t ncde_dp_workspace_bytes(const NcdeProblem* p, int n_t, int adj);
+bool ncde_dp_supported(const NcdeProblem* p, int adj, char* why, size_t n);
+int ncde_dp_solve(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* op, int adj, float* out, const float* z_out,
+                  const float* grad_out, const NcdeGrads* g, void* ws, size_t ws_bytes, hipStream_t st, NcdeAdaptiveStats* stats,
+                  char* err, size_t errn);

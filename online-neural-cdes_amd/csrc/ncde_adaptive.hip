@@ -59,6 +59,8 @@ struct DpArgs {
     float* KT;               // [7][theta1] reduced parameter-part stage derivatives (incl. vjp_t)
     float* G0T; float* GCT;  // [theta1] current / candidate parameter part
     double* PN;              // [n_wg][4] per-workgroup partial sums of squares
+    double* TR;              // [trace_cap][4] diagnostics: t0, dt, accepted, error ratio per attempt
+    int trace_cap;
     float* out;              // forward: [B][n_t][H]
     const float* z_out;      // adjoint
     const float* grad_out;
@@ -538,6 +540,10 @@ extern "C" __global__ __launch_bounds__(256) void ncde_dp_control(DpArgs d) {
         if (dt <= d.min_step) accept = true;
         if (!(ratio == ratio) || !(fabs(ratio) <= 1.79e308)) { c->error = 2; accept = false; }      // non-finite state
         c->nfe += 6;
+        if (c->n_attempts < d.trace_cap) {
+            double* tr = d.TR + 4LL * c->n_attempts;
+            tr[0] = c->t0; tr[1] = dt; tr[2] = accept ? 1.0 : 0.0; tr[3] = (double)ratiof;
+        }
         c->n_attempts += 1;
         c->steps_this_solve += 1;
         if (c->steps_this_solve > d.max_num_steps) c->error = 3;
@@ -662,12 +668,13 @@ extern "C" __global__ __launch_bounds__(256) void ncde_dp_commit(DpArgs d) {
 namespace {
 
 struct DpPlan {
-    size_t off_ctrl, off_t, off_knots, off_xout, off_y0, off_yc, off_ky, off_a0, off_ac, off_ka, off_gp, off_kt, off_g0t, off_gct, off_pn;
+    size_t off_ctrl, off_t, off_knots, off_xout, off_y0, off_yc, off_ky, off_a0, off_ac, off_ka, off_gp, off_kt, off_g0t, off_gct, off_pn, off_tr;
     size_t total;
     int theta1, n_wg;
 };
 
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+constexpr int kTraceCap = 8192;      // attempts the diagnostic trace can hold
 
 DpPlan dp_plan(const NcdeProblem* p, const Layout& y, int n_t, bool adj) {
     DpPlan w{};
@@ -684,6 +691,7 @@ DpPlan dp_plan(const NcdeProblem* p, const Layout& y, int n_t, bool adj) {
     w.off_yc = take(4 * BH);
     w.off_ky = take(4 * 7 * BH);
     w.off_pn = take(sizeof(double) * 4 * w.n_wg);
+    w.off_tr = take(sizeof(double) * 4 * kTraceCap);
     if (adj) {
         w.off_a0 = take(4 * BH);
         w.off_ac = take(4 * BH);
@@ -738,6 +746,8 @@ int ncde_dp_solve(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdapti
     d.XOUT = (float*)(base + w.off_xout);
     d.Y0 = (float*)(base + w.off_y0); d.YC = (float*)(base + w.off_yc); d.KY = (float*)(base + w.off_ky);
     d.PN = (double*)(base + w.off_pn);
+    d.TR = (double*)(base + w.off_tr);
+    d.trace_cap = op->trace && op->trace_capacity > 0 ? std::min(op->trace_capacity, kTraceCap) : 0;
     if (adj) {
         d.A0 = (float*)(base + w.off_a0); d.AC = (float*)(base + w.off_ac); d.KA = (float*)(base + w.off_ka);
         d.GP = (float*)(base + w.off_gp); d.KT = (float*)(base + w.off_kt);
@@ -809,6 +819,10 @@ int ncde_dp_solve(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdapti
         DP_TRY(hipMemcpyAsync(&hc, d.ctrl, sizeof(DpCtrl), hipMemcpyDeviceToHost, st));
         DP_TRY(hipStreamSynchronize(st));
         if (hc.error != 0 || hc.phase == DP_DONE) break;
+    }
+    if (d.trace_cap > 0) {
+        const int rows = std::min(d.trace_cap, hc.n_attempts);
+        if (rows > 0) DP_TRY(hipMemcpy(op->trace, d.TR, sizeof(double) * 4 * rows, hipMemcpyDeviceToHost));
     }
     if (stats) {
         stats->nfe = hc.nfe; stats->n_accepted = hc.n_accept; stats->n_rejected = hc.n_reject;

@@ -49,10 +49,8 @@ class NeuralCDE(nn.Module):
         self.spline = SPLINES[interpolation]
         # the reference asserts solver in ["rk4", "dopri5"] (ncde.py:129); the fixed-step family is what is fused
         assert solver in ("rk4", "dopri5", "midpoint", "euler")
-        if solver == "dopri5":
-            raise NotImplementedError("adaptive dopri5 is outside the fused path (SURVEY.md §8f row 4); use solver='rk4'")
         self.atol, self.rtol = 1e-5, 1e-3
-        self.cdeint_options = {"step_size": 1}
+        self.cdeint_options = {"min_step": 0.5} if solver == "dopri5" else {"step_size": 1}      # ncde.py:130-134
         if vector_field not in VECTOR_FIELDS:
             raise NotImplementedError("vector_field '%s' (sparse / low-rank) is outside the fused path" % vector_field)
         self.func = VECTOR_FIELDS[vector_field](input_dim=input_dim, hidden_dim=hidden_dim,

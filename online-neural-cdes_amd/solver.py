@@ -251,6 +251,102 @@ class _FusedCdeint(torch.autograd.Function):
         return (grad_z0 if ctx.needs_input_grad[0] else None, None, None, *grads)
 
 
+class _AdaptiveSpec:
+    """Host description of one dopri5 call: output times / knots as host doubles + NcdeAdaptiveOptions."""
+
+    def __init__(self, X, t, rtol, atol, options):
+        tt = torch.as_tensor(t).detach()
+        self.tv = np.ascontiguousarray(tt.cpu().double().numpy())
+        assert self.tv.ndim == 1, "t must be one dimensional"
+        assert (self.tv[1:] > self.tv[:-1]).all() or (self.tv[1:] < self.tv[:-1]).all(), "t must be strictly increasing or decreasing"
+        if self.tv[1] < self.tv[0]:
+            raise NotImplementedError("decreasing output times are outside the fused path")
+        self.kn = None if X._default_grid else np.ascontiguousarray(X._t.detach().cpu().double().numpy())
+        dp = ctypes.POINTER(ctypes.c_double)
+        self.ts = _lib.NcdeTimeSpec(n_t=len(self.tv), time_is_f64=1, t=self.tv.ctypes.data_as(dp), step_size=1.0,
+                                    knots=None if self.kn is None else self.kn.ctypes.data_as(dp))
+        o = _lib.NcdeAdaptiveOptions()
+        o.rtol, o.atol = float(rtol), float(atol)
+        for k in ("min_step", "max_step", "first_step", "safety", "ifactor", "dfactor"):
+            if options.get(k) is not None:
+                setattr(o, k, float(options[k]))
+        if options.get("max_num_steps") is not None:
+            o.max_num_steps = int(options["max_num_steps"])
+        self.trace = None
+        if options.get("_trace"):           # diagnostics (tests): keep the step sequence (t0, dt, accepted, error ratio)
+            self.trace = np.zeros((int(options["_trace"]), 4), dtype=np.float64)
+            o.trace_capacity = self.trace.shape[0]
+            o.trace = self.trace.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        self.opt = o
+
+
+class _FusedDopri5(torch.autograd.Function):
+    """method='dopri5': forward = ncde_dopri5_forward; backward = ncde_dopri5_adjoint (one adaptive reverse solve per output
+    interval, adjoint.py:37-145).  Both calls synchronise: the number of attempts depends on the data."""
+
+    @staticmethod
+    def forward(ctx, z0, coeffs, cfg, *params):
+        spec, ad = cfg["spec"], cfg["adaptive"]
+        z0c = z0.detach().contiguous()
+        p = build_problem(coeffs, cfg["interp"], z0c, spec, "rk4", _lib.OUT_INTERVAL, cfg["flags"])
+        out = torch.empty(z0.shape[0], len(ad.tv), z0.shape[1], dtype=torch.float32, device=z0.device)
+        lib = _lib.lib()
+        stats = _lib.NcdeAdaptiveStats()
+        with torch.cuda.device(z0.device):
+            need = _lib.check(lib.ncde_dopri5_workspace_bytes(ctypes.byref(p), ctypes.byref(ad.ts), 0), "ncde_dopri5_workspace_bytes")
+            ws = torch.empty(int(need), dtype=torch.uint8, device=z0.device)
+            rc = lib.ncde_dopri5_forward(ctypes.byref(p), ctypes.byref(ad.ts), ctypes.byref(ad.opt), out.data_ptr(), ws.data_ptr(),
+                                         ws.numel(), _stream_ptr(), ctypes.byref(stats))
+        if rc == -1:
+            raise AssertionError(lib.ncde_last_error_string().decode())      # the reference asserts (rk_common.py:232-233, 195)
+        _lib.check(rc, "ncde_dopri5_forward")
+        cfg["stats_forward"] = (stats.nfe, stats.n_accepted, stats.n_rejected)
+        if ad.trace is not None and cfg["func"] is not None:
+            cfg["func"].dopri5_trace = ad.trace[:stats.n_accepted + stats.n_rejected].copy()
+        if cfg["func"] is not None and hasattr(cfg["func"], "nfe"):
+            cfg["func"].nfe += stats.nfe
+        ctx.cfg, ctx.coeffs, ctx.z0_shape = cfg, coeffs, z0.shape
+        ctx.save_for_backward(out, *params)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        cfg = ctx.cfg
+        out, *params = ctx.saved_tensors
+        spec, ad = cfg["spec"], cfg["adaptive_backward"]
+        dev = out.device
+        grad_out = grad_out.contiguous().float()
+        p = build_problem(ctx.coeffs, cfg["interp"], out[:, 0], spec, "rk4", _lib.OUT_INTERVAL, cfg["flags"])
+        uniq = spec.unique_params()
+        gbuf = {id(q): torch.empty_like(q, memory_format=torch.contiguous_format) for q in uniq}
+        g = _lib.NcdeGrads()
+        grad_z0 = torch.empty(ctx.z0_shape, dtype=torch.float32, device=dev)
+        g.grad_z0 = grad_z0.data_ptr()
+        for i, (w, b) in enumerate(spec.layers):
+            g.grad_layer_W[i], g.grad_layer_b[i] = gbuf[id(w)].data_ptr(), gbuf[id(b)].data_ptr()
+        g.grad_Wo, g.grad_bo = gbuf[id(spec.Wo)].data_ptr(), gbuf[id(spec.bo)].data_ptr()
+        lib = _lib.lib()
+        stats = _lib.NcdeAdaptiveStats()
+        with torch.cuda.device(dev):
+            need = _lib.check(lib.ncde_dopri5_workspace_bytes(ctypes.byref(p), ctypes.byref(ad.ts), 1), "ncde_dopri5_workspace_bytes")
+            ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+            rc = lib.ncde_dopri5_adjoint(ctypes.byref(p), ctypes.byref(ad.ts), ctypes.byref(ad.opt), out.data_ptr(), grad_out.data_ptr(),
+                                         ctypes.byref(g), ws.data_ptr(), ws.numel(), _stream_ptr(), ctypes.byref(stats))
+        if rc == -1:
+            raise AssertionError(lib.ncde_last_error_string().decode())
+        _lib.check(rc, "ncde_dopri5_adjoint")
+        cfg["stats_backward"] = (stats.nfe, stats.n_accepted, stats.n_rejected)
+        if cfg["func"] is not None and hasattr(cfg["func"], "nfe"):
+            cfg["func"].nfe += stats.nfe
+        keep = cfg["adjoint_param_ids"]
+        grads = [gbuf[id(q)] if needs and (keep is None or id(q) in keep) else None for q, needs in zip(params, ctx.needs_input_grad[3:])]
+        return (grad_z0 if ctx.needs_input_grad[0] else None, None, None, *grads)
+
+
+_DOPRI5_OPTIONS = ("min_step", "max_step", "first_step", "safety", "ifactor", "dfactor", "max_num_steps", "_trace")
+
+
 def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
     r"""Solve ``z_t = z_{t_0} + \int f(z_s) dX_s``; returns ``[batch, len(t), hidden]`` like the reference.
 
@@ -268,17 +364,33 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
     options = dict(kwargs.pop("options", None) or {})
     flags = kwargs.pop("kernel_flags", 0)
     adjoint_params = kwargs.pop("adjoint_params", None)
-    kwargs.pop("atol"), kwargs.pop("rtol")
+    atol, rtol = kwargs.pop("atol"), kwargs.pop("rtol")
+    adjoint_rtol, adjoint_atol = kwargs.pop("adjoint_rtol", None), kwargs.pop("adjoint_atol", None)
+    adjoint_options = kwargs.pop("adjoint_options", None)
+    adjoint_method = kwargs.pop("adjoint_method", None)
     for k in kwargs:
         warnings.warn("cdeint: Unexpected arguments {}".format({k: kwargs[k]}))  # misc.py:9-11
     if method is None:
         method = "dopri5"
     if method not in _ALL_METHODS:
         raise ValueError('Invalid method "{}". Must be one of {}'.format(method, '{"' + '", "'.join(_ALL_METHODS) + '"}.'))
-    if method not in _FIXED_METHODS:
-        raise NotImplementedError("method '%s': only the fixed-step solvers %s run on the fused path" % (method, _FIXED_METHODS))
+    if method not in _FIXED_METHODS and method != "dopri5":
+        raise NotImplementedError("method '%s': the fixed-step solvers %s and adaptive dopri5 run on the fused path" % (method, _FIXED_METHODS))
+    if adjoint_method is not None and adjoint_method != method:
+        raise NotImplementedError("adjoint_method != method is outside the fused path")
     if not isinstance(X, (LinearInterpolation, NaturalCubicSpline)):
         raise NotImplementedError("X must be ncde_amd.LinearInterpolation or ncde_amd.NaturalCubicSpline")
+    adaptive = method == "dopri5"
+    if adaptive:
+        if not adjoint:
+            raise NotImplementedError("method='dopri5' with adjoint=False (autograd through the adaptive solver, including its "
+                                      "data-dependent first step) is not implemented; use adjoint=True or a fixed-step method")
+        for k in list(options):
+            if k not in _DOPRI5_OPTIONS and k != "norm":
+                warnings.warn("cdeint: Unexpected arguments {}".format({k: options.pop(k)}))
+        if options.pop("norm", None) is not None:
+            raise NotImplementedError("a custom error norm is outside the fused path (the reference's rms / mixed norms are built in)")
+        options.setdefault("step_size", 1.0)      # unused by the adaptive solver; keeps the common argument checks below uniform
     step = options.pop("step_size", None)
     if "grid_constructor" in options:
         raise NotImplementedError("options['grid_constructor'] is outside the fused path; give options={'step_size': h}")
@@ -291,6 +403,7 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
         raise ValueError("step_size must be positive")
     if options.pop("perturb", False):
         warnings.warn("cdeint: options['perturb'] is ignored by the fused fixed-step kernels (stage times are exact knots/fractions)")
+    ad_options = {k: options.pop(k) for k in list(options) if adaptive and k in _DOPRI5_OPTIONS}
     for k in options:
         warnings.warn("cdeint: Unexpected arguments {}".format({k: options[k]}))
     if not torch.is_tensor(z0):
@@ -334,6 +447,18 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
         ap = ap & set(id(q) for q in uniq)
     else:
         ap = None
+    if adaptive:
+        if spec.kind != "original" or spec.mode != "matmul":
+            raise NotImplementedError("method='dopri5' runs the original vector field with the matmul input only")
+        bopt = dict(ad_options) if adjoint_options is None else {k: v for k, v in adjoint_options.items() if k in _DOPRI5_OPTIONS}
+        cfg = {"spec": spec, "interp": X.interp_name, "flags": flags, "func": func, "adjoint_param_ids": ap,
+               "adaptive": _AdaptiveSpec(X, t, rtol, atol, ad_options),
+               "adaptive_backward": _AdaptiveSpec(X, t, rtol if adjoint_rtol is None else adjoint_rtol,
+                                                  atol if adjoint_atol is None else adjoint_atol, bopt)}
+        out = _FusedDopri5.apply(z0, coeffs.detach(), cfg, *uniq)
+        if len(batch_shape) != 1:
+            out = out.reshape(*batch_shape, out.shape[-2], out.shape[-1])
+        return out
     output = _time_mode(X, t) if float(step) == 1.0 else None
     stages = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
     plan = None

@@ -34,7 +34,7 @@ def _problem(B=32, T=49, C=20, H=32, HH=32, nl=3, interp=0, method=2, output=0, 
 def test_library_loads_and_exports_every_declared_symbol():
     lib = ncde_amd.lib()
     header = open(os.path.join(ROOT, "include", "ncde_hip.h")).read()
-    declared = set(re.findall(r"\b(ncde_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(ncde_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
@@ -201,8 +201,12 @@ def test_cdeint_argument_errors_mirror_the_reference():
         ncde_amd.cdeint(X, f, z0, X.interval, vector_field_type="bogus")
     with pytest.raises(ValueError, match="Invalid method"):
         ncde_amd.cdeint(X, f, z0, X.interval, method="rk5", options={"step_size": 1})
-    with pytest.raises(NotImplementedError, match="dopri5"):
-        ncde_amd.cdeint(X, f, z0, X.interval)                       # the reference's default is adaptive dopri5
+    with pytest.raises(NotImplementedError, match="GPU"):
+        ncde_amd.cdeint(X, f, z0, X.interval)                       # the reference's default, adaptive dopri5: past the argument
+    with pytest.raises(NotImplementedError, match="adjoint=False"):  # checks, stops at the CPU tensors (no CPU fallback)
+        ncde_amd.cdeint(X, f, z0, X.interval, adjoint=False)
+    with pytest.raises(NotImplementedError, match="bosh3"):
+        ncde_amd.cdeint(X, f, z0, X.interval, method="bosh3")
     with pytest.raises(NotImplementedError, match="step_size"):
         ncde_amd.cdeint(X, f, z0, X.interval, method="rk4")
     with pytest.raises(ValueError, match="positive"):
@@ -219,8 +223,10 @@ def test_no_cpu_fallback_product_path_fails_loudly_on_cpu_tensors():
     m = ncde_amd.NeuralCDE(3, 4, 1, hidden_hidden_dim=8)
     with pytest.raises(NotImplementedError):
         m(torch.zeros(2, 5, 3))
-    with pytest.raises(NotImplementedError, match="dopri5"):
-        ncde_amd.NeuralCDE(3, 4, 1, solver="dopri5")
+    m5 = ncde_amd.NeuralCDE(3, 4, 1, solver="dopri5")
+    assert m5.cdeint_options == {"min_step": 0.5} and (m5.rtol, m5.atol) == (1e-3, 1e-5)      # src/ncde/ncde.py:130-134
+    with pytest.raises(NotImplementedError):
+        m5(torch.zeros(2, 5, 3))
 
 
 def test_control_path_gradients_are_refused_not_dropped():
