@@ -324,14 +324,18 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, uns
 
 __device__ __forceinline__ Split3 split8(const float* v) {
     Split3 o;
+    // piece by piece (all hi, then all mid, then all lo): the consumers' first MFMAs need only hi
+    float r[8], l[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        unsigned h_, m_, l_;
-        split_pair(v[2 * q], v[2 * q + 1], h_, m_, l_);
-        o.hi[q] = h_;
-        o.mid[q] = m_;
-        o.lo[q] = l_;
-    }
+    for (int q = 0; q < 4; ++q) o.hi[q] = __builtin_amdgcn_perm(__float_as_uint(v[2 * q + 1]), __float_as_uint(v[2 * q]), 0x07060302u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = v[j] - __uint_as_float(__float_as_uint(v[j]) & 0xFFFF0000u);  // exact
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o.mid[q] = __builtin_amdgcn_perm(__float_as_uint(r[2 * q + 1]), __float_as_uint(r[2 * q]), 0x07060302u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) l[j] = r[j] - __uint_as_float(__float_as_uint(r[j]) & 0xFFFF0000u);  // exact
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o.lo[q] = __builtin_amdgcn_perm(__float_as_uint(l[2 * q + 1]), __float_as_uint(l[2 * q]), 0x07060302u);
     return o;
 }
 
@@ -344,18 +348,29 @@ __device__ __forceinline__ f32x16 mfma_bf32(u32x4 a, u32x4 b, f32x16 c) {  // 32
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// c += A * B over one K chunk of 32, fp32-equivalent (smallest partial products first)
+// c += A * B over one K chunk of 32, fp32-equivalent.  Product order: everything that needs only the hi piece of the
+// (freshly split) B operand first, then mid, then lo -- on the serial chain the B operand comes straight out of the
+// VALU split of the previous layer, so the first three MFMAs can issue while the mid / lo pieces are still being formed.
 __device__ __forceinline__ f32x4 mfma_split(const Split3& A, const Split3& B, f32x4 c) {
     c = mfma_bf(A.lo, B.hi, c);
-    c = mfma_bf(A.hi, B.lo, c);
-    c = mfma_bf(A.mid, B.mid, c);
     c = mfma_bf(A.mid, B.hi, c);
-    c = mfma_bf(A.hi, B.mid, c);
     c = mfma_bf(A.hi, B.hi, c);
+    c = mfma_bf(A.mid, B.mid, c);
+    c = mfma_bf(A.hi, B.mid, c);
+    c = mfma_bf(A.hi, B.lo, c);
     return c;
 }
 
-template <int H, int HH, int C, int NW, int INTERP, int METHOD, int PROF = 0>
+// relu on the bit pattern: max_i32(bits, 0) is 0 for every negative float (and -0.0) and the identity otherwise -- ONE
+// VALU op, no canonicalisation of the MFMA result (v_max_f32 / v_med3_f32 get a v_max x,x,x in front).
+__device__ __forceinline__ float relu_bits(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
+// NLT = number of layers known at compile time (0 = runtime): with the layer loop unrolled the whole stage is ONE basic
+// block, so the scheduler can issue the hi-piece MFMAs of layer l+1 under the mid / lo split of layer l.
+template <int H, int HH, int C, int NW, int INTERP, int METHOD, int PROF = 0, int NLT = 0>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs a) {
     unsigned long long prof[4] = {0, 0, 0, 0}, tlast = 0;
 #define NCDE_TICK(k)                                                \
@@ -520,10 +535,10 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
 #pragma unroll
             for (int tt = 0; tt < HT; ++tt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hv[tt >> 1][4 * (tt & 1) + r] = relu_dev(acc[tt][r]);
+                for (int r = 0; r < 4; ++r) hv[tt >> 1][4 * (tt & 1) + r] = relu_bits(acc[tt][r]);
 #pragma unroll
             for (int c = 0; c < KC; ++c) xb[c] = split8(hv[c]);
-            for (int rep = 0; rep < n_inner; ++rep) {
+            auto inner_layer = [&]() {
 #pragma unroll
                 for (int tt = 0; tt < HT; ++tt) acc[tt] = bias1[tt];
 #pragma unroll
@@ -533,9 +548,15 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
 #pragma unroll
                 for (int tt = 0; tt < HT; ++tt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) hv[tt >> 1][4 * (tt & 1) + r] = relu_dev(acc[tt][r]);
+                    for (int r = 0; r < 4; ++r) hv[tt >> 1][4 * (tt & 1) + r] = relu_bits(acc[tt][r]);
 #pragma unroll
                 for (int c = 0; c < KC; ++c) xb[c] = split8(hv[c]);
+            };
+            if constexpr (NLT > 0) {
+#pragma unroll
+                for (int rep = 0; rep < NLT - 1; ++rep) inner_layer();
+            } else {
+                for (int rep = 0; rep < n_inner; ++rep) inner_layer();
             }
             NCDE_TICK(0)
             // ---- output layer tiles owned by this wave: tanh + channel contraction -----------------------
@@ -2360,9 +2381,9 @@ FwdFn pick_fwd(int interp, int method) {
 }
 
 template <int H, int HH, int C, int NW>
-FwdFn pick_fwd_bf3(int interp, int method) {
+FwdFn pick_fwd_bf3(int interp, int method, int n_layers) {
 #define NCDE_PICK(I, M) \
-    if (interp == I && method == M) return ncde_fwd_fast_bf3<H, HH, C, NW, I, M>;
+    if (interp == I && method == M) return n_layers == 3 ? ncde_fwd_fast_bf3<H, HH, C, NW, I, M, 0, 3> : ncde_fwd_fast_bf3<H, HH, C, NW, I, M>;
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_RK4_38)
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_MIDPOINT)
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_EULER)
@@ -2460,7 +2481,7 @@ struct FastEntry {
     int nw;
     FwdFn (*fwd)(int, int);
     const char* fwd_name;
-    FwdFn (*fwd_bf3)(int, int);     // split-bf16 variant (default); NCDE_FLAG_FP32_MFMA selects `fwd`
+    FwdFn (*fwd_bf3)(int, int, int);  // split-bf16 variant (default); NCDE_FLAG_FP32_MFMA selects `fwd`
     const char* fwd_bf3_name;
     int nw_bf3;
     int adj_layers;                 // n_layers the adjoint instantiation is built for (0 = none)
@@ -2543,10 +2564,11 @@ int ncde_fast_forward(const NcdeProblem* p, float* out, float* stages, void* ws,
     a.out = out;
     a.stages = stages;
     const bool bf3 = (p->flags & NCDE_FLAG_FP32_MFMA) == 0 && e->fwd_bf3 != nullptr;
-    if (bf3) fn = e->fwd_bf3(p->interp, p->method);
+    if (bf3) fn = e->fwd_bf3(p->interp, p->method, p->n_layers);
     if (p->flags & NCDE_FLAG_DEBUG_PROFILE) {  // phase-cycle counters -> workspace [n_wg][NW][4] u64
         if (!(e->shape.H == 32 && e->shape.C == 20 && p->interp == NCDE_INTERP_LINEAR && p->method == NCDE_RK4_38)) return NCDE_ERR_UNSUPPORTED;
-        fn = bf3 ? ncde_fwd_fast_bf3<32, 32, 20, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>
+        fn = bf3 ? (p->n_layers == 3 ? ncde_fwd_fast_bf3<32, 32, 20, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1, 3>
+                                     : ncde_fwd_fast_bf3<32, 32, 20, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>)
                  : ncde_fwd_fast<32, 32, 20, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>;
         a.gpart = (float*)ws;
     }

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 import bench
 c = dict(bench.CONFIGS["cfg2"])
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-coeffs = torch.from_numpy(bench.make_inputs(c, B, 0)).cuda()
+coeffs = bench.make_inputs(c, B, 0, torch.device("cuda", 0))
 model, fw, rw = bench.make_model(c, "cuda")
 spec = model.func.fused_spec()
 with torch.no_grad():
