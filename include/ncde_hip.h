@@ -66,8 +66,11 @@ typedef enum NcdeOutput { NCDE_OUT_INTERVAL = 0, NCDE_OUT_KNOTS = 1, NCDE_OUT_TI
 #define NCDE_FLAG_TILED_NS1 0x1000u    /* batch-tiled forward: force 1 / 2 / 4 sixteen-sample tiles per workgroup     */
 #define NCDE_FLAG_TILED_NS2 0x2000u    /*   (default: the largest that still gives >= 256 workgroups)                 */
 #define NCDE_FLAG_TILED_NS4 0x4000u
-#define NCDE_FLAG_FORCE_TILED 0x8000u  /* use the batch-tiled family wherever it is supported (default: forward always,
-                                          backward when the output-layer matrix is >= 1 MB) */
+#define NCDE_FLAG_FORCE_TILED 0x8000u  /* use the batch-tiled family also where a shape-specialised kernel exists (default order:
+                                          specialised, then batch-tiled wherever its shape constraints hold, then generic).
+                                          Its backward keeps per-stage records for a WINDOW of steps only (sweep W steps, fold
+                                          them into the output-layer gradient, reuse the record): workspace O(B H W), W sized to
+                                          a 192 MB record budget (environment variable NCDE_TILED_WINDOW_MB overrides) */
 
 typedef struct NcdeProblem {
     int32_t abi_version;  /* = NCDE_ABI_VERSION */

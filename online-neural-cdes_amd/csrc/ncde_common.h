@@ -38,6 +38,10 @@ struct KArgs {
     float* recC;      // w * cotangent  [stage][sample tile][H][16]
     float* recD;      // dX/dt          [stage][sample tile][C/4][16][4]
     int gstride;      // floats per workgroup partial in gpart (hidden-layer parameters only)
+    // time-windowed backward of the batch-tiled family: one launch sweeps the reverse steps n = win_hi .. win_lo + 1; the
+    // carried state (y, a per element) and the hidden-layer partial in gpart link consecutive windows
+    int win_hi, win_lo, resume;
+    float* carry;     // [2][n_workgroups][H * 16]
     // vector-field variants (generic family only): gated heads, reset net, evaluate / derivative input modes
     int field_kind, field_input;
     int d0;           // width of the field input u: H (matmul) or H + C

@@ -1943,7 +1943,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
 #pragma unroll
                     for (int tt = 0; tt < HT; ++tt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) x[0][4 * tt + r] = relu_dev(acc[tt][r]);
+                        for (int r = 0; r < 4; ++r) x[0][4 * tt + r] = relu_bits(acc[tt][r]);
 #pragma unroll
                     for (int l = 1; l < NL; ++l) {
                         xb = split8(x[l - 1]);
@@ -1952,7 +1952,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
 #pragma unroll
                         for (int tt = 0; tt < HT; ++tt)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) x[l][4 * tt + r] = relu_dev(acc[tt][r]);
+                            for (int r = 0; r < 4; ++r) x[l][4 * tt + r] = relu_bits(acc[tt][r]);
                     }
                     xb = split8(x[NL - 1]);
                 }

@@ -586,13 +586,19 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
         if (e < HS) {
             const int u = ((e >> 2) / NSP) * 4 + (e & 3), s = (e >> 2) % NSP, b = b0 + s;
             const long long o = ((long long)b * a.n_out + last_row) * H + u;
-            const float g = b < a.B ? a.grad_out[o] : 0.0f;
+            float g, y;
+            if (a.resume) {      // a later time window: (y, a) at knot win_hi as the previous launch left them
+                y = a.carry[(long long)blockIdx.x * HS + e];
+                g = a.carry[((long long)gridDim.x + blockIdx.x) * HS + e];
+            } else {
+                g = b < a.B ? a.grad_out[o] : 0.0f;
+                y = (!disc && b < a.B) ? a.z_out[o] : 0.0f;
+            }
             a0[q] = g;
             if (disc) {
                 AS[e] = a.method == NCDE_RK4_38 ? g * 0.125f : g;
                 YS[e] = 0.0f;
             } else {
-                const float y = b < a.B ? a.z_out[o] : 0.0f;
                 y0[q] = y;
                 YS[e] = y;
                 AS[e] = g;
@@ -604,6 +610,35 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     float db0 = 0.0f, db1 = 0.0f;
 #pragma unroll
     for (int q = 0; q < TL_DWT; ++q) dw0[q] = dw1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.resume) {      // continue this workgroup's hidden-layer partial where the previous window stopped
+        const float* gp = a.gpart + (long long)blockIdx.x * a.gstride;
+        const int li = lane & 15, lk = lane >> 4;
+        int l1 = -1;
+        for (int l = 1; l < L; ++l)
+            if (a.gW_off[l] != a.gW_off[0]) { l1 = l; break; }
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot) {
+            const int l = slot == 0 ? 0 : l1;
+            if (l < 0) continue;
+            const int N = a.dout[l], K = a.din[l], nit = K >> 4, ntile = (N >> 4) * nit;
+#pragma unroll
+            for (int q = 0; q < TL_DWT; ++q) {
+                const int tt = wave + NWV * q;
+                if (tt < ntile) {
+                    const int jt = tt / nit, it = tt - jt * nit;
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gp[a.gW_off[l] + (16 * jt + 4 * lk + r) * K + 16 * it + li];
+                    if (slot == 0) dw0[q] = v;
+                    else dw1[q] = v;
+                }
+            }
+            if (tid < N) {
+                if (slot == 0) db0 = gp[a.gb_off[l] + tid];
+                else db1 = gp[a.gb_off[l] + tid];
+            }
+        }
+    }
 
     // ---- resident weight fragments (RES) -------------------------------------------------------------------------------
     Panel<PK> wf[2];          // forward row tile `wave` of the layer-0 matrix / of the other matrix
@@ -701,17 +736,17 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
             }
         }
     };
-    prefetch(a.T - 1, 0);
+    prefetch(a.win_hi, 0);
     publish();
     __syncthreads();
 
-    int sc = 0;
-    for (int n = a.T - 1; n >= 1; --n) {
+    int sc = 0;      // stage counter within this time window = record index
+    for (int n = a.win_hi; n > a.win_lo; --n) {
         for (int j = 0; j < S; ++j, ++sc) {
             const float w = disc ? 1.0f : stage_weight(a.method, j);
             {   // next stage's inputs; consumed (publish) in this stage's bookkeeping phase
                 const int jn = j + 1 < S ? j + 1 : 0, nn = j + 1 < S ? n : n - 1;
-                if (nn >= 1) prefetch(nn, jn);
+                if (nn > a.win_lo) prefetch(nn, jn);
             }
             // ---- forward recompute, keeping x_1 .. x_L -------------------------------------------------------------
             const float* in = YS;
@@ -886,6 +921,16 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
             __syncthreads();
         }
     }
+    if (a.win_lo > 0) {      // hand (y, a) at knot win_lo to the next time window
+#pragma unroll
+        for (int q = 0; q < TL_EADJ; ++q) {
+            const int e = tid + q * NT;
+            if (e < HS) {
+                a.carry[(long long)blockIdx.x * HS + e] = y0[q];
+                a.carry[((long long)gridDim.x + blockIdx.x) * HS + e] = a0[q];
+            }
+        }
+    }
     // ---- this workgroup's partial of the hidden-layer parameter gradients ------------------------------------------
     float* gp = a.gpart + (long long)blockIdx.x * a.gstride;
     {
@@ -923,6 +968,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
 // sigmoid head (Wg, bg); either run recomputes both pre-activations (M = sigmoid(Pg) * tanh(Pt)), accumulates one.
 template <int PK, int HEAD = 0>
 __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_st, float* gpartB) {
+    // n_sc = stages recorded in this time window; a.resume != 0: add to the partial the earlier windows left in gpartB
     __shared__ float patch[4][16 * 17];
     __shared__ __attribute__((aligned(16))) float red[4][PK * 256 + 64];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1039,11 +1085,13 @@ __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_s
         const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
         const int r = e & 3, ln = (e >> 2) & 63, jt = e >> 8;
         const int row = (4 * hb + (ln >> 4)) * C + 4 * cq + r;
-        gp[(long long)row * dlast + 16 * jt + (ln & 15)] = v;
+        float* dst = gp + (long long)row * dlast + 16 * jt + (ln & 15);
+        *dst = a.resume ? *dst + v : v;
     }
     if (tid < 16) {
         const float v = (red[0][PK * 256 + tid] + red[1][PK * 256 + tid]) + (red[2][PK * 256 + tid] + red[3][PK * 256 + tid]);
-        gp[wo_sz + (4 * hb + (tid >> 2)) * C + 4 * cq + (tid & 3)] = v;
+        float* dst = gp + wo_sz + (4 * hb + (tid >> 2)) * C + 4 * cq + (tid & 3);
+        *dst = a.resume ? *dst + v : v;
     }
 }
 
@@ -1103,18 +1151,32 @@ bool tiled_adj_ok(const NcdeProblem* p) {
 }
 
 struct TiledAdjPlan {
-    int n_st, n_sc, gstride, parts;
-    long long recA, recB, recC, recD, gpartA, gpartB, total;   // float offsets into the workspace
+    int n_st, n_sc, gstride, parts, window, S;
+    long long recA, recB, recC, recD, gpartA, gpartB, carry, total;   // float offsets into the workspace
     long long theta_o;
 };
+
+// Record budget of one time window.  The continuous adjoint exists to be O(1) in memory (torchcde README: "slower but more
+// memory efficient"), so the per-stage records pass B consumes are kept for a WINDOW of steps only: the sweep (pass A) runs W
+// steps, the output-layer gradient pass (pass B) folds those W steps into its accumulators, and the record is reused.  The
+// default budget is sized to stay resident in the 256 MB Infinity Cache between the two passes (NCDE_TILED_WINDOW_MB overrides).
+long long tiled_window_budget_bytes() {
+    const char* e = getenv("NCDE_TILED_WINDOW_MB");      // read per call: tests shrink it to force several windows
+    if (e && atof(e) > 0.0) return (long long)(atof(e) * (double)(1LL << 20));
+    return 192LL << 20;
+}
 
 TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
     TiledAdjPlan t{};
     const int S = p->method == NCDE_RK4_38 ? 4 : (p->method == NCDE_MIDPOINT ? 2 : 1);
     const long long dlast = y.dlast;
+    t.S = S;
     t.n_st = (p->batch + 15) / 16;
-    t.n_sc = (p->n_knots - 1) * S;
     t.gstride = y.gWo_off;
+    const long long per_step = (long long)S * t.n_st * (2 * dlast + p->hidden + p->channels) * 16 * (long long)sizeof(float);
+    const int steps = p->n_knots - 1;
+    t.window = (int)std::max<long long>(1, std::min<long long>(steps, tiled_window_budget_bytes() / per_step));
+    t.n_sc = t.window * S;
     const long long tiles = (long long)t.n_sc * t.n_st;
     long long off = 64;
     t.recA = off; off += tiles * dlast * 16;
@@ -1128,6 +1190,7 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
     t.parts = 1;
     while (t.parts < 64 && row_tiles * 4 * t.parts < 4096 && 4 * t.parts * 2 <= t.n_st) t.parts *= 2;
     t.gpartB = off; off += (long long)t.parts * t.theta_o * (p->field_kind == NCDE_FIELD_MINIMAL ? 2 : 1);
+    t.carry = off; off += 2LL * t.n_st * p->hidden * 16;
     t.total = off + 64;
     return t;
 }
@@ -1230,15 +1293,25 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
         fb2 = pk == 8 ? ncde_dwo_tiled<8, 2> : (pk == 4 ? ncde_dwo_tiled<4, 2> : (pk == 2 ? ncde_dwo_tiled<2, 2> : ncde_dwo_tiled<1, 2>));
     }
     const size_t lds = tiled_adj_lds(p);
-    if (hipFuncSetAttribute((const void*)fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NCDE_ERR_HIP;
-    hipLaunchKernelGGL(fa, dim3(t.n_st), dim3(64 * TL_ADJ_NW), lds, st, a);
-    if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
+    static const void* attr_done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // set once per kernel, not per launch
+    bool seen = false;
+    for (const void* q : attr_done) seen = seen || q == (const void*)fa;
+    if (!seen) {
+        if (hipFuncSetAttribute((const void*)fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess) return NCDE_ERR_HIP;
+        for (const void*& q : attr_done)
+            if (!q) { q = (const void*)fa; break; }
+    }
+    a.carry = w + t.carry;
     float* gB = w + t.gpartB;
-    hipLaunchKernelGGL(fb, dim3(p->hidden * p->channels / 16, t.parts), dim3(256), 0, st, a, t.n_sc, t.n_st, gB);
-    if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
     float* gB2 = gB + (long long)t.parts * t.theta_o;
-    if (fb2) {
-        hipLaunchKernelGGL(fb2, dim3(p->hidden * p->channels / 16, t.parts), dim3(256), 0, st, a, t.n_sc, t.n_st, gB2);
+    // time windows, newest first: sweep W steps (pass A), fold their records into the output-layer gradient (pass B)
+    for (int hi = p->n_knots - 1, first = 1; hi >= 1; hi -= t.window, first = 0) {
+        const int lo = std::max(0, hi - t.window);
+        a.win_hi = hi; a.win_lo = lo; a.resume = first ? 0 : 1;
+        hipLaunchKernelGGL(fa, dim3(t.n_st), dim3(64 * TL_ADJ_NW), lds, st, a);
+        const int n_sc = (hi - lo) * t.S;
+        hipLaunchKernelGGL(fb, dim3(p->hidden * p->channels / 16, t.parts), dim3(256), 0, st, a, n_sc, t.n_st, gB);
+        if (fb2) hipLaunchKernelGGL(fb2, dim3(p->hidden * p->channels / 16, t.parts), dim3(256), 0, st, a, n_sc, t.n_st, gB2);
         if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
     }
     if (main_kernel_only) return NCDE_OK;

@@ -527,6 +527,45 @@ def test_tiled_family_vs_oracle(shape, interp, method, seq, gpu_lib):
         assert e <= TIGHT_G, ("tiled discrete backward on the oracle's stage record", k, e)
 
 
+@pytest.mark.parametrize("shape,gated", [((80, 128, 128, 3), False), ((8, 48, 64, 2), False), ((20, 32, 32, 3), True)])
+@pytest.mark.parametrize("interp,method,seq", [("linear", "rk4", False), ("cubic", "midpoint", True)])
+def test_tiled_backward_time_windows(shape, gated, interp, method, seq, gpu_lib, monkeypatch):
+    """The batch-tiled backward keeps its per-stage records for a WINDOW of steps only (workspace O(B H W), not O(B H T)):
+    forcing windows of one / a few steps (NCDE_TILED_WINDOW_MB) must reproduce the single-window result -- bit for bit for
+    dL/dz0 and the hidden-layer gradients (the carried (y, a) and the hidden-layer partial are exact hand-overs), to summation
+    order (1e-6) for the head gradients (pass B adds one partial per window instead of running one long accumulation) -- for
+    the continuous adjoint and the exact discrete backward; the workspace query shrinks accordingly."""
+    import ctypes
+    import gpu_util
+    from ncde_amd import _lib, solver
+    C, H, HH, nl = shape
+    case = _seeded_case(interp, method, seq, B=37, L=7, C=C, H=H, HH=HH, nl=nl, seed=900 + C, kind="minimal" if gated else "original")
+    FT = 0x8000
+    monkeypatch.delenv("NCDE_TILED_WINDOW_MB", raising=False)
+    ref = gpu_util.run_adjoint_direct(case, case["expect"]["z_out"], flags=FT)
+    refd = gpu_util.run_adjoint_direct(case, case["expect"]["z_out"], flags=FT, stages=case["stage_record"])
+    coeffs = torch.from_numpy(case["coeffs"]).cuda()
+    func = gpu_util.case_field(case, "cuda")
+    p = solver.build_problem(coeffs, interp, torch.from_numpy(case["z0"]).cuda(), func.fused_spec(), method, int(seq), FT)
+    full = _lib.lib().ncde_workspace_bytes(ctypes.byref(p), 1)
+    S = {"rk4": 4, "midpoint": 2, "euler": 1}[method]
+    n_steps = case["coeffs"].shape[1] - 1 + (interp == "cubic")
+    per_step_mb = S * 3 * (2 * HH + H + C) * 16 * 4 / 2 ** 20          # 3 sample tiles of 16
+    for steps in (1, 5):
+        monkeypatch.setenv("NCDE_TILED_WINDOW_MB", repr(per_step_mb * steps * 1.001))
+        small = _lib.lib().ncde_workspace_bytes(ctypes.byref(p), 1)
+        assert small < full and full - small >= (n_steps - steps - 1) * per_step_mb * 2 ** 20 * 0.99
+        got = gpu_util.run_adjoint_direct(case, case["expect"]["z_out"], flags=FT)
+        gotd = gpu_util.run_adjoint_direct(case, case["expect"]["z_out"], flags=FT, stages=case["stage_record"])
+        for g_, r_ in ((got, ref), (gotd, refd)):
+            assert np.array_equal(g_["dz0"], r_["dz0"])
+            for k in r_["grads"]:
+                if k in ("Wo", "bo", "Wg", "bg"):
+                    assert gu.relerr(g_["grads"][k], r_["grads"][k]) <= 1e-6, (steps, k)
+                else:
+                    assert np.array_equal(g_["grads"][k], r_["grads"][k]), (steps, k)
+
+
 @pytest.mark.parametrize("shape", [(8, 32, 32, 2), (20, 32, 32, 3), (4, 64, 64, 3), (80, 128, 128, 2)])
 @pytest.mark.parametrize("interp,method,seq", [("linear", "rk4", False), ("cubic", "midpoint", True)])
 def test_tiled_minimal_gated_vs_oracle(shape, interp, method, seq, gpu_lib):
