@@ -315,14 +315,9 @@ __device__ void cubic_series_missing(const float* xs, float* os, float* wb, floa
     }
 }
 
-__global__ __launch_bounds__(64) void ncde_cubic_coeffs_kernel(const float* __restrict__ x, int B, int L, int C,
-                                                                 float* __restrict__ out, float* __restrict__ ws,
-                                                                 const float* __restrict__ diag_swept, float* __restrict__ ws_d) {
-    // one wave per workgroup: the serial recurrences are latency-bound, so many small workgroups (all CUs, many waves in
-    // flight) beat few large ones -- 32768 series at cfg4 are only 128 workgroups of 256
-    const long long tid = (long long)blockIdx.x * 64 + threadIdx.x;
-    if (tid >= (long long)B * C) return;
-    const int b = (int)(tid / C), c = (int)(tid - (long long)b * C);
+// one (sample, channel) series straight on global memory: any size, missing values included
+__device__ void cubic_series_global(const float* __restrict__ x, int L, int C, float* __restrict__ out, float* __restrict__ ws,
+                                    const float* __restrict__ diag_swept, float* __restrict__ ws_d, int b, int c) {
     const float* xs = x + (long long)b * L * C + c;
     float* os = out + (long long)b * (L - 1) * 4 * C + c;
     // missing values?  (NaN anywhere in the series)
@@ -390,21 +385,239 @@ __global__ __launch_bounds__(64) void ncde_cubic_coeffs_kernel(const float* __re
     }
 }
 
-// swept diagonal of the natural-spline system on the unit grid: d_0 = 2, d_i = diag_i - (1/d_{i-1}) * 1
-__global__ void ncde_cubic_diag_kernel(int L, float* diag_swept) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float d_prev = 0.0f;
-    for (int i = 0; i < L; ++i) {
-        float diag = (i < L - 1 ? 1.0f : 0.0f) + (i > 0 ? 1.0f : 0.0f);
-        diag *= 2.0f;
-        float d = diag;
-        if (i > 0) {
-            const float w = 1.0f / d_prev;
-            d = diag - w * 1.0f;
+__global__ __launch_bounds__(64) void ncde_cubic_coeffs_kernel(const float* __restrict__ x, int B, int L, int C,
+                                                                 float* __restrict__ out, float* __restrict__ ws,
+                                                                 const float* __restrict__ diag_swept, float* __restrict__ ws_d) {
+    // one wave per workgroup: the serial recurrences are latency-bound, so many small workgroups (all CUs, many waves in
+    // flight) beat few large ones -- 32768 series at cfg4 are only 128 workgroups of 256
+    const long long tid = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (tid >= (long long)B * C) return;
+    const int b = (int)(tid / C), c = (int)(tid - (long long)b * C);
+    cubic_series_global(x, L, C, out, ws, diag_swept, ws_d, b, c);
+}
+
+// LDS-staged variant for complete series (no missing values): one wave = NSMP whole samples (lane <-> (sample, channel)).
+//   * the samples' [L][C] blocks come in with 16-byte loads (one contiguous region per workgroup) into LDS, sample stride
+//     padded so that the 64 lanes of a time step hit distinct banks;
+//   * the swept diagonal d_i and 1/d_{i-1} depend on i only (constant-coefficient system on the integer grid): read from a
+//     table, so the forward sweep is one multiply-subtract per step and series, its result kept in LDS (no global scratch);
+//   * back substitution is the chain only (the one true division per step: bit-exactness with the reference's x / d rules
+//     out a reciprocal), its result kd_i written over the swept right-hand side in LDS;
+//   * the a | b | 2c | 3d rows are then an embarrassingly parallel pass over (sample, piece, section, four channels): LDS
+//     reads, one 16-byte store per item, consecutive lanes on consecutive addresses.
+// Arithmetic per element is exactly cubic_series_global()'s, so the output is bit-identical (golden g8).  A workgroup
+// that finds a NaN among its samples falls back to cubic_series_global for all of them.
+#define CUBIC_NT 256
+__global__ __launch_bounds__(CUBIC_NT) void ncde_cubic_coeffs_lds_kernel(const float* __restrict__ x, int B, int L, int C, int NSMP,
+                                                                     int sstride, float* __restrict__ out, float* __restrict__ ws,
+                                                                     const float* __restrict__ diag_swept, float* __restrict__ ws_d) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xs = lds;                                 // [NSMP][sstride]  (sample block [L][C] + padding)
+    float* nbs = xs + (size_t)NSMP * sstride;        // [NSMP][sstride]  forward-swept right-hand side
+    float* dtab = nbs + (size_t)NSMP * sstride;      // [L] swept diagonal d_i
+    float* wtab = dtab + ((L + 3) & ~3);             // [L] 1 / d_{i-1}
+    const int lane = threadIdx.x;      // all CUBIC_NT threads stage and emit; the first 64 (one wave) run the chains
+    const int b0 = blockIdx.x * NSMP;
+    const int nsmp = min(NSMP, B - b0);
+    const int LC = L * C;
+    // ---- stage the samples (contiguous region of nsmp * L * C floats), detect missing values ------------------------------
+    const float* src = x + (long long)b0 * LC;
+    bool bad = false;
+    if ((LC & 3) == 0 && (((uintptr_t)src) & 15) == 0) {
+        const int nv = LC >> 2, tot = nsmp * nv;
+        int e = lane;
+        for (; e + 3 * CUBIC_NT < tot; e += 4 * CUBIC_NT) {      // four 16-byte loads in flight per lane
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(src + 4LL * (e + CUBIC_NT * q));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ee = e + CUBIC_NT * q, sm = ee / nv, k = ee - sm * nv;
+                bad = bad || isnan(v[q].x) || isnan(v[q].y) || isnan(v[q].z) || isnan(v[q].w);
+                *reinterpret_cast<float4*>(xs + (size_t)sm * sstride + 4 * k) = v[q];
+            }
         }
-        diag_swept[i] = d;
-        d_prev = d;
+        for (; e < tot; e += CUBIC_NT) {
+            const int sm = e / nv, k = e - sm * nv;
+            const float4 v = *reinterpret_cast<const float4*>(src + 4LL * e);
+            bad = bad || isnan(v.x) || isnan(v.y) || isnan(v.z) || isnan(v.w);
+            *reinterpret_cast<float4*>(xs + (size_t)sm * sstride + 4 * k) = v;
+        }
+    } else {
+        for (int e = lane; e < nsmp * LC; e += CUBIC_NT) {
+            const int sm = e / LC, k = e - sm * LC;
+            const float v = src[e];
+            bad = bad || isnan(v);
+            xs[(size_t)sm * sstride + k] = v;
+        }
     }
+    for (int i = lane; i < L; i += CUBIC_NT) {
+        dtab[i] = diag_swept[i];
+        wtab[i] = i > 0 ? 1.0f / diag_swept[i - 1] : 0.0f;      // the same division cubic_series_global does per step
+    }
+    if (__syncthreads_or(bad)) {      // missing values somewhere in this workgroup: the general per-series path
+        for (int e = lane; e < nsmp * C; e += CUBIC_NT) cubic_series_global(x, L, C, out, ws, diag_swept, ws_d, b0 + e / C, e % C);
+        return;
+    }
+    const int sm = lane / C, c = lane - sm * C;
+    const bool live = sm < nsmp && lane < 64;
+    const float* xl = xs + (size_t)(live ? sm : 0) * sstride + c;
+    float* nl = nbs + (size_t)(live ? sm : 0) * sstride + c;
+    if (L == 2) {
+        if (live) {
+            float* os = out + (long long)(b0 + sm) * (L - 1) * 4 * C + c;
+            os[0] = xl[0]; os[C] = xl[C] - xl[0]; os[2 * C] = 0.0f; os[3 * C] = 0.0f;
+        }
+        return;
+    }
+    // The two recurrences are latency chains (forward: multiply-subtract; backward: subtract + true division, ~60 cycles), so
+    // everything that is NOT on the chain -- LDS reads, the right-hand side, the coefficient rows -- is done for a block of
+    // CUBIC_BLK steps at a time around a register-only chain.
+    constexpr int BLK = 8;
+    // ---- forward sweep (same operation order as cubic_series_global) --------------------------------------------------------
+    // full blocks are branch-free (guards inside an unrolled block turn every load into its own branch + wait); the tail
+    // runs step by step
+    if (lane < 64) {
+        float x_cur = xl[C];
+        float scaled_prev = (3.0f * (x_cur - xl[0])) * 1.0f;
+        float nb_prev = scaled_prev;
+        nl[0] = nb_prev;
+        int i0 = 1;
+        for (; i0 + BLK <= L - 1; i0 += BLK) {      // steps i0 .. i0+BLK-1, all < L-1
+            float xn[BLK], wv[BLK], rhs[BLK], nbv[BLK];
+#pragma unroll
+            for (int k = 0; k < BLK; ++k) {
+                xn[k] = xl[(i0 + k + 1) * C];
+                wv[k] = wtab[i0 + k];               // 1 / d_{i-1}
+            }
+#pragma unroll
+            for (int k = 0; k < BLK; ++k) {
+                const float scaled = (3.0f * (xn[k] - x_cur)) * 1.0f;
+                rhs[k] = scaled + scaled_prev;
+                scaled_prev = scaled;
+                x_cur = xn[k];
+            }
+#pragma unroll
+            for (int k = 0; k < BLK; ++k) {
+                nbv[k] = rhs[k] - wv[k] * nb_prev;
+                nb_prev = nbv[k];
+            }
+#pragma unroll
+            for (int k = 0; k < BLK; ++k) nl[(i0 + k) * C] = nbv[k];
+        }
+        for (int i = i0; i < L; ++i) {
+            float rhs;
+            if (i < L - 1) {
+                const float x_next = xl[(i + 1) * C];
+                const float scaled = (3.0f * (x_next - x_cur)) * 1.0f;
+                rhs = scaled + scaled_prev;
+                scaled_prev = scaled;
+                x_cur = x_next;
+            } else {
+                rhs = 0.0f + scaled_prev;
+            }
+            const float nb = rhs - wtab[i] * nb_prev;
+            nl[i * C] = nb;
+            nb_prev = nb;
+        }
+    }
+    // ---- back substitution: the chain only; kd_i overwrites the swept right-hand side in place --------------------------------
+    if (lane < 64) {
+        float kd_next = nl[(L - 1) * C] / dtab[L - 1];
+        nl[(L - 1) * C] = kd_next;
+        int ib = L - 2;
+        for (; ib - BLK + 1 >= 0; ib -= BLK) {      // pieces ib .. ib-BLK+1
+            float nbv[BLK], dv[BLK], kdv[BLK + 1];
+#pragma unroll
+            for (int k = 0; k < BLK; ++k) {
+                nbv[k] = nl[(ib - k) * C];
+                dv[k] = dtab[ib - k];
+            }
+            kdv[0] = kd_next;
+#pragma unroll
+            for (int k = 0; k < BLK; ++k) kdv[k + 1] = (nbv[k] - 1.0f * kdv[k]) / dv[k];      // the chain: one true division per step
+#pragma unroll
+            for (int k = 0; k < BLK; ++k) nl[(ib - k) * C] = kdv[k + 1];
+            kd_next = kdv[BLK];
+        }
+        for (int i = ib; i >= 0; --i) {
+            const float kd = (nl[i * C] - 1.0f * kd_next) / dtab[i];
+            nl[i * C] = kd;
+            kd_next = kd;
+        }
+    }
+    __syncthreads();
+    // ---- coefficient rows a | b | 2c | 3d: embarrassingly parallel over (sample, piece, section, channels) -----------------------
+    // out[b][p][4C]; one item = one 16-byte store (four channels of one section) when C % 4 == 0, else one float
+    const int C4 = 4 * C;
+    if ((C & 3) == 0 && ((uintptr_t)out & 15) == 0) {
+        const int cq = C >> 2, per_row = 4 * cq, per_smp = (L - 1) * per_row;
+        for (int e = lane; e < nsmp * per_smp; e += CUBIC_NT) {
+            const int s2 = e / per_smp, r = e - s2 * per_smp;
+            const int pp = r / per_row, q4 = r - pp * per_row;
+            const int part = q4 / cq, q = q4 - part * cq;
+            const float* xa = xs + (size_t)s2 * sstride + pp * C + 4 * q;
+            const float* ka = nbs + (size_t)s2 * sstride + pp * C + 4 * q;
+            const float4 xi = *reinterpret_cast<const float4*>(xa), xi1 = *reinterpret_cast<const float4*>(xa + C);
+            const float4 kd = *reinterpret_cast<const float4*>(ka), kn = *reinterpret_cast<const float4*>(ka + C);
+            float4 v;
+            if (part == 0) v = xi;
+            else if (part == 1) v = kd;
+            else {
+                const float xv[4] = {xi.x, xi.y, xi.z, xi.w}, x1[4] = {xi1.x, xi1.y, xi1.z, xi1.w};
+                const float kv[4] = {kd.x, kd.y, kd.z, kd.w}, k1[4] = {kn.x, kn.y, kn.z, kn.w};
+                float o[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float six = 2.0f * (3.0f * (x1[t] - xv[t]));
+                    o[t] = part == 2 ? (six * 1.0f - 4.0f * kv[t] - 2.0f * k1[t]) * 1.0f : (-six * 1.0f + 3.0f * (kv[t] + k1[t])) * 1.0f;
+                }
+                v = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            *reinterpret_cast<float4*>(out + ((long long)(b0 + s2) * (L - 1) + pp) * C4 + part * C + 4 * q) = v;
+        }
+    } else {
+        const int per_smp = (L - 1) * C4;
+        for (int e = lane; e < nsmp * per_smp; e += CUBIC_NT) {
+            const int s2 = e / per_smp, r = e - s2 * per_smp;
+            const int pp = r / C4, q4 = r - pp * C4;
+            const int part = q4 / C, c2 = q4 - part * C;
+            const float xi = xs[(size_t)s2 * sstride + pp * C + c2], xi1 = xs[(size_t)s2 * sstride + (pp + 1) * C + c2];
+            const float kd = nbs[(size_t)s2 * sstride + pp * C + c2], kn = nbs[(size_t)s2 * sstride + (pp + 1) * C + c2];
+            const float six = 2.0f * (3.0f * (xi1 - xi));
+            float v = xi;
+            if (part == 1) v = kd;
+            else if (part == 2) v = (six * 1.0f - 4.0f * kd - 2.0f * kn) * 1.0f;
+            else if (part == 3) v = (-six * 1.0f + 3.0f * (kd + kn)) * 1.0f;
+            out[((long long)(b0 + s2) * (L - 1) + pp) * C4 + q4] = v;
+        }
+    }
+}
+
+// swept diagonal of the natural-spline system on the unit grid: d_0 = 2, d_i = diag_i - (1/d_{i-1}) * 1
+// (one wave; the interior iteration d <- 4 - 1/d reaches its fp32 fixed point after a handful of steps, after which every
+// lane fills its share of the table: the serial part is ~10 steps, not L)
+__global__ void ncde_cubic_diag_kernel(int L, float* diag_swept) {
+    if (blockIdx.x != 0) return;
+    auto next = [](float d_prev, int i, int L_) {
+        float diag = (i < L_ - 1 ? 1.0f : 0.0f) + (i > 0 ? 1.0f : 0.0f);
+        diag *= 2.0f;
+        if (i == 0) return diag;
+        const float w = 1.0f / d_prev;
+        return diag - w * 1.0f;
+    };
+    float d_prev = 0.0f;
+    int i = 0;
+    for (; i < L; ++i) {                       // every lane runs the same serial prefix (uniform)
+        const float d = next(d_prev, i, L);
+        if (threadIdx.x == 0) diag_swept[i] = d;
+        const bool fixed = i > 0 && i < L - 2 && d == d_prev;
+        d_prev = d;
+        if (fixed) { ++i; break; }
+    }
+    // interior entries i .. L-2 all equal the fixed point; the last one sees diag = 2
+    for (int k = i + (int)threadIdx.x; k < L - 1; k += (int)blockDim.x) diag_swept[k] = d_prev;
+    if (threadIdx.x == 0 && i < L) diag_swept[L - 1] = next(d_prev, L - 1, L);
 }
 
 
@@ -443,6 +656,26 @@ int ncde_prepare_cubic(const float* x, int B, int L, int C, float* out, void* wo
     float* diag = ws_d + (size_t)B * L * C;
     hipLaunchKernelGGL(ncde_cubic_diag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, L, diag);
     const long long n = (long long)B * C;
+    // LDS-staged variant: NSMP whole samples per wave (lane <-> (sample, channel)), as many as fit 64 lanes and the LDS budget
+    if (C <= 64) {
+        const int LC = L * C;
+        int sstride = LC + ((C - (LC % 32)) % 32 + 32) % 32;      // stride == C (mod 32): the lanes of one time step fall on distinct banks
+        sstride = (sstride + 3) & ~3;
+        int nsmp = 64 / C;
+        auto lds_of = [&](int ns) { return sizeof(float) * ((size_t)2 * ns * sstride + 2 * ((L + 3) & ~3)); };
+        // the recurrences are latency chains: prefer several resident workgroups per CU (<= 28 KB each: measured best at cfg4 size) over full waves
+        const char* ev = getenv("NCDE_CUBIC_LDS_KB");      // development knob
+        const size_t budget = (size_t)(ev && atoi(ev) > 0 ? atoi(ev) : 28) * 1024;
+        while (nsmp > 1 && lds_of(nsmp) > budget) --nsmp;
+        if (lds_of(nsmp) <= (size_t)150 * 1024) {
+            const size_t lds = lds_of(nsmp);
+            if (hipFuncSetAttribute((const void*)ncde_cubic_coeffs_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return NCDE_ERR_HIP;
+            hipLaunchKernelGGL(ncde_cubic_coeffs_lds_kernel, dim3((unsigned)((B + nsmp - 1) / nsmp)), dim3(CUBIC_NT), lds, (hipStream_t)stream, x, B, L, C,
+                               nsmp, sstride, out, ws, diag, ws_d);
+            return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
+        }
+    }
     hipLaunchKernelGGL(ncde_cubic_coeffs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, x, B, L, C, out,
                        ws, diag, ws_d);
     return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
