@@ -150,3 +150,28 @@ def test_oracle_dopri5_matches_reference_golden(name):
     assert gu.relerr(dz0, f["dz0"]) <= tol
     for pname, g in zip(m["param_names"], gp):
         assert gu.relerr(g, f["d" + pname]) <= tol, pname
+
+
+@pytest.mark.parametrize("name", gu.SOLVE_CASES)
+def test_cpu_cabi_restatement_matches_reference_golden(name):
+    """oracle/ncde_cpu.cpp -- the scalar C++ / OpenMP restatement behind the SAME C-ABI as the HIP library --
+    against the reference's goldens: forward, continuous adjoint, recording forward + exact discrete backward, through the
+    identical NcdeProblem / NcdeGrads plumbing the GPU tests use (host pointers instead of device pointers)."""
+    import cpu_lib_util as cu
+    case = gu.load_case(name)
+    m, ex = case["meta"], case["expect"]
+    cc = cu.CpuCase(case["coeffs"], m["kind"], case["z0"], case["params"], case["layers"], m["method"], m["sequence"])
+    z = cc.forward()
+    assert gu.relerr(z, ex["z_out"]) <= TOL_Z
+    dz0, g = cc.backward(ex["z_out"], ex["grad_out"])
+    zr, rec = cc.forward(record=True)
+    assert np.array_equal(zr, z)
+    bdz0, bg = cc.backward(rec, ex["grad_out"], discrete=True)
+    for prefix, dz, gg in (("", dz0, g), ("bp_", bdz0, bg)):
+        assert gu.relerr(dz, ex[prefix + "dz0"]) <= TOL_G, prefix
+        for pname in m["param_names"]:
+            key = prefix + "d" + pname
+            if key in ex:
+                assert gu.relerr(gg[pname], ex[key]) <= TOL_G, (prefix, pname)
+            else:
+                assert gu.relerr(gg[pname][::16], ex[key + "__rows16"]) <= TOL_G, (prefix, pname)
