@@ -1957,16 +1957,23 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                     xb = split8(x[NL - 1]);
                 }
                 NCDE_TICK(0)
-                if (wq != 0.0f && pw == 0) {  // [unit][sample] images for the gradient waves
+                if (wq != 0.0f) {  // [unit][sample] images for the gradient waves: the chain waves hold identical copies, wave pw
+                                   // writes image pw (stage input, x_1 .. x_NL) -- NL + 1 <= 4 images, one per wave
                     float* xi = ximg + par * XROWS * 16;
+                    if (pw == 0) {
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) xi[(8 * g + jj) * 16 + s] = zreg[jj];
+                        for (int jj = 0; jj < 8; ++jj) xi[(8 * g + jj) * 16 + s] = zreg[jj];
+                    }
 #pragma unroll
                     for (int l = 0; l < NL; ++l)
+                        if (pw == (l + 1) % NW) {
 #pragma unroll
-                        for (int jj = 0; jj < 8; ++jj) xi[(H + l * HH + 8 * g + jj) * 16 + s] = x[l][jj];
-                    wave_lds_order();
-                    *xflag = sc;
+                            for (int jj = 0; jj < 8; ++jj) xi[(H + l * HH + 8 * g + jj) * 16 + s] = x[l][jj];
+                            if (l == NL - 1) {      // x_L is what the gradient waves' dWo blocks of THIS stage wait for
+                                wave_lds_order();
+                                *xflag = sc;
+                            }
+                        }
                 }
                 // ---- output tiles: P, r = 1/(exp(2P)+1), f, dP -> LDS tile + flag -----------------------------------
                 float kout[NB];
@@ -2010,8 +2017,10 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                             if constexpr (DISC == 0) kout[nb] = fmaf(rr, dx[r], kout[nb]);
                             tl[(4 * g + r) * 16 + s] = (a4 * dx[r]) * fmaf(-rr, rr, rr);
                         }
-                        wave_lds_order();
-                        my_flags[tau] = sc;
+                        if (nb == NB - 1) {      // one publication per block (= cq, both tiles): the gradient wave polls odd tiles only
+                            wave_lds_order();
+                            my_flags[tau] = sc;
+                        }
                     }
                 }
 #pragma unroll
@@ -2030,7 +2039,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                 // ---- hidden layers backward (split-bf16) -----------------------------------------------------------------
 #pragma unroll
                 for (int l = NL - 1; l >= 1; --l) {
-                    if (wq != 0.0f && pw == 0) {
+                    if (wq != 0.0f && pw == l % NW) {      // one image per chain wave (all hold the same gpre)
 #pragma unroll
                         for (int jj = 0; jj < 8; ++jj) dpimg[(l * HH + 8 * g + jj) * 16 + s] = gpre[jj];
                     }
