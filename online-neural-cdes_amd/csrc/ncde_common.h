@@ -54,6 +54,9 @@ struct KArgs {
     // general time axis (generic / variant families): host-built time plan (ncde_plan.h), NULL = default integer grid, step 1
     const int* plan;
     int n_steps_fwd, n_steps_adj;
+    // batch-tiled family: fragment-ordered copies of the output layer and of the gate head (ncde_pack_panels)
+    const float* Wo_pk;
+    const float* Wg_pk;
 };
 
 // ---- time plan (built on the host by ncde_time_plan_build, csrc/ncde_timeplan.hip; layout in 4-byte words) -------------

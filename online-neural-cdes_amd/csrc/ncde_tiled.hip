@@ -13,6 +13,7 @@
 // Shapes: H, layer widths multiples of 16, C a multiple of 4 (anything else runs on the generic family).
 // Reference semantics restated: see the header of ncde_generic.hip (same op sequence, same citations).
 #include "ncde_common.h"
+#include "ncde_bf3.h"
 #include "ncde_host.h"
 #include "ncde_tiled.h"
 
@@ -62,6 +63,17 @@ __device__ __forceinline__ Panel<PK> tl_load_panel(const float* wrow, int kb0) {
     for (int i = 0; i < PK; ++i) P.v[i] = *reinterpret_cast<const f32x4*>(wrow + 16 * (kb0 + i));
     return P;
 }
+// The same fragments from the PACKED copy of the output layer (ncde_pack_panels below): tile-major, then k-block, then
+// lane, so one load instruction of a wave reads 1 KB contiguous.  Read in place, a fragment load touches 64 different
+// 16-byte pieces (lane -> weight row), and the texture path spends a cycle per piece: measured at cfg5, the forward
+// sat at 340k cycles per stage and SIMD whether or not the MFMAs were issued and whether or not the loads hit L1.
+template <int PK>
+__device__ __forceinline__ Panel<PK> tl_load_panel_packed(const float* tile, int lane) {
+    Panel<PK> P;
+#pragma unroll
+    for (int i = 0; i < PK; ++i) P.v[i] = *reinterpret_cast<const f32x4*>(tile + (i * 64 + lane) * 4);
+    return P;
+}
 // acc[st] += panel x activations (k-blocks kb0 .. kb0+PK-1 of `in`)
 template <int NS, int PK>
 __device__ __forceinline__ void tl_mma_panel(const Panel<PK>& P, const float* in, int kb0, int li, int lk, f32x4 (&acc)[NS]) {
@@ -82,9 +94,11 @@ __host__ __device__ __forceinline__ int tl_panel_k(int nkb) { return (nkb % 8 ==
 
 // out = relu(W in + bias): W [N][K] row-major in global memory, in/out in the LDS layout above.
 // The (row tile, panel) pairs of this wave form one sequence; the panel of pair q+1 is in flight while pair q computes.
+// xb != NULL: additionally leave the result as three bf16 pieces in the B-operand order of v_mfma_f32_16x16x32_bf16
+// (NS = 1 only): word (((c * 3 + piece) * 4 + kg) * 16 + sample) * 4 + dw holds units 32 c + 8 kg + 2 dw, + 1.
 template <int NS, int PK, int NWV>
 __device__ __forceinline__ void tl_dense_relu_pk(const float* __restrict__ W, const float* __restrict__ bias, int N, int K,
-                                                 const float* in, float* out, int wave, int lane) {
+                                                 const float* in, float* out, int wave, int lane, unsigned* xb = nullptr) {
     constexpr int NSP = NS * 16;
     const int li = lane & 15, lk = lane >> 4;
     const int npan = (K >> 4) / PK;
@@ -114,18 +128,30 @@ __device__ __forceinline__ void tl_dense_relu_pk(const float* __restrict__ W, co
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = relu_dev(acc[st][r]);
                 *reinterpret_cast<f32x4*>(out + ((4 * t + lk) * NSP + st * 16 + li) * 4) = o;
+                if constexpr (NS == 1) {
+                    if (xb) {      // units 16 t + 4 lk + r: chunk t >> 1, k-group 2 (t & 1) + (lk >> 1), dwords 2 (lk & 1), + 1
+                        unsigned h0, m0, l0, h1, m1, l1;
+                        split_pair(o[0], o[1], h0, m0, l0);
+                        split_pair(o[2], o[3], h1, m1, l1);
+                        unsigned* dst = xb + ((((t >> 1) * 3) * 4 + 2 * (t & 1) + (lk >> 1)) * 16 + li) * 4 + 2 * (lk & 1);
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
+                        *reinterpret_cast<u32x2*>(dst + 256) = (u32x2){m0, m1};
+                        *reinterpret_cast<u32x2*>(dst + 512) = (u32x2){l0, l1};
+                    }
+                }
             }
         }
     }
 }
 template <int NS, int NWV>
 __device__ __forceinline__ void tl_dense_relu(const float* __restrict__ W, const float* __restrict__ bias, int N, int K,
-                                              const float* in, float* out, int wave, int lane) {
+                                              const float* in, float* out, int wave, int lane, unsigned* xb = nullptr) {
     switch (tl_panel_k(K >> 4)) {
-        case 8: tl_dense_relu_pk<NS, 8, NWV>(W, bias, N, K, in, out, wave, lane); break;
-        case 4: tl_dense_relu_pk<NS, 4, NWV>(W, bias, N, K, in, out, wave, lane); break;
-        case 2: tl_dense_relu_pk<NS, 2, NWV>(W, bias, N, K, in, out, wave, lane); break;
-        default: tl_dense_relu_pk<NS, 1, NWV>(W, bias, N, K, in, out, wave, lane); break;
+        case 8: tl_dense_relu_pk<NS, 8, NWV>(W, bias, N, K, in, out, wave, lane, xb); break;
+        case 4: tl_dense_relu_pk<NS, 4, NWV>(W, bias, N, K, in, out, wave, lane, xb); break;
+        case 2: tl_dense_relu_pk<NS, 2, NWV>(W, bias, N, K, in, out, wave, lane, xb); break;
+        default: tl_dense_relu_pk<NS, 1, NWV>(W, bias, N, K, in, out, wave, lane, xb); break;
     }
 }
 
@@ -199,7 +225,7 @@ struct TlTile<PK, 1> {
 // GATED: the minimal-gated field (gating.py:7-32) -- a second head Wg, M = sigmoid(Wg x + bg) * tanh(Wo x + bo)
 template <int NS, int PK, int NWV, int GATED>
 __device__ __forceinline__ void tl_output_whole(const KArgs& a, const float* in, const float* DX, float* KO, int wave, int lane) {
-    constexpr int NSP = NS * 16, dlast = 16 * PK;
+    constexpr int NSP = NS * 16;
     const int li = lane & 15, lk = lane >> 4;
     const int C = a.C, nhb = a.H >> 2, ncq = C >> 2;
     const int nhb_w = (nhb - wave + NWV - 1) / NWV;
@@ -210,11 +236,11 @@ __device__ __forceinline__ void tl_output_whole(const KArgs& a, const float* in,
     auto fetch = [&]() {
         const int hb = wave + NWV * fhi;
         TileIn t;
-        const long long woff = (long long)((4 * hb + (li >> 2)) * C + 4 * fcq + (li & 3)) * dlast + 4 * lk;
-        t.P = tl_load_panel<PK>(a.Wo + woff, 0);
+        const long long woff = (long long)(hb * ncq + fcq) * (PK * 256);
+        t.P = tl_load_panel_packed<PK>(a.Wo_pk + woff, lane);
         t.bias = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb + lk) * C + 4 * fcq);
         if constexpr (GATED != 0) {
-            t.G = tl_load_panel<PK>(a.Wg + woff, 0);
+            t.G = tl_load_panel_packed<PK>(a.Wg_pk + woff, lane);
             t.biasg = *reinterpret_cast<const f32x4*>(a.bg + (4 * hb + lk) * C + 4 * fcq);
         }
         const bool more = fq + 1 < nq, wrap = fcq + 1 == ncq;
@@ -257,10 +283,119 @@ __device__ __forceinline__ void tl_output_whole(const KArgs& a, const float* in,
     };
     TileIn TA = fetch(), TB;
     for (int i = 0; i < (nq >> 1); ++i) {
+        // the scheduling fences keep each tile's loads a whole tile ahead of their use: left alone, the machine scheduler
+        // sinks them next to the MFMAs that consume them (load, wait, four MFMAs, load, ...), which exposes the L2 latency
         TB = fetch();
+        __builtin_amdgcn_sched_barrier(0);
         step(TA);
+        __builtin_amdgcn_sched_barrier(0);
         TA = fetch();
+        __builtin_amdgcn_sched_barrier(0);
         step(TB);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nq & 1) step(TA);
+}
+
+// ---- split-bf16 output tiles (NS = 1, last hidden width a multiple of 32) ---------------------------------------------
+// The fp32 tiles above run the MFMA pipe at the fp32 vector rate: 32 MFMAs x 32 cycles per tile.  Here both operands arrive
+// as three bf16 pieces -- the weights split ONCE per call by ncde_pack_panels_bf (fragment order, 1.5 x the fp32 bytes), the
+// activations split by the layer that produced them (tl_dense_relu_pk, xb) -- and a tile is 6 x (K/32) bf16 MFMAs of 16
+// cycles (ncde_bf3.h: fp32-equivalent, dropped terms <= 3 * 2^-24 relative).
+template <int NCH, int GATED>
+struct BfTile {
+    u32x4 w[NCH][3];
+    f32x4 bias;
+    u32x4 g[GATED ? NCH : 1][3];
+    f32x4 biasg;
+};
+template <int NCH>
+__device__ __forceinline__ void tl_load_bf(const unsigned* tile, int lane, u32x4 (&w)[NCH][3]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) w[c][p] = *reinterpret_cast<const u32x4*>(tile + ((c * 3 + p) * 64 + lane) * 4);
+}
+// acc += W(tile) x, x read from its split image; two accumulator chains (even / odd chunks)
+template <int NCH>
+__device__ __forceinline__ f32x4 tl_mma_bf(const u32x4 (&w)[NCH][3], const unsigned* xb, int lane, f32x4 acc) {
+    f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        Split3 A, B;
+        A.hi = w[c][0]; A.mid = w[c][1]; A.lo = w[c][2];
+        B.hi = *reinterpret_cast<const u32x4*>(xb + ((c * 3 + 0) * 64 + lane) * 4);
+        B.mid = *reinterpret_cast<const u32x4*>(xb + ((c * 3 + 1) * 64 + lane) * 4);
+        B.lo = *reinterpret_cast<const u32x4*>(xb + ((c * 3 + 2) * 64 + lane) * 4);
+        if (c & 1) acc2 = mfma_split(A, B, acc2);
+        else acc = mfma_split(A, B, acc);
+    }
+    if constexpr (NCH > 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
+    }
+    return acc;
+}
+
+template <int NCH, int NWV, int GATED>
+__device__ __forceinline__ void tl_output_bf(const KArgs& a, const unsigned* xb, const float* DX, float* KO, int wave, int lane) {
+    constexpr int NSP = 16;
+    const int li = lane & 15, lk = lane >> 4;
+    const int C = a.C, nhb = a.H >> 2, ncq = C >> 2;
+    const int nhb_w = (nhb - wave + NWV - 1) / NWV;
+    if (nhb_w <= 0) return;
+    const int nq = nhb_w * ncq;
+    using TileIn = BfTile<NCH, GATED>;
+    const unsigned* wo = reinterpret_cast<const unsigned*>(a.Wo_pk);
+    const unsigned* wg = reinterpret_cast<const unsigned*>(a.Wg_pk);
+    int fhi = 0, fcq = 0, fq = 0;
+    auto fetch = [&]() {
+        const int hb = wave + NWV * fhi;
+        TileIn t;
+        const long long woff = (long long)(hb * ncq + fcq) * (NCH * 3 * 256);
+        tl_load_bf<NCH>(wo + woff, lane, t.w);
+        t.bias = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb + lk) * C + 4 * fcq);
+        if constexpr (GATED != 0) {
+            tl_load_bf<NCH>(wg + woff, lane, t.g);
+            t.biasg = *reinterpret_cast<const f32x4*>(a.bg + (4 * hb + lk) * C + 4 * fcq);
+        }
+        const bool more = fq + 1 < nq, wrap = fcq + 1 == ncq;
+        fq += more ? 1 : 0;
+        fhi += (more && wrap) ? 1 : 0;
+        fcq = more ? (wrap ? 0 : fcq + 1) : fcq;
+        return t;
+    };
+    int chi = 0, ccq = 0;
+    float kacc = 0.0f;
+    auto step = [&](const TileIn& t) {
+        const int hb = wave + NWV * chi;
+        const f32x4 acc = tl_mma_bf<NCH>(t.w, xb, lane, t.bias);
+        f32x4 accg;
+        if constexpr (GATED != 0) accg = tl_mma_bf<NCH>(t.g, xb, lane, t.biasg);
+        const f32x4 dx = *reinterpret_cast<const f32x4*>(DX + (ccq * NSP + li) * 4);
+        float kk = ccq == 0 ? 0.0f : kacc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float m = tanh_dev(acc[r]);
+            if constexpr (GATED != 0) m = tl_sigmoid(accg[r]) * m;
+            kk = fmaf(m, dx[r], kk);
+        }
+        kacc = kk;
+        KO[(hb * NSP + li) * 4 + lk] = kk;     // running sum; the last channel quad leaves the total
+        const bool wrap = ccq + 1 == ncq;
+        chi += wrap ? 1 : 0;
+        ccq = wrap ? 0 : ccq + 1;
+    };
+    TileIn TA = fetch(), TB;
+    for (int i = 0; i < (nq >> 1); ++i) {
+        TB = fetch();          // fences: see tl_output_whole
+        __builtin_amdgcn_sched_barrier(0);
+        step(TA);
+        __builtin_amdgcn_sched_barrier(0);
+        TA = fetch();
+        __builtin_amdgcn_sched_barrier(0);
+        step(TB);
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (nq & 1) step(TA);
 }
@@ -268,10 +403,52 @@ __device__ __forceinline__ void tl_output_whole(const KArgs& a, const float* in,
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
+// output-layer weights in fragment order (once per call: the parameters change every training step)
+// ------------------------------------------------------------------------------------------------
+// dst[((tile * PK + i) * 64 + lane) * 4 + e] = W[row(tile, lane & 15)][16 i + 4 (lane >> 4) + e], tile = hb * (C/4) + cq,
+// row(tile, li) = (4 hb + (li >> 2)) * C + 4 cq + (li & 3): exactly what lane `lane` feeds the i-th MFMA group of the tile.
+__global__ __launch_bounds__(256) void ncde_pack_panels(const float* __restrict__ W, float* __restrict__ dst, int H, int C, int pk) {
+    const long long n = (long long)H * C * pk * 4;          // float4 pieces
+    const int ncq = C >> 2;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < n; v += (long long)gridDim.x * 256) {
+        const int lane = (int)(v & 63);
+        const long long ti = v >> 6;
+        const int i = (int)(ti % pk);
+        const int tile = (int)(ti / pk);
+        const int hb = tile / ncq, cq = tile - hb * ncq, li = lane & 15, lk = lane >> 4;
+        const long long row = (long long)(4 * hb + (li >> 2)) * C + 4 * cq + (li & 3);
+        reinterpret_cast<f32x4*>(dst)[v] = *reinterpret_cast<const f32x4*>(W + row * (16 * pk) + 16 * i + 4 * lk);
+    }
+}
+
+// The split-bf16 copy: word (((tile * NCH + c) * 3 + piece) * 64 + lane) * 4 + dw = bf16 pieces of
+// W[row(tile, lane & 15)][32 c + 8 (lane >> 4) + 2 dw, + 1] -- the A operand of v_mfma_f32_16x16x32_bf16.
+__global__ __launch_bounds__(256) void ncde_pack_panels_bf(const float* __restrict__ W, unsigned* __restrict__ dst, int H, int C, int nch) {
+    const long long n = (long long)H * C / 16 * nch * 64;          // (tile, chunk, lane) triples
+    const int ncq = C >> 2;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < n; v += (long long)gridDim.x * 256) {
+        const int lane = (int)(v & 63);
+        const long long tc = v >> 6;
+        const int c = (int)(tc % nch);
+        const int tile = (int)(tc / nch);
+        const int hb = tile / ncq, cq = tile - hb * ncq, li = lane & 15, kg = lane >> 4;
+        const long long row = (long long)(4 * hb + (li >> 2)) * C + 4 * cq + (li & 3);
+        const float* src = W + row * (32 * nch) + 32 * c + 8 * kg;
+        float vals[8];
+        *reinterpret_cast<f32x4*>(vals) = *reinterpret_cast<const f32x4*>(src);
+        *reinterpret_cast<f32x4*>(vals + 4) = *reinterpret_cast<const f32x4*>(src + 4);
+        const Split3 sp = split8(vals);
+        u32x4* o = reinterpret_cast<u32x4*>(dst) + (tc * 3) * 64 + lane;
+        o[0] = sp.hi; o[64] = sp.mid; o[128] = sp.lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int NS, int NWV, int EM, int GATED = 0>
+template <int NS, int NWV, int EM, int GATED = 0, int BF = 0>
 __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
+    static_assert(BF == 0 || NS == 1, "the split-bf16 output tiles are built for one sample tile per workgroup");
     constexpr int NSP = NS * 16, NT = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -286,6 +463,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
     float* ACT1 = ACT0 + DS;
     float* KO = ACT1 + DS;      // f(z).dX of the stage
     float* DX = KO + HS;        // [C/4][NSP][4]
+    unsigned* XB = reinterpret_cast<unsigned*>(DX + a.C * NSP);   // BF: x_L as three bf16 pieces, B-operand order
 
     // state slice of this thread: element e = tid + q * NT of the [H/4][NSP][4] arrays
     float y0[EM], k1[EM], k2[EM];
@@ -324,10 +502,18 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
             const float* in = YS;
             for (int l = 0; l < a.n_layers; ++l) {
                 float* outb = (l & 1) ? ACT1 : ACT0;
-                tl_dense_relu<NS, NWV>(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane);
+                tl_dense_relu<NS, NWV>(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane,
+                                       (BF != 0 && l == a.n_layers - 1) ? XB : nullptr);
                 __syncthreads();
                 in = outb;
             }
+            if constexpr (BF != 0) {
+                switch (nkb_o) {
+                    case 8: tl_output_bf<4, NWV, GATED>(a, XB, DX, KO, wave, lane); break;
+                    case 4: tl_output_bf<2, NWV, GATED>(a, XB, DX, KO, wave, lane); break;
+                    default: tl_output_bf<1, NWV, GATED>(a, XB, DX, KO, wave, lane); break;
+                }
+            } else
             switch (nkb_o) {
                 case 8: tl_output_whole<NS, 8, NWV, GATED>(a, in, DX, KO, wave, lane); break;
                 case 4: tl_output_whole<NS, 4, NWV, GATED>(a, in, DX, KO, wave, lane); break;
@@ -398,7 +584,7 @@ __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, c
     static_assert(!(RES != 0 && GATED != 0), "resident weights are built for the original field only");
     constexpr int NSP = 16, SCS = 16 * PK + 4;
     const int li = lane & 15, lk = lane >> 4;
-    const int C = a.C, nhb = a.H >> 2, ncq = C >> 2, dlast = 16 * PK;
+    const int C = a.C, nhb = a.H >> 2, ncq = C >> 2;
     f32x4 accJ[PK];
 #pragma unroll
     for (int jt = 0; jt < PK; ++jt) accJ[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -409,11 +595,11 @@ __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, c
     auto fetch = [&]() {
         const int hb = wave + NWV * fhi;
         TileIn t;
-        const long long woff = (long long)((4 * hb + (li >> 2)) * C + 4 * fcq + (li & 3)) * dlast + 4 * lk;
-        t.P = tl_load_panel<PK>(a.Wo + woff, 0);
+        const long long woff = (long long)(hb * ncq + fcq) * (PK * 256);
+        t.P = tl_load_panel_packed<PK>(a.Wo_pk + woff, lane);
         t.bias = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb + lk) * C + 4 * fcq);
         if constexpr (GATED != 0) {
-            t.G = tl_load_panel<PK>(a.Wg + woff, 0);
+            t.G = tl_load_panel_packed<PK>(a.Wg_pk + woff, lane);
             t.biasg = *reinterpret_cast<const f32x4*>(a.bg + (4 * hb + lk) * C + 4 * fcq);
         }
         const bool more = fq + 1 < nq, wrap = fcq + 1 == ncq;
@@ -481,10 +667,14 @@ __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, c
         if (nq > 0) {
             TileIn TA = fetch(), TB;
             for (int i = 0; i < (nq >> 1); ++i) {
-                TB = fetch();
+                TB = fetch();          // fences: see tl_output_whole
+                __builtin_amdgcn_sched_barrier(0);
                 step(TA);
+                __builtin_amdgcn_sched_barrier(0);
                 TA = fetch();
+                __builtin_amdgcn_sched_barrier(0);
                 step(TB);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (nq & 1) step(TA);
         }
@@ -1106,8 +1296,43 @@ int tiled_dmax(const NcdeProblem* p) {
     return D;
 }
 
+int tiled_fwd_ns(const NcdeProblem* p);
+// Split-bf16 output tiles in the forward: one sample tile per workgroup, last hidden width 32 / 64 / 128, unless the caller
+// asks for plain fp32-input MFMA (NCDE_FLAG_FP32_MFMA).
+bool tiled_fwd_bf(const NcdeProblem* p) {
+    const int dl = p->layer_out[p->n_layers - 1];
+    return !(p->flags & NCDE_FLAG_FP32_MFMA) && (dl == 32 || dl == 64 || dl == 128) && tiled_fwd_ns(p) == 1;
+}
+// Floats of the fragment-ordered copy of the output layer (and of the gate head): 0 when the last hidden width is not one
+// of the whole-panel cases the kernels read packed.  The split-bf16 copy (forward, pass 0) takes 1.5 x.
+int64_t tiled_pack_floats(const NcdeProblem* p, bool bf) {
+    const int dl = p->layer_out[p->n_layers - 1];
+    if (dl != 16 && dl != 32 && dl != 64 && dl != 128) return 0;
+    const int64_t n = (int64_t)p->hidden * p->channels * dl * (p->field_kind == NCDE_FIELD_MINIMAL ? 2 : 1);
+    return bf ? n + n / 2 : n;
+}
+// Packs Wo (and Wg) into `dst` and hands the copies to the kernels.
+void tiled_pack_launch(const NcdeProblem* p, KArgs* a, float* dst, bool bf, hipStream_t st) {
+    const int dl = p->layer_out[p->n_layers - 1];
+    const long long n4 = (long long)p->hidden * p->channels * dl / 4;
+    const long long per = bf ? n4 * 6 : n4 * 4;       // floats per packed matrix
+    const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    const bool gated = p->field_kind == NCDE_FIELD_MINIMAL;
+    if (bf) {
+        hipLaunchKernelGGL(ncde_pack_panels_bf, dim3(grid), dim3(256), 0, st, a->Wo, (unsigned*)dst, p->hidden, p->channels, dl / 32);
+        if (gated) hipLaunchKernelGGL(ncde_pack_panels_bf, dim3(grid), dim3(256), 0, st, a->Wg, (unsigned*)(dst + per), p->hidden, p->channels, dl / 32);
+    } else {
+        hipLaunchKernelGGL(ncde_pack_panels, dim3(grid), dim3(256), 0, st, a->Wo, dst, p->hidden, p->channels, dl / 16);
+        if (gated) hipLaunchKernelGGL(ncde_pack_panels, dim3(grid), dim3(256), 0, st, a->Wg, dst + per, p->hidden, p->channels, dl / 16);
+    }
+    a->Wo_pk = dst;
+    if (gated) a->Wg_pk = dst + per;
+}
+
 size_t tiled_fwd_lds(const NcdeProblem* p, int ns) {
-    return sizeof(float) * (size_t)(ns * 16) * (size_t)(2 * p->hidden + 2 * tiled_dmax(p) + p->channels);
+    // (+ the split image of x_L for the bf16 output tiles, NS = 1: 6 bytes per element)
+    const size_t xb = ns == 1 ? (size_t)p->layer_out[p->n_layers - 1] * 16 * 6 : 0;
+    return sizeof(float) * (size_t)(ns * 16) * (size_t)(2 * p->hidden + 2 * tiled_dmax(p) + p->channels) + xb;
 }
 
 // forward sample tiles per workgroup.  More tiles = more reuse of each weight fragment, but measured on MI355X
@@ -1152,7 +1377,7 @@ bool tiled_adj_ok(const NcdeProblem* p) {
 
 struct TiledAdjPlan {
     int n_st, n_sc, gstride, parts, window, S;
-    long long recA, recB, recC, recD, gpartA, gpartB, carry, total;   // float offsets into the workspace
+    long long recA, recB, recC, recD, gpartA, gpartB, carry, pack, total;   // float offsets into the workspace
     long long theta_o;
 };
 
@@ -1191,6 +1416,7 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
     while (t.parts < 64 && row_tiles * 4 * t.parts < 4096 && 4 * t.parts * 2 <= t.n_st) t.parts *= 2;
     t.gpartB = off; off += (long long)t.parts * t.theta_o * (p->field_kind == NCDE_FIELD_MINIMAL ? 2 : 1);
     t.carry = off; off += 2LL * t.n_st * p->hidden * 16;
+    t.pack = off; off += tiled_pack_floats(p, false);
     t.total = off + 64;
     return t;
 }
@@ -1234,19 +1460,21 @@ const char* ncde_tiled_kernel_name(const NcdeProblem* p, int pass) {
 
 int64_t ncde_tiled_workspace_bytes(const NcdeProblem* p, int pass) {
     if (!ncde_tiled_supported(p, pass)) return NCDE_ERR_UNSUPPORTED;
-    if (pass == 0) return 256;
+    if (pass == 0) return 256 + tiled_pack_floats(p, tiled_fwd_bf(p)) * (int64_t)sizeof(float);
     const Layout y = make_layout(p);
     return (int64_t)sizeof(float) * tiled_adj_plan(p, y).total;
 }
 
 int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws, size_t ws_bytes, hipStream_t st) {
-    (void)ws; (void)ws_bytes;
     if (!ncde_tiled_supported(p, 0)) return NCDE_ERR_UNSUPPORTED;
+    if ((int64_t)ws_bytes < ncde_tiled_workspace_bytes(p, 0)) return NCDE_ERR_WORKSPACE;
     const Layout y = make_layout(p);
     KArgs a;
     fill_kargs(p, y, &a);
     a.out = out;
     a.stages = stages;
+    const bool bf = tiled_fwd_bf(p);
+    if (tiled_pack_floats(p, bf) > 0) tiled_pack_launch(p, &a, (float*)ws + 64, bf, st);
     const int ns = tiled_fwd_ns(p);
     const size_t lds = tiled_fwd_lds(p, ns);
     const bool small = p->hidden * ns * 16 <= 4 * TL_THREADS;   // state slice of <= 4 elements per thread: fewer live registers
@@ -1255,6 +1483,10 @@ int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws
                                            : (small ? ncde_fwd_tiled<1, TL_NW, 4> : ncde_fwd_tiled<1, TL_NW, 16>));
     if (p->field_kind == NCDE_FIELD_MINIMAL)
         fn = ns == 4 ? ncde_fwd_tiled<4, TL_NW, 16, 1> : (ns == 2 ? ncde_fwd_tiled<2, TL_NW, 16, 1> : ncde_fwd_tiled<1, TL_NW, 16, 1>);
+    if (bf) {
+        if (p->field_kind == NCDE_FIELD_MINIMAL) fn = small ? ncde_fwd_tiled<1, TL_NW, 4, 1, 1> : ncde_fwd_tiled<1, TL_NW, 16, 1, 1>;
+        else fn = small ? ncde_fwd_tiled<1, TL_NW, 4, 0, 1> : ncde_fwd_tiled<1, TL_NW, 16, 0, 1>;
+    }
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NCDE_ERR_HIP;
     const int nwg = (p->batch + ns * 16 - 1) / (ns * 16);
     hipLaunchKernelGGL(fn, dim3(nwg), dim3(TL_THREADS), lds, st, a);
@@ -1276,6 +1508,7 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     a.recA = w + t.recA; a.recB = w + t.recB; a.recC = w + t.recC; a.recD = w + t.recD;
     a.gpart = w + t.gpartA;
     a.gstride = t.gstride;
+    tiled_pack_launch(p, &a, w + t.pack, false, st);
     const int pk = tiled_adj_pk(p);
     // small square models: every weight fragment register-resident (see ncde_adj_tiled)
     const bool gated = p->field_kind == NCDE_FIELD_MINIMAL;

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import bench, ncde_amd
 c = dict(bench.CONFIGS["cfg2"])
 B = int(os.environ.get("B", 4096))
-coeffs = torch.from_numpy(bench.make_inputs(c, B, 0)).cuda()
+coeffs = bench.make_inputs(c, B, 0, torch.device("cuda", 0))
 y = (torch.rand(B, 1, device="cuda") > 0.5).float()
 for vf, vft in (("original", "matmul"), ("minimal", "matmul"), ("gru", "matmul"), ("original", "evaluate"), ("gru", "derivative")):
     torch.manual_seed(0)
