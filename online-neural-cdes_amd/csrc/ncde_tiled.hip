@@ -739,8 +739,11 @@ __device__ __forceinline__ void tl_dw_acc(const float* gpre, const float* xin, i
 // tiles): every weight fragment a wave needs -- its forward row tile and its transposed tile of the (at most two)
 // hidden matrices, its (at most two) output tiles -- is loaded ONCE and stays in registers, so no phase of a stage
 // waits on an L2 round trip (cfg4: 11.3 -> see DESIGN.md).
-template <int PK, int NWV, int RES = 0, int GATED = 0>
+// BF = 1: x_L is additionally kept as three bf16 pieces (XBA, written by the last hidden layer) and THAT image is what pass B
+// gets as its record A, so the recompute of P there runs on the bf16 matrix cores.
+template <int PK, int NWV, int RES = 0, int GATED = 0, int BF = 0>
 __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
+    static_assert(BF == 0 || (RES == 0 && PK >= 2), "split record: streamed weights, last hidden width a multiple of 32");
     constexpr int NT = 64 * NWV, TL_EADJ = RES ? (16 * 16 * PK + NT - 1) / NT : 2048 / NT;
     constexpr int TL_DWT = RES ? (PK * PK + NWV - 1) / NWV : 64 / NWV;   // hidden dW tiles per wave and weight slot
     constexpr int NSP = 16, SCW = (16 * (16 * PK + 4) > 16 * PK * NSP) ? 16 * (16 * PK + 4) : 16 * PK * NSP;
@@ -762,6 +765,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     float* DX = G1 + DS;           // [C/4][16][4]
     float* SC = DX + C * NSP;      // per-wave scratch
     float* scr = SC + wave * SCW;
+    unsigned* XBA = reinterpret_cast<unsigned*>(SC + NWV * SCW);   // BF: split image of x_L (24 words per unit)
     const bool disc = a.discrete != 0;
     const int S = n_stages(a.method);
     const int dlast = 16 * PK;
@@ -956,7 +960,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                         *reinterpret_cast<f32x4*>(outb + ((4 * wave + lk) * NSP + li) * 4) = o;
                     }
                 } else {
-                    tl_dense_relu<1, NWV>(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane);
+                    tl_dense_relu<1, NWV>(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane, (BF != 0 && l == L - 1) ? XBA : nullptr);
                 }
                 __syncthreads();
                 in = outb;
@@ -966,12 +970,16 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
             // ---- records for pass B (x_L twice, weighted cotangent, dX/dt) --------------------------------------------
             {
                 const long long tile = (long long)sc * n_st + blockIdx.x;
-                float* ra = a.recA + tile * (dlast * NSP);
+                float* ra = a.recA + tile * (BF != 0 ? dlast * 24 : dlast * NSP);
                 float* rb = a.recB + tile * (dlast * NSP);
                 float* rc = a.recC + tile * (H * NSP);
                 float* rd = a.recD + tile * (C * NSP);
+                if constexpr (BF != 0) {
+                    for (int e = tid; e < dlast * 6; e += NT)
+                        reinterpret_cast<u32x4*>(ra)[e] = reinterpret_cast<const u32x4*>(XBA)[e];
+                }
                 for (int e = tid; e < dlast * NSP; e += NT) {
-                    ra[e] = in[e];
+                    if constexpr (BF == 0) ra[e] = in[e];
                     const int jj = e >> 4, s = e & 15;
                     rb[e] = in[((jj >> 2) * NSP + s) * 4 + (jj & 3)];
                 }
@@ -1156,87 +1164,160 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
 // dWo_tile += dP x_L^T (PK*4 MFMAs, samples are the K dim; dP transposed through a 16x17 LDS patch).
 // HEAD 0: the original field (tanh head).  Minimal-gated field: HEAD 1 = gradient of the tanh head (Wo, bo), HEAD 2 = of the
 // sigmoid head (Wg, bg); either run recomputes both pre-activations (M = sigmoid(Pg) * tanh(Pt)), accumulates one.
-template <int PK, int HEAD = 0>
+// NRT = row tiles per wave: each fragment of records (16 KB at cfg5, re-read by every row tile) then feeds NRT tiles --
+// measured at cfg5 with one tile per wave the pass moved 13.7 TB/s through the L2 (3.9 M fragments x 16 KB per 4.7 ms
+// window) and sat at that, not at the MFMA rate.  One wave per SIMD, so the 512-register file holds NRT = 4 tiles.
+// BF = 1: record A is the split image of x_L and the weight tile is split once at the start, so P = Wo_tile x_L + bo takes
+// 6 PK/2 bf16 MFMAs of 16 cycles instead of 4 PK fp32-input MFMAs of 32 (ncde_bf3.h); dWo stays on fp32 inputs.
+template <int PK, int HEAD = 0, int NRT = 1, int BF = 0>
 __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_st, float* gpartB) {
+    static_assert(BF == 0 || PK >= 2, "split record needs a last hidden width that is a multiple of 32");
+    constexpr int NCH = PK >= 2 ? PK / 2 : 1;
     // n_sc = stages recorded in this time window; a.resume != 0: add to the partial the earlier windows left in gpartB
-    __shared__ float patch[4][16 * 17];
+    __shared__ float patch[4][NRT][16 * 17];
     __shared__ __attribute__((aligned(16))) float red[4][PK * 256 + 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int C = a.C, H = a.H, ncq = C >> 2, dlast = 16 * PK;
-    const int tile = blockIdx.x, hb = tile / ncq, cq = tile - hb * ncq;
     const int part = blockIdx.y * 4 + wave, nparts = gridDim.y * 4;
-    const long long woff = (long long)((4 * hb + (li >> 2)) * C + 4 * cq + (li & 3)) * dlast + 4 * lk;
-    const Panel<PK> Wp = tl_load_panel<PK>(a.Wo + woff, 0);
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb + lk) * C + 4 * cq);
-    Panel<PK> Wq;        // sigmoid head (gated field)
-    f32x4 bq;
-    if constexpr (HEAD != 0) {
-        Wq = tl_load_panel<PK>(a.Wg + woff, 0);
-        bq = *reinterpret_cast<const f32x4*>(a.bg + (4 * hb + lk) * C + 4 * cq);
-    }
-    f32x4 gW[PK];
-    float gb[4] = {0.f, 0.f, 0.f, 0.f};
+    int hb[NRT], cq[NRT];
+    Panel<PK> Wp[BF != 0 ? 1 : NRT];
+    f32x4 bv[NRT];
+    Panel<PK> Wq[(HEAD != 0 && BF == 0) ? NRT : 1];        // sigmoid head (gated field)
+    f32x4 bq[HEAD != 0 ? NRT : 1];
+    u32x4 Ws[BF != 0 ? NRT : 1][NCH][3], Wqs[(BF != 0 && HEAD != 0) ? NRT : 1][NCH][3];   // BF: the tiles as bf16 pieces
+    f32x4 gW[NRT][PK];
+    float gb[NRT][4];
 #pragma unroll
-    for (int jt = 0; jt < PK; ++jt) gW[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float* pt = patch[wave];
+    for (int rt = 0; rt < NRT; ++rt) {
+        const int tile = blockIdx.x * NRT + rt;
+        hb[rt] = tile / ncq;
+        cq[rt] = tile - hb[rt] * ncq;
+        const long long wrow = (long long)((4 * hb[rt] + (li >> 2)) * C + 4 * cq[rt] + (li & 3)) * dlast;
+        const long long woff = wrow + 4 * lk;
+        bv[rt] = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb[rt] + lk) * C + 4 * cq[rt]);
+        if constexpr (HEAD != 0) bq[rt] = *reinterpret_cast<const f32x4*>(a.bg + (4 * hb[rt] + lk) * C + 4 * cq[rt]);
+        if constexpr (BF != 0) {      // lane (row li, k-group lk) of chunk c: k = 32 c + 8 lk + 0..7
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                float v[8];
+                *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(a.Wo + wrow + 32 * c + 8 * lk);
+                *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(a.Wo + wrow + 32 * c + 8 * lk + 4);
+                const Split3 sp = split8(v);
+                Ws[rt][c][0] = sp.hi; Ws[rt][c][1] = sp.mid; Ws[rt][c][2] = sp.lo;
+                if constexpr (HEAD != 0) {
+                    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(a.Wg + wrow + 32 * c + 8 * lk);
+                    *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(a.Wg + wrow + 32 * c + 8 * lk + 4);
+                    const Split3 sq = split8(v);
+                    Wqs[rt][c][0] = sq.hi; Wqs[rt][c][1] = sq.mid; Wqs[rt][c][2] = sq.lo;
+                }
+            }
+        } else {
+            Wp[rt] = tl_load_panel<PK>(a.Wo + woff, 0);
+            if constexpr (HEAD != 0) Wq[rt] = tl_load_panel<PK>(a.Wg + woff, 0);
+        }
+#pragma unroll
+        for (int jt = 0; jt < PK; ++jt) gW[rt][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gb[rt][r] = 0.0f;
+    }
     const int my_n = part < n_st ? (n_st - part + nparts - 1) / nparts : 0;   // sample tiles part, part + nparts, ...
     struct Frag {
-        f32x4 xa[PK], xb[PK], dx;
-        float cot;
+        f32x4 xa[BF != 0 ? 1 : PK], xb[PK], dx[NRT];
+        u32x4 xs[BF != 0 ? NCH : 1][3];
+        float cot[NRT];
     };
     // fragment of (stage sc, k-th sample tile of this wave); past the end: the last one again with a zero cotangent
     auto load_frag = [&](int sc, int k, bool live) {
         const long long t = (long long)sc * n_st + (part + nparts * k);
         Frag f;
-        f.cot = a.recC[t * (H * 16) + (4 * hb + lk) * 16 + li];
-        if (!live) f.cot = 0.0f;
-        f.dx = *reinterpret_cast<const f32x4*>(a.recD + t * (C * 16) + (cq * 16 + li) * 4);
-        const float* ra = a.recA + t * (dlast * 16) + (lk * 16 + li) * 4;
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+            f.cot[rt] = a.recC[t * (H * 16) + (4 * hb[rt] + lk) * 16 + li];
+            if (!live) f.cot[rt] = 0.0f;
+            f.dx[rt] = *reinterpret_cast<const f32x4*>(a.recD + t * (C * 16) + (cq[rt] * 16 + li) * 4);
+        }
         const float* rb = a.recB + t * (dlast * 16) + li * 16 + 4 * lk;
 #pragma unroll
-        for (int i = 0; i < PK; ++i) {
-            f.xa[i] = *reinterpret_cast<const f32x4*>(ra + i * 256);
-            f.xb[i] = *reinterpret_cast<const f32x4*>(rb + i * 256);
+        for (int i = 0; i < PK; ++i) f.xb[i] = *reinterpret_cast<const f32x4*>(rb + i * 256);
+        if constexpr (BF != 0) {
+            const unsigned* ra = reinterpret_cast<const unsigned*>(a.recA + t * (dlast * 24)) + lane * 4;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) f.xs[c][pc] = *reinterpret_cast<const u32x4*>(ra + (c * 3 + pc) * 256);
+        } else {
+            const float* ra = a.recA + t * (dlast * 16) + (lk * 16 + li) * 4;
+#pragma unroll
+            for (int i = 0; i < PK; ++i) f.xa[i] = *reinterpret_cast<const f32x4*>(ra + i * 256);
         }
         return f;
     };
     auto step = [&](const Frag& f) {
-        f32x4 acc = bv;
 #pragma unroll
-        for (int i = 0; i < PK; ++i)
+        for (int rt = 0; rt < NRT; ++rt) {
+            float* pt = patch[wave][rt];
+            f32x4 acc = bv[rt];
+            f32x4 accq;
+            if constexpr (BF != 0) {
+                f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f}, accq2 = acc2;
+                if constexpr (HEAD != 0) accq = bq[rt];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = mfma16(Wp.v[i][e], f.xa[i][e], acc);
-        f32x4 accq;
-        if constexpr (HEAD != 0) {
-            accq = bq;
+                for (int c = 0; c < NCH; ++c) {
+                    Split3 A, B;
+                    B.hi = f.xs[c][0]; B.mid = f.xs[c][1]; B.lo = f.xs[c][2];
+                    A.hi = Ws[rt][c][0]; A.mid = Ws[rt][c][1]; A.lo = Ws[rt][c][2];
+                    if (c & 1) acc2 = mfma_split(A, B, acc2);
+                    else acc = mfma_split(A, B, acc);
+                    if constexpr (HEAD != 0) {
+                        A.hi = Wqs[rt][c][0]; A.mid = Wqs[rt][c][1]; A.lo = Wqs[rt][c][2];
+                        if (c & 1) accq2 = mfma_split(A, B, accq2);
+                        else accq = mfma_split(A, B, accq);
+                    }
+                }
+                if constexpr (NCH > 1) {
 #pragma unroll
-            for (int i = 0; i < PK; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) accq = mfma16(Wq.v[i][e], f.xa[i][e], accq);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float m = tanh_dev(acc[r]);
-            const float dm = f.cot * f.dx[r];
-            float dp;
-            if constexpr (HEAD == 0) {
-                dp = dm * (1.0f - m * m);
+                    for (int r = 0; r < 4; ++r) {
+                        acc[r] += acc2[r];
+                        if constexpr (HEAD != 0) accq[r] += accq2[r];
+                    }
+                }
             } else {
-                const float sg = tl_sigmoid(accq[r]);
-                dp = HEAD == 1 ? (dm * sg) * (1.0f - m * m) : (dm * m) * (sg * (1.0f - sg));
+#pragma unroll
+                for (int i = 0; i < PK; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = mfma16(Wp[rt].v[i][e], f.xa[i][e], acc);
+                if constexpr (HEAD != 0) {
+                    accq = bq[rt];
+#pragma unroll
+                    for (int i = 0; i < PK; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) accq = mfma16(Wq[rt].v[i][e], f.xa[i][e], accq);
+                }
             }
-            gb[r] += dp;
-            pt[(4 * lk + r) * 17 + li] = dp;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float m = tanh_dev(acc[r]);
+                const float dm = f.cot[rt] * f.dx[rt][r];
+                float dp;
+                if constexpr (HEAD == 0) {
+                    dp = dm * (1.0f - m * m);
+                } else {
+                    const float sg = tl_sigmoid(accq[r]);
+                    dp = HEAD == 1 ? (dm * sg) * (1.0f - m * m) : (dm * m) * (sg * (1.0f - sg));
+                }
+                gb[rt][r] += dp;
+                pt[(4 * lk + r) * 17 + li] = dp;
+            }
+            float av[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[e] = pt[li * 17 + 4 * lk + e];
+#pragma unroll
+            for (int jt = 0; jt < PK; ++jt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gW[rt][jt] = mfma16(av[e], f.xb[jt][e], gW[rt][jt]);
         }
-        float av[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) av[e] = pt[li * 17 + 4 * lk + e];
-#pragma unroll
-        for (int jt = 0; jt < PK; ++jt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gW[jt] = mfma16(av[e], f.xb[jt][e], gW[jt]);
     };
     // two named fragment buffers, loop unrolled by two: the loads of one buffer are in flight while the other computes
     if (my_n > 0 && n_sc > 0) {
@@ -1260,28 +1341,32 @@ __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_s
         }
     }
     // ---- sum the four waves of the workgroup, write this part-group's partial ----------------------------------------
-#pragma unroll
-    for (int jt = 0; jt < PK; ++jt) *reinterpret_cast<f32x4*>(&red[wave][(jt * 64 + lane) * 4]) = gW[jt];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float v = gb[r];
-        v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
-        if (li == 0) red[wave][PK * 256 + 4 * lk + r] = v;
-    }
-    __syncthreads();
     const long long wo_sz = (long long)H * C * dlast, theta_o = wo_sz + (long long)H * C;
     float* gp = gpartB + (long long)blockIdx.y * theta_o;
-    for (int e = tid; e < PK * 256; e += 256) {
-        const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-        const int r = e & 3, ln = (e >> 2) & 63, jt = e >> 8;
-        const int row = (4 * hb + (ln >> 4)) * C + 4 * cq + r;
-        float* dst = gp + (long long)row * dlast + 16 * jt + (ln & 15);
-        *dst = a.resume ? *dst + v : v;
-    }
-    if (tid < 16) {
-        const float v = (red[0][PK * 256 + tid] + red[1][PK * 256 + tid]) + (red[2][PK * 256 + tid] + red[3][PK * 256 + tid]);
-        float* dst = gp + wo_sz + (4 * hb + (tid >> 2)) * C + 4 * cq + (tid & 3);
-        *dst = a.resume ? *dst + v : v;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+        if (rt > 0) __syncthreads();
+#pragma unroll
+        for (int jt = 0; jt < PK; ++jt) *reinterpret_cast<f32x4*>(&red[wave][(jt * 64 + lane) * 4]) = gW[rt][jt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = gb[rt][r];
+            v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+            if (li == 0) red[wave][PK * 256 + 4 * lk + r] = v;
+        }
+        __syncthreads();
+        for (int e = tid; e < PK * 256; e += 256) {
+            const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+            const int r = e & 3, ln = (e >> 2) & 63, jt = e >> 8;
+            const int row = (4 * hb[rt] + (ln >> 4)) * C + 4 * cq[rt] + r;
+            float* dst = gp + (long long)row * dlast + 16 * jt + (ln & 15);
+            *dst = a.resume ? *dst + v : v;
+        }
+        if (tid < 16) {
+            const float v = (red[0][PK * 256 + tid] + red[1][PK * 256 + tid]) + (red[2][PK * 256 + tid] + red[3][PK * 256 + tid]);
+            float* dst = gp + wo_sz + (4 * hb[rt] + (tid >> 2)) * C + 4 * cq[rt] + (tid & 3);
+            *dst = a.resume ? *dst + v : v;
+        }
     }
 }
 
@@ -1354,10 +1439,27 @@ int tiled_adj_pk(const NcdeProblem* p) {
     return (dlast == 128) ? 8 : (dlast == 64 ? 4 : (dlast == 32 ? 2 : (dlast == 16 ? 1 : 0)));
 }
 
-size_t tiled_adj_lds(const NcdeProblem* p) {
+// small square models: every weight fragment register-resident (see ncde_adj_tiled, RES)
+bool tiled_adj_res(const NcdeProblem* p) {
+    const int pk = tiled_adj_pk(p);
+    bool res = p->field_kind != NCDE_FIELD_MINIMAL && pk >= 1 && pk <= 4 && p->hidden == 16 * pk && p->hidden * p->channels / 16 <= 2 * TL_ADJ_NW;
+    for (int l = 0; l < p->n_layers; ++l) res = res && p->layer_out[l] == 16 * pk && p->layer_in[l] == 16 * pk;
+    return res;
+}
+size_t tiled_adj_lds_base(const NcdeProblem* p) {
     const int pk = tiled_adj_pk(p), D = tiled_dmax(p);
     const int scw = std::max(16 * (16 * pk + 4), 16 * pk * 16);
     return sizeof(float) * (size_t)(4 * p->hidden * 16 + (p->n_layers + 2) * D * 16 + p->channels * 16 + TL_ADJ_NW * scw);
+}
+// split-bf16 record A / recompute in pass B: streamed weights, last hidden width 32 / 64 / 128, room for the split image of
+// x_L in the sweep's LDS, and the caller did not ask for plain fp32-input MFMA
+bool tiled_adj_bf(const NcdeProblem* p) {
+    const int pk = tiled_adj_pk(p);
+    return !(p->flags & NCDE_FLAG_FP32_MFMA) && pk >= 2 && !tiled_adj_res(p) &&
+           tiled_adj_lds_base(p) + (size_t)pk * 16 * 16 * 6 <= (size_t)kLdsLimit;
+}
+size_t tiled_adj_lds(const NcdeProblem* p) {
+    return tiled_adj_lds_base(p) + (tiled_adj_bf(p) ? (size_t)tiled_adj_pk(p) * 16 * 16 * 6 : 0);
 }
 
 bool tiled_adj_ok(const NcdeProblem* p) {
@@ -1376,7 +1478,7 @@ bool tiled_adj_ok(const NcdeProblem* p) {
 }
 
 struct TiledAdjPlan {
-    int n_st, n_sc, gstride, parts, window, S;
+    int n_st, n_sc, gstride, parts, window, S, nrt;
     long long recA, recB, recC, recD, gpartA, gpartB, carry, pack, total;   // float offsets into the workspace
     long long theta_o;
 };
@@ -1398,13 +1500,15 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
     t.S = S;
     t.n_st = (p->batch + 15) / 16;
     t.gstride = y.gWo_off;
-    const long long per_step = (long long)S * t.n_st * (2 * dlast + p->hidden + p->channels) * 16 * (long long)sizeof(float);
+    const bool bf = tiled_adj_bf(p);
+    const long long recA_tile = bf ? dlast * 24 : dlast * 16;      // floats per (stage, sample tile) of record A
+    const long long per_step = (long long)S * t.n_st * (recA_tile + (dlast + p->hidden + p->channels) * 16) * (long long)sizeof(float);
     const int steps = p->n_knots - 1;
     t.window = (int)std::max<long long>(1, std::min<long long>(steps, tiled_window_budget_bytes() / per_step));
     t.n_sc = t.window * S;
     const long long tiles = (long long)t.n_sc * t.n_st;
     long long off = 64;
-    t.recA = off; off += tiles * dlast * 16;
+    t.recA = off; off += tiles * recA_tile;
     t.recB = off; off += tiles * dlast * 16;
     t.recC = off; off += tiles * p->hidden * 16;
     t.recD = off; off += tiles * p->channels * 16;
@@ -1412,8 +1516,12 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
     t.theta_o = (long long)p->hidden * p->channels * dlast + (long long)p->hidden * p->channels;
     // pass B wants >= 4096 waves (four rounds of one wave per SIMD) for balance; each part-group = 4 waves of one row tile
     const int row_tiles = p->hidden * p->channels / 16;
+    // row tiles per wave of pass B (original field; the gated heads keep one: two weight panels per tile)
+    // (PK = 8: four tiles no longer fit the register file -- measured at cfg5: 1 tile 1382 ms, 2 tiles 1335 ms, 4 tiles 1725 ms)
+    t.nrt = p->field_kind == NCDE_FIELD_MINIMAL ? 1 : (row_tiles % 4 == 0 && row_tiles >= 64 && dlast < 128 ? 4 : (row_tiles % 2 == 0 && row_tiles >= 32 ? 2 : 1));
+    if (const char* e = getenv("NCDE_TILED_NRT")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && row_tiles % v == 0 && p->field_kind != NCDE_FIELD_MINIMAL) t.nrt = v; }   // TEMPORARY
     t.parts = 1;
-    while (t.parts < 64 && row_tiles * 4 * t.parts < 4096 && 4 * t.parts * 2 <= t.n_st) t.parts *= 2;
+    while (t.parts < 64 && (row_tiles / t.nrt) * 4 * t.parts < 4096 && 4 * t.parts * 2 <= t.n_st) t.parts *= 2;
     t.gpartB = off; off += (long long)t.parts * t.theta_o * (p->field_kind == NCDE_FIELD_MINIMAL ? 2 : 1);
     t.carry = off; off += 2LL * t.n_st * p->hidden * 16;
     t.pack = off; off += tiled_pack_floats(p, false);
@@ -1510,23 +1618,35 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     a.gstride = t.gstride;
     tiled_pack_launch(p, &a, w + t.pack, false, st);
     const int pk = tiled_adj_pk(p);
-    // small square models: every weight fragment register-resident (see ncde_adj_tiled)
     const bool gated = p->field_kind == NCDE_FIELD_MINIMAL;
-    bool res = !gated && pk <= 4 && p->hidden == 16 * pk && p->hidden * p->channels / 16 <= 2 * TL_ADJ_NW;
-    for (int l = 0; l < p->n_layers; ++l) res = res && p->layer_out[l] == 16 * pk && p->layer_in[l] == 16 * pk;
+    const bool res = tiled_adj_res(p), bf = tiled_adj_bf(p);
     void (*fa)(KArgs) = pk == 8 ? ncde_adj_tiled<8, TL_ADJ_NW>
                                 : (pk == 4 ? (res ? ncde_adj_tiled<4, TL_ADJ_NW, 1> : ncde_adj_tiled<4, TL_ADJ_NW>)
                                            : (pk == 2 ? (res ? ncde_adj_tiled<2, TL_ADJ_NW, 1> : ncde_adj_tiled<2, TL_ADJ_NW>)
                                                       : (res ? ncde_adj_tiled<1, TL_ADJ_NW, 1> : ncde_adj_tiled<1, TL_ADJ_NW>)));
     void (*fb)(KArgs, int, int, float*) = pk == 8 ? ncde_dwo_tiled<8> : (pk == 4 ? ncde_dwo_tiled<4> : (pk == 2 ? ncde_dwo_tiled<2> : ncde_dwo_tiled<1>));
+    if (t.nrt == 4) fb = pk == 8 ? ncde_dwo_tiled<8, 0, 4> : (pk == 4 ? ncde_dwo_tiled<4, 0, 4> : (pk == 2 ? ncde_dwo_tiled<2, 0, 4> : ncde_dwo_tiled<1, 0, 4>));
+    if (t.nrt == 2) fb = pk == 8 ? ncde_dwo_tiled<8, 0, 2> : (pk == 4 ? ncde_dwo_tiled<4, 0, 2> : (pk == 2 ? ncde_dwo_tiled<2, 0, 2> : ncde_dwo_tiled<1, 0, 2>));
     void (*fb2)(KArgs, int, int, float*) = nullptr;
     if (gated) {
         fa = pk == 8 ? ncde_adj_tiled<8, TL_ADJ_NW, 0, 1> : (pk == 4 ? ncde_adj_tiled<4, TL_ADJ_NW, 0, 1> : (pk == 2 ? ncde_adj_tiled<2, TL_ADJ_NW, 0, 1> : ncde_adj_tiled<1, TL_ADJ_NW, 0, 1>));
         fb = pk == 8 ? ncde_dwo_tiled<8, 1> : (pk == 4 ? ncde_dwo_tiled<4, 1> : (pk == 2 ? ncde_dwo_tiled<2, 1> : ncde_dwo_tiled<1, 1>));
         fb2 = pk == 8 ? ncde_dwo_tiled<8, 2> : (pk == 4 ? ncde_dwo_tiled<4, 2> : (pk == 2 ? ncde_dwo_tiled<2, 2> : ncde_dwo_tiled<1, 2>));
     }
+    if (bf) {
+        if (gated) {
+            fa = pk == 8 ? ncde_adj_tiled<8, TL_ADJ_NW, 0, 1, 1> : (pk == 4 ? ncde_adj_tiled<4, TL_ADJ_NW, 0, 1, 1> : ncde_adj_tiled<2, TL_ADJ_NW, 0, 1, 1>);
+            fb = pk == 8 ? ncde_dwo_tiled<8, 1, 1, 1> : (pk == 4 ? ncde_dwo_tiled<4, 1, 1, 1> : ncde_dwo_tiled<2, 1, 1, 1>);
+            fb2 = pk == 8 ? ncde_dwo_tiled<8, 2, 1, 1> : (pk == 4 ? ncde_dwo_tiled<4, 2, 1, 1> : ncde_dwo_tiled<2, 2, 1, 1>);
+        } else {
+            fa = pk == 8 ? ncde_adj_tiled<8, TL_ADJ_NW, 0, 0, 1> : (pk == 4 ? ncde_adj_tiled<4, TL_ADJ_NW, 0, 0, 1> : ncde_adj_tiled<2, TL_ADJ_NW, 0, 0, 1>);
+            if (t.nrt == 4) fb = pk == 8 ? ncde_dwo_tiled<8, 0, 4, 1> : (pk == 4 ? ncde_dwo_tiled<4, 0, 4, 1> : ncde_dwo_tiled<2, 0, 4, 1>);
+            else if (t.nrt == 2) fb = pk == 8 ? ncde_dwo_tiled<8, 0, 2, 1> : (pk == 4 ? ncde_dwo_tiled<4, 0, 2, 1> : ncde_dwo_tiled<2, 0, 2, 1>);
+            else fb = pk == 8 ? ncde_dwo_tiled<8, 0, 1, 1> : (pk == 4 ? ncde_dwo_tiled<4, 0, 1, 1> : ncde_dwo_tiled<2, 0, 1, 1>);
+        }
+    }
     const size_t lds = tiled_adj_lds(p);
-    static const void* attr_done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // set once per kernel, not per launch
+    static const void* attr_done[32] = {};   // set once per kernel, not per launch
     bool seen = false;
     for (const void* q : attr_done) seen = seen || q == (const void*)fa;
     if (!seen) {
@@ -1543,8 +1663,8 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
         a.win_hi = hi; a.win_lo = lo; a.resume = first ? 0 : 1;
         hipLaunchKernelGGL(fa, dim3(t.n_st), dim3(64 * TL_ADJ_NW), lds, st, a);
         const int n_sc = (hi - lo) * t.S;
-        hipLaunchKernelGGL(fb, dim3(p->hidden * p->channels / 16, t.parts), dim3(256), 0, st, a, n_sc, t.n_st, gB);
-        if (fb2) hipLaunchKernelGGL(fb2, dim3(p->hidden * p->channels / 16, t.parts), dim3(256), 0, st, a, n_sc, t.n_st, gB2);
+        hipLaunchKernelGGL(fb, dim3(p->hidden * p->channels / 16 / t.nrt, t.parts), dim3(256), 0, st, a, n_sc, t.n_st, gB);
+        if (fb2) hipLaunchKernelGGL(fb2, dim3(p->hidden * p->channels / 16 / t.nrt, t.parts), dim3(256), 0, st, a, n_sc, t.n_st, gB2);
         if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
     }
     if (main_kernel_only) return NCDE_OK;
