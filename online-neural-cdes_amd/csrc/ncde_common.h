@@ -57,6 +57,7 @@ struct KArgs {
     // batch-tiled family: fragment-ordered copies of the output layer and of the gate head (ncde_pack_panels)
     const float* Wo_pk;
     const float* Wg_pk;
+    const unsigned* Wo_bf;   // split-bf16 copy (backward sweep: beside the fp32 copy, which feeds the transposed products)
 };
 
 // ---- time plan (built on the host by ncde_time_plan_build, csrc/ncde_timeplan.hip; layout in 4-byte words) -------------

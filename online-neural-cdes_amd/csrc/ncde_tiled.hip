@@ -12,6 +12,7 @@
 //   * the Butcher state (y0, k1, k2 ...) stays in registers, a fixed slice per thread.
 // Shapes: H, layer widths multiples of 16, C a multiple of 4 (anything else runs on the generic family).
 // Reference semantics restated: see the header of ncde_generic.hip (same op sequence, same citations).
+#include <type_traits>
 #include "ncde_common.h"
 #include "ncde_bf3.h"
 #include "ncde_host.h"
@@ -578,10 +579,15 @@ template <int PK>
 using WoTile = TlTile<PK, 0>;
 
 // RES = 1: the (at most two) output tiles of this wave are resident in registers (`res`), nothing is fetched.
-template <int PK, int NWV, int RES, int GATED>
+// BFP = 1 (original field, streamed weights): P from the split-bf16 copy of the tile (prefetched a tile ahead) and the split
+// image xb of x_L; the fp32 copy of the SAME tile, needed only for the transposed products, is requested at the top of the
+// step and lands under the P MFMAs and the tanh.
+template <int PK, int NWV, int RES, int GATED, int BFP = 0>
 __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, const float* AS, const float* DX, float* KOY,
-                                              float* scr, int wave, int lane, const WoTile<PK>* res) {
+                                              float* scr, int wave, int lane, const WoTile<PK>* res, const unsigned* xb = nullptr) {
     static_assert(!(RES != 0 && GATED != 0), "resident weights are built for the original field only");
+    static_assert(BFP == 0 || (RES == 0 && GATED == 0 && PK >= 2), "split-bf16 P: original field, streamed weights");
+    constexpr int NCH = PK >= 2 ? PK / 2 : 1;
     constexpr int NSP = 16, SCS = 16 * PK + 4;
     const int li = lane & 15, lk = lane >> 4;
     const int C = a.C, nhb = a.H >> 2, ncq = C >> 2;
@@ -590,13 +596,18 @@ __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, c
     for (int jt = 0; jt < PK; ++jt) accJ[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nhb_w = (nhb - wave + NWV - 1) / NWV;
     const int nq = nhb_w > 0 ? nhb_w * ncq : 0;
-    using TileIn = TlTile<PK, GATED>;
+    struct BfIn {
+        u32x4 w[NCH][3];
+        f32x4 bias;
+    };
+    using TileIn = std::conditional_t<BFP != 0, BfIn, TlTile<PK, GATED>>;
     int fhi = 0, fcq = 0, fq = 0;
     auto fetch = [&]() {
         const int hb = wave + NWV * fhi;
         TileIn t;
         const long long woff = (long long)(hb * ncq + fcq) * (PK * 256);
-        t.P = tl_load_panel_packed<PK>(a.Wo_pk + woff, lane);
+        if constexpr (BFP != 0) tl_load_bf<NCH>(a.Wo_bf + (long long)(hb * ncq + fcq) * (NCH * 3 * 256), lane, t.w);
+        else t.P = tl_load_panel_packed<PK>(a.Wo_pk + woff, lane);
         t.bias = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb + lk) * C + 4 * fcq);
         if constexpr (GATED != 0) {
             t.G = tl_load_panel_packed<PK>(a.Wg_pk + woff, lane);
@@ -613,11 +624,18 @@ __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, c
     // straight-line body (no branches), two named buffers: the next tile's loads stay in flight across the MFMAs
     auto step = [&](const TileIn& t) {
         const int hb = wave + NWV * chi, cq = ccq;
-#pragma unroll
-        for (int i = 0; i < PK; ++i) *reinterpret_cast<f32x4*>(scr + li * SCS + 16 * i + 4 * lk) = t.P.v[i];
         f32x4 acc[1];
-        acc[0] = t.bias;
-        tl_mma_panel<1, PK>(t.P, xL, 0, li, lk, acc);
+        if constexpr (BFP != 0) {
+            const Panel<PK> Pf = tl_load_panel_packed<PK>(a.Wo_pk + (long long)(hb * ncq + cq) * (PK * 256), lane);
+            acc[0] = tl_mma_bf<NCH>(t.w, xb, lane, t.bias);
+#pragma unroll
+            for (int i = 0; i < PK; ++i) *reinterpret_cast<f32x4*>(scr + li * SCS + 16 * i + 4 * lk) = Pf.v[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < PK; ++i) *reinterpret_cast<f32x4*>(scr + li * SCS + 16 * i + 4 * lk) = t.P.v[i];
+            acc[0] = t.bias;
+            tl_mma_panel<1, PK>(t.P, xL, 0, li, lk, acc);
+        }
         const float aval = AS[(hb * NSP + li) * 4 + lk];
         const f32x4 dx = *reinterpret_cast<const f32x4*>(DX + (cq * NSP + li) * 4);
         float dP[4], dPg[4];
@@ -966,7 +984,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                 in = outb;
             }
             // ---- output layer: f, dP, per-wave partial of dL/dx_L -----------------------------------------------------
-            tl_output_vjp<PK, NWV, RES, GATED>(a, in, AS, DX, KOY, scr, wave, lane, wo);
+            tl_output_vjp<PK, NWV, RES, GATED, (BF != 0 && GATED == 0) ? 1 : 0>(a, in, AS, DX, KOY, scr, wave, lane, wo, XBA);
             // ---- records for pass B (x_L twice, weighted cotangent, dX/dt) --------------------------------------------
             {
                 const long long tile = (long long)sc * n_st + blockIdx.x;
@@ -1479,7 +1497,7 @@ bool tiled_adj_ok(const NcdeProblem* p) {
 
 struct TiledAdjPlan {
     int n_st, n_sc, gstride, parts, window, S, nrt;
-    long long recA, recB, recC, recD, gpartA, gpartB, carry, pack, total;   // float offsets into the workspace
+    long long recA, recB, recC, recD, gpartA, gpartB, carry, pack, pack_bf, total;   // float offsets into the workspace
     long long theta_o;
 };
 
@@ -1525,6 +1543,7 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
     t.gpartB = off; off += (long long)t.parts * t.theta_o * (p->field_kind == NCDE_FIELD_MINIMAL ? 2 : 1);
     t.carry = off; off += 2LL * t.n_st * p->hidden * 16;
     t.pack = off; off += tiled_pack_floats(p, false);
+    t.pack_bf = off; off += (bf && p->field_kind != NCDE_FIELD_MINIMAL) ? tiled_pack_floats(p, true) : 0;
     t.total = off + 64;
     return t;
 }
@@ -1617,6 +1636,13 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     a.gpart = w + t.gpartA;
     a.gstride = t.gstride;
     tiled_pack_launch(p, &a, w + t.pack, false, st);
+    if (tiled_adj_bf(p) && p->field_kind != NCDE_FIELD_MINIMAL) {
+        const int dl = p->layer_out[p->n_layers - 1];
+        const long long n4 = (long long)p->hidden * p->channels * dl / 4;
+        const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(ncde_pack_panels_bf, dim3(grid), dim3(256), 0, st, a.Wo, (unsigned*)(w + t.pack_bf), p->hidden, p->channels, dl / 32);
+        a.Wo_bf = (const unsigned*)(w + t.pack_bf);
+    }
     const int pk = tiled_adj_pk(p);
     const bool gated = p->field_kind == NCDE_FIELD_MINIMAL;
     const bool res = tiled_adj_res(p), bf = tiled_adj_bf(p);

@@ -332,12 +332,29 @@ def test_full_size_cfg4_cfg5_sample_subset_vs_oracle(cfg, gpu_lib):
     assert gu.relerr(rs["z_out"], z) <= TIGHT_Z
     iso = gpu_util.run_adjoint_direct(sub, z.numpy())
     dz0, gp = orc.solve_adjoint(ctl, field, z, sub["expect"]["grad_out"], method, False)
-    # cfg5 re-integrates y over 798 steps (3192 stages): two fp32 implementations drift apart by ~2e-4 there
-    # (the reference's own fp32-vs-fp64 spread is 3e-5..4e-4) -> documented tolerances; cfg4: the tight guard
-    tol_g, tol_z0 = (E2E_G, E2E_G) if cfg == "cfg4" else (TOL_DTHETA, TOL_DZ0)
-    assert gu.relerr(iso["dz0"], dz0) <= tol_z0
-    for pname, g in zip(names, gp):
-        assert gu.relerr(iso["grads"][pname], g) <= tol_g, pname
+    if cfg == "cfg4":      # the tight guard
+        assert gu.relerr(iso["dz0"], dz0) <= E2E_G
+        for pname, g in zip(names, gp):
+            assert gu.relerr(iso["grads"][pname], g) <= E2E_G, pname
+        return
+    # cfg5 re-integrates y over 798 steps (3192 stages) and the max-norm gradient error of ANY fp32 implementation of that sweep is
+    # 1e-4 .. 1.5e-3 (a few ReLU masks flip): measured here by running the oracle itself in fp64 (the exact-arithmetic version of
+    # the same discrete scheme; the fp32 oracle is bit-pinned to the reference).  The bar for the kernel: as close to the fp64
+    # result as the fp32 reference arithmetic gets, within 2x (floor 5e-4) -- for the split-bf16 and the fp32-input MFMA path.
+    c64 = dict(sub, params={k: v.astype(np.float64) for k, v in sub["params"].items()})
+    f64 = gu.oracle_field(c64)
+    ctl64 = orc.Control(sub["coeffs"].astype(np.float64), interp)
+    z64 = orc.solve_forward(ctl64, f64, sub["z0"].astype(np.float64), method, False)
+    dz64, gp64 = orc.solve_adjoint(ctl64, f64, z64, sub["expect"]["grad_out"].astype(np.float64), method, False)
+    ref = {"dz0": gu.relerr(dz0.numpy(), dz64.numpy())}
+    ref.update({n: gu.relerr(g.numpy(), g64.numpy()) for n, g, g64 in zip(names, gp, gp64)})
+    for flags in (gpu_util._lib.FLAG_AUTO, gpu_util._lib.FLAG_FP32_MFMA):
+        it = iso if flags == gpu_util._lib.FLAG_AUTO else gpu_util.run_adjoint_direct(sub, z.numpy(), flags=flags)
+        err = {"dz0": gu.relerr(it["dz0"], dz64.numpy())}
+        err.update({n: gu.relerr(it["grads"][n], g64.numpy()) for n, g64 in zip(names, gp64)})
+        print("flags", flags, {k: "%.1e (fp32 oracle %.1e)" % (err[k], ref[k]) for k in err})
+        for k in err:
+            assert err[k] <= max(2.0 * ref[k], 5e-4), (flags, k, err[k], ref[k])
 
 
 def test_ragged_batch_and_determinism(gpu_lib):
