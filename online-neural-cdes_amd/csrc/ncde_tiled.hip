@@ -989,17 +989,42 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
             {
                 const long long tile = (long long)sc * n_st + blockIdx.x;
                 float* ra = a.recA + tile * (BF != 0 ? dlast * 24 : dlast * NSP);
-                float* rb = a.recB + tile * (dlast * NSP);
                 float* rc = a.recC + tile * (H * NSP);
                 float* rd = a.recD + tile * (C * NSP);
                 if constexpr (BF != 0) {
                     for (int e = tid; e < dlast * 6; e += NT)
                         reinterpret_cast<u32x4*>(ra)[e] = reinterpret_cast<const u32x4*>(XBA)[e];
-                }
-                for (int e = tid; e < dlast * NSP; e += NT) {
-                    if constexpr (BF == 0) ra[e] = in[e];
-                    const int jj = e >> 4, s = e & 15;
-                    rb[e] = in[((jj >> 2) * NSP + s) * 4 + (jj & 3)];
+                    // record B, split and PAIRED: sample tiles 2i and 2i+1 share one block, the K = 32 samples of the bf16 MFMA
+                    // that accumulates dWo in pass B.  Word ((jt * 3 + piece) * 64 + lane) * 4 + 2 half + d of the pair's block
+                    // holds x_L[k = 16 jt + (lane & 15)][samples 4 (lane >> 4) + 2 d, + 1] of tile `half`.
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    unsigned* rbp = reinterpret_cast<unsigned*>(a.recB) + ((long long)sc * ((n_st + 1) >> 1) + (blockIdx.x >> 1)) * (dlast * 48);
+                    const int half = blockIdx.x & 1;
+                    for (int e = tid; e < dlast * 4; e += NT) {
+                        const int k = e >> 2, kg = e & 3, ln = (k & 15) + 16 * kg;
+                        float v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = in[((k >> 2) * NSP + 4 * kg + q) * 4 + (k & 3)];
+                        unsigned h0, m0, l0, h1, m1, l1;
+                        split_pair(v[0], v[1], h0, m0, l0);
+                        split_pair(v[2], v[3], h1, m1, l1);
+                        unsigned* dst = rbp + (((k >> 4) * 3) * 64 + ln) * 4 + 2 * half;
+                        *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
+                        *reinterpret_cast<u32x2*>(dst + 256) = (u32x2){m0, m1};
+                        *reinterpret_cast<u32x2*>(dst + 512) = (u32x2){l0, l1};
+                        if (half == 0 && blockIdx.x + 1 == n_st) {      // odd tile count: the missing partner contributes zeros
+                            *reinterpret_cast<u32x2*>(dst + 2) = (u32x2){0u, 0u};
+                            *reinterpret_cast<u32x2*>(dst + 258) = (u32x2){0u, 0u};
+                            *reinterpret_cast<u32x2*>(dst + 514) = (u32x2){0u, 0u};
+                        }
+                    }
+                } else {
+                    float* rb = a.recB + tile * (dlast * NSP);
+                    for (int e = tid; e < dlast * NSP; e += NT) {
+                        ra[e] = in[e];
+                        const int jj = e >> 4, s = e & 15;
+                        rb[e] = in[((jj >> 2) * NSP + s) * 4 + (jj & 3)];
+                    }
                 }
                 for (int e = tid; e < H * NSP; e += NT) {
                     const int hh = e >> 4, s = e & 15;
@@ -1185,12 +1210,9 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
 // NRT = row tiles per wave: each fragment of records (16 KB at cfg5, re-read by every row tile) then feeds NRT tiles --
 // measured at cfg5 with one tile per wave the pass moved 13.7 TB/s through the L2 (3.9 M fragments x 16 KB per 4.7 ms
 // window) and sat at that, not at the MFMA rate.  One wave per SIMD, so the 512-register file holds NRT = 4 tiles.
-// BF = 1: record A is the split image of x_L and the weight tile is split once at the start, so P = Wo_tile x_L + bo takes
-// 6 PK/2 bf16 MFMAs of 16 cycles instead of 4 PK fp32-input MFMAs of 32 (ncde_bf3.h); dWo stays on fp32 inputs.
-template <int PK, int HEAD = 0, int NRT = 1, int BF = 0>
+// (fp32 records; the sweep's split-record mode is consumed by ncde_dwo_pair below)
+template <int PK, int HEAD = 0, int NRT = 1>
 __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_st, float* gpartB) {
-    static_assert(BF == 0 || PK >= 2, "split record needs a last hidden width that is a multiple of 32");
-    constexpr int NCH = PK >= 2 ? PK / 2 : 1;
     // n_sc = stages recorded in this time window; a.resume != 0: add to the partial the earlier windows left in gpartB
     __shared__ float patch[4][NRT][16 * 17];
     __shared__ __attribute__((aligned(16))) float red[4][PK * 256 + 64];
@@ -1200,11 +1222,10 @@ __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_s
     const int C = a.C, H = a.H, ncq = C >> 2, dlast = 16 * PK;
     const int part = blockIdx.y * 4 + wave, nparts = gridDim.y * 4;
     int hb[NRT], cq[NRT];
-    Panel<PK> Wp[BF != 0 ? 1 : NRT];
+    Panel<PK> Wp[NRT];
     f32x4 bv[NRT];
-    Panel<PK> Wq[(HEAD != 0 && BF == 0) ? NRT : 1];        // sigmoid head (gated field)
+    Panel<PK> Wq[HEAD != 0 ? NRT : 1];        // sigmoid head (gated field)
     f32x4 bq[HEAD != 0 ? NRT : 1];
-    u32x4 Ws[BF != 0 ? NRT : 1][NCH][3], Wqs[(BF != 0 && HEAD != 0) ? NRT : 1][NCH][3];   // BF: the tiles as bf16 pieces
     f32x4 gW[NRT][PK];
     float gb[NRT][4];
 #pragma unroll
@@ -1212,28 +1233,12 @@ __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_s
         const int tile = blockIdx.x * NRT + rt;
         hb[rt] = tile / ncq;
         cq[rt] = tile - hb[rt] * ncq;
-        const long long wrow = (long long)((4 * hb[rt] + (li >> 2)) * C + 4 * cq[rt] + (li & 3)) * dlast;
-        const long long woff = wrow + 4 * lk;
+        const long long woff = (long long)((4 * hb[rt] + (li >> 2)) * C + 4 * cq[rt] + (li & 3)) * dlast + 4 * lk;
         bv[rt] = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb[rt] + lk) * C + 4 * cq[rt]);
-        if constexpr (HEAD != 0) bq[rt] = *reinterpret_cast<const f32x4*>(a.bg + (4 * hb[rt] + lk) * C + 4 * cq[rt]);
-        if constexpr (BF != 0) {      // lane (row li, k-group lk) of chunk c: k = 32 c + 8 lk + 0..7
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                float v[8];
-                *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(a.Wo + wrow + 32 * c + 8 * lk);
-                *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(a.Wo + wrow + 32 * c + 8 * lk + 4);
-                const Split3 sp = split8(v);
-                Ws[rt][c][0] = sp.hi; Ws[rt][c][1] = sp.mid; Ws[rt][c][2] = sp.lo;
-                if constexpr (HEAD != 0) {
-                    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(a.Wg + wrow + 32 * c + 8 * lk);
-                    *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(a.Wg + wrow + 32 * c + 8 * lk + 4);
-                    const Split3 sq = split8(v);
-                    Wqs[rt][c][0] = sq.hi; Wqs[rt][c][1] = sq.mid; Wqs[rt][c][2] = sq.lo;
-                }
-            }
-        } else {
-            Wp[rt] = tl_load_panel<PK>(a.Wo + woff, 0);
-            if constexpr (HEAD != 0) Wq[rt] = tl_load_panel<PK>(a.Wg + woff, 0);
+        Wp[rt] = tl_load_panel<PK>(a.Wo + woff, 0);
+        if constexpr (HEAD != 0) {
+            bq[rt] = *reinterpret_cast<const f32x4*>(a.bg + (4 * hb[rt] + lk) * C + 4 * cq[rt]);
+            Wq[rt] = tl_load_panel<PK>(a.Wg + woff, 0);
         }
 #pragma unroll
         for (int jt = 0; jt < PK; ++jt) gW[rt][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1242,8 +1247,7 @@ __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_s
     }
     const int my_n = part < n_st ? (n_st - part + nparts - 1) / nparts : 0;   // sample tiles part, part + nparts, ...
     struct Frag {
-        f32x4 xa[BF != 0 ? 1 : PK], xb[PK], dx[NRT];
-        u32x4 xs[BF != 0 ? NCH : 1][3];
+        f32x4 xa[PK], xb[PK], dx[NRT];
         float cot[NRT];
     };
     // fragment of (stage sc, k-th sample tile of this wave); past the end: the last one again with a zero cotangent
@@ -1256,19 +1260,12 @@ __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_s
             if (!live) f.cot[rt] = 0.0f;
             f.dx[rt] = *reinterpret_cast<const f32x4*>(a.recD + t * (C * 16) + (cq[rt] * 16 + li) * 4);
         }
+        const float* ra = a.recA + t * (dlast * 16) + (lk * 16 + li) * 4;
         const float* rb = a.recB + t * (dlast * 16) + li * 16 + 4 * lk;
 #pragma unroll
-        for (int i = 0; i < PK; ++i) f.xb[i] = *reinterpret_cast<const f32x4*>(rb + i * 256);
-        if constexpr (BF != 0) {
-            const unsigned* ra = reinterpret_cast<const unsigned*>(a.recA + t * (dlast * 24)) + lane * 4;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc) f.xs[c][pc] = *reinterpret_cast<const u32x4*>(ra + (c * 3 + pc) * 256);
-        } else {
-            const float* ra = a.recA + t * (dlast * 16) + (lk * 16 + li) * 4;
-#pragma unroll
-            for (int i = 0; i < PK; ++i) f.xa[i] = *reinterpret_cast<const f32x4*>(ra + i * 256);
+        for (int i = 0; i < PK; ++i) {
+            f.xa[i] = *reinterpret_cast<const f32x4*>(ra + i * 256);
+            f.xb[i] = *reinterpret_cast<const f32x4*>(rb + i * 256);
         }
         return f;
     };
@@ -1277,42 +1274,17 @@ __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_s
         for (int rt = 0; rt < NRT; ++rt) {
             float* pt = patch[wave][rt];
             f32x4 acc = bv[rt];
+#pragma unroll
+            for (int i = 0; i < PK; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = mfma16(Wp[rt].v[i][e], f.xa[i][e], acc);
             f32x4 accq;
-            if constexpr (BF != 0) {
-                f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f}, accq2 = acc2;
-                if constexpr (HEAD != 0) accq = bq[rt];
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    Split3 A, B;
-                    B.hi = f.xs[c][0]; B.mid = f.xs[c][1]; B.lo = f.xs[c][2];
-                    A.hi = Ws[rt][c][0]; A.mid = Ws[rt][c][1]; A.lo = Ws[rt][c][2];
-                    if (c & 1) acc2 = mfma_split(A, B, acc2);
-                    else acc = mfma_split(A, B, acc);
-                    if constexpr (HEAD != 0) {
-                        A.hi = Wqs[rt][c][0]; A.mid = Wqs[rt][c][1]; A.lo = Wqs[rt][c][2];
-                        if (c & 1) accq2 = mfma_split(A, B, accq2);
-                        else accq = mfma_split(A, B, accq);
-                    }
-                }
-                if constexpr (NCH > 1) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        acc[r] += acc2[r];
-                        if constexpr (HEAD != 0) accq[r] += accq2[r];
-                    }
-                }
-            } else {
+            if constexpr (HEAD != 0) {
+                accq = bq[rt];
 #pragma unroll
                 for (int i = 0; i < PK; ++i)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = mfma16(Wp[rt].v[i][e], f.xa[i][e], acc);
-                if constexpr (HEAD != 0) {
-                    accq = bq[rt];
-#pragma unroll
-                    for (int i = 0; i < PK; ++i)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) accq = mfma16(Wq[rt].v[i][e], f.xa[i][e], accq);
-                }
+                    for (int e = 0; e < 4; ++e) accq = mfma16(Wq[rt].v[i][e], f.xa[i][e], accq);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1356,6 +1328,217 @@ __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_s
             step(fA);
             fA = fetch();
             step(fB);
+        }
+    }
+    // ---- sum the four waves of the workgroup, write this part-group's partial ----------------------------------------
+    const long long wo_sz = (long long)H * C * dlast, theta_o = wo_sz + (long long)H * C;
+    float* gp = gpartB + (long long)blockIdx.y * theta_o;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+        if (rt > 0) __syncthreads();
+#pragma unroll
+        for (int jt = 0; jt < PK; ++jt) *reinterpret_cast<f32x4*>(&red[wave][(jt * 64 + lane) * 4]) = gW[rt][jt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = gb[rt][r];
+            v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+            if (li == 0) red[wave][PK * 256 + 4 * lk + r] = v;
+        }
+        __syncthreads();
+        for (int e = tid; e < PK * 256; e += 256) {
+            const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+            const int r = e & 3, ln = (e >> 2) & 63, jt = e >> 8;
+            const int row = (4 * hb[rt] + (ln >> 4)) * C + 4 * cq[rt] + r;
+            float* dst = gp + (long long)row * dlast + 16 * jt + (ln & 15);
+            *dst = a.resume ? *dst + v : v;
+        }
+        if (tid < 16) {
+            const float v = (red[0][PK * 256 + tid] + red[1][PK * 256 + tid]) + (red[2][PK * 256 + tid] + red[3][PK * 256 + tid]);
+            float* dst = gp + wo_sz + (4 * hb[rt] + (tid >> 2)) * C + 4 * cq[rt] + (tid & 3);
+            *dst = a.resume ? *dst + v : v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass B on the bf16 matrix cores: sample tiles in PAIRS
+// ------------------------------------------------------------------------------------------------
+// Same job and same grid as ncde_dwo_tiled, for the split records the sweep writes in its BF mode.  One step = one PAIR of
+// sample tiles (2i, 2i+1) of one stage:
+//   P_a, P_b = Wo_tile x_L + bo        6 PK/2 bf16 MFMAs each (weights split once at the start, x_L split in record A)
+//   dP       = cot (x) dX (1 - tanh^2) per tile, transposed through a 16x17 LDS patch, split on the fly
+//   dWo_tile += [dP_a dP_b] [x_L,a x_L,b]^T   the 32 samples of the pair are the K dim: 6 bf16 MFMAs per 16 columns
+// against 4 PK + 4 PK fp32-input MFMAs of twice the cycles per tile.  Every record piece has ONE register buffer that is
+// re-requested for the next pair right after its last use (one wave per SIMD: the file is the limit, not occupancy).
+template <int PK, int HEAD = 0, int NRT = 1>
+__global__ __launch_bounds__(256) void ncde_dwo_pair(KArgs a, int n_sc, int n_st, float* gpartB) {
+    static_assert(PK >= 2, "split records need a last hidden width that is a multiple of 32");
+    constexpr int NCH = PK / 2;
+    __shared__ float patch[4][NRT][2][16 * 17];
+    __shared__ __attribute__((aligned(16))) float red[4][PK * 256 + 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int C = a.C, H = a.H, ncq = C >> 2, dlast = 16 * PK;
+    const int part = blockIdx.y * 4 + wave, nparts = gridDim.y * 4;
+    const int n_pair = (n_st + 1) >> 1;
+    int hb[NRT], cq[NRT];
+    f32x4 bv[NRT], bq[HEAD != 0 ? NRT : 1];
+    u32x4 Ws[NRT][NCH][3], Wqs[HEAD != 0 ? NRT : 1][NCH][3];
+    f32x4 gW[NRT][PK];
+    float gb[NRT][4];
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+        const int tile = blockIdx.x * NRT + rt;
+        hb[rt] = tile / ncq;
+        cq[rt] = tile - hb[rt] * ncq;
+        const long long wrow = (long long)((4 * hb[rt] + (li >> 2)) * C + 4 * cq[rt] + (li & 3)) * dlast;
+        bv[rt] = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb[rt] + lk) * C + 4 * cq[rt]);
+        if constexpr (HEAD != 0) bq[rt] = *reinterpret_cast<const f32x4*>(a.bg + (4 * hb[rt] + lk) * C + 4 * cq[rt]);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {      // lane (row li, k-group lk) of chunk c: k = 32 c + 8 lk + 0..7
+            float v[8];
+            *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(a.Wo + wrow + 32 * c + 8 * lk);
+            *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(a.Wo + wrow + 32 * c + 8 * lk + 4);
+            const Split3 sp = split8(v);
+            Ws[rt][c][0] = sp.hi; Ws[rt][c][1] = sp.mid; Ws[rt][c][2] = sp.lo;
+            if constexpr (HEAD != 0) {
+                *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(a.Wg + wrow + 32 * c + 8 * lk);
+                *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(a.Wg + wrow + 32 * c + 8 * lk + 4);
+                const Split3 sq = split8(v);
+                Wqs[rt][c][0] = sq.hi; Wqs[rt][c][1] = sq.mid; Wqs[rt][c][2] = sq.lo;
+            }
+        }
+#pragma unroll
+        for (int jt = 0; jt < PK; ++jt) gW[rt][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gb[rt][r] = 0.0f;
+    }
+    const int my_n = part < n_pair ? (n_pair - part + nparts - 1) / nparts : 0;   // pairs part, part + nparts, ...
+    // record pieces of the pair being processed / requested
+    u32x4 xs[2][NCH][3];     // x_L of tile a / b, B operand of P
+    u32x4 xp[PK][3];         // x_L^T of the pair, B operand of dWo
+    f32x4 dxv[2][NRT];
+    float cot[2][NRT];
+    int sc = 0, k = 0;       // position of the pair to request next
+    auto tiles_of = [&](int kk, int& ta, int& tb, bool& has_b) {
+        const int pr = part + nparts * kk;
+        ta = 2 * pr;
+        has_b = ta + 1 < n_st;
+        tb = has_b ? ta + 1 : ta;       // odd tile count: tile a again, with a zero cotangent (its record-B half is zeros)
+    };
+    auto load_xs = [&](int which) {
+        int ta, tb; bool hb_;
+        tiles_of(k, ta, tb, hb_);
+        const long long t = (long long)sc * n_st + (which == 0 ? ta : tb);
+        const unsigned* ra = reinterpret_cast<const unsigned*>(a.recA + t * (dlast * 24)) + lane * 4;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) xs[which][c][pc] = *reinterpret_cast<const u32x4*>(ra + (c * 3 + pc) * 256);
+    };
+    auto load_meta = [&]() {
+        int ta, tb; bool has_b;
+        tiles_of(k, ta, tb, has_b);
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) {
+            const long long t = (long long)sc * n_st + (w2 == 0 ? ta : tb);
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) {
+                const float cv = a.recC[t * (H * 16) + (4 * hb[rt] + lk) * 16 + li];
+                cot[w2][rt] = (w2 == 1 && !has_b) ? 0.0f : cv;
+                dxv[w2][rt] = *reinterpret_cast<const f32x4*>(a.recD + t * (C * 16) + (cq[rt] * 16 + li) * 4);
+            }
+        }
+    };
+    auto load_xp = [&]() {
+        const int pr = part + nparts * k;
+        const unsigned* rb = reinterpret_cast<const unsigned*>(a.recB) + ((long long)sc * n_pair + pr) * (dlast * 48) + lane * 4;
+#pragma unroll
+        for (int jt = 0; jt < PK; ++jt)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) xp[jt][pc] = *reinterpret_cast<const u32x4*>(rb + (jt * 3 + pc) * 256);
+    };
+    if (my_n > 0 && n_sc > 0) {
+        const long long nq = (long long)n_sc * my_n;
+        load_xs(0); load_xs(1); load_meta(); load_xp();
+        for (long long q = 0; q < nq; ++q) {
+            // position of the NEXT pair (the last iteration re-requests its own: harmless)
+            if (q + 1 < nq) { if (++k == my_n) { k = 0; ++sc; } }
+            f32x4 acc[2][NRT], accq[2][HEAD != 0 ? NRT : 1];
+#pragma unroll
+            for (int w2 = 0; w2 < 2; ++w2) {
+#pragma unroll
+                for (int rt = 0; rt < NRT; ++rt) {
+                    f32x4 c0 = bv[rt], c1 = (f32x4){0.f, 0.f, 0.f, 0.f}, q0 = c1, q1 = c1;
+                    if constexpr (HEAD != 0) q0 = bq[rt];
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        Split3 A, B;
+                        B.hi = xs[w2][c][0]; B.mid = xs[w2][c][1]; B.lo = xs[w2][c][2];
+                        A.hi = Ws[rt][c][0]; A.mid = Ws[rt][c][1]; A.lo = Ws[rt][c][2];
+                        if (c & 1) c1 = mfma_split(A, B, c1);
+                        else c0 = mfma_split(A, B, c0);
+                        if constexpr (HEAD != 0) {
+                            A.hi = Wqs[rt][c][0]; A.mid = Wqs[rt][c][1]; A.lo = Wqs[rt][c][2];
+                            if (c & 1) q1 = mfma_split(A, B, q1);
+                            else q0 = mfma_split(A, B, q0);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc[w2][rt][r] = NCH > 1 ? c0[r] + c1[r] : c0[r];
+                        if constexpr (HEAD != 0) accq[w2][rt][r] = NCH > 1 ? q0[r] + q1[r] : q0[r];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                load_xs(w2);       // this buffer is free: request the next pair's
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // dP of both tiles -> patches (row u = 4 lk + r, column = sample li)
+#pragma unroll
+            for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+                for (int rt = 0; rt < NRT; ++rt) {
+                    float* pt = patch[wave][rt][w2];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float m = tanh_dev(acc[w2][rt][r]);
+                        const float dm = cot[w2][rt] * dxv[w2][rt][r];
+                        float dp;
+                        if constexpr (HEAD == 0) {
+                            dp = dm * (1.0f - m * m);
+                        } else {
+                            const float sg = tl_sigmoid(accq[w2][rt][r]);
+                            dp = HEAD == 1 ? (dm * sg) * (1.0f - m * m) : (dm * m) * (sg * (1.0f - sg));
+                        }
+                        gb[rt][r] += dp;
+                        pt[(4 * lk + r) * 17 + li] = dp;
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            load_meta();
+            __builtin_amdgcn_sched_barrier(0);
+            // A operand of dWo: lane (row u = li, k-group lk) holds samples 4 lk .. 4 lk + 3 of tile a, then of tile b
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = patch[wave][rt][0][li * 17 + 4 * lk + e];
+                    v[4 + e] = patch[wave][rt][1][li * 17 + 4 * lk + e];
+                }
+                const Split3 A = split8(v);
+#pragma unroll
+                for (int jt = 0; jt < PK; ++jt) {
+                    Split3 B;
+                    B.hi = xp[jt][0]; B.mid = xp[jt][1]; B.lo = xp[jt][2];
+                    gW[rt][jt] = mfma_split(A, B, gW[rt][jt]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_xp();
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // ---- sum the four waves of the workgroup, write this part-group's partial ----------------------------------------
@@ -1520,14 +1703,14 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
     t.gstride = y.gWo_off;
     const bool bf = tiled_adj_bf(p);
     const long long recA_tile = bf ? dlast * 24 : dlast * 16;      // floats per (stage, sample tile) of record A
-    const long long per_step = (long long)S * t.n_st * (recA_tile + (dlast + p->hidden + p->channels) * 16) * (long long)sizeof(float);
+    const long long per_step = (long long)S * t.n_st * (2 * recA_tile + (p->hidden + p->channels) * 16) * (long long)sizeof(float);
     const int steps = p->n_knots - 1;
     t.window = (int)std::max<long long>(1, std::min<long long>(steps, tiled_window_budget_bytes() / per_step));
     t.n_sc = t.window * S;
     const long long tiles = (long long)t.n_sc * t.n_st;
     long long off = 64;
     t.recA = off; off += tiles * recA_tile;
-    t.recB = off; off += tiles * dlast * 16;
+    t.recB = off; off += bf ? (long long)t.n_sc * ((t.n_st + 1) / 2) * dlast * 48 : tiles * dlast * 16;   // bf: one block per tile PAIR
     t.recC = off; off += tiles * p->hidden * 16;
     t.recD = off; off += tiles * p->channels * 16;
     t.gpartA = off; off += (long long)t.n_st * t.gstride;
@@ -1537,7 +1720,6 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
     // row tiles per wave of pass B (original field; the gated heads keep one: two weight panels per tile)
     // (PK = 8: four tiles no longer fit the register file -- measured at cfg5: 1 tile 1382 ms, 2 tiles 1335 ms, 4 tiles 1725 ms)
     t.nrt = p->field_kind == NCDE_FIELD_MINIMAL ? 1 : (row_tiles % 4 == 0 && row_tiles >= 64 && dlast < 128 ? 4 : (row_tiles % 2 == 0 && row_tiles >= 32 ? 2 : 1));
-    if (const char* e = getenv("NCDE_TILED_NRT")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && row_tiles % v == 0 && p->field_kind != NCDE_FIELD_MINIMAL) t.nrt = v; }   // TEMPORARY
     t.parts = 1;
     while (t.parts < 64 && (row_tiles / t.nrt) * 4 * t.parts < 4096 && 4 * t.parts * 2 <= t.n_st) t.parts *= 2;
     t.gpartB = off; off += (long long)t.parts * t.theta_o * (p->field_kind == NCDE_FIELD_MINIMAL ? 2 : 1);
@@ -1662,15 +1844,16 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     if (bf) {
         if (gated) {
             fa = pk == 8 ? ncde_adj_tiled<8, TL_ADJ_NW, 0, 1, 1> : (pk == 4 ? ncde_adj_tiled<4, TL_ADJ_NW, 0, 1, 1> : ncde_adj_tiled<2, TL_ADJ_NW, 0, 1, 1>);
-            fb = pk == 8 ? ncde_dwo_tiled<8, 1, 1, 1> : (pk == 4 ? ncde_dwo_tiled<4, 1, 1, 1> : ncde_dwo_tiled<2, 1, 1, 1>);
-            fb2 = pk == 8 ? ncde_dwo_tiled<8, 2, 1, 1> : (pk == 4 ? ncde_dwo_tiled<4, 2, 1, 1> : ncde_dwo_tiled<2, 2, 1, 1>);
+            fb = pk == 8 ? ncde_dwo_pair<8, 1, 1> : (pk == 4 ? ncde_dwo_pair<4, 1, 1> : ncde_dwo_pair<2, 1, 1>);
+            fb2 = pk == 8 ? ncde_dwo_pair<8, 2, 1> : (pk == 4 ? ncde_dwo_pair<4, 2, 1> : ncde_dwo_pair<2, 2, 1>);
         } else {
             fa = pk == 8 ? ncde_adj_tiled<8, TL_ADJ_NW, 0, 0, 1> : (pk == 4 ? ncde_adj_tiled<4, TL_ADJ_NW, 0, 0, 1> : ncde_adj_tiled<2, TL_ADJ_NW, 0, 0, 1>);
-            if (t.nrt == 4) fb = pk == 8 ? ncde_dwo_tiled<8, 0, 4, 1> : (pk == 4 ? ncde_dwo_tiled<4, 0, 4, 1> : ncde_dwo_tiled<2, 0, 4, 1>);
-            else if (t.nrt == 2) fb = pk == 8 ? ncde_dwo_tiled<8, 0, 2, 1> : (pk == 4 ? ncde_dwo_tiled<4, 0, 2, 1> : ncde_dwo_tiled<2, 0, 2, 1>);
-            else fb = pk == 8 ? ncde_dwo_tiled<8, 0, 1, 1> : (pk == 4 ? ncde_dwo_tiled<4, 0, 1, 1> : ncde_dwo_tiled<2, 0, 1, 1>);
+            if (t.nrt == 4) fb = pk == 8 ? ncde_dwo_pair<8, 0, 4> : (pk == 4 ? ncde_dwo_pair<4, 0, 4> : ncde_dwo_pair<2, 0, 4>);
+            else if (t.nrt == 2) fb = pk == 8 ? ncde_dwo_pair<8, 0, 2> : (pk == 4 ? ncde_dwo_pair<4, 0, 2> : ncde_dwo_pair<2, 0, 2>);
+            else fb = pk == 8 ? ncde_dwo_pair<8, 0, 1> : (pk == 4 ? ncde_dwo_pair<4, 0, 1> : ncde_dwo_pair<2, 0, 1>);
         }
     }
+    const dim3 gridB(p->hidden * p->channels / 16 / t.nrt, t.parts);
     const size_t lds = tiled_adj_lds(p);
     static const void* attr_done[32] = {};   // set once per kernel, not per launch
     bool seen = false;
@@ -1689,8 +1872,8 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
         a.win_hi = hi; a.win_lo = lo; a.resume = first ? 0 : 1;
         hipLaunchKernelGGL(fa, dim3(t.n_st), dim3(64 * TL_ADJ_NW), lds, st, a);
         const int n_sc = (hi - lo) * t.S;
-        hipLaunchKernelGGL(fb, dim3(p->hidden * p->channels / 16 / t.nrt, t.parts), dim3(256), 0, st, a, n_sc, t.n_st, gB);
-        if (fb2) hipLaunchKernelGGL(fb2, dim3(p->hidden * p->channels / 16 / t.nrt, t.parts), dim3(256), 0, st, a, n_sc, t.n_st, gB2);
+        hipLaunchKernelGGL(fb, gridB, dim3(256), 0, st, a, n_sc, t.n_st, gB);
+        if (fb2) hipLaunchKernelGGL(fb2, gridB, dim3(256), 0, st, a, n_sc, t.n_st, gB2);
         if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
     }
     if (main_kernel_only) return NCDE_OK;
