@@ -58,6 +58,9 @@ struct KArgs {
     const float* Wo_pk;
     const float* Wg_pk;
     const unsigned* Wo_bf;   // split-bf16 copy (backward sweep: beside the fp32 copy, which feeds the transposed products)
+    // variant family: LDS-resident copies of weight matrices (float offset into the dynamic LDS, -1 = streamed from L2);
+    // a resident matrix [N][K] is stored with row stride K + 1, column K holding the bias
+    int wres[NCDE_MAX_LAYERS], wres_o, wres_g, wres_r;
 };
 
 // ---- time plan (built on the host by ncde_time_plan_build, csrc/ncde_timeplan.hip; layout in 4-byte words) -------------

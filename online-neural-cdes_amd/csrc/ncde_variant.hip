@@ -57,9 +57,11 @@ __device__ void vr_load_cin(const KArgs& a, int b0, const StageDesc& sd, bool va
 
 // out[n][s] = act(sum_k W[n][k] in[k][s] + bias[n]), n < ru16(N) (rows >= N come out as act(0) masked to 0)
 // ACT: 0 = relu, 1 = sigmoid
+// wl != NULL: the matrix is resident in LDS (row stride K + 1, bias in column K): at the model sizes of the reference's
+// vector-field grids the first weight loads of every phase of a stage are otherwise an exposed L2 round trip.
 template <int ACT>
 __device__ void vr_dense(const float* __restrict__ W, const float* __restrict__ bias, int N, int K, const float* in, float* out,
-                         int wave, int lane) {
+                         int wave, int lane, const float* wl = nullptr) {
     const int li = lane & 15, lk = lane >> 4;
     const int ntiles = (N + 15) >> 4, nks = (K + 3) >> 2;
     for (int t = wave; t < ntiles; t += VR_NW) {
@@ -70,8 +72,17 @@ __device__ void vr_dense(const float* __restrict__ W, const float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * t + 4 * lk + r;
-            acc[r] = row < N ? bias[row] : 0.0f;
+            acc[r] = row < N ? (wl ? wl[row * (K + 1) + K] : bias[row]) : 0.0f;
         }
+        if (wl) {
+            const float* lrow = wl + (rv ? rowA : 0) * (K + 1);
+#pragma unroll 4
+            for (int ks = 0; ks < nks; ++ks) {
+                const int k = 4 * ks + lk;
+                const float av = (rv && k < K) ? lrow[k] : 0.0f;
+                acc = mfma16(av, in[k * 16 + li], acc);
+            }
+        } else
 #pragma unroll 4
         for (int ks = 0; ks < nks; ++ks) {
             const int k = 4 * ks + lk;
@@ -89,14 +100,34 @@ __device__ void vr_dense(const float* __restrict__ W, const float* __restrict__ 
 
 // x_1 .. x_L of the inner net for input `in`; all layers kept when X_all (adjoint), else ping-pong into A0/A1.
 // Returns the buffer holding x_L.
-__device__ const float* vr_net(const KArgs& a, const float* in, float* X, int DS, bool keep_all, int wave, int lane) {
+__device__ const float* vr_net(const KArgs& a, const float* in, float* X, int DS, bool keep_all, int wave, int lane, const float* lds) {
     for (int l = 0; l < a.n_layers; ++l) {
         float* outb = keep_all ? X + l * DS : X + (l & 1) * DS;
-        vr_dense<0>(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane);
+        vr_dense<0>(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane, a.wres[l] >= 0 ? lds + a.wres[l] : nullptr);
         __syncthreads();
         in = outb;
     }
     return in;
+}
+
+// copy the matrices the host marked resident into LDS: [N][K] -> row stride K + 1, bias in column K
+__device__ void vr_fill_resident(const KArgs& a, float* lds, int tid) {
+    auto fill = [&](const float* W, const float* b, int N, int K, int off) {
+        for (int e = tid; e < N * K; e += VR_THREADS) {
+            const int r = e / K, c = e - r * K;
+            lds[off + r * (K + 1) + c] = W[e];
+        }
+        for (int r = tid; r < N; r += VR_THREADS) lds[off + r * (K + 1) + K] = b[r];
+    };
+    for (int l = 0; l < a.n_layers; ++l) {
+        bool first = a.wres[l] >= 0;
+        for (int q = 0; q < l; ++q) first = first && a.wres[q] != a.wres[l];
+        if (first) fill(a.W[l], a.b[l], a.dout[l], a.din[l], a.wres[l]);
+    }
+    const int dlast = a.n_layers ? a.dout[a.n_layers - 1] : a.d0;
+    if (a.wres_o >= 0) fill(a.Wo, a.bo, a.rows, dlast, a.wres_o);
+    if (a.wres_g >= 0) fill(a.Wg, a.bg, a.rows, dlast, a.wres_g);
+    if (a.wres_r >= 0) fill(a.Wr, a.br, a.d0, a.d0, a.wres_r);
 }
 
 struct HeadTile {
@@ -133,12 +164,22 @@ __device__ __forceinline__ HeadTile vr_head_tile(const KArgs& a, int q, int ncq,
 }
 
 __device__ __forceinline__ f32x4 vr_head_gemm(const float* __restrict__ W, const float* __restrict__ bias, const HeadTile& t, int K,
-                                              const float* in, int li, int lk) {
+                                              const float* in, int li, int lk, const float* wl = nullptr) {
     f32x4 acc;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = t.rowD[r] >= 0 ? bias[t.rowD[r]] : 0.0f;
+    for (int r = 0; r < 4; ++r) acc[r] = t.rowD[r] >= 0 ? (wl ? wl[t.rowD[r] * (K + 1) + K] : bias[t.rowD[r]]) : 0.0f;
     const float* wrow = W + (long long)(t.rowA >= 0 ? t.rowA : 0) * K;
     const int nks = (K + 3) >> 2;
+    if (wl) {
+        const float* lrow = wl + (t.rowA >= 0 ? t.rowA : 0) * (K + 1);
+#pragma unroll 4
+        for (int ks = 0; ks < nks; ++ks) {
+            const int k = 4 * ks + lk;
+            const float av = (t.rowA >= 0 && k < K) ? lrow[k] : 0.0f;
+            acc = mfma16(av, in[k * 16 + li], acc);
+        }
+        return acc;
+    }
 #pragma unroll 4
     for (int ks = 0; ks < nks; ++ks) {
         const int k = 4 * ks + lk;
@@ -175,6 +216,10 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_fwd_variant(KArgs 
     float* CIN = KO + HS;        // [Cp][16]
     const int total = 7 * DS + 4 * HS + Cp * 16;
     for (int e = tid; e < total; e += VR_THREADS) lds[e] = 0.0f;
+    vr_fill_resident(a, lds, tid);
+    const float* wl_o = a.wres_o >= 0 ? lds + a.wres_o : nullptr;
+    const float* wl_g = a.wres_g >= 0 ? lds + a.wres_g : nullptr;
+    const float* wl_r = a.wres_r >= 0 ? lds + a.wres_r : nullptr;
     __syncthreads();
     for (int e = tid; e < HS; e += VR_THREADS) {
         const int h = e >> 4, s = e & 15, b = b0 + s;
@@ -209,13 +254,13 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_fwd_variant(KArgs 
             }
             __syncthreads();
             if (gru) {
-                vr_dense<1>(a.Wr, a.br, d0, d0, U, RG, wave, lane);
+                vr_dense<1>(a.Wr, a.br, d0, d0, U, RG, wave, lane, wl_r);
                 __syncthreads();
                 for (int e = tid; e < ru16(d0) * 16; e += VR_THREADS) RU[e] = RG[e] * U[e];
                 __syncthreads();
             }
-            const float* xi = vr_net(a, U, XA, DS, false, wave, lane);
-            const float* xr = gru ? vr_net(a, RU, XB, DS, false, wave, lane) : xi;
+            const float* xi = vr_net(a, U, XA, DS, false, wave, lane, lds);
+            const float* xr = gru ? vr_net(a, RU, XB, DS, false, wave, lane, lds) : xi;
             // groups of head tiles: matmul -> one h-block (all its channel quads, contraction accumulated in a
             // register); evaluate / derivative -> one 16-row tile
             for (int grp = wave; grp < ngrp; grp += VR_NW) {
@@ -223,9 +268,9 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_fwd_variant(KArgs 
                 for (int qi = 0; qi < per_grp; ++qi) {
                     int cq;
                     const HeadTile ht = vr_head_tile(a, grp * per_grp + qi, ncq, li, lk, cq);
-                    const f32x4 pt = vr_head_gemm(a.Wo, a.bo, ht, dlast, xr, li, lk);
+                    const f32x4 pt = vr_head_gemm(a.Wo, a.bo, ht, dlast, xr, li, lk, wl_o);
                     f32x4 ps = pt;
-                    if (gated) ps = vr_head_gemm(a.Wg, a.bg, ht, dlast, xi, li, lk);
+                    if (gated) ps = vr_head_gemm(a.Wg, a.bg, ht, dlast, xi, li, lk, wl_g);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float m = tanh_dev(pt[r]);
@@ -297,12 +342,20 @@ __device__ void vr_dw_acc(const float* gpre, const float* xin, int N, int K, flo
 
 // out[i][s] (+)= sum_j W[j][i] gpre[j][s], i < ru16(K); optionally x relu'(mask[i][s])
 __device__ void vr_bwd_data(const float* __restrict__ W, int N, int K, const float* gpre, const float* mask, float* out, bool accumulate,
-                            int wave, int lane) {
+                            int wave, int lane, const float* wl = nullptr) {
     const int li = lane & 15, lk = lane >> 4;
     const int nit = (K + 15) >> 4, nks = (N + 3) >> 2;
     for (int it = wave; it < nit; it += VR_NW) {
         const int col = 16 * it + li;
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (wl) {
+#pragma unroll 4
+            for (int ks = 0; ks < nks; ++ks) {
+                const int k = 4 * ks + lk;
+                const float av = (k < N && col < K) ? wl[k * (K + 1) + col] : 0.0f;
+                acc = mfma16(av, gpre[k * 16 + li], acc);
+            }
+        } else
 #pragma unroll 4
         for (int ks = 0; ks < nks; ++ks) {
             const int k = 4 * ks + lk;
@@ -356,6 +409,10 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
     float* GL = SC + VR_NW * 16 * 17;
     const int total = (15 + 2 * L) * DS + 9 * HS + Cp * 16 + VR_NW * 16 * 17 + (a.gacc_in_lds ? a.theta_size : 0);
     for (int e = tid; e < total; e += VR_THREADS) lds[e] = 0.0f;
+    vr_fill_resident(a, lds, tid);
+    const float* wl_o = a.wres_o >= 0 ? lds + a.wres_o : nullptr;
+    const float* wl_g = a.wres_g >= 0 ? lds + a.wres_g : nullptr;
+    const float* wl_r = a.wres_r >= 0 ? lds + a.wres_r : nullptr;
     float* gacc = a.gacc_in_lds ? GL : a.gpart + (long long)blockIdx.x * a.theta_size;
     if (!a.gacc_in_lds)
         for (int e = tid; e < a.theta_size; e += VR_THREADS) gacc[e] = 0.0f;
@@ -412,13 +469,13 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
                 __syncthreads();
             }
             if (gru) {
-                vr_dense<1>(a.Wr, a.br, d0, d0, U, RG, wave, lane);
+                vr_dense<1>(a.Wr, a.br, d0, d0, U, RG, wave, lane, wl_r);
                 __syncthreads();
                 for (int e = tid; e < ru16(d0) * 16; e += VR_THREADS) RU[e] = RG[e] * U[e];
                 __syncthreads();
             }
-            const float* xi = vr_net(a, U, XI, DS, true, wave, lane);
-            const float* xr = gru ? vr_net(a, RU, XR, DS, true, wave, lane) : xi;
+            const float* xi = vr_net(a, U, XI, DS, true, wave, lane, lds);
+            const float* xr = gru ? vr_net(a, RU, XR, DS, true, wave, lane, lds) : xi;
             // ---- heads: f, cotangents of the two pre-activations, head parameter gradients, partials of dL/dx_L ------
             f32x4 accI[VR_MAXJT], accR[VR_MAXJT];
 #pragma unroll
@@ -428,9 +485,9 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
                 for (int qi = 0; qi < per_grp; ++qi) {
                     int cq;
                     const HeadTile ht = vr_head_tile(a, grp * per_grp + qi, ncq, li, lk, cq);
-                    const f32x4 pt = vr_head_gemm(a.Wo, a.bo, ht, dlast, xr, li, lk);
+                    const f32x4 pt = vr_head_gemm(a.Wo, a.bo, ht, dlast, xr, li, lk, wl_o);
                     f32x4 ps = pt;
-                    if (gated) ps = vr_head_gemm(a.Wg, a.bg, ht, dlast, xi, li, lk);
+                    if (gated) ps = vr_head_gemm(a.Wg, a.bg, ht, dlast, xi, li, lk, wl_g);
                     float dPt[4], dPs[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -458,11 +515,11 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const bool ok = ht.rowD[r] >= 0 && jcol < dlast;
-                                const float avt = ok ? a.Wo[(long long)ht.rowD[r] * dlast + jcol] : 0.0f;
+                                const float avt = ok ? (wl_o ? wl_o[ht.rowD[r] * (dlast + 1) + jcol] : a.Wo[(long long)ht.rowD[r] * dlast + jcol]) : 0.0f;
                                 if (gru) accR[jt] = mfma16(avt, dPt[r], accR[jt]);
                                 else accI[jt] = mfma16(avt, dPt[r], accI[jt]);
                                 if (gated) {
-                                    const float avs = ok ? a.Wg[(long long)ht.rowD[r] * dlast + jcol] : 0.0f;
+                                    const float avs = ok ? (wl_g ? wl_g[ht.rowD[r] * (dlast + 1) + jcol] : a.Wg[(long long)ht.rowD[r] * dlast + jcol]) : 0.0f;
                                     accI[jt] = mfma16(avs, dPs[r], accI[jt]);
                                 }
                             }
@@ -532,7 +589,7 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
                     const int N = a.dout[l], K = a.din[l];
                     const float* xin = l == 0 ? x0 : Xp + (l - 1) * DS;
                     if (w != 0.0f) vr_dw_acc(gpre, xin, N, K, w, gacc + a.gW_off[l], gacc + a.gb_off[l], tid, wave, lane);
-                    vr_bwd_data(a.W[l], N, K, gpre, l > 0 ? xin : nullptr, l == 0 ? du : gx, false, wave, lane);
+                    vr_bwd_data(a.W[l], N, K, gpre, l > 0 ? xin : nullptr, l == 0 ? du : gx, false, wave, lane, a.wres[l] >= 0 ? lds + a.wres[l] : nullptr);
                     __syncthreads();
                     float* tmp = gpre; gpre = gx; gx = tmp;
                 }
@@ -546,7 +603,7 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
                 }
                 __syncthreads();
                 if (w != 0.0f) vr_dw_acc(GA, U, d0, d0, w, gacc + a.gWr_off, gacc + a.gbr_off, tid, wave, lane);
-                vr_bwd_data(a.Wr, d0, d0, GA, nullptr, DUI, true, wave, lane);
+                vr_bwd_data(a.Wr, d0, d0, GA, nullptr, DUI, true, wave, lane, wl_r);
                 __syncthreads();
             }
             // ---- Butcher bookkeeping (KOA = dL/dy of the stage = the first H rows of du) -----------------------------------
@@ -633,10 +690,43 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+struct VrRes {
+    int w[NCDE_MAX_LAYERS], o, g, r;   // float offsets of the resident copies, -1 = streamed
+};
 struct VrPlan {
     size_t lds_fwd, lds_adj;
     int gacc_in_lds;
+    VrRes res_fwd, res_adj;
 };
+
+// Which weight matrices get an LDS-resident copy (row stride K + 1): whatever fits behind the activations -- reset gate,
+// inner layers (a shared layer once), then the heads.
+VrRes vr_residency(const NcdeProblem* p, const Layout& y, size_t& bytes) {
+    VrRes r;
+    for (int l = 0; l < NCDE_MAX_LAYERS; ++l) r.w[l] = -1;
+    r.o = r.g = r.r = -1;
+    size_t off = bytes / sizeof(float);
+    auto take = [&](int N, int K) -> int {
+        const size_t need = (size_t)N * (K + 1);
+        if ((off + need) * sizeof(float) > (size_t)kLdsLimit) return -1;
+        const int at = (int)off;
+        off += need;
+        return at;
+    };
+    const int d0 = p->field_input == NCDE_INPUT_MATMUL ? p->hidden : p->hidden + p->channels;
+    const int rows = p->field_input == NCDE_INPUT_MATMUL ? p->hidden * p->channels : p->hidden;
+    if (p->field_kind == NCDE_FIELD_GRU) r.r = take(d0, d0);
+    for (int l = 0; l < p->n_layers; ++l) {
+        int shared = -1;
+        for (int q = 0; q < l; ++q)
+            if (p->layer_W[q] == p->layer_W[l]) shared = q;
+        r.w[l] = shared >= 0 ? r.w[shared] : take(p->layer_out[l], p->layer_in[l]);
+    }
+    r.o = take(rows, y.dlast);
+    if (p->field_kind != NCDE_FIELD_ORIGINAL) r.g = take(rows, y.dlast);
+    bytes = off * sizeof(float);
+    return r;
+}
 
 VrPlan vr_plan(const NcdeProblem* p, const Layout& y) {
     VrPlan v{};
@@ -645,6 +735,8 @@ VrPlan vr_plan(const NcdeProblem* p, const Layout& y) {
     const size_t adj = sizeof(float) * ((15 + 2 * L) * DS + 9 * HS + (size_t)y.Cp * 16 + VR_NW * 16 * 17);
     v.gacc_in_lds = adj + sizeof(float) * (size_t)y.theta_size <= (size_t)kLdsLimit;
     v.lds_adj = adj + (v.gacc_in_lds ? sizeof(float) * (size_t)y.theta_size : 0);
+    if (v.lds_fwd <= (size_t)kLdsLimit) v.res_fwd = vr_residency(p, y, v.lds_fwd);
+    if (v.lds_adj <= (size_t)kLdsLimit) v.res_adj = vr_residency(p, y, v.lds_adj);
     return v;
 }
 
@@ -672,6 +764,8 @@ int ncde_variant_forward(const NcdeProblem* p, float* out, float* stages, hipStr
     fill_kargs(p, y, &a);
     a.out = out;
     a.stages = stages;
+    for (int l = 0; l < NCDE_MAX_LAYERS; ++l) a.wres[l] = v.res_fwd.w[l];
+    a.wres_o = v.res_fwd.o; a.wres_g = v.res_fwd.g; a.wres_r = v.res_fwd.r;
     if (hipFuncSetAttribute((const void*)ncde_fwd_variant, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds_fwd) != hipSuccess) return NCDE_ERR_HIP;
     hipLaunchKernelGGL(ncde_fwd_variant, dim3(y.n_wg), dim3(VR_THREADS), v.lds_fwd, st, a);
     return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
@@ -689,6 +783,8 @@ int ncde_variant_adjoint(const NcdeProblem* p, const float* src, const float* gr
     else a.z_out = src;
     a.gpart = (float*)ws;
     a.gacc_in_lds = v.gacc_in_lds;
+    for (int l = 0; l < NCDE_MAX_LAYERS; ++l) a.wres[l] = v.res_adj.w[l];
+    a.wres_o = v.res_adj.o; a.wres_g = v.res_adj.g; a.wres_r = v.res_adj.r;
     if (hipFuncSetAttribute((const void*)ncde_adj_variant, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds_adj) != hipSuccess) return NCDE_ERR_HIP;
     hipLaunchKernelGGL(ncde_adj_variant, dim3(y.n_wg), dim3(VR_THREADS), v.lds_adj, st, a);
     if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
