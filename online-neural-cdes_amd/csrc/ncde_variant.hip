@@ -57,8 +57,10 @@ __device__ void vr_load_cin(const KArgs& a, int b0, const StageDesc& sd, bool va
 
 // out[n][s] = act(sum_k W[n][k] in[k][s] + bias[n]), n < ru16(N) (rows >= N come out as act(0) masked to 0)
 // ACT: 0 = relu, 1 = sigmoid
-// wl != NULL: the matrix is resident in LDS (row stride K + 1, bias in column K): at the model sizes of the reference's
-// vector-field grids the first weight loads of every phase of a stage are otherwise an exposed L2 round trip.
+// wl != NULL: the matrix is resident in LDS, zero-padded to [ru16(N)][ru16(K)] with row stride ru16(K) + 1 and the bias in
+// column ru16(K): at the model sizes of the reference's vector-field grids the first weight loads of every phase of a stage
+// are otherwise an exposed L2 round trip, and with the padding the inner loops carry no guards (a guarded load compiles to
+// an exec-mask branch per element).
 template <int ACT>
 __device__ void vr_dense(const float* __restrict__ W, const float* __restrict__ bias, int N, int K, const float* in, float* out,
                          int wave, int lane, const float* wl = nullptr) {
@@ -69,25 +71,36 @@ __device__ void vr_dense(const float* __restrict__ W, const float* __restrict__ 
         const bool rv = rowA < N;
         const float* wrow = W + (long long)(rv ? rowA : 0) * K;
         f32x4 acc;
+        if (wl) {
+            const int Kp = ru16(K);
+            const float* lrow = wl + rowA * (Kp + 1) + lk;
+            const float* brow = in + lk * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = wl[(16 * t + 4 * lk + r) * (Kp + 1) + Kp];
+            f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int kb = 0; kb < Kp; kb += 16) {
+                float av[4], bv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { av[e] = lrow[kb + 4 * e]; bv[e] = brow[(kb + 4 * e) * 16]; }
+                acc = mfma16(av[0], bv[0], acc);
+                acc2 = mfma16(av[1], bv[1], acc2);
+                acc = mfma16(av[2], bv[2], acc);
+                acc2 = mfma16(av[3], bv[3], acc2);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
+        } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * t + 4 * lk + r;
-            acc[r] = row < N ? (wl ? wl[row * (K + 1) + K] : bias[row]) : 0.0f;
+            acc[r] = row < N ? bias[row] : 0.0f;
         }
-        if (wl) {
-            const float* lrow = wl + (rv ? rowA : 0) * (K + 1);
-#pragma unroll 4
-            for (int ks = 0; ks < nks; ++ks) {
-                const int k = 4 * ks + lk;
-                const float av = (rv && k < K) ? lrow[k] : 0.0f;
-                acc = mfma16(av, in[k * 16 + li], acc);
-            }
-        } else
 #pragma unroll 4
         for (int ks = 0; ks < nks; ++ks) {
             const int k = 4 * ks + lk;
             const float av = (rv && k < K) ? wrow[k] : 0.0f;
             acc = mfma16(av, in[k * 16 + li], acc);
+        }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -110,14 +123,16 @@ __device__ const float* vr_net(const KArgs& a, const float* in, float* X, int DS
     return in;
 }
 
-// copy the matrices the host marked resident into LDS: [N][K] -> row stride K + 1, bias in column K
+// copy the matrices the host marked resident into LDS: [N][K] -> zero-padded [ru16(N)][ru16(K) + 1], bias in the last column
 __device__ void vr_fill_resident(const KArgs& a, float* lds, int tid) {
     auto fill = [&](const float* W, const float* b, int N, int K, int off) {
-        for (int e = tid; e < N * K; e += VR_THREADS) {
-            const int r = e / K, c = e - r * K;
-            lds[off + r * (K + 1) + c] = W[e];
+        const int Kp = ru16(K), Np = ru16(N), ld = Kp + 1;
+        for (int e = tid; e < Np * ld; e += VR_THREADS) {
+            const int r = e / ld, c = e - r * ld;
+            float v = 0.0f;
+            if (r < N) v = c < K ? W[(long long)r * K + c] : (c == Kp ? b[r] : 0.0f);
+            lds[off + e] = v;
         }
-        for (int r = tid; r < N; r += VR_THREADS) lds[off + r * (K + 1) + K] = b[r];
     };
     for (int l = 0; l < a.n_layers; ++l) {
         bool first = a.wres[l] >= 0;
@@ -166,20 +181,34 @@ __device__ __forceinline__ HeadTile vr_head_tile(const KArgs& a, int q, int ncq,
 __device__ __forceinline__ f32x4 vr_head_gemm(const float* __restrict__ W, const float* __restrict__ bias, const HeadTile& t, int K,
                                               const float* in, int li, int lk, const float* wl = nullptr) {
     f32x4 acc;
+    if (wl) {      // an absent row (rowA < 0) reads row 0 and multiplies by zero
+        const int Kp = ru16(K);
+        const float* lrow = wl + (t.rowA >= 0 ? t.rowA : 0) * (Kp + 1) + lk;
+        const float* brow = in + lk * 16 + li;
+        const float am = t.rowA >= 0 ? 1.0f : 0.0f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = t.rowD[r] >= 0 ? (wl ? wl[t.rowD[r] * (K + 1) + K] : bias[t.rowD[r]]) : 0.0f;
-    const float* wrow = W + (long long)(t.rowA >= 0 ? t.rowA : 0) * K;
-    const int nks = (K + 3) >> 2;
-    if (wl) {
-        const float* lrow = wl + (t.rowA >= 0 ? t.rowA : 0) * (K + 1);
-#pragma unroll 4
-        for (int ks = 0; ks < nks; ++ks) {
-            const int k = 4 * ks + lk;
-            const float av = (t.rowA >= 0 && k < K) ? lrow[k] : 0.0f;
-            acc = mfma16(av, in[k * 16 + li], acc);
+        for (int r = 0; r < 4; ++r) {
+            const float bvv = wl[(t.rowD[r] >= 0 ? t.rowD[r] : 0) * (Kp + 1) + Kp];
+            acc[r] = t.rowD[r] >= 0 ? bvv : 0.0f;
         }
+        f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < Kp; kb += 16) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { av[e] = lrow[kb + 4 * e] * am; bv[e] = brow[(kb + 4 * e) * 16]; }
+            acc = mfma16(av[0], bv[0], acc);
+            acc2 = mfma16(av[1], bv[1], acc2);
+            acc = mfma16(av[2], bv[2], acc);
+            acc2 = mfma16(av[3], bv[3], acc2);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
         return acc;
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = t.rowD[r] >= 0 ? bias[t.rowD[r]] : 0.0f;
+    const float* wrow = W + (long long)(t.rowA >= 0 ? t.rowA : 0) * K;
+    const int nks = (K + 3) >> 2;
 #pragma unroll 4
     for (int ks = 0; ks < nks; ++ks) {
         const int k = 4 * ks + lk;
@@ -349,12 +378,21 @@ __device__ void vr_bwd_data(const float* __restrict__ W, int N, int K, const flo
         const int col = 16 * it + li;
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (wl) {
-#pragma unroll 4
-            for (int ks = 0; ks < nks; ++ks) {
-                const int k = 4 * ks + lk;
-                const float av = (k < N && col < K) ? wl[k * (K + 1) + col] : 0.0f;
-                acc = mfma16(av, gpre[k * 16 + li], acc);
+            const int Kp = ru16(K), Np = ru16(N);
+            const float* lcol = wl + lk * (Kp + 1) + col;      // col < ru16(K): a zero column of the resident copy when >= K
+            const float* brow = gpre + lk * 16 + li;
+            f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int kb = 0; kb < Np; kb += 16) {
+                float av[4], bv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { av[e] = lcol[(kb + 4 * e) * (Kp + 1)]; bv[e] = brow[(kb + 4 * e) * 16]; }
+                acc = mfma16(av[0], bv[0], acc);
+                acc2 = mfma16(av[1], bv[1], acc2);
+                acc = mfma16(av[2], bv[2], acc);
+                acc2 = mfma16(av[3], bv[3], acc2);
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
         } else
 #pragma unroll 4
         for (int ks = 0; ks < nks; ++ks) {
@@ -515,11 +553,11 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const bool ok = ht.rowD[r] >= 0 && jcol < dlast;
-                                const float avt = ok ? (wl_o ? wl_o[ht.rowD[r] * (dlast + 1) + jcol] : a.Wo[(long long)ht.rowD[r] * dlast + jcol]) : 0.0f;
+                                const float avt = ok ? (wl_o ? wl_o[ht.rowD[r] * (ru16(dlast) + 1) + jcol] : a.Wo[(long long)ht.rowD[r] * dlast + jcol]) : 0.0f;
                                 if (gru) accR[jt] = mfma16(avt, dPt[r], accR[jt]);
                                 else accI[jt] = mfma16(avt, dPt[r], accI[jt]);
                                 if (gated) {
-                                    const float avs = ok ? (wl_g ? wl_g[ht.rowD[r] * (dlast + 1) + jcol] : a.Wg[(long long)ht.rowD[r] * dlast + jcol]) : 0.0f;
+                                    const float avs = ok ? (wl_g ? wl_g[ht.rowD[r] * (ru16(dlast) + 1) + jcol] : a.Wg[(long long)ht.rowD[r] * dlast + jcol]) : 0.0f;
                                     accI[jt] = mfma16(avs, dPs[r], accI[jt]);
                                 }
                             }
@@ -706,8 +744,9 @@ VrRes vr_residency(const NcdeProblem* p, const Layout& y, size_t& bytes) {
     for (int l = 0; l < NCDE_MAX_LAYERS; ++l) r.w[l] = -1;
     r.o = r.g = r.r = -1;
     size_t off = bytes / sizeof(float);
+    auto ru16h = [](int v) { return (v + 15) & ~15; };
     auto take = [&](int N, int K) -> int {
-        const size_t need = (size_t)N * (K + 1);
+        const size_t need = (size_t)ru16h(N) * (ru16h(K) + 1);
         if ((off + need) * sizeof(float) > (size_t)kLdsLimit) return -1;
         const int at = (int)off;
         off += need;
