@@ -345,14 +345,24 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_fwd_variant(KArgs 
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+// *p += v on this workgroup's PRIVATE gradient partial.  In global memory (in_lds == 0; matmul heads: 41k floats per stage at
+// cfg2 dims): a hardware float add without return instead of load / add / store, so nothing waits for the old value -- the
+// read-modify-write round trips were the longest thing in a stage (gru/matmul 268 -> 205 ms).  Every address is only ever
+// touched by one wave, in program order, so the sum order -- and the result -- is the same on every run.  In LDS a plain
+// read-modify-write is the faster one (flat atomics into the LDS aperture: evaluate 32 -> 38 ms).
+__device__ __forceinline__ void vr_accum(float* p, float v, int in_lds) {
+    if (in_lds) *p += v;
+    else unsafeAtomicAdd(p, v);
+}
+
 // gW[j][i] += w sum_s gpre[j][s] xin[i][s];  gb[j] += w sum_s gpre[j][s]      (samples are the K dim of the MFMA)
-__device__ void vr_dw_acc(const float* gpre, const float* xin, int N, int K, float w, float* gW, float* gb, int tid, int wave, int lane) {
+__device__ void vr_dw_acc(const float* gpre, const float* xin, int N, int K, float w, float* gW, float* gb, int tid, int wave, int lane, int in_lds) {
     const int li = lane & 15, lk = lane >> 4;
     for (int jj = tid; jj < N; jj += VR_THREADS) {
         float sum = 0.0f;
 #pragma unroll
         for (int s = 0; s < 16; ++s) sum += gpre[jj * 16 + s];
-        gb[jj] += w * sum;
+        vr_accum(gb + jj, w * sum, in_lds);
     }
     const int njt = (N + 15) >> 4, nit = (K + 15) >> 4;
     for (int tt = wave; tt < njt * nit; tt += VR_NW) {
@@ -364,7 +374,7 @@ __device__ void vr_dw_acc(const float* gpre, const float* xin, int N, int K, flo
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * jt + 4 * lk + r;
-            if (row < N && col < K) gW[(long long)row * K + col] += w * g[r];
+            if (row < N && col < K) vr_accum(gW + (long long)row * K + col, w * g[r], in_lds);
         }
     }
 }
@@ -574,7 +584,7 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const float sum = row16_sum(dP[r]);
-                                if (li == 0 && ht.rowD[r] >= 0) gbh[ht.rowD[r]] += w * sum;
+                                if (li == 0 && ht.rowD[r] >= 0) vr_accum(gbh + ht.rowD[r], w * sum, a.gacc_in_lds);
                             }
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -587,7 +597,7 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
                                 const int jcol = 16 * jt + li;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r)
-                                    if (ht.rowD[r] >= 0 && jcol < dlast) gWh[(long long)ht.rowD[r] * dlast + jcol] += g[r];
+                                    if (ht.rowD[r] >= 0 && jcol < dlast) vr_accum(gWh + (long long)ht.rowD[r] * dlast + jcol, g[r], a.gacc_in_lds);
                             }
                         }
                     }
@@ -626,7 +636,7 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
                 for (int l = L - 1; l >= 0; --l) {
                     const int N = a.dout[l], K = a.din[l];
                     const float* xin = l == 0 ? x0 : Xp + (l - 1) * DS;
-                    if (w != 0.0f) vr_dw_acc(gpre, xin, N, K, w, gacc + a.gW_off[l], gacc + a.gb_off[l], tid, wave, lane);
+                    if (w != 0.0f) vr_dw_acc(gpre, xin, N, K, w, gacc + a.gW_off[l], gacc + a.gb_off[l], tid, wave, lane, a.gacc_in_lds);
                     vr_bwd_data(a.W[l], N, K, gpre, l > 0 ? xin : nullptr, l == 0 ? du : gx, false, wave, lane, a.wres[l] >= 0 ? lds + a.wres[l] : nullptr);
                     __syncthreads();
                     float* tmp = gpre; gpre = gx; gx = tmp;
@@ -640,7 +650,7 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
                     GA[e] = (dru * u) * (rg * (1.0f - rg));
                 }
                 __syncthreads();
-                if (w != 0.0f) vr_dw_acc(GA, U, d0, d0, w, gacc + a.gWr_off, gacc + a.gbr_off, tid, wave, lane);
+                if (w != 0.0f) vr_dw_acc(GA, U, d0, d0, w, gacc + a.gWr_off, gacc + a.gbr_off, tid, wave, lane, a.gacc_in_lds);
                 vr_bwd_data(a.Wr, d0, d0, GA, nullptr, DUI, true, wave, lane, wl_r);
                 __syncthreads();
             }
