@@ -1760,9 +1760,14 @@ bool ncde_tiled_preferred(const NcdeProblem* p, int pass) {
 const char* ncde_tiled_kernel_name(const NcdeProblem* p, int pass) {
     if (!ncde_tiled_supported(p, pass)) return nullptr;
     const bool gated = p->field_kind == NCDE_FIELD_MINIMAL;
+    if (pass >= 1 && tiled_adj_bf(p)) {      // split-bf16 records: the pair kernel is pass B
+        if (pass == 1) return gated ? "ncde_adj_tiled<gated,bf16>+ncde_dwo_pair" : "ncde_adj_tiled<bf16>+ncde_dwo_pair";
+        return gated ? "ncde_adj_tiled<gated,discrete,bf16>+ncde_dwo_pair" : "ncde_adj_tiled<discrete,bf16>+ncde_dwo_pair";
+    }
     if (pass == 1) return gated ? "ncde_adj_tiled<gated>+ncde_dwo_tiled" : "ncde_adj_tiled+ncde_dwo_tiled";
     if (pass == 2) return gated ? "ncde_adj_tiled<gated,discrete>+ncde_dwo_tiled" : "ncde_adj_tiled<discrete>+ncde_dwo_tiled";
     const int ns = tiled_fwd_ns(p);
+    if (tiled_fwd_bf(p)) return gated ? "ncde_fwd_tiled<NS1,gated,bf16>" : "ncde_fwd_tiled<NS1,bf16>";
     if (gated) return ns == 4 ? "ncde_fwd_tiled<NS4,gated>" : (ns == 2 ? "ncde_fwd_tiled<NS2,gated>" : "ncde_fwd_tiled<NS1,gated>");
     return ns == 4 ? "ncde_fwd_tiled<NS4>" : (ns == 2 ? "ncde_fwd_tiled<NS2>" : "ncde_fwd_tiled<NS1>");
 }

@@ -524,7 +524,11 @@ def test_tiled_family_vs_oracle(shape, interp, method, seq, gpu_lib):
         res = gpu_util.run_case(case, flags=flag, need_grads=False)
         assert res["kernels"][0].startswith("ncde_fwd_tiled"), res["kernels"]
         if ns:
-            assert res["kernels"][0] == "ncde_fwd_tiled<NS%d>" % ns
+            assert res["kernels"][0] in ("ncde_fwd_tiled<NS%d>" % ns, "ncde_fwd_tiled<NS1,bf16>"), res["kernels"]
+            if ns == 1 and HH % 32 == 0:      # one sample tile, last hidden width a multiple of 32: the split-bf16 output tiles ...
+                assert res["kernels"][0] == "ncde_fwd_tiled<NS1,bf16>"
+                r32 = gpu_util.run_case(case, flags=flag | _lib.FLAG_FP32_MFMA, need_grads=False)      # ... and the fp32-input MFMA ones
+                assert r32["kernels"][0] == "ncde_fwd_tiled<NS1>" and gu.relerr(r32["z_out"], ex["z_out"]) <= TIGHT_Z
         assert gu.relerr(res["z_out"], ex["z_out"]) <= TIGHT_Z, (flag, gu.relerr(res["z_out"], ex["z_out"]))
     FT = 0x8000                                                  # force the tiled backward also where generic is preferred
     res = gpu_util.run_case(case, flags=FT)                      # sweep (pass A) + output-layer gradient pass (pass B)
@@ -542,6 +546,14 @@ def test_tiled_family_vs_oracle(shape, interp, method, seq, gpu_lib):
     isod = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=FT, stages=case["stage_record"])
     for k, e in _grad_errors(case, isod, "bp_").items():
         assert e <= TIGHT_G, ("tiled discrete backward on the oracle's stage record", k, e)
+    # the same two backward passes on fp32-input MFMA and fp32 records (what NCDE_FLAG_FP32_MFMA selects; the default above ran the
+    # split-bf16 records + ncde_dwo_pair wherever the last hidden width is a multiple of 32)
+    iso32 = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=FT | _lib.FLAG_FP32_MFMA)
+    for k, e in _grad_errors(case, iso32).items():
+        assert e <= TIGHT_G, ("tiled adjoint (fp32 MFMA) on oracle z_out", k, e)
+    isod32 = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=FT | _lib.FLAG_FP32_MFMA, stages=case["stage_record"])
+    for k, e in _grad_errors(case, isod32, "bp_").items():
+        assert e <= TIGHT_G, ("tiled discrete backward (fp32 MFMA) on the oracle's stage record", k, e)
 
 
 @pytest.mark.parametrize("shape,gated", [((80, 128, 128, 3), False), ((8, 48, 64, 2), False), ((20, 32, 32, 3), True)])

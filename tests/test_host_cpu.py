@@ -68,7 +68,7 @@ def test_version1_structs_are_still_accepted():
     p.field_kind, p.field_input = 1, 0
     assert lib.ncde_num_outputs(ctypes.byref(p)) == -1 and b"Wg" in lib.ncde_last_error_string()
     p.Wg, p.bg = 0x6000, 0x6100
-    assert lib.ncde_kernel_name(ctypes.byref(p), 1) == b"ncde_adj_tiled<gated>+ncde_dwo_tiled"      # minimal gating: tiled family
+    assert lib.ncde_kernel_name(ctypes.byref(p), 1).startswith(b"ncde_adj_tiled<gated")            # minimal gating: tiled family
     p.field_kind, p.Wr, p.br = 2, 0x7000, 0x7100
     assert lib.ncde_kernel_name(ctypes.byref(p), 1) == b"ncde_adj_variant"                           # GRU: variant kernels
     # a version-2 caller's struct ends before time_plan: garbage there must not be read
