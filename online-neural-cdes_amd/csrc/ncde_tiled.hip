@@ -321,15 +321,20 @@ __device__ __forceinline__ void tl_load_bf(const unsigned* tile, int lane, u32x4
 template <int NCH>
 __device__ __forceinline__ f32x4 tl_mma_bf(const u32x4 (&w)[NCH][3], const unsigned* xb, int lane, f32x4 acc) {
     f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int kPA[6] = {2, 1, 0, 1, 0, 0}, kPB[6] = {0, 0, 0, 1, 1, 2};      // the products of mfma_split: piece 0 hi, 1 mid, 2 lo
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        Split3 A, B;
-        A.hi = w[c][0]; A.mid = w[c][1]; A.lo = w[c][2];
-        B.hi = *reinterpret_cast<const u32x4*>(xb + ((c * 3 + 0) * 64 + lane) * 4);
-        B.mid = *reinterpret_cast<const u32x4*>(xb + ((c * 3 + 1) * 64 + lane) * 4);
-        B.lo = *reinterpret_cast<const u32x4*>(xb + ((c * 3 + 2) * 64 + lane) * 4);
-        if (c & 1) acc2 = mfma_split(A, B, acc2);
-        else acc = mfma_split(A, B, acc);
+    for (int c = 0; c < NCH; c += 2) {      // two chunks at a time: consecutive MFMAs alternate between the two accumulator chains
+        u32x4 B0[3], B1[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+            B0[pc] = *reinterpret_cast<const u32x4*>(xb + ((c * 3 + pc) * 64 + lane) * 4);
+            if constexpr (NCH > 1) B1[pc] = *reinterpret_cast<const u32x4*>(xb + (((c + 1) * 3 + pc) * 64 + lane) * 4);
+        }
+#pragma unroll
+        for (int pp = 0; pp < 6; ++pp) {
+            acc = mfma_bf(w[c][kPA[pp]], B0[kPB[pp]], acc);
+            if constexpr (NCH > 1) acc2 = mfma_bf(w[c + 1][kPA[pp]], B1[kPB[pp]], acc2);
+        }
     }
     if constexpr (NCH > 1) {
 #pragma unroll
@@ -1465,36 +1470,51 @@ __global__ __launch_bounds__(256) void ncde_dwo_pair(KArgs a, int n_sc, int n_st
         for (long long q = 0; q < nq; ++q) {
             // position of the NEXT pair (the last iteration re-requests its own: harmless)
             if (q + 1 < nq) { if (++k == my_n) { k = 0; ++sc; } }
+            // One wave per SIMD: nothing hides the latency of an MFMA that waits for the previous one's accumulator, so the six
+            // partial products of a split product (kPA x kPB, the order of mfma_split) form the OUTER loop and consecutive MFMAs
+            // go to different accumulators -- here 2 tiles x NRT row tiles x 2 chunk parities (x 2 heads) chains.  Every
+            // accumulator still receives its products in the same order as before.
+            constexpr int kPA[6] = {2, 1, 0, 1, 0, 0}, kPB[6] = {0, 0, 0, 1, 1, 2};      // piece index: 0 hi, 1 mid, 2 lo
             f32x4 acc[2][NRT], accq[2][HEAD != 0 ? NRT : 1];
+            {
+                f32x4 c0[2][NRT], c1[2][NRT], q0[2][HEAD != 0 ? NRT : 1], q1[2][HEAD != 0 ? NRT : 1];
 #pragma unroll
-            for (int w2 = 0; w2 < 2; ++w2) {
+                for (int w2 = 0; w2 < 2; ++w2)
 #pragma unroll
-                for (int rt = 0; rt < NRT; ++rt) {
-                    f32x4 c0 = bv[rt], c1 = (f32x4){0.f, 0.f, 0.f, 0.f}, q0 = c1, q1 = c1;
-                    if constexpr (HEAD != 0) q0 = bq[rt];
+                    for (int rt = 0; rt < NRT; ++rt) {
+                        c0[w2][rt] = bv[rt];
+                        c1[w2][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if constexpr (HEAD != 0) { q0[w2][rt] = bq[rt]; q1[w2][rt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+                    }
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        Split3 A, B;
-                        B.hi = xs[w2][c][0]; B.mid = xs[w2][c][1]; B.lo = xs[w2][c][2];
-                        A.hi = Ws[rt][c][0]; A.mid = Ws[rt][c][1]; A.lo = Ws[rt][c][2];
-                        if (c & 1) c1 = mfma_split(A, B, c1);
-                        else c0 = mfma_split(A, B, c0);
-                        if constexpr (HEAD != 0) {
-                            A.hi = Wqs[rt][c][0]; A.mid = Wqs[rt][c][1]; A.lo = Wqs[rt][c][2];
-                            if (c & 1) q1 = mfma_split(A, B, q1);
-                            else q0 = mfma_split(A, B, q0);
+                for (int c2 = 0; c2 < NCH; c2 += 2)
+#pragma unroll
+                    for (int pp = 0; pp < 6; ++pp)
+#pragma unroll
+                        for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+                            for (int rt = 0; rt < NRT; ++rt) {
+                                c0[w2][rt] = mfma_bf(Ws[rt][c2][kPA[pp]], xs[w2][c2][kPB[pp]], c0[w2][rt]);
+                                if constexpr (HEAD != 0) q0[w2][rt] = mfma_bf(Wqs[rt][c2][kPA[pp]], xs[w2][c2][kPB[pp]], q0[w2][rt]);
+                                if constexpr (NCH > 1) {
+                                    c1[w2][rt] = mfma_bf(Ws[rt][c2 + 1][kPA[pp]], xs[w2][c2 + 1][kPB[pp]], c1[w2][rt]);
+                                    if constexpr (HEAD != 0) q1[w2][rt] = mfma_bf(Wqs[rt][c2 + 1][kPA[pp]], xs[w2][c2 + 1][kPB[pp]], q1[w2][rt]);
+                                }
+                            }
+#pragma unroll
+                for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+                    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            acc[w2][rt][r] = NCH > 1 ? c0[w2][rt][r] + c1[w2][rt][r] : c0[w2][rt][r];
+                            if constexpr (HEAD != 0) accq[w2][rt][r] = NCH > 1 ? q0[w2][rt][r] + q1[w2][rt][r] : q0[w2][rt][r];
                         }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        acc[w2][rt][r] = NCH > 1 ? c0[r] + c1[r] : c0[r];
-                        if constexpr (HEAD != 0) accq[w2][rt][r] = NCH > 1 ? q0[r] + q1[r] : q0[r];
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                load_xs(w2);       // this buffer is free: request the next pair's
-                __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            load_xs(0);            // both buffers are free: request the next pair's
+            load_xs(1);
+            __builtin_amdgcn_sched_barrier(0);
             // dP of both tiles -> patches (row u = 4 lk + r, column = sample li)
 #pragma unroll
             for (int w2 = 0; w2 < 2; ++w2)
@@ -1520,6 +1540,7 @@ __global__ __launch_bounds__(256) void ncde_dwo_pair(KArgs a, int n_sc, int n_st
             load_meta();
             __builtin_amdgcn_sched_barrier(0);
             // A operand of dWo: lane (row u = li, k-group lk) holds samples 4 lk .. 4 lk + 3 of tile a, then of tile b
+            u32x4 Ap[NRT][3];
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) {
                 float v[8];
@@ -1529,13 +1550,14 @@ __global__ __launch_bounds__(256) void ncde_dwo_pair(KArgs a, int n_sc, int n_st
                     v[4 + e] = patch[wave][rt][1][li * 17 + 4 * lk + e];
                 }
                 const Split3 A = split8(v);
-#pragma unroll
-                for (int jt = 0; jt < PK; ++jt) {
-                    Split3 B;
-                    B.hi = xp[jt][0]; B.mid = xp[jt][1]; B.lo = xp[jt][2];
-                    gW[rt][jt] = mfma_split(A, B, gW[rt][jt]);
-                }
+                Ap[rt][0] = A.hi; Ap[rt][1] = A.mid; Ap[rt][2] = A.lo;
             }
+#pragma unroll
+            for (int pp = 0; pp < 6; ++pp)           // products outermost: NRT x PK independent accumulators in a row
+#pragma unroll
+                for (int jt = 0; jt < PK; ++jt)
+#pragma unroll
+                    for (int rt = 0; rt < NRT; ++rt) gW[rt][jt] = mfma_bf(Ap[rt][kPA[pp]], xp[jt][kPB[pp]], gW[rt][jt]);
             __builtin_amdgcn_sched_barrier(0);
             load_xp();
             __builtin_amdgcn_sched_barrier(0);
