@@ -1379,7 +1379,8 @@ template <int PK, int HEAD = 0, int NRT = 1>
 __global__ __launch_bounds__(256) void ncde_dwo_pair(KArgs a, int n_sc, int n_st, float* gpartB) {
     static_assert(PK >= 2, "split records need a last hidden width that is a multiple of 32");
     constexpr int NCH = PK / 2;
-    __shared__ float patch[4][NRT][2][16 * 17];
+    constexpr int NH = HEAD == 3 ? 2 : 1;      // HEAD 3 (minimal-gated field): both heads' gradients from ONE recompute of P
+    __shared__ float patch[4][NRT][2][NH][16 * 17];
     __shared__ __attribute__((aligned(16))) float red[4][PK * 256 + 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1390,8 +1391,8 @@ __global__ __launch_bounds__(256) void ncde_dwo_pair(KArgs a, int n_sc, int n_st
     int hb[NRT], cq[NRT];
     f32x4 bv[NRT], bq[HEAD != 0 ? NRT : 1];
     u32x4 Ws[NRT][NCH][3], Wqs[HEAD != 0 ? NRT : 1][NCH][3];
-    f32x4 gW[NRT][PK];
-    float gb[NRT][4];
+    f32x4 gW[NH][NRT][PK];
+    float gb[NH][NRT][4];
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) {
         const int tile = blockIdx.x * NRT + rt;
@@ -1415,9 +1416,12 @@ __global__ __launch_bounds__(256) void ncde_dwo_pair(KArgs a, int n_sc, int n_st
             }
         }
 #pragma unroll
-        for (int jt = 0; jt < PK; ++jt) gW[rt][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int hh = 0; hh < NH; ++hh) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gb[rt][r] = 0.0f;
+            for (int jt = 0; jt < PK; ++jt) gW[hh][rt][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gb[hh][rt][r] = 0.0f;
+        }
     }
     const int my_n = part < n_pair ? (n_pair - part + nparts - 1) / nparts : 0;   // pairs part, part + nparts, ...
     // record pieces of the pair being processed / requested
@@ -1520,44 +1524,52 @@ __global__ __launch_bounds__(256) void ncde_dwo_pair(KArgs a, int n_sc, int n_st
             for (int w2 = 0; w2 < 2; ++w2)
 #pragma unroll
                 for (int rt = 0; rt < NRT; ++rt) {
-                    float* pt = patch[wave][rt][w2];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float m = tanh_dev(acc[w2][rt][r]);
                         const float dm = cot[w2][rt] * dxv[w2][rt][r];
-                        float dp;
+                        float dp[NH];
                         if constexpr (HEAD == 0) {
-                            dp = dm * (1.0f - m * m);
+                            dp[0] = dm * (1.0f - m * m);
                         } else {
                             const float sg = tl_sigmoid(accq[w2][rt][r]);
-                            dp = HEAD == 1 ? (dm * sg) * (1.0f - m * m) : (dm * m) * (sg * (1.0f - sg));
+                            const float dt = (dm * sg) * (1.0f - m * m), dg = (dm * m) * (sg * (1.0f - sg));
+                            if constexpr (HEAD == 3) { dp[0] = dt; dp[1] = dg; }
+                            else dp[0] = HEAD == 1 ? dt : dg;
                         }
-                        gb[rt][r] += dp;
-                        pt[(4 * lk + r) * 17 + li] = dp;
+#pragma unroll
+                        for (int hh = 0; hh < NH; ++hh) {
+                            gb[hh][rt][r] += dp[hh];
+                            patch[wave][rt][w2][hh][(4 * lk + r) * 17 + li] = dp[hh];
+                        }
                     }
                 }
             __builtin_amdgcn_sched_barrier(0);
             load_meta();
             __builtin_amdgcn_sched_barrier(0);
             // A operand of dWo: lane (row u = li, k-group lk) holds samples 4 lk .. 4 lk + 3 of tile a, then of tile b
-            u32x4 Ap[NRT][3];
+            u32x4 Ap[NH][NRT][3];
 #pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) {
-                float v[8];
+            for (int hh = 0; hh < NH; ++hh)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = patch[wave][rt][0][li * 17 + 4 * lk + e];
-                    v[4 + e] = patch[wave][rt][1][li * 17 + 4 * lk + e];
+                for (int rt = 0; rt < NRT; ++rt) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = patch[wave][rt][0][hh][li * 17 + 4 * lk + e];
+                        v[4 + e] = patch[wave][rt][1][hh][li * 17 + 4 * lk + e];
+                    }
+                    const Split3 A = split8(v);
+                    Ap[hh][rt][0] = A.hi; Ap[hh][rt][1] = A.mid; Ap[hh][rt][2] = A.lo;
                 }
-                const Split3 A = split8(v);
-                Ap[rt][0] = A.hi; Ap[rt][1] = A.mid; Ap[rt][2] = A.lo;
-            }
 #pragma unroll
-            for (int pp = 0; pp < 6; ++pp)           // products outermost: NRT x PK independent accumulators in a row
+            for (int pp = 0; pp < 6; ++pp)           // products outermost: NH x NRT x PK independent accumulators in a row
 #pragma unroll
                 for (int jt = 0; jt < PK; ++jt)
 #pragma unroll
-                    for (int rt = 0; rt < NRT; ++rt) gW[rt][jt] = mfma_bf(Ap[rt][kPA[pp]], xp[jt][kPB[pp]], gW[rt][jt]);
+                    for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+                        for (int rt = 0; rt < NRT; ++rt) gW[hh][rt][jt] = mfma_bf(Ap[hh][rt][kPA[pp]], xp[jt][kPB[pp]], gW[hh][rt][jt]);
             __builtin_amdgcn_sched_barrier(0);
             load_xp();
             __builtin_amdgcn_sched_barrier(0);
@@ -1565,15 +1577,17 @@ __global__ __launch_bounds__(256) void ncde_dwo_pair(KArgs a, int n_sc, int n_st
     }
     // ---- sum the four waves of the workgroup, write this part-group's partial ----------------------------------------
     const long long wo_sz = (long long)H * C * dlast, theta_o = wo_sz + (long long)H * C;
-    float* gp = gpartB + (long long)blockIdx.y * theta_o;
 #pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) {
-        if (rt > 0) __syncthreads();
+    for (int hr = 0; hr < NH * NRT; ++hr) {
+        const int hh = hr / NRT, rt = hr - hh * NRT;
+        // HEAD 3: the gate head's partials follow the tanh head's gridDim.y partials (the host's gB2 = gB + parts * theta_o)
+        float* gp = gpartB + ((long long)hh * gridDim.y + blockIdx.y) * theta_o;
+        if (hr > 0) __syncthreads();
 #pragma unroll
-        for (int jt = 0; jt < PK; ++jt) *reinterpret_cast<f32x4*>(&red[wave][(jt * 64 + lane) * 4]) = gW[rt][jt];
+        for (int jt = 0; jt < PK; ++jt) *reinterpret_cast<f32x4*>(&red[wave][(jt * 64 + lane) * 4]) = gW[hh][rt][jt];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float v = gb[rt][r];
+            float v = gb[hh][rt][r];
             v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
             if (li == 0) red[wave][PK * 256 + 4 * lk + r] = v;
         }
@@ -1871,8 +1885,9 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     if (bf) {
         if (gated) {
             fa = pk == 8 ? ncde_adj_tiled<8, TL_ADJ_NW, 0, 1, 1> : (pk == 4 ? ncde_adj_tiled<4, TL_ADJ_NW, 0, 1, 1> : ncde_adj_tiled<2, TL_ADJ_NW, 0, 1, 1>);
-            fb = pk == 8 ? ncde_dwo_pair<8, 1, 1> : (pk == 4 ? ncde_dwo_pair<4, 1, 1> : ncde_dwo_pair<2, 1, 1>);
-            fb2 = pk == 8 ? ncde_dwo_pair<8, 2, 1> : (pk == 4 ? ncde_dwo_pair<4, 2, 1> : ncde_dwo_pair<2, 2, 1>);
+            // both heads in one pass where the two accumulator sets fit the register file; at 128 columns one pass per head
+            if (pk == 8) { fb = ncde_dwo_pair<8, 1, 1>; fb2 = ncde_dwo_pair<8, 2, 1>; }
+            else { fb = pk == 4 ? ncde_dwo_pair<4, 3, 1> : ncde_dwo_pair<2, 3, 1>; fb2 = nullptr; }
         } else {
             fa = pk == 8 ? ncde_adj_tiled<8, TL_ADJ_NW, 0, 0, 1> : (pk == 4 ? ncde_adj_tiled<4, TL_ADJ_NW, 0, 0, 1> : ncde_adj_tiled<2, TL_ADJ_NW, 0, 0, 1>);
             if (t.nrt == 4) fb = pk == 8 ? ncde_dwo_pair<8, 0, 4> : (pk == 4 ? ncde_dwo_pair<4, 0, 4> : ncde_dwo_pair<2, 0, 4>);
@@ -1925,7 +1940,7 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     so.off[0] = 0; so.len[0] = wo_sz; so.dst[0] = g->grad_Wo;
     so.off[1] = wo_sz; so.len[1] = p->hidden * p->channels; so.dst[1] = g->grad_bo;
     hipLaunchKernelGGL(ncde_reduce_partials, dim3(((int)t.theta_o + 255) / 256), dim3(256), 0, st, (const float*)gB, t.parts, (int)t.theta_o, so);
-    if (fb2) {
+    if (gated) {      // the gate head's partials: written by fb2, or by the two-head pass behind the tanh head's
         if (!g->grad_Wg || !g->grad_bg) return NCDE_ERR_INVALID;
         so.dst[0] = g->grad_Wg;
         so.dst[1] = g->grad_bg;
