@@ -452,9 +452,13 @@ __global__ __launch_bounds__(256) void ncde_pack_panels_bf(const float* __restri
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int NS, int NWV, int EM, int GATED = 0, int BF = 0>
+// RESH = H/16 > 0 (small square hidden stack, every layer H x H, NS = 1): the hidden matrices' fragments -- one row tile per
+// wave, at most two distinct matrices -- are loaded once and stay in registers, so the hidden layers of a stage do not start
+// with an L2 round trip each (the backward sweep's RES modes do the same).
+template <int NS, int NWV, int EM, int GATED = 0, int BF = 0, int RESH = 0>
 __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
     static_assert(BF == 0 || NS == 1, "the split-bf16 output tiles are built for one sample tile per workgroup");
+    static_assert(RESH == 0 || (NS == 1 && RESH <= NWV), "resident hidden fragments: one sample tile, one row tile per wave");
     constexpr int NSP = NS * 16, NT = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -488,6 +492,21 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
     const int S = n_stages(a.method);
     const int dlast = a.dout[a.n_layers - 1];
     const int nkb_o = dlast >> 4;
+    Panel<RESH ? RESH : 1> wf[2];      // RESH: row tile `wave` of the layer-0 matrix / of the other matrix
+    f32x4 bfv[2];
+    if constexpr (RESH != 0) {
+        const int li = lane & 15, lk = lane >> 4;
+        int l1 = 0;
+        for (int l = 1; l < a.n_layers; ++l)
+            if (a.W[l] != a.W[0]) { l1 = l; break; }
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const int l = sl == 0 ? 0 : l1;
+            const int tw = wave < RESH ? wave : 0;
+            wf[sl] = tl_load_panel<RESH ? RESH : 1>(a.W[l] + (long long)(16 * tw + li) * (16 * RESH) + 4 * lk, 0);
+            bfv[sl] = *reinterpret_cast<const f32x4*>(a.b[l] + 16 * tw + 4 * lk);
+        }
+    }
     int cur_idx = -1;
     for (int n = 0; n < a.T - 1; ++n) {
         for (int j = 0; j < S; ++j) {
@@ -508,6 +527,32 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
             const float* in = YS;
             for (int l = 0; l < a.n_layers; ++l) {
                 float* outb = (l & 1) ? ACT1 : ACT0;
+                if constexpr (RESH != 0) {
+                    if (wave < RESH) {
+                        const int li = lane & 15, lk = lane >> 4;
+                        const bool s0 = a.W[l] == a.W[0];
+                        f32x4 acc[1];
+                        acc[0] = s0 ? bfv[0] : bfv[1];
+                        if (s0) tl_mma_panel<1, RESH ? RESH : 1>(wf[0], in, 0, li, lk, acc);
+                        else tl_mma_panel<1, RESH ? RESH : 1>(wf[1], in, 0, li, lk, acc);
+                        f32x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = relu_dev(acc[0][r]);
+                        *reinterpret_cast<f32x4*>(outb + ((4 * wave + lk) * NSP + li) * 4) = o;
+                        if constexpr (BF != 0) {
+                            if (l == a.n_layers - 1) {      // split image of x_L, as tl_dense_relu_pk writes it (row tile t = wave)
+                                unsigned h0, m0, l0, h1, m1, l1;
+                                split_pair(o[0], o[1], h0, m0, l0);
+                                split_pair(o[2], o[3], h1, m1, l1);
+                                unsigned* dst = XB + ((((wave >> 1) * 3) * 4 + 2 * (wave & 1) + (lk >> 1)) * 16 + li) * 4 + 2 * (lk & 1);
+                                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                                *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
+                                *reinterpret_cast<u32x2*>(dst + 256) = (u32x2){m0, m1};
+                                *reinterpret_cast<u32x2*>(dst + 512) = (u32x2){l0, l1};
+                            }
+                        }
+                    }
+                } else
                 tl_dense_relu<NS, NWV>(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane,
                                        (BF != 0 && l == a.n_layers - 1) ? XB : nullptr);
                 __syncthreads();
@@ -590,8 +635,8 @@ using WoTile = TlTile<PK, 0>;
 template <int PK, int NWV, int RES, int GATED, int BFP = 0>
 __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, const float* AS, const float* DX, float* KOY,
                                               float* scr, int wave, int lane, const WoTile<PK>* res, const unsigned* xb = nullptr) {
-    static_assert(!(RES != 0 && GATED != 0), "resident weights are built for the original field only");
-    static_assert(BFP == 0 || (RES == 0 && GATED == 0 && PK >= 2), "split-bf16 P: original field, streamed weights");
+    static_assert(!(RES == 1 && GATED != 0), "resident output tiles are built for the original field only");
+    static_assert(BFP == 0 || (RES != 1 && GATED == 0 && PK >= 2), "split-bf16 P: original field, streamed output tiles");
     constexpr int NCH = PK >= 2 ? PK / 2 : 1;
     constexpr int NSP = 16, SCS = 16 * PK + 4;
     const int li = lane & 15, lk = lane >> 4;
@@ -683,7 +728,7 @@ __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, c
         chi += wrap ? 1 : 0;
         ccq = wrap ? 0 : ccq + 1;
     };
-    if constexpr (RES != 0) {
+    if constexpr (RES == 1) {
         if (nq > 0) step(res[0]);
         if (nq > 1) step(res[1]);
     } else {
@@ -762,11 +807,13 @@ __device__ __forceinline__ void tl_dw_acc(const float* gpre, const float* xin, i
 // tiles): every weight fragment a wave needs -- its forward row tile and its transposed tile of the (at most two)
 // hidden matrices, its (at most two) output tiles -- is loaded ONCE and stays in registers, so no phase of a stage
 // waits on an L2 round trip (cfg4: 11.3 -> see DESIGN.md).
+// RES = 2: only the hidden matrices are resident (their fragments cost 16 PK registers), the output tiles are streamed: any
+// number of output tiles, gated heads, split records -- the hidden phases, six per stage, no longer start with an L2 round trip.
 // BF = 1: x_L is additionally kept as three bf16 pieces (XBA, written by the last hidden layer) and THAT image is what pass B
 // gets as its record A, so the recompute of P there runs on the bf16 matrix cores.
 template <int PK, int NWV, int RES = 0, int GATED = 0, int BF = 0>
 __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
-    static_assert(BF == 0 || (RES == 0 && PK >= 2), "split record: streamed weights, last hidden width a multiple of 32");
+    static_assert(BF == 0 || (RES != 1 && PK >= 2), "split record: streamed output tiles, last hidden width a multiple of 32");
     constexpr int NT = 64 * NWV, TL_EADJ = RES ? (16 * 16 * PK + NT - 1) / NT : 2048 / NT;
     constexpr int TL_DWT = RES ? (PK * PK + NWV - 1) / NWV : 64 / NWV;   // hidden dW tiles per wave and weight slot
     constexpr int NSP = 16, SCW = (16 * (16 * PK + 4) > 16 * PK * NSP) ? 16 * (16 * PK + 4) : 16 * PK * NSP;
@@ -879,13 +926,15 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) wb[sl][4 * kb + e] = a.W[l][(long long)(16 * kb + 4 * lk + e) * K + 16 * tw + li];
         }
-        const int nhb = H >> 2, ncq = C >> 2;
+        if constexpr (RES == 1) {
+            const int nhb = H >> 2, ncq = C >> 2;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            int hb = wave + NWV * (q / ncq), cq = q % ncq;
-            if (hb >= nhb) { hb = 0; cq = 0; }
-            wo[q].P = tl_load_panel<PK>(a.Wo + (long long)((4 * hb + (li >> 2)) * C + 4 * cq + (li & 3)) * dlast + 4 * lk, 0);
-            wo[q].bias = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb + lk) * C + 4 * cq);
+            for (int q = 0; q < 2; ++q) {
+                int hb = wave + NWV * (q / ncq), cq = q % ncq;
+                if (hb >= nhb) { hb = 0; cq = 0; }
+                wo[q].P = tl_load_panel<PK>(a.Wo + (long long)((4 * hb + (li >> 2)) * C + 4 * cq + (li & 3)) * dlast + 4 * lk, 0);
+                wo[q].bias = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb + lk) * C + 4 * cq);
+            }
         }
     }
 
@@ -981,6 +1030,18 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[r] = relu_dev(acc[0][r]);
                         *reinterpret_cast<f32x4*>(outb + ((4 * wave + lk) * NSP + li) * 4) = o;
+                        if constexpr (BF != 0) {
+                            if (l == L - 1) {      // split image of x_L (same layout as tl_dense_relu_pk's xb), row tile t = wave
+                                unsigned h0, m0, l0, h1, m1, l1;
+                                split_pair(o[0], o[1], h0, m0, l0);
+                                split_pair(o[2], o[3], h1, m1, l1);
+                                unsigned* dst = XBA + ((((wave >> 1) * 3) * 4 + 2 * (wave & 1) + (lk >> 1)) * 16 + li) * 4 + 2 * (lk & 1);
+                                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                                *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
+                                *reinterpret_cast<u32x2*>(dst + 256) = (u32x2){m0, m1};
+                                *reinterpret_cast<u32x2*>(dst + 512) = (u32x2){l0, l1};
+                            }
+                        }
                     }
                 } else {
                     tl_dense_relu<1, NWV>(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane, (BF != 0 && l == L - 1) ? XBA : nullptr);
@@ -1688,6 +1749,13 @@ size_t tiled_adj_lds_base(const NcdeProblem* p) {
     const int scw = std::max(16 * (16 * pk + 4), 16 * pk * 16);
     return sizeof(float) * (size_t)(4 * p->hidden * 16 + (p->n_layers + 2) * D * 16 + p->channels * 16 + TL_ADJ_NW * scw);
 }
+// hidden matrices resident, output tiles streamed (RES = 2): small square hidden stacks that do not qualify for RES = 1
+bool tiled_adj_res2(const NcdeProblem* p) {
+    const int pk = tiled_adj_pk(p);
+    bool ok = !tiled_adj_res(p) && pk >= 1 && pk <= 4 && p->hidden == 16 * pk && getenv("NCDE_TILED_NO_RES2") == nullptr;
+    for (int l = 0; l < p->n_layers; ++l) ok = ok && p->layer_out[l] == 16 * pk && p->layer_in[l] == 16 * pk;
+    return ok;
+}
 // split-bf16 record A / recompute in pass B: streamed weights, last hidden width 32 / 64 / 128, room for the split image of
 // x_L in the sweep's LDS, and the caller did not ask for plain fp32-input MFMA
 bool tiled_adj_bf(const NcdeProblem* p) {
@@ -1836,6 +1904,14 @@ int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws
     if (bf) {
         if (p->field_kind == NCDE_FIELD_MINIMAL) fn = small ? ncde_fwd_tiled<1, TL_NW, 4, 1, 1> : ncde_fwd_tiled<1, TL_NW, 16, 1, 1>;
         else fn = small ? ncde_fwd_tiled<1, TL_NW, 4, 0, 1> : ncde_fwd_tiled<1, TL_NW, 16, 0, 1>;
+        // small square hidden stack (H = every width = 32 or 64): hidden fragments resident
+        bool sq = (p->hidden == 32 || p->hidden == 64) && getenv("NCDE_TILED_NO_RES2") == nullptr;
+        for (int l = 0; l < p->n_layers; ++l) sq = sq && p->layer_out[l] == p->hidden && p->layer_in[l] == p->hidden;
+        if (sq) {
+            const bool g = p->field_kind == NCDE_FIELD_MINIMAL;
+            if (p->hidden == 32) fn = g ? ncde_fwd_tiled<1, TL_NW, 4, 1, 1, 2> : ncde_fwd_tiled<1, TL_NW, 4, 0, 1, 2>;
+            else fn = g ? ncde_fwd_tiled<1, TL_NW, 4, 1, 1, 4> : ncde_fwd_tiled<1, TL_NW, 4, 0, 1, 4>;
+        }
     }
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NCDE_ERR_HIP;
     const int nwg = (p->batch + ns * 16 - 1) / (ns * 16);
@@ -1882,14 +1958,21 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
         fb = pk == 8 ? ncde_dwo_tiled<8, 1> : (pk == 4 ? ncde_dwo_tiled<4, 1> : (pk == 2 ? ncde_dwo_tiled<2, 1> : ncde_dwo_tiled<1, 1>));
         fb2 = pk == 8 ? ncde_dwo_tiled<8, 2> : (pk == 4 ? ncde_dwo_tiled<4, 2> : (pk == 2 ? ncde_dwo_tiled<2, 2> : ncde_dwo_tiled<1, 2>));
     }
+    const bool res2 = tiled_adj_res2(p);
+    if (res2 && !bf) {
+        if (gated) fa = pk == 4 ? ncde_adj_tiled<4, TL_ADJ_NW, 2, 1> : (pk == 2 ? ncde_adj_tiled<2, TL_ADJ_NW, 2, 1> : ncde_adj_tiled<1, TL_ADJ_NW, 2, 1>);
+        else fa = pk == 4 ? ncde_adj_tiled<4, TL_ADJ_NW, 2> : (pk == 2 ? ncde_adj_tiled<2, TL_ADJ_NW, 2> : ncde_adj_tiled<1, TL_ADJ_NW, 2>);
+    }
     if (bf) {
         if (gated) {
             fa = pk == 8 ? ncde_adj_tiled<8, TL_ADJ_NW, 0, 1, 1> : (pk == 4 ? ncde_adj_tiled<4, TL_ADJ_NW, 0, 1, 1> : ncde_adj_tiled<2, TL_ADJ_NW, 0, 1, 1>);
+            if (res2) fa = pk == 4 ? ncde_adj_tiled<4, TL_ADJ_NW, 2, 1, 1> : ncde_adj_tiled<2, TL_ADJ_NW, 2, 1, 1>;
             // both heads in one pass where the two accumulator sets fit the register file; at 128 columns one pass per head
             if (pk == 8) { fb = ncde_dwo_pair<8, 1, 1>; fb2 = ncde_dwo_pair<8, 2, 1>; }
             else { fb = pk == 4 ? ncde_dwo_pair<4, 3, 1> : ncde_dwo_pair<2, 3, 1>; fb2 = nullptr; }
         } else {
             fa = pk == 8 ? ncde_adj_tiled<8, TL_ADJ_NW, 0, 0, 1> : (pk == 4 ? ncde_adj_tiled<4, TL_ADJ_NW, 0, 0, 1> : ncde_adj_tiled<2, TL_ADJ_NW, 0, 0, 1>);
+            if (res2) fa = pk == 4 ? ncde_adj_tiled<4, TL_ADJ_NW, 2, 0, 1> : ncde_adj_tiled<2, TL_ADJ_NW, 2, 0, 1>;
             if (t.nrt == 4) fb = pk == 8 ? ncde_dwo_pair<8, 0, 4> : (pk == 4 ? ncde_dwo_pair<4, 0, 4> : ncde_dwo_pair<2, 0, 4>);
             else if (t.nrt == 2) fb = pk == 8 ? ncde_dwo_pair<8, 0, 2> : (pk == 4 ? ncde_dwo_pair<4, 0, 2> : ncde_dwo_pair<2, 0, 2>);
             else fb = pk == 8 ? ncde_dwo_pair<8, 0, 1> : (pk == 4 ? ncde_dwo_pair<4, 0, 1> : ncde_dwo_pair<2, 0, 1>);
