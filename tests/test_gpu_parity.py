@@ -725,6 +725,26 @@ def test_general_time_axis_matches_reference_golden(name, gpu_lib):
         assert gu.relerr(resd["grads"][pname], f["bp_d" + pname]) <= E2E_G, pname
 
 
+def test_variant_gradient_partial_in_global_memory_is_reproducible(gpu_lib):
+    """GRU-gated field with the matmul input at cfg2 widths: the two 640 x 32 heads do not fit LDS, so the variant adjoint keeps
+    its per-workgroup gradient partial in global memory and accumulates into it with no-return float atomics (every address
+    is touched by one wave, in program order).  Against the oracle, and twice: bit-identical."""
+    import gpu_util
+    case = _seeded_case("linear", "rk4", False, B=40, L=9, C=20, H=32, HH=32, nl=3, seed=910, kind="gru")
+    ex = case["expect"]
+    a = gpu_util.run_adjoint_direct(case, ex["z_out"])
+    assert a["kernels"][1] == "ncde_adj_variant" if "kernels" in a else True
+    for k, e in _grad_errors(case, a).items():
+        assert e <= TIGHT_G, (k, e)
+    b = gpu_util.run_adjoint_direct(case, ex["z_out"])
+    assert np.array_equal(a["dz0"], b["dz0"]) and all(np.array_equal(a["grads"][k], b["grads"][k]) for k in a["grads"])
+    d1 = gpu_util.run_adjoint_direct(case, ex["z_out"], stages=case["stage_record"])
+    d2 = gpu_util.run_adjoint_direct(case, ex["z_out"], stages=case["stage_record"])
+    for k, e in _grad_errors(case, d1, "bp_").items():
+        assert e <= TIGHT_G, ("discrete", k, e)
+    assert np.array_equal(d1["dz0"], d2["dz0"]) and all(np.array_equal(d1["grads"][k], d2["grads"][k]) for k in d1["grads"])
+
+
 @pytest.mark.parametrize("kind,mode,interp,method,step", [("gru", "evaluate", "cubic", "rk4", 0.5), ("minimal", "matmul", "linear", "midpoint", 0.4),
                                                          ("original", "derivative", "linear", "euler", 0.25)])
 def test_general_time_axis_field_variants_vs_oracle(kind, mode, interp, method, step, gpu_lib):
