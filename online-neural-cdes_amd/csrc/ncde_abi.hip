@@ -97,8 +97,15 @@ int generic_supported(const NcdeProblem* p, const Layout& y, int pass) {
 
 // pick the kernel family: 1 = fast (shape-specialised), 2 = tiled (batch-tiled, large hidden), 0 = generic, <0 = error
 int select_family(const NcdeProblem* p, const Layout& y, int pass) {
-    if (p->output == NCDE_OUT_TIMES) {   // general time axis: the plan-driven generic / variant kernels
-        if (p->flags & (NCDE_FLAG_FORCE_FAST | NCDE_FLAG_FORCE_TILED)) return fail(NCDE_ERR_UNSUPPORTED, "the general time axis runs on the generic family only");
+    if (p->output == NCDE_OUT_TIMES) {   // general time axis: the plan-driven kernels -- batch-tiled where the shape allows
+                                         // (multiples of 16 / 4; 2.8x the generic family at cfg2 widths, 10x at cfg5's), else generic / variant
+        if (p->flags & NCDE_FLAG_FORCE_FAST) return fail(NCDE_ERR_UNSUPPORTED, "the shape-specialised kernels run the default time axis only");
+        const bool tiled_ok = !(p->flags & NCDE_FLAG_FORCE_GENERIC) && ncde_tiled_supported(p, pass);
+        if (p->flags & NCDE_FLAG_FORCE_TILED) {
+            if (!tiled_ok) return fail(NCDE_ERR_UNSUPPORTED, "the batch-tiled family does not cover this problem (pass %d)", pass);
+            return 2;
+        }
+        if (tiled_ok && ncde_tiled_preferred(p, pass)) return 2;
         if (y.variant) {
             if (!ncde_variant_supported(p, pass)) return fail(NCDE_ERR_UNSUPPORTED, "vector-field variant outside what ncde_variant.hip covers (pass %d)", pass);
             return 3;

@@ -26,7 +26,7 @@ namespace {
 
 // dX/dt(t) of the tile's samples -> DX[(c>>2)][s][c&3]
 template <int NS, int NT>
-__device__ __forceinline__ void tl_load_dx(const KArgs& a, int b0, int idx, float frac, float* DX, int tid) {
+__device__ __forceinline__ void tl_load_dx(const KArgs& a, int b0, int idx, float frac, float kdt, float* DX, int tid) {
     constexpr int NSP = NS * 16;
     const int C = a.C;
     for (int e = tid; e < NSP * C; e += NT) {
@@ -37,6 +37,7 @@ __device__ __forceinline__ void tl_load_dx(const KArgs& a, int b0, int idx, floa
             const float* p = a.coeffs + (long long)b * a.cs_b + (long long)idx * a.cs_t;
             if (a.interp == NCDE_INTERP_LINEAR) {
                 v = p[a.cs_t + c] - p[c];
+                if (kdt != 1.0f) v = v / kdt;      // user knot grid (interpolation_linear.py:231-234); 1 on the default grid
             } else {
                 const float bb = p[C + c], cc = p[2 * C + c], dd = p[3 * C + c];
                 const float inner = cc + dd * frac;
@@ -508,12 +509,19 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
         }
     }
     int cur_idx = -1;
-    for (int n = 0; n < a.T - 1; ++n) {
+    // general time axis (a.plan != NULL; csrc/ncde_timeplan.hip): per-step dt, per-stage (piece, offset, knot spacing), and the
+    // output rows each step emits -- same semantics as the generic / variant kernels, whose plan mode is pinned to the reference
+    const bool planned = a.plan != nullptr;
+    const int n_steps = planned ? a.n_steps_fwd : a.T - 1;
+    const int* pout = planned ? a.plan + plan_off_out(S, a.n_steps_fwd) : nullptr;
+    for (int n = 0; n < n_steps; ++n) {
+        const int* pstep = planned ? a.plan + plan_off_fwd() + n * plan_step_words(S) : nullptr;
+        const float dt = planned ? __int_as_float(pstep[0]) : 1.0f;
         for (int j = 0; j < S; ++j) {
-            const float t = (float)n + stage_offset(a.method, j);
-            const int idx = piece_index(t, a.n_pieces);
+            const StageDesc sd = planned ? plan_stage(pstep, j) : default_stage(a.method, (float)n + stage_offset(a.method, j), a.n_pieces);
+            const int idx = sd.idx;
             if (a.interp != NCDE_INTERP_LINEAR || idx != cur_idx) {
-                tl_load_dx<NS, NT>(a, b0, idx, t - (float)idx, DX, tid);
+                tl_load_dx<NS, NT>(a, b0, idx, sd.frac, sd.kdt, DX, tid);
                 cur_idx = idx;
             }
             __syncthreads();
@@ -581,25 +589,21 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
             for (int q = 0; q < EM; ++q) {
                 const int e = tid + q * NT;
                 if (e < HS) {
-                    const float k = KO[e];
-                    float ys;
-                    bool last = false;
-                    if (a.method == NCDE_RK4_38) {
-                        if (j == 0) { k1[q] = k; ys = y0[q] + k * 0.333333343267440796f; }
-                        else if (j == 1) { k2[q] = k; ys = y0[q] + (k - k1[q] * 0.333333343267440796f); }
-                        else if (j == 2) { ys = y0[q] + ((k1[q] - k2[q]) + k); k2[q] = k2[q] + k; }
-                        else { y0[q] = y0[q] + ((k1[q] + 3.0f * k2[q]) + k) * 0.125f; ys = y0[q]; last = true; }
-                    } else if (a.method == NCDE_MIDPOINT) {
-                        if (j == 0) { ys = y0[q] + k * 0.5f; }
-                        else { y0[q] = y0[q] + k; ys = y0[q]; last = true; }
-                    } else {
-                        y0[q] = y0[q] + k; ys = y0[q]; last = true;
-                    }
+                    const float yprev = y0[q];
+                    bool last;
+                    const float ys = StageCombine::apply(a.method, j, KO[e], dt, y0[q], k1[q], k2[q], last);   // dt = 1: exact products
                     YS[e] = ys;
                     if (last) {
                         const int u = ((e >> 2) / NSP) * 4 + (e & 3), s = (e >> 2) % NSP, b = b0 + s;
                         if (b < a.B) {
-                            if (a.output == NCDE_OUT_KNOTS) a.out[((long long)b * a.n_out + (n + 1)) * H + u] = ys;
+                            if (planned) {      // output pick / interpolation between the step's end points (solvers.py:103-117)
+                                const int q0 = pstep[1], q1 = q0 + pstep[2];
+                                for (int r = q0; r < q1; ++r) {
+                                    const int kind = pout[2 * r];
+                                    const float slope = __int_as_float(pout[2 * r + 1]);
+                                    a.out[((long long)b * a.n_out + r) * H + u] = kind == 1 ? ys : (kind == 0 ? yprev : yprev + slope * (ys - yprev));
+                                }
+                            } else if (a.output == NCDE_OUT_KNOTS) a.out[((long long)b * a.n_out + (n + 1)) * H + u] = ys;
                             else if (n == a.T - 2) a.out[((long long)b * a.n_out + 1) * H + u] = ys;
                         }
                     }
@@ -841,6 +845,16 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     const int dlast = 16 * PK;
     const int last_row = a.n_out - 1;
     const int n_st = gridDim.x;
+    // general time axis (a.plan): reverse step n = n_rsteps .. 1 is plan step rstep = n_rsteps - n of the adjoint table
+    // (continuous adjoint) or the transpose of forward step m = n - 1 (discrete backward) -- as in ncde_variant.hip, whose
+    // plan mode is pinned to the reference
+    const bool planned = a.plan != nullptr;
+    const int pw_ = plan_step_words(S);
+    const int* pfwd = planned ? a.plan + plan_off_fwd() : nullptr;
+    const int* pout = planned ? a.plan + plan_off_out(S, a.n_steps_fwd) : nullptr;
+    const int* padj = planned ? a.plan + plan_off_adj(S, a.n_steps_fwd, a.n_out) : nullptr;
+    const int n_rsteps = planned ? (disc ? a.n_steps_fwd : a.n_steps_adj) : a.T - 1;
+    auto step_of = [&](int n) { return planned ? (disc ? pfwd + (n - 1) * pw_ : padj + (n_rsteps - n) * pw_) : nullptr; };
 
     float y0[TL_EADJ], ky1[TL_EADJ], ky2[TL_EADJ], a0[TL_EADJ], ka1[TL_EADJ], ka2[TL_EADJ];
 #pragma unroll
@@ -856,11 +870,14 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                 g = a.carry[((long long)gridDim.x + blockIdx.x) * HS + e];
             } else {
                 g = b < a.B ? a.grad_out[o] : 0.0f;
+                if (planned && disc && b < a.B) g = plan_out_cotangent(a, pfwd + (a.n_steps_fwd - 1) * pw_, pout, 1, (long long)b * a.n_out, u);
                 y = (!disc && b < a.B) ? a.z_out[o] : 0.0f;
             }
             a0[q] = g;
             if (disc) {
-                AS[e] = a.method == NCDE_RK4_38 ? g * 0.125f : g;
+                // cotangent of the LAST stage input of the step about to be transposed (step a.win_hi)
+                const float dtl = planned ? __int_as_float(step_of(a.win_hi)[0]) : 1.0f;
+                AS[e] = a.method == NCDE_RK4_38 ? (g * dtl) * 0.125f : dtl * g;
                 YS[e] = 0.0f;
             } else {
                 y0[q] = y;
@@ -942,13 +959,14 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     // stage ahead and stored to LDS in the bookkeeping phase, so no stage starts with an exposed global round trip
     constexpr int DXE = (NSP * 80 + NT - 1) / NT, YSE = TL_EADJ;      // C <= 80 on this path (host check)
     float dxn[DXE], ysn[YSE];
-    auto stage_time = [&](int n, int j) {
-        return disc ? (float)(n - 1) + stage_offset(a.method, S - 1 - j) : -(-(float)n + stage_offset(a.method, j));
+    auto stage_desc = [&](int n, int j) {
+        if (planned) return plan_stage(step_of(n), disc ? S - 1 - j : j);
+        return default_stage(a.method, disc ? (float)(n - 1) + stage_offset(a.method, S - 1 - j) : -(-(float)n + stage_offset(a.method, j)), a.n_pieces);
     };
     auto prefetch = [&](int n, int j) {
-        const float t = stage_time(n, j);
-        const int idx = piece_index(t, a.n_pieces);
-        const float frac = t - (float)idx;
+        const StageDesc sd = stage_desc(n, j);
+        const int idx = sd.idx;
+        const float frac = sd.frac, kdt = sd.kdt;
 #pragma unroll
         for (int q = 0; q < DXE; ++q) {
             const int e = tid + q * NT;
@@ -959,6 +977,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                     const float* cp = a.coeffs + (long long)b * a.cs_b + (long long)idx * a.cs_t;
                     if (a.interp == NCDE_INTERP_LINEAR) {
                         v = cp[a.cs_t + c] - cp[c];
+                        if (kdt != 1.0f) v = v / kdt;
                     } else {
                         const float bb = cp[C + c], cc = cp[2 * C + c], dd = cp[3 * C + c];
                         const float inner = cc + dd * frac;
@@ -1008,8 +1027,10 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
 
     int sc = 0;      // stage counter within this time window = record index
     for (int n = a.win_hi; n > a.win_lo; --n) {
+        const int* pstep = step_of(n);
+        const float dt = planned ? __int_as_float(pstep[0]) : 1.0f;
         for (int j = 0; j < S; ++j, ++sc) {
-            const float w = disc ? 1.0f : stage_weight(a.method, j);
+            const float w = disc ? 1.0f : stage_weight(a.method, j) * dt;
             {   // next stage's inputs; consumed (publish) in this stage's bookkeeping phase
                 const int jn = j + 1 < S ? j + 1 : 0, nn = j + 1 < S ? n : n - 1;
                 if (nn > a.win_lo) prefetch(nn, jn);
@@ -1159,56 +1180,54 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                     const bool valid = b < a.B;
                     const float d = KOA[e];
                     if (disc) {
-                        // transpose of the Butcher step: d = dL/dY of this stage (see ncde_generic.hip)
+                        // transpose of the Butcher step: d = dL/dY of this stage (see ncde_generic.hip / ncde_variant.hip)
                         bool last = false;
                         float next = 0.0f;
                         if (a.method == NCDE_RK4_38) {
-                            const float c4 = a0[q] * 0.125f;
-                            if (j == 0) { ka1[q] = d; next = 3.0f * c4 + d; }
-                            else if (j == 1) { ka2[q] = d; next = (3.0f * c4 - ka1[q]) + d; }
-                            else if (j == 2) { ky1[q] = d; next = ((c4 + ka1[q]) - 0.333333343267440796f * ka2[q]) + 0.333333343267440796f * d; }
+                            const float c4 = (a0[q] * dt) * 0.125f;
+                            const float dt3 = dt * 0.333333343267440796f;
+                            if (j == 0) { ka1[q] = d; next = 3.0f * c4 + dt * d; }
+                            else if (j == 1) { ka2[q] = d; next = (3.0f * c4 - dt * ka1[q]) + dt * d; }
+                            else if (j == 2) { ky1[q] = d; next = ((c4 + dt * ka1[q]) - dt3 * ka2[q]) + dt3 * d; }
                             else { a0[q] = (((a0[q] + ka1[q]) + ka2[q]) + ky1[q]) + d; last = true; }
                         } else if (a.method == NCDE_MIDPOINT) {
-                            if (j == 0) { ka1[q] = d; next = 0.5f * d; }
+                            if (j == 0) { ka1[q] = d; next = (0.5f * dt) * d; }
                             else { a0[q] = (a0[q] + ka1[q]) + d; last = true; }
                         } else {
                             a0[q] = a0[q] + d; last = true;
                         }
                         if (last) {
-                            if (a.output == NCDE_OUT_KNOTS || n == 1)
+                            float dtp = 1.0f;      // dt of the forward step transposed next (n - 1 -> n - 2)
+                            if (planned) {
+                                if (valid) {
+                                    const long long brow = (long long)b * a.n_out;
+                                    a0[q] = a0[q] + plan_out_cotangent(a, pstep, pout, 0, brow, u);
+                                    if (n > 1) a0[q] = a0[q] + plan_out_cotangent(a, pstep - pw_, pout, 1, brow, u);
+                                    else a0[q] = a0[q] + a.grad_out[brow * H + u];
+                                }
+                                if (n > 1) dtp = __int_as_float(pstep[-pw_]);
+                            } else if (a.output == NCDE_OUT_KNOTS || n == 1) {
                                 a0[q] += valid ? a.grad_out[((long long)b * a.n_out + (a.output == NCDE_OUT_KNOTS ? n - 1 : 0)) * H + u] : 0.0f;
-                            next = a.method == NCDE_RK4_38 ? a0[q] * 0.125f : a0[q];
+                            }
+                            next = a.method == NCDE_RK4_38 ? (a0[q] * dtp) * 0.125f : dtp * a0[q];
                             if (n == 1 && valid) a.grad_z0[(long long)b * H + u] = a0[q];
                         }
                         AS[e] = next;
                     } else {
                         // negated time: dy/ds = -f, da/ds = +a^T df/dy; same operation order as StageCombine
-                        const float ky = -KOY[e];
-                        float ys, as;
-                        bool last = false;
-                        if (a.method == NCDE_RK4_38) {
-                            if (j == 0) {
-                                ky1[q] = ky; ys = y0[q] + ky * 0.333333343267440796f;
-                                ka1[q] = d; as = a0[q] + d * 0.333333343267440796f;
-                            } else if (j == 1) {
-                                ky2[q] = ky; ys = y0[q] + (ky - ky1[q] * 0.333333343267440796f);
-                                ka2[q] = d; as = a0[q] + (d - ka1[q] * 0.333333343267440796f);
-                            } else if (j == 2) {
-                                ys = y0[q] + ((ky1[q] - ky2[q]) + ky); ky2[q] = ky2[q] + ky;
-                                as = a0[q] + ((ka1[q] - ka2[q]) + d); ka2[q] = ka2[q] + d;
-                            } else {
-                                y0[q] = y0[q] + ((ky1[q] + 3.0f * ky2[q]) + ky) * 0.125f; ys = y0[q];
-                                a0[q] = a0[q] + ((ka1[q] + 3.0f * ka2[q]) + d) * 0.125f; as = a0[q];
-                                last = true;
-                            }
-                        } else if (a.method == NCDE_MIDPOINT) {
-                            if (j == 0) { ys = y0[q] + ky * 0.5f; as = a0[q] + d * 0.5f; }
-                            else { y0[q] = y0[q] + ky; ys = y0[q]; a0[q] = a0[q] + d; as = a0[q]; last = true; }
-                        } else {
-                            y0[q] = y0[q] + ky; ys = y0[q]; a0[q] = a0[q] + d; as = a0[q]; last = true;
-                        }
+                        bool last;
+                        const float ys0 = StageCombine::apply(a.method, j, -KOY[e], dt, y0[q], ky1[q], ky2[q], last);
+                        const float as0 = StageCombine::apply(a.method, j, d, dt, a0[q], ka1[q], ka2[q], last);
+                        float ys = ys0, as = as0;
                         if (last) {
-                            if (a.output == NCDE_OUT_KNOTS) {  // reset y to the stored value, add dL/dz at this knot
+                            if (planned) {      // one reverse solve per output interval: reset y to the stored value, add dL/dz there
+                                const int row = pstep[1];
+                                if (row >= 0) {
+                                    const long long o = ((long long)b * a.n_out + row) * H + u;
+                                    y0[q] = valid ? a.z_out[o] : 0.0f;
+                                    a0[q] = a0[q] + (valid ? a.grad_out[o] : 0.0f);
+                                }
+                            } else if (a.output == NCDE_OUT_KNOTS) {  // reset y to the stored value, add dL/dz at this knot
                                 const long long o = ((long long)b * a.n_out + (n - 1)) * H + u;
                                 y0[q] = valid ? a.z_out[o] : 0.0f;
                                 a0[q] = a0[q] + (valid ? a.grad_out[o] : 0.0f);
@@ -1808,7 +1827,7 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
     const bool bf = tiled_adj_bf(p);
     const long long recA_tile = bf ? dlast * 24 : dlast * 16;      // floats per (stage, sample tile) of record A
     const long long per_step = (long long)S * t.n_st * (2 * recA_tile + (p->hidden + p->channels) * 16) * (long long)sizeof(float);
-    const int steps = p->n_knots - 1;
+    const int steps = p->output == NCDE_OUT_TIMES ? std::max(p->n_steps_fwd, p->n_steps_adj) : p->n_knots - 1;
     t.window = (int)std::max<long long>(1, std::min<long long>(steps, tiled_window_budget_bytes() / per_step));
     t.n_sc = t.window * S;
     const long long tiles = (long long)t.n_sc * t.n_st;
@@ -1992,7 +2011,8 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     float* gB = w + t.gpartB;
     float* gB2 = gB + (long long)t.parts * t.theta_o;
     // time windows, newest first: sweep W steps (pass A), fold their records into the output-layer gradient (pass B)
-    for (int hi = p->n_knots - 1, first = 1; hi >= 1; hi -= t.window, first = 0) {
+    const int n_rsteps = p->output == NCDE_OUT_TIMES ? (discrete ? p->n_steps_fwd : p->n_steps_adj) : p->n_knots - 1;
+    for (int hi = n_rsteps, first = 1; hi >= 1; hi -= t.window, first = 0) {
         const int lo = std::max(0, hi - t.window);
         a.win_hi = hi; a.win_lo = lo; a.resume = first ? 0 : 1;
         hipLaunchKernelGGL(fa, dim3(t.n_st), dim3(64 * TL_ADJ_NW), lds, st, a);

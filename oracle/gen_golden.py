@@ -295,6 +295,10 @@ def gen_g11():
         ("g11_knots_interval_rk4", "cubic", knots, "rk4", 1.0, np.array([knots[0], knots[-1]], np.float32)),
         # fp64 output times with an fp32 state: the grid arithmetic runs in fp64, the control path sees fp32 stage times
         ("g11_times_f64_rk4", "linear", None, "rk4", 0.3, np.array([0.1, 0.7, 2.3, 5.9, 7.25], np.float64)),
+        # cubic + RK4 + a step that does not divide the output intervals: non-uniform last step per interval, RK4 stage times
+        # that land exactly on knots, interior outputs (found while porting the time plan to the batch-tiled family: the
+        # generic kernels and the tiled ones disagreed on exactly this combination)
+        ("g11_times_cubic_rk4_ragged", "cubic", None, "rk4", 0.75, np.array([0.0, 4.0, 8.0], np.float32)),
     ]
     for name, interp, kn, method, step, tout in cases:
         xt = torch.from_numpy(x)

@@ -322,13 +322,17 @@ def test_time_plan_builder_reproduces_torch_time_arithmetic():
     assert rc == -1 and b"knot" in ncde_amd.lib().ncde_last_error_string()
 
 
-def test_general_time_axis_dispatches_to_the_generic_family():
+def test_general_time_axis_dispatches_to_the_plan_driven_families():
     lib = ncde_amd.lib()
     p = _problem()                       # cfg2 shape: specialised kernels on the default axis ...
     assert (lib.ncde_kernel_name(ctypes.byref(p), 0) or b"").startswith(b"ncde_fwd_fast")
     p.output, p.time_plan, p.n_t_out, p.n_steps_fwd, p.n_steps_adj = _lib.OUT_TIMES, 0x9000, 5, 12, 14
-    assert lib.ncde_kernel_name(ctypes.byref(p), 0) == b"ncde_fwd_generic"        # ... plan-driven generic kernels otherwise
+    assert lib.ncde_kernel_name(ctypes.byref(p), 0).startswith(b"ncde_fwd_tiled")     # ... a plan-driven family otherwise: batch-tiled
+    assert lib.ncde_kernel_name(ctypes.byref(p), 1).startswith(b"ncde_adj_tiled")     # where every width is a multiple of 16 (C of 4),
+    p.flags = _lib.FLAG_FORCE_GENERIC
+    assert lib.ncde_kernel_name(ctypes.byref(p), 0) == b"ncde_fwd_generic"            # generic for any shape
     assert lib.ncde_kernel_name(ctypes.byref(p), 1) == b"ncde_adj_generic"
+    p.flags = 0
     assert lib.ncde_num_outputs(ctypes.byref(p)) == 5
     assert lib.ncde_stage_record_bytes(ctypes.byref(p)) == 4 * 12 * 4 * 32 * 32      # bytes: steps x stages x B x H
     p.flags = _lib.FLAG_FORCE_FAST
