@@ -294,7 +294,7 @@ def test_time_plan_builder_reproduces_torch_time_arithmetic():
     import json
     import ncde_oracle as orc
     for name in ("g11_times_rk4_half", "g11_times_midpoint_third", "g11_knots_rk4", "g11_knots_cubic_euler",
-                 "g11_knots_interval_rk4", "g11_times_f64_rk4"):
+                 "g11_knots_interval_rk4", "g11_times_f64_rk4", "g11_times_cubic_rk4_ragged"):
         f = np.load(os.path.join(gu.GOLD, name + ".npz"))
         m = json.loads(str(f["meta"]))
         kn = f["knots"] if "knots" in f.files else None

@@ -175,3 +175,29 @@ def test_cpu_cabi_restatement_matches_reference_golden(name):
                 assert gu.relerr(gg[pname], ex[key]) <= TOL_G, (prefix, pname)
             else:
                 assert gu.relerr(gg[pname][::16], ex[key + "__rows16"]) <= TOL_G, (prefix, pname)
+
+
+@pytest.mark.parametrize("name", ["g11_times_rk4_half", "g11_times_midpoint_third", "g11_knots_rk4", "g11_knots_cubic_euler",
+                                  "g11_knots_interval_rk4", "g11_times_f64_rk4", "g11_times_cubic_rk4_ragged"])
+def test_oracle_general_time_axis_matches_reference_golden(name):
+    """The oracle's general-time functions (any output times, step size, user knot grid) against the reference's own outputs
+    (goldens g11, written by oracle/gen_golden.py from the imported torchcde / torchdiffeq): forward, continuous adjoint
+    (one reverse solve per output interval) and the autograd-through-the-solver gradients."""
+    import json
+    import os
+    f = dict(np.load(os.path.join(gu.GOLD, name + ".npz")))
+    m = json.loads(str(f["meta"]))
+    p = {k[2:]: f[k] for k in f if k.startswith("p_")}
+    d = m["dims"]
+    field = orc.Field.original(p, d["H"], d["C"], d["nl"])
+    ctl = orc.Control(f["coeffs"], m["kind"], t=f["knots"] if "knots" in f else None)
+    z = orc.solve_forward_times(ctl, field, f["z0"], f["t_out"], m["method"], m["step_size"])
+    assert gu.relerr(z.numpy(), f["z_out"]) <= 2e-6
+    dz0, gp = orc.solve_adjoint_times(ctl, field, f["t_out"], z, f["grad_out"], m["method"], m["step_size"])
+    assert gu.relerr(dz0.numpy(), f["dz0"]) <= 2e-5
+    for n, g in zip(m["param_names"], gp):
+        assert gu.relerr(g.numpy(), f["d" + n]) <= 2e-5, n
+    bdz0, bgp = orc.solve_discrete_backward_times(ctl, field, f["z0"], f["t_out"], f["grad_out"], m["method"], m["step_size"])
+    assert gu.relerr(bdz0.numpy(), f["bp_dz0"]) <= 2e-5
+    for n, g in zip(m["param_names"], bgp):
+        assert gu.relerr(g.numpy(), f["bp_d" + n]) <= 2e-5, n
