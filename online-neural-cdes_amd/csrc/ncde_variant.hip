@@ -379,6 +379,50 @@ __device__ void vr_dw_acc(const float* gpre, const float* xin, int N, int K, flo
     }
 }
 
+// The same weight gradient kept in this wave's REGISTERS for the whole sweep (tiles tt = wave + 4 q, q < VR_DWT): no
+// read-modify-write of the partial and no guards per stage -- the partial is touched once, at the end (vr_dw_flush).  Used
+// for the hidden matrices and the reset gate when there are at most two distinct hidden matrices of <= 4 VR_DWT tiles each
+// (the reference's stack: one input layer + ONE shared inner layer); the bias gradient stays a plain accumulate.
+#define VR_DWT 4
+__device__ __forceinline__ void vr_dw_acc_reg(const float* gpre, const float* xin, int N, int K, float w, f32x4 (&acc)[VR_DWT], float* gb,
+                                              int tid, int wave, int lane, int in_lds) {
+    const int li = lane & 15, lk = lane >> 4;
+    for (int jj = tid; jj < N; jj += VR_THREADS) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) sum += gpre[jj * 16 + s];
+        vr_accum(gb + jj, w * sum, in_lds);
+    }
+    const int nit = (K + 15) >> 4, ntile = ((N + 15) >> 4) * nit;
+#pragma unroll
+    for (int q = 0; q < VR_DWT; ++q) {
+        const int tt = wave + VR_NW * q;
+        if (tt < ntile) {
+            const int jt = tt / nit, it = tt - jt * nit;
+            const float* ap = gpre + (16 * jt + li) * 16 + lk;      // rows >= N / columns >= K of the padded activations are zero
+            const float* bp = xin + (16 * it + li) * 16 + lk;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc[q] = mfma16(w * ap[4 * ks], bp[4 * ks], acc[q]);
+        }
+    }
+}
+__device__ __forceinline__ void vr_dw_flush(const f32x4 (&acc)[VR_DWT], int N, int K, float* gW, int wave, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    const int nit = (K + 15) >> 4, ntile = ((N + 15) >> 4) * nit;
+#pragma unroll
+    for (int q = 0; q < VR_DWT; ++q) {
+        const int tt = wave + VR_NW * q;
+        if (tt < ntile) {
+            const int jt = tt / nit, it = tt - jt * nit, col = 16 * it + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * jt + 4 * lk + r;
+                if (row < N && col < K) gW[(long long)row * K + col] += acc[q][r];
+            }
+        }
+    }
+}
+
 // out[i][s] (+)= sum_j W[j][i] gpre[j][s], i < ru16(K); optionally x relu'(mask[i][s])
 __device__ void vr_bwd_data(const float* __restrict__ W, int N, int K, const float* gpre, const float* mask, float* out, bool accumulate,
                             int wave, int lane, const float* wl = nullptr) {
@@ -494,6 +538,22 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
     const int ncq = Cp >> 2, ngrp = matmul ? (Hp >> 2) : (Hp >> 4), per_grp = matmul ? ncq : 1;
     const int njt = (dlast + 15) >> 4;
     float* sc = SC + wave * 16 * 17;
+    // hidden / reset-gate weight gradients in registers (see vr_dw_acc_reg): slot 0 = layer 0's matrix, slot 1 = the other one
+    f32x4 dwA[VR_DWT], dwB[VR_DWT], dwR[VR_DWT];
+#pragma unroll
+    for (int q = 0; q < VR_DWT; ++q) dwA[q] = dwB[q] = dwR[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int l_other = -1;
+    bool dw_reg = true;
+    {
+        auto tiles = [](int N, int K) { return ((N + 15) >> 4) * ((K + 15) >> 4); };
+        for (int l = 0; l < L; ++l) {
+            if (a.gW_off[l] == a.gW_off[0]) { dw_reg = dw_reg && a.dout[l] == a.dout[0] && a.din[l] == a.din[0]; continue; }
+            if (l_other < 0) l_other = l;
+            dw_reg = dw_reg && a.gW_off[l] == a.gW_off[l_other] && a.dout[l] == a.dout[l_other] && a.din[l] == a.din[l_other];
+        }
+        dw_reg = dw_reg && tiles(a.dout[0], a.din[0]) <= VR_NW * VR_DWT && (l_other < 0 || tiles(a.dout[l_other], a.din[l_other]) <= VR_NW * VR_DWT) &&
+                 (!gru || tiles(d0, d0) <= VR_NW * VR_DWT);
+    }
     for (int rstep = 0; rstep < n_rsteps; ++rstep) {
         const int n = a.T - 1 - rstep, m = n_rsteps - 1 - rstep;   // default grid: reverse step n -> n-1; m = forward step transposed
         const int* pstep = planned ? (disc ? pfwd + m * pw_ : padj + rstep * pw_) : nullptr;
@@ -636,7 +696,11 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
                 for (int l = L - 1; l >= 0; --l) {
                     const int N = a.dout[l], K = a.din[l];
                     const float* xin = l == 0 ? x0 : Xp + (l - 1) * DS;
-                    if (w != 0.0f) vr_dw_acc(gpre, xin, N, K, w, gacc + a.gW_off[l], gacc + a.gb_off[l], tid, wave, lane, a.gacc_in_lds);
+                    if (w != 0.0f) {
+                        if (!dw_reg) vr_dw_acc(gpre, xin, N, K, w, gacc + a.gW_off[l], gacc + a.gb_off[l], tid, wave, lane, a.gacc_in_lds);
+                        else if (a.gW_off[l] == a.gW_off[0]) vr_dw_acc_reg(gpre, xin, N, K, w, dwA, gacc + a.gb_off[l], tid, wave, lane, a.gacc_in_lds);
+                        else vr_dw_acc_reg(gpre, xin, N, K, w, dwB, gacc + a.gb_off[l], tid, wave, lane, a.gacc_in_lds);
+                    }
                     vr_bwd_data(a.W[l], N, K, gpre, l > 0 ? xin : nullptr, l == 0 ? du : gx, false, wave, lane, a.wres[l] >= 0 ? lds + a.wres[l] : nullptr);
                     __syncthreads();
                     float* tmp = gpre; gpre = gx; gx = tmp;
@@ -650,7 +714,10 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
                     GA[e] = (dru * u) * (rg * (1.0f - rg));
                 }
                 __syncthreads();
-                if (w != 0.0f) vr_dw_acc(GA, U, d0, d0, w, gacc + a.gWr_off, gacc + a.gbr_off, tid, wave, lane, a.gacc_in_lds);
+                if (w != 0.0f) {
+                    if (dw_reg) vr_dw_acc_reg(GA, U, d0, d0, w, dwR, gacc + a.gbr_off, tid, wave, lane, a.gacc_in_lds);
+                    else vr_dw_acc(GA, U, d0, d0, w, gacc + a.gWr_off, gacc + a.gbr_off, tid, wave, lane, a.gacc_in_lds);
+                }
                 vr_bwd_data(a.Wr, d0, d0, GA, nullptr, DUI, true, wave, lane, wl_r);
                 __syncthreads();
             }
@@ -726,6 +793,12 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
             }
             __syncthreads();
         }
+    }
+    if (dw_reg) {      // the register-held weight gradients join the partial (each element has one owner: plain adds)
+        vr_dw_flush(dwA, a.dout[0], a.din[0], gacc + a.gW_off[0], wave, lane);
+        if (l_other >= 0) vr_dw_flush(dwB, a.dout[l_other], a.din[l_other], gacc + a.gW_off[l_other], wave, lane);
+        if (gru) vr_dw_flush(dwR, d0, d0, gacc + a.gWr_off, wave, lane);
+        __syncthreads();
     }
     if (a.gacc_in_lds) {
         float* dst = a.gpart + (long long)blockIdx.x * a.theta_size;

@@ -7,7 +7,8 @@ c = dict(bench.CONFIGS["cfg2"])
 B = int(os.environ.get("B", 4096))
 coeffs = bench.make_inputs(c, B, 0, torch.device("cuda", 0))
 y = (torch.rand(B, 1, device="cuda") > 0.5).float()
-for vf, vft in (("original", "matmul"), ("minimal", "matmul"), ("gru", "matmul"), ("original", "evaluate"), ("gru", "derivative")):
+ALL = [(a, b) for a in ("original", "minimal", "gru") for b in ("matmul", "evaluate", "derivative")]
+for vf, vft in (ALL if os.environ.get("ALL") else (("original", "matmul"), ("minimal", "matmul"), ("gru", "matmul"), ("original", "evaluate"), ("gru", "derivative"))):
     torch.manual_seed(0)
     m = ncde_amd.NeuralCDE(c["C"], c["H"], 1, hidden_hidden_dim=c["HH"], num_layers=c["nl"], interpolation="rectilinear",
                            vector_field=vf, vector_field_type=vft, adjoint=True, solver="rk4").cuda()
