@@ -98,7 +98,9 @@ __host__ __device__ __forceinline__ int tl_panel_k(int nkb) { return (nkb % 8 ==
 // The (row tile, panel) pairs of this wave form one sequence; the panel of pair q+1 is in flight while pair q computes.
 // xb != NULL: additionally leave the result as three bf16 pieces in the B-operand order of v_mfma_f32_16x16x32_bf16
 // (NS = 1 only): word (((c * 3 + piece) * 4 + kg) * 16 + sample) * 4 + dw holds units 32 c + 8 kg + 2 dw, + 1.
-template <int NS, int PK, int NWV>
+// ACT: 0 relu (hidden layers), 1 tanh, 2 sigmoid (the heads of the evaluate / derivative input modes, which are plain
+// H-row dense layers)
+template <int NS, int PK, int NWV, int ACT = 0>
 __device__ __forceinline__ void tl_dense_relu_pk(const float* __restrict__ W, const float* __restrict__ bias, int N, int K,
                                                  const float* in, float* out, int wave, int lane, unsigned* xb = nullptr) {
     constexpr int NSP = NS * 16;
@@ -128,9 +130,9 @@ __device__ __forceinline__ void tl_dense_relu_pk(const float* __restrict__ W, co
             for (int st = 0; st < NS; ++st) {
                 f32x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = relu_dev(acc[st][r]);
+                for (int r = 0; r < 4; ++r) o[r] = ACT == 0 ? relu_dev(acc[st][r]) : (ACT == 1 ? tanh_dev(acc[st][r]) : tl_sigmoid(acc[st][r]));
                 *reinterpret_cast<f32x4*>(out + ((4 * t + lk) * NSP + st * 16 + li) * 4) = o;
-                if constexpr (NS == 1) {
+                if constexpr (NS == 1 && ACT == 0) {
                     if (xb) {      // units 16 t + 4 lk + r: chunk t >> 1, k-group 2 (t & 1) + (lk >> 1), dwords 2 (lk & 1), + 1
                         unsigned h0, m0, l0, h1, m1, l1;
                         split_pair(o[0], o[1], h0, m0, l0);
@@ -146,14 +148,47 @@ __device__ __forceinline__ void tl_dense_relu_pk(const float* __restrict__ W, co
         }
     }
 }
-template <int NS, int NWV>
+template <int NS, int NWV, int ACT = 0>
 __device__ __forceinline__ void tl_dense_relu(const float* __restrict__ W, const float* __restrict__ bias, int N, int K,
                                               const float* in, float* out, int wave, int lane, unsigned* xb = nullptr) {
     switch (tl_panel_k(K >> 4)) {
-        case 8: tl_dense_relu_pk<NS, 8, NWV>(W, bias, N, K, in, out, wave, lane, xb); break;
-        case 4: tl_dense_relu_pk<NS, 4, NWV>(W, bias, N, K, in, out, wave, lane, xb); break;
-        case 2: tl_dense_relu_pk<NS, 2, NWV>(W, bias, N, K, in, out, wave, lane, xb); break;
-        default: tl_dense_relu_pk<NS, 1, NWV>(W, bias, N, K, in, out, wave, lane, xb); break;
+        case 8: tl_dense_relu_pk<NS, 8, NWV, ACT>(W, bias, N, K, in, out, wave, lane, xb); break;
+        case 4: tl_dense_relu_pk<NS, 4, NWV, ACT>(W, bias, N, K, in, out, wave, lane, xb); break;
+        case 2: tl_dense_relu_pk<NS, 2, NWV, ACT>(W, bias, N, K, in, out, wave, lane, xb); break;
+        default: tl_dense_relu_pk<NS, 1, NWV, ACT>(W, bias, N, K, in, out, wave, lane, xb); break;
+    }
+}
+
+// control input of the evaluate / derivative modes for the tile's samples -> rows row0 .. row0 + C - 1 of the activation array
+// `U` ([unit/4][sample][unit%4]): value = false: dX/dt(t); value = true: X(t)  (ncde_variant.hip's vr_load_cin; linear
+// interpolation_linear.py:221-234, cubic interpolation_cubic.py:324-336)
+template <int NS, int NT>
+__device__ __forceinline__ void tl_load_cin(const KArgs& a, int b0, const StageDesc& sd, bool value, float* U, int row0, int tid) {
+    constexpr int NSP = NS * 16;
+    const int C = a.C;
+    for (int e = tid; e < NSP * C; e += NT) {
+        const int s = e / C, c = e - s * C;
+        const int b = b0 + s;
+        float v = 0.0f;
+        if (b < a.B) {
+            const float* p = a.coeffs + (long long)b * a.cs_b + (long long)sd.idx * a.cs_t;
+            if (a.interp == NCDE_INTERP_LINEAR) {
+                const float d = p[a.cs_t + c] - p[c];
+                v = value ? p[c] + (sd.frac * d) / sd.kdt : (sd.kdt != 1.0f ? d / sd.kdt : d);
+            } else {
+                const float aa = p[c], bb = p[C + c], cc = p[2 * C + c], dd = p[3 * C + c];
+                if (value) {
+                    float inner = 0.5f * cc + (dd * sd.frac) / 3.0f;
+                    inner = bb + inner * sd.frac;
+                    v = aa + inner * sd.frac;
+                } else {
+                    const float inner = cc + dd * sd.frac;
+                    v = bb + inner * sd.frac;
+                }
+            }
+        }
+        const int u = row0 + c;
+        U[((u >> 2) * NSP + s) * 4 + (u & 3)] = v;
     }
 }
 
@@ -428,6 +463,14 @@ __global__ __launch_bounds__(256) void ncde_pack_panels(const float* __restrict_
     }
 }
 
+// dst[N][Kp] = W[N][K] with zero columns K .. Kp - 1 (layer 0 of the evaluate / derivative modes: K = H + C, any value)
+__global__ __launch_bounds__(256) void ncde_pad_columns(const float* __restrict__ W, float* __restrict__ dst, int N, int K, int Kp) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < N * Kp; e += gridDim.x * 256) {
+        const int r = e / Kp, c = e - r * Kp;
+        dst[e] = c < K ? W[(long long)r * K + c] : 0.0f;
+    }
+}
+
 // The split-bf16 copy: word (((tile * NCH + c) * 3 + piece) * 64 + lane) * 4 + dw = bf16 pieces of
 // W[row(tile, lane & 15)][32 c + 8 (lane >> 4) + 2 dw, + 1] -- the A operand of v_mfma_f32_16x16x32_bf16.
 __global__ __launch_bounds__(256) void ncde_pack_panels_bf(const float* __restrict__ W, unsigned* __restrict__ dst, int H, int C, int nch) {
@@ -456,8 +499,12 @@ __global__ __launch_bounds__(256) void ncde_pack_panels_bf(const float* __restri
 // RESH = H/16 > 0 (small square hidden stack, every layer H x H, NS = 1): the hidden matrices' fragments -- one row tile per
 // wave, at most two distinct matrices -- are loaded once and stay in registers, so the hidden layers of a stage do not start
 // with an L2 round trip each (the backward sweep's RES modes do the same).
-template <int NS, int NWV, int EM, int GATED = 0, int BF = 0, int RESH = 0>
+// DIRECT = 1: the evaluate / derivative input modes (solver.py:112-137): the field input is u = [z, X(t)] or [z, dX/dt(t)]
+// (H + C rows; layer 0 arrives zero-padded to a multiple of 16 columns, a.din[0]) and the heads are H-row dense layers with no
+// channel contraction, dz/dt = tanh(Wo x_L + bo) (x sigmoid(Wg x_L + bg)).
+template <int NS, int NWV, int EM, int GATED = 0, int BF = 0, int RESH = 0, int DIRECT = 0>
 __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
+    static_assert(DIRECT == 0 || (BF == 0 && RESH == 0), "direct heads: plain fp32 dense layers");
     static_assert(BF == 0 || NS == 1, "the split-bf16 output tiles are built for one sample tile per workgroup");
     static_assert(RESH == 0 || (NS == 1 && RESH <= NWV), "resident hidden fragments: one sample tile, one row tile per wave");
     constexpr int NSP = NS * 16, NT = 64 * NWV;
@@ -468,13 +515,18 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
     const int H = a.H;
     int D = H;
     for (int l = 0; l < a.n_layers; ++l) D = max(D, a.dout[l]);
+    if (DIRECT) D = max(D, a.din[0]);
     const int HS = H * NSP, DS = D * NSP;
+    const int US = DIRECT ? max(H, a.din[0]) * NSP : HS;      // the stage input carries the control rows in the direct modes
     float* YS = lds;            // stage input
-    float* ACT0 = YS + HS;
+    float* ACT0 = YS + US;
     float* ACT1 = ACT0 + DS;
     float* KO = ACT1 + DS;      // f(z).dX of the stage
     float* DX = KO + HS;        // [C/4][NSP][4]
     unsigned* XB = reinterpret_cast<unsigned*>(DX + a.C * NSP);   // BF: x_L as three bf16 pieces, B-operand order
+    if constexpr (DIRECT != 0) {
+        for (int e = HS + tid; e < US; e += NT) YS[e] = 0.0f;      // rows H + C .. of the padded input stay zero
+    }
 
     // state slice of this thread: element e = tid + q * NT of the [H/4][NSP][4] arrays
     float y0[EM], k1[EM], k2[EM];
@@ -520,7 +572,9 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
         for (int j = 0; j < S; ++j) {
             const StageDesc sd = planned ? plan_stage(pstep, j) : default_stage(a.method, (float)n + stage_offset(a.method, j), a.n_pieces);
             const int idx = sd.idx;
-            if (a.interp != NCDE_INTERP_LINEAR || idx != cur_idx) {
+            if constexpr (DIRECT != 0) {
+                tl_load_cin<NS, NT>(a, b0, sd, a.field_input == NCDE_INPUT_EVALUATE, YS, H, tid);
+            } else if (a.interp != NCDE_INTERP_LINEAR || idx != cur_idx) {
                 tl_load_dx<NS, NT>(a, b0, idx, sd.frac, sd.kdt, DX, tid);
                 cur_idx = idx;
             }
@@ -566,6 +620,11 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                 __syncthreads();
                 in = outb;
             }
+            float* KG = in == ACT0 ? ACT1 : ACT0;      // direct gated head: the free ping-pong buffer takes sigmoid(Wg x_L + bg)
+            if constexpr (DIRECT != 0) {
+                tl_dense_relu<NS, NWV, 1>(a.Wo, a.bo, H, dlast, in, KO, wave, lane);
+                if constexpr (GATED != 0) tl_dense_relu<NS, NWV, 2>(a.Wg, a.bg, H, dlast, in, KG, wave, lane);
+            } else
             if constexpr (BF != 0) {
                 switch (nkb_o) {
                     case 8: tl_output_bf<4, NWV, GATED>(a, XB, DX, KO, wave, lane); break;
@@ -591,7 +650,8 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                 if (e < HS) {
                     const float yprev = y0[q];
                     bool last;
-                    const float ys = StageCombine::apply(a.method, j, KO[e], dt, y0[q], k1[q], k2[q], last);   // dt = 1: exact products
+                    const float kst = (DIRECT != 0 && GATED != 0) ? KG[e] * KO[e] : KO[e];
+                    const float ys = StageCombine::apply(a.method, j, kst, dt, y0[q], k1[q], k2[q], last);   // dt = 1: exact products
                     YS[e] = ys;
                     if (last) {
                         const int u = ((e >> 2) / NSP) * 4 + (e & 3), s = (e >> 2) % NSP, b = b0 + s;
@@ -1734,6 +1794,10 @@ void tiled_pack_launch(const NcdeProblem* p, KArgs* a, float* dst, bool bf, hipS
 size_t tiled_fwd_lds(const NcdeProblem* p, int ns) {
     // (+ the split image of x_L for the bf16 output tiles, NS = 1: 6 bytes per element)
     const size_t xb = ns == 1 ? (size_t)p->layer_out[p->n_layers - 1] * 16 * 6 : 0;
+    if (p->field_input != NCDE_INPUT_MATMUL) {      // direct modes: the stage input carries H + C rows (padded), D covers it
+        const int d0p = (p->layer_in[0] + 15) & ~15, D = std::max(tiled_dmax(p), d0p);
+        return sizeof(float) * (size_t)(ns * 16) * (size_t)(std::max(p->hidden, d0p) + p->hidden + 2 * D + p->channels) + xb;
+    }
     return sizeof(float) * (size_t)(ns * 16) * (size_t)(2 * p->hidden + 2 * tiled_dmax(p) + p->channels) + xb;
 }
 
@@ -1858,9 +1922,18 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
 bool ncde_tiled_supported(const NcdeProblem* p, int pass) {
     if (p->n_layers < 1 || p->hidden % 16 || p->channels % 4) return false;
     auto aligned = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    // field variants: the minimal-gated field with the matmul input (a second head on the same activations)
-    if (p->field_input != NCDE_INPUT_MATMUL) return false;
     if (p->field_kind == NCDE_FIELD_GRU) return false;
+    if (p->field_input != NCDE_INPUT_MATMUL) {
+        // evaluate / derivative inputs: the FORWARD only (one sample tile per workgroup; layer 0 is re-laid out with its H + C
+        // columns padded to a multiple of 16, so its own alignment does not matter); the backward stays on the variant kernels
+        if (pass != 0 || p->layer_in[0] != p->hidden + p->channels) return false;
+        for (int l = 0; l < p->n_layers; ++l)
+            if (p->layer_out[l] % 16 || (l > 0 && (p->layer_in[l] % 16 || !aligned(p->layer_W[l]))) || !aligned(p->layer_b[l])) return false;
+        if (!aligned(p->Wo) || !aligned(p->bo)) return false;
+        if (p->field_kind == NCDE_FIELD_MINIMAL && (!aligned(p->Wg) || !aligned(p->bg))) return false;
+        return tiled_fwd_lds(p, 1) <= (size_t)kLdsLimit && p->hidden * 16 <= TL_EMAX * TL_THREADS;
+    }
+    // field variants: the minimal-gated field with the matmul input (a second head on the same activations)
     if (p->field_kind == NCDE_FIELD_MINIMAL) {
         const int nkb = p->layer_out[p->n_layers - 1] / 16;
         if (!aligned(p->Wg) || !aligned(p->bg) || !(nkb == 1 || nkb == 2 || nkb == 4 || nkb == 8)) return false;
@@ -1889,6 +1962,7 @@ const char* ncde_tiled_kernel_name(const NcdeProblem* p, int pass) {
     }
     if (pass == 1) return gated ? "ncde_adj_tiled<gated>+ncde_dwo_tiled" : "ncde_adj_tiled+ncde_dwo_tiled";
     if (pass == 2) return gated ? "ncde_adj_tiled<gated,discrete>+ncde_dwo_tiled" : "ncde_adj_tiled<discrete>+ncde_dwo_tiled";
+    if (p->field_input != NCDE_INPUT_MATMUL) return gated ? "ncde_fwd_tiled<NS1,gated,direct>" : "ncde_fwd_tiled<NS1,direct>";
     const int ns = tiled_fwd_ns(p);
     if (tiled_fwd_bf(p)) return gated ? "ncde_fwd_tiled<NS1,gated,bf16>" : "ncde_fwd_tiled<NS1,bf16>";
     if (gated) return ns == 4 ? "ncde_fwd_tiled<NS4,gated>" : (ns == 2 ? "ncde_fwd_tiled<NS2,gated>" : "ncde_fwd_tiled<NS1,gated>");
@@ -1897,6 +1971,7 @@ const char* ncde_tiled_kernel_name(const NcdeProblem* p, int pass) {
 
 int64_t ncde_tiled_workspace_bytes(const NcdeProblem* p, int pass) {
     if (!ncde_tiled_supported(p, pass)) return NCDE_ERR_UNSUPPORTED;
+    if (pass == 0 && p->field_input != NCDE_INPUT_MATMUL) return 256 + (int64_t)sizeof(float) * p->layer_out[0] * ((p->layer_in[0] + 15) & ~15);
     if (pass == 0) return 256 + tiled_pack_floats(p, tiled_fwd_bf(p)) * (int64_t)sizeof(float);
     const Layout y = make_layout(p);
     return (int64_t)sizeof(float) * tiled_adj_plan(p, y).total;
@@ -1910,9 +1985,16 @@ int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws
     fill_kargs(p, y, &a);
     a.out = out;
     a.stages = stages;
-    const bool bf = tiled_fwd_bf(p);
-    if (tiled_pack_floats(p, bf) > 0) tiled_pack_launch(p, &a, (float*)ws + 64, bf, st);
-    const int ns = tiled_fwd_ns(p);
+    const bool direct = p->field_input != NCDE_INPUT_MATMUL;
+    const bool bf = !direct && tiled_fwd_bf(p);
+    if (direct) {      // layer 0 with its H + C columns zero-padded to a multiple of 16
+        const int d0p = (p->layer_in[0] + 15) & ~15, n0 = p->layer_out[0];
+        float* w0 = (float*)ws + 64;
+        hipLaunchKernelGGL(ncde_pad_columns, dim3((n0 * d0p + 255) / 256), dim3(256), 0, st, a.W[0], w0, n0, p->layer_in[0], d0p);
+        a.W[0] = w0;
+        a.din[0] = d0p;
+    } else if (tiled_pack_floats(p, bf) > 0) tiled_pack_launch(p, &a, (float*)ws + 64, bf, st);
+    const int ns = direct ? 1 : tiled_fwd_ns(p);
     const size_t lds = tiled_fwd_lds(p, ns);
     const bool small = p->hidden * ns * 16 <= 4 * TL_THREADS;   // state slice of <= 4 elements per thread: fewer live registers
     void (*fn)(KArgs) = ns == 4 ? (small ? ncde_fwd_tiled<4, TL_NW, 4> : ncde_fwd_tiled<4, TL_NW, 16>)
@@ -1931,6 +2013,10 @@ int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws
             if (p->hidden == 32) fn = g ? ncde_fwd_tiled<1, TL_NW, 4, 1, 1, 2> : ncde_fwd_tiled<1, TL_NW, 4, 0, 1, 2>;
             else fn = g ? ncde_fwd_tiled<1, TL_NW, 4, 1, 1, 4> : ncde_fwd_tiled<1, TL_NW, 4, 0, 1, 4>;
         }
+    }
+    if (direct) {
+        if (p->field_kind == NCDE_FIELD_MINIMAL) fn = small ? ncde_fwd_tiled<1, TL_NW, 4, 1, 0, 0, 1> : ncde_fwd_tiled<1, TL_NW, 16, 1, 0, 0, 1>;
+        else fn = small ? ncde_fwd_tiled<1, TL_NW, 4, 0, 0, 0, 1> : ncde_fwd_tiled<1, TL_NW, 16, 0, 0, 0, 1>;
     }
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NCDE_ERR_HIP;
     const int nwg = (p->batch + ns * 16 - 1) / (ns * 16);

@@ -783,6 +783,57 @@ def test_general_time_axis_on_the_batch_tiled_family_vs_oracle(kind, interp, met
     assert np.sum(per <= E2E_G) >= B - 2, np.sort(per)[-4:]
 
 
+@pytest.mark.parametrize("kind", ["original", "minimal"])
+@pytest.mark.parametrize("mode,interp,method", [("evaluate", "linear", "rk4"), ("derivative", "cubic", "midpoint"), ("evaluate", "cubic", "euler")])
+def test_evaluate_derivative_inputs_on_the_batch_tiled_forward(kind, mode, interp, method, gpu_lib):
+    """The evaluate / derivative input modes (field input [z, X(t)] / [z, dX/dt]; H-row heads) where every width is a multiple
+    of 16 and C of 4: the forward runs on the batch-tiled family (layer 0 re-laid out with its H + C columns zero-padded), the
+    backward on the variant kernels.  Against the oracle (variant fields pinned to the reference on g9): forward, continuous
+    adjoint and exact discrete backward end to end, default axis and a general one; and the variant-kernel forward agrees."""
+    import gpu_util
+    import ncde_oracle as orc
+    from ncde_amd import _lib
+    B, L, C, H, HH, nl = 37, 7, 8, 32, 48, 3
+    coeffs = gu.data.make_cubic_coeffs(B, L, C - 1, seed=61) if interp == "cubic" else gu.data.make_rectilinear_coeffs(B, L, C - 1, missing=0.3, seed=61)
+    p = gu.data.make_variant_weights(H, HH, C, seed=29, kind=kind, mode=mode)
+    z0 = (gu.data.normal(47, B * H, stream=2).reshape(B, H) * 0.5).astype(np.float32)
+    field = orc.Field.variant(p, H, C, nl, kind, mode)
+    ctl = orc.Control(coeffs, interp)
+    names = [n for n in ("W0", "b0", "W1", "b1", "Wg", "bg", "Wo", "bo") if n in p]
+    layers = [("W0", "b0")] + [("W1", "b1")] * (nl - 1)
+    meta = {"kind": interp, "method": method, "sequence": True, "param_names": names, "field_kind": kind, "field_mode": mode,
+            "dims": {"C": C, "H": H, "HH": HH, "nl": nl}, "field": "original"}
+    z = orc.solve_forward(ctl, field, z0, method, True)
+    gout = (gu.data.normal(31, z.numel(), stream=1).reshape(z.shape) / np.sqrt(z.shape[1])).astype(np.float32)
+    dz0, gp = orc.solve_adjoint(ctl, field, z, gout, method, True)
+    bdz0, bgp = orc.solve_discrete_backward(ctl, field, z0, gout, method, True)
+    case = {"meta": meta, "coeffs": coeffs, "z0": z0, "params": p, "layers": layers, "H": H, "C": C, "expect": {"grad_out": gout}}
+    res = gpu_util.run_case(case)
+    assert res["kernels"][0] == ("ncde_fwd_tiled<NS1,gated,direct>" if kind == "minimal" else "ncde_fwd_tiled<NS1,direct>"), res["kernels"]
+    assert res["kernels"][1] == "ncde_adj_variant"
+    assert gu.relerr(res["z_out"], z) <= TIGHT_Z, gu.relerr(res["z_out"], z)
+    assert gu.relerr(res["dz0"], dz0) <= E2E_G
+    for n_, g_ in zip(names, gp):
+        assert gu.relerr(res["grads"][n_], g_) <= E2E_G, n_
+    resd = gpu_util.run_case(case, adjoint=False)                 # the tiled forward writes the stage record the variant backward reads
+    assert np.array_equal(resd["z_out"], res["z_out"])
+    assert gu.relerr(resd["dz0"], bdz0) <= E2E_G
+    for n_, g_ in zip(names, bgp):
+        assert gu.relerr(resd["grads"][n_], g_) <= E2E_G, ("discrete", n_)
+    ref = gpu_util.run_case(case, flags=_lib.FLAG_FORCE_GENERIC, need_grads=False)      # the variant kernels' own forward
+    assert ref["kernels"][0] == "ncde_fwd_variant" and gu.relerr(ref["z_out"], z) <= TIGHT_Z
+    # general time axis (step 0.5, off-grid outputs) through the same tiled forward
+    tout = np.array([0.0, 1.25, 3.0, float(ctl.n_knots - 1) - 0.5], np.float32)
+    zt = orc.solve_forward_times(ctl, field, z0, tout, method, 0.5)
+    gt = (gu.data.normal(33, zt.numel(), stream=1).reshape(zt.shape) / 2.0).astype(np.float32)
+    dzt, gpt = orc.solve_adjoint_times(ctl, field, tout, zt, gt, method, 0.5)
+    rt = gpu_util.run_times_case({"coeffs": coeffs, "z0": z0, "t_out": tout, "grad_out": gt}, {"kind": interp, "method": method, "step_size": 0.5, "dims": {"nl": nl}},
+                                 adjoint=True, kind=kind, mode=mode, params=p)
+    assert gu.relerr(rt["z_out"], zt) <= TIGHT_Z and gu.relerr(rt["dz0"], dzt) <= E2E_G
+    for n_, g_ in zip(names, gpt):
+        assert gu.relerr(rt["grads"][n_], g_) <= E2E_G, ("times", n_)
+
+
 def test_variant_gradient_partial_in_global_memory_is_reproducible(gpu_lib):
     """GRU-gated field with the matmul input at cfg2 widths: the two 640 x 32 heads do not fit LDS, so the variant adjoint keeps
     its per-workgroup gradient partial in global memory and accumulates into it with no-return float atomics (every address
