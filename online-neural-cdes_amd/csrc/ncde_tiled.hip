@@ -817,9 +817,11 @@ __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, c
 }
 
 // out[i][s] = sum_j W[j][i] gpre[j][s]  (x relu'(xin[i][s]) when mask); W [N][K] row-major.
+// W2 / gpre2 (same shape): + sum_j W2[j][i] gpre2[j][s] in the same accumulator (the two heads of the gated direct modes).
 template <int NWV>
 __device__ __forceinline__ void tl_hidden_bwd(const float* __restrict__ W, int N, int K, const float* gpre, const float* xin,
-                                              bool mask, float* out, int wave, int lane) {
+                                              bool mask, float* out, int wave, int lane, const float* __restrict__ W2 = nullptr,
+                                              const float* gpre2 = nullptr) {
     constexpr int NSP = 16;
     const int li = lane & 15, lk = lane >> 4;
     const int nkb = N >> 4;
@@ -834,6 +836,18 @@ __device__ __forceinline__ void tl_hidden_bwd(const float* __restrict__ W, int N
             const f32x4 Bv = *reinterpret_cast<const f32x4*>(gpre + ((4 * kb + lk) * NSP + li) * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = mfma16(av[e], Bv[e], acc);
+        }
+        if (W2) {
+            const float* wcol2 = W2 + (long long)(4 * lk) * K + 16 * it + li;
+#pragma unroll 4
+            for (int kb = 0; kb < nkb; ++kb) {
+                float av[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[e] = wcol2[(long long)(16 * kb + e) * K];
+                const f32x4 Bv = *reinterpret_cast<const f32x4*>(gpre2 + ((4 * kb + lk) * NSP + li) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = mfma16(av[e], Bv[e], acc);
+            }
         }
         const int o = ((4 * it + lk) * NSP + li) * 4;
         if (mask) {
@@ -875,9 +889,14 @@ __device__ __forceinline__ void tl_dw_acc(const float* gpre, const float* xin, i
 // number of output tiles, gated heads, split records -- the hidden phases, six per stage, no longer start with an L2 round trip.
 // BF = 1: x_L is additionally kept as three bf16 pieces (XBA, written by the last hidden layer) and THAT image is what pass B
 // gets as its record A, so the recompute of P there runs on the bf16 matrix cores.
-template <int PK, int NWV, int RES = 0, int GATED = 0, int BF = 0>
+// DIRECT = 1: the evaluate / derivative input modes (see ncde_fwd_tiled): the stage input carries the control rows, layer 0
+// arrives column-padded (a.din[0]; its gradient is written back with the real row stride a.d0), the heads are H-row dense
+// layers whose VJP and parameter gradients (register accumulators, like the hidden layers') stay in this kernel -- no records,
+// no pass B, one launch for the whole sweep.
+template <int PK, int NWV, int RES = 0, int GATED = 0, int BF = 0, int DIRECT = 0>
 __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     static_assert(BF == 0 || (RES != 1 && PK >= 2), "split record: streamed output tiles, last hidden width a multiple of 32");
+    static_assert(DIRECT == 0 || (RES == 0 && BF == 0), "direct heads: streamed fp32 layers");
     constexpr int NT = 64 * NWV, TL_EADJ = RES ? (16 * 16 * PK + NT - 1) / NT : 2048 / NT;
     constexpr int TL_DWT = RES ? (PK * PK + NWV - 1) / NWV : 64 / NWV;   // hidden dW tiles per wave and weight slot
     constexpr int NSP = 16, SCW = (16 * (16 * PK + 4) > 16 * PK * NSP) ? 16 * (16 * PK + 4) : 16 * PK * NSP;
@@ -888,12 +907,14 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     const int H = a.H, C = a.C, L = a.n_layers;
     int D = H;
     for (int l = 0; l < L; ++l) D = max(D, a.dout[l]);
+    if (DIRECT) D = max(D, a.din[0]);
     const int HS = H * NSP, DS = D * NSP;
+    const int US = DIRECT ? max(H, a.din[0]) * NSP : HS;      // direct modes: H + C (padded) rows of field input / of its cotangent
     float* YS = lds;               // stage input y (= x_0)
-    float* AS = YS + HS;           // stage cotangent
+    float* AS = YS + US;           // stage cotangent
     float* KOY = AS + HS;          // f(y).dX of the stage
     float* KOA = KOY + HS;         // J^T cotangent of the stage
-    float* X = KOA + HS;           // x_1 .. x_L
+    float* X = KOA + US;           // x_1 .. x_L
     float* G0 = X + L * DS;
     float* G1 = G0 + DS;
     float* DX = G1 + DS;           // [C/4][16][4]
@@ -902,7 +923,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     unsigned* XBA = reinterpret_cast<unsigned*>(SC + NWV * SCW);   // BF: split image of x_L (24 words per unit)
     const bool disc = a.discrete != 0;
     const int S = n_stages(a.method);
-    const int dlast = 16 * PK;
+    const int dlast = DIRECT ? a.dout[L - 1] : 16 * PK;      // direct heads: any multiple of 16 (PK only sizes the unused tile scratch)
     const int last_row = a.n_out - 1;
     const int n_st = gridDim.x;
     // general time axis (a.plan): reverse step n = n_rsteps .. 1 is plan step rstep = n_rsteps - n of the adjoint table
@@ -946,11 +967,21 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
             }
         }
     }
+    if constexpr (DIRECT != 0) {
+        for (int e = HS + tid; e < US; e += NT) YS[e] = 0.0f;      // rows H + C .. of the padded field input stay zero
+    }
     // hidden-layer parameter gradients: at most two distinct (W, b) pairs (layer 0, and ONE matrix shared by the rest)
     f32x4 dw0[TL_DWT], dw1[TL_DWT];
     float db0 = 0.0f, db1 = 0.0f;
 #pragma unroll
     for (int q = 0; q < TL_DWT; ++q) dw0[q] = dw1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // DIRECT: the heads' parameter gradients, same scheme (tiles tt = wave + NWV q of [H][dlast])
+    f32x4 dwo[DIRECT ? TL_DWT : 1], dwg[(DIRECT && GATED) ? TL_DWT : 1];
+    float dbo = 0.0f, dbg = 0.0f;
+#pragma unroll
+    for (int q = 0; q < (DIRECT ? TL_DWT : 1); ++q) dwo[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < ((DIRECT && GATED) ? TL_DWT : 1); ++q) dwg[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (a.resume) {      // continue this workgroup's hidden-layer partial where the previous window stopped
         const float* gp = a.gpart + (long long)blockIdx.x * a.gstride;
         const int li = lane & 15, lk = lane >> 4;
@@ -1035,13 +1066,21 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                 const int s = e / C, c = e - s * C, b = b0 + s;
                 if (b < a.B) {
                     const float* cp = a.coeffs + (long long)b * a.cs_b + (long long)idx * a.cs_t;
+                    const bool value = DIRECT != 0 && a.field_input == NCDE_INPUT_EVALUATE;      // X(t) instead of dX/dt(t)
                     if (a.interp == NCDE_INTERP_LINEAR) {
                         v = cp[a.cs_t + c] - cp[c];
-                        if (kdt != 1.0f) v = v / kdt;
+                        if (value) v = cp[c] + (frac * v) / kdt;
+                        else if (kdt != 1.0f) v = v / kdt;
                     } else {
                         const float bb = cp[C + c], cc = cp[2 * C + c], dd = cp[3 * C + c];
-                        const float inner = cc + dd * frac;
-                        v = bb + inner * frac;
+                        if (value) {
+                            float inner = 0.5f * cc + (dd * frac) / 3.0f;
+                            inner = bb + inner * frac;
+                            v = cp[c] + inner * frac;
+                        } else {
+                            const float inner = cc + dd * frac;
+                            v = bb + inner * frac;
+                        }
                     }
                 }
             }
@@ -1067,7 +1106,8 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
             const int e = tid + q * NT;
             if (e < NSP * C) {
                 const int s = e / C, c = e - s * C;
-                DX[((c >> 2) * NSP + s) * 4 + (c & 3)] = dxn[q];
+                if constexpr (DIRECT != 0) YS[(((H + c) >> 2) * NSP + s) * 4 + ((H + c) & 3)] = dxn[q];      // control rows of the field input
+                else DX[((c >> 2) * NSP + s) * 4 + (c & 3)] = dxn[q];
             }
         }
         if (disc) {
@@ -1130,64 +1170,102 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                 __syncthreads();
                 in = outb;
             }
-            // ---- output layer: f, dP, per-wave partial of dL/dx_L -----------------------------------------------------
-            tl_output_vjp<PK, NWV, RES, GATED, (BF != 0 && GATED == 0) ? 1 : 0>(a, in, AS, DX, KOY, scr, wave, lane, wo, XBA);
-            // ---- records for pass B (x_L twice, weighted cotangent, dX/dt) --------------------------------------------
-            {
-                const long long tile = (long long)sc * n_st + blockIdx.x;
-                float* ra = a.recA + tile * (BF != 0 ? dlast * 24 : dlast * NSP);
-                float* rc = a.recC + tile * (H * NSP);
-                float* rd = a.recD + tile * (C * NSP);
-                if constexpr (BF != 0) {
-                    for (int e = tid; e < dlast * 6; e += NT)
-                        reinterpret_cast<u32x4*>(ra)[e] = reinterpret_cast<const u32x4*>(XBA)[e];
-                    // record B, split and PAIRED: sample tiles 2i and 2i+1 share one block, the K = 32 samples of the bf16 MFMA
-                    // that accumulates dWo in pass B.  Word ((jt * 3 + piece) * 64 + lane) * 4 + 2 half + d of the pair's block
-                    // holds x_L[k = 16 jt + (lane & 15)][samples 4 (lane >> 4) + 2 d, + 1] of tile `half`.
-                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                    unsigned* rbp = reinterpret_cast<unsigned*>(a.recB) + ((long long)sc * ((n_st + 1) >> 1) + (blockIdx.x >> 1)) * (dlast * 48);
-                    const int half = blockIdx.x & 1;
-                    for (int e = tid; e < dlast * 4; e += NT) {
-                        const int k = e >> 2, kg = e & 3, ln = (k & 15) + 16 * kg;
-                        float v[4];
+            if constexpr (DIRECT != 0) {
+                // ---- direct heads: m = tanh(Wo x_L + bo) (x sigmoid(Wg x_L + bg)) IS dz/dt; cotangents of the two pre-activations ----
+                float* DPT = G0;      // dL/dPt  [H][16]
+                float* SG = SC;       // sigmoid(Pg), then dL/dPg (the per-wave scratch area is free in this mode)
+                tl_dense_relu<1, NWV, 1>(a.Wo, a.bo, H, dlast, in, KOY, wave, lane);
+                if constexpr (GATED != 0) tl_dense_relu<1, NWV, 2>(a.Wg, a.bg, H, dlast, in, SG, wave, lane);
+                __syncthreads();
+                for (int e = tid; e < HS; e += NT) {
+                    const float th = KOY[e], dm = AS[e];
+                    if constexpr (GATED != 0) {
+                        const float sg = SG[e];
+                        KOY[e] = sg * th;
+                        DPT[e] = (dm * sg) * (1.0f - th * th);
+                        SG[e] = (dm * th) * (sg * (1.0f - sg));
+                    } else {
+                        DPT[e] = dm * (1.0f - th * th);
+                    }
+                }
+                __syncthreads();
+                if (w != 0.0f) {      // head parameter gradients (x_L = `in`)
+                    tl_dw_acc<NWV, TL_DWT>(DPT, in, H, dlast, w, dwo, wave, lane);
+                    if constexpr (GATED != 0) tl_dw_acc<NWV, TL_DWT>(SG, in, H, dlast, w, dwg, wave, lane);
+                    if (tid < H) {
+                        float sum = 0.0f, sumg = 0.0f;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = in[((k >> 2) * NSP + 4 * kg + q) * 4 + (k & 3)];
-                        unsigned h0, m0, l0, h1, m1, l1;
-                        split_pair(v[0], v[1], h0, m0, l0);
-                        split_pair(v[2], v[3], h1, m1, l1);
-                        unsigned* dst = rbp + (((k >> 4) * 3) * 64 + ln) * 4 + 2 * half;
-                        *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
-                        *reinterpret_cast<u32x2*>(dst + 256) = (u32x2){m0, m1};
-                        *reinterpret_cast<u32x2*>(dst + 512) = (u32x2){l0, l1};
-                        if (half == 0 && blockIdx.x + 1 == n_st) {      // odd tile count: the missing partner contributes zeros
-                            *reinterpret_cast<u32x2*>(dst + 2) = (u32x2){0u, 0u};
-                            *reinterpret_cast<u32x2*>(dst + 258) = (u32x2){0u, 0u};
-                            *reinterpret_cast<u32x2*>(dst + 514) = (u32x2){0u, 0u};
+                        for (int s = 0; s < NSP; ++s) {
+                            sum += DPT[((tid >> 2) * NSP + s) * 4 + (tid & 3)];
+                            if constexpr (GATED != 0) sumg += SG[((tid >> 2) * NSP + s) * 4 + (tid & 3)];
+                        }
+                        dbo += w * sum;
+                        dbg += w * sumg;
+                    }
+                }
+                // dL/dpre_L = (Wo^T dPt + Wg^T dPg) relu'(x_L)
+                tl_hidden_bwd<NWV>(a.Wo, H, dlast, DPT, in, true, G1, wave, lane, GATED != 0 ? a.Wg : nullptr, GATED != 0 ? SG : nullptr);
+                __syncthreads();
+            } else {
+                // ---- output layer: f, dP, per-wave partial of dL/dx_L -----------------------------------------------------
+                tl_output_vjp<PK, NWV, RES, GATED, (BF != 0 && GATED == 0) ? 1 : 0>(a, in, AS, DX, KOY, scr, wave, lane, wo, XBA);
+                // ---- records for pass B (x_L twice, weighted cotangent, dX/dt) --------------------------------------------
+                {
+                    const long long tile = (long long)sc * n_st + blockIdx.x;
+                    float* ra = a.recA + tile * (BF != 0 ? dlast * 24 : dlast * NSP);
+                    float* rc = a.recC + tile * (H * NSP);
+                    float* rd = a.recD + tile * (C * NSP);
+                    if constexpr (BF != 0) {
+                        for (int e = tid; e < dlast * 6; e += NT)
+                            reinterpret_cast<u32x4*>(ra)[e] = reinterpret_cast<const u32x4*>(XBA)[e];
+                        // record B, split and PAIRED: sample tiles 2i and 2i+1 share one block, the K = 32 samples of the bf16 MFMA
+                        // that accumulates dWo in pass B.  Word ((jt * 3 + piece) * 64 + lane) * 4 + 2 half + d of the pair's block
+                        // holds x_L[k = 16 jt + (lane & 15)][samples 4 (lane >> 4) + 2 d, + 1] of tile `half`.
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        unsigned* rbp = reinterpret_cast<unsigned*>(a.recB) + ((long long)sc * ((n_st + 1) >> 1) + (blockIdx.x >> 1)) * (dlast * 48);
+                        const int half = blockIdx.x & 1;
+                        for (int e = tid; e < dlast * 4; e += NT) {
+                            const int k = e >> 2, kg = e & 3, ln = (k & 15) + 16 * kg;
+                            float v[4];
+    #pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] = in[((k >> 2) * NSP + 4 * kg + q) * 4 + (k & 3)];
+                            unsigned h0, m0, l0, h1, m1, l1;
+                            split_pair(v[0], v[1], h0, m0, l0);
+                            split_pair(v[2], v[3], h1, m1, l1);
+                            unsigned* dst = rbp + (((k >> 4) * 3) * 64 + ln) * 4 + 2 * half;
+                            *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
+                            *reinterpret_cast<u32x2*>(dst + 256) = (u32x2){m0, m1};
+                            *reinterpret_cast<u32x2*>(dst + 512) = (u32x2){l0, l1};
+                            if (half == 0 && blockIdx.x + 1 == n_st) {      // odd tile count: the missing partner contributes zeros
+                                *reinterpret_cast<u32x2*>(dst + 2) = (u32x2){0u, 0u};
+                                *reinterpret_cast<u32x2*>(dst + 258) = (u32x2){0u, 0u};
+                                *reinterpret_cast<u32x2*>(dst + 514) = (u32x2){0u, 0u};
+                            }
+                        }
+                    } else {
+                        float* rb = a.recB + tile * (dlast * NSP);
+                        for (int e = tid; e < dlast * NSP; e += NT) {
+                            ra[e] = in[e];
+                            const int jj = e >> 4, s = e & 15;
+                            rb[e] = in[((jj >> 2) * NSP + s) * 4 + (jj & 3)];
                         }
                     }
-                } else {
-                    float* rb = a.recB + tile * (dlast * NSP);
-                    for (int e = tid; e < dlast * NSP; e += NT) {
-                        ra[e] = in[e];
-                        const int jj = e >> 4, s = e & 15;
-                        rb[e] = in[((jj >> 2) * NSP + s) * 4 + (jj & 3)];
+                    for (int e = tid; e < H * NSP; e += NT) {
+                        const int hh = e >> 4, s = e & 15;
+                        rc[e] = w * AS[((hh >> 2) * NSP + s) * 4 + (hh & 3)];
                     }
+                    for (int e = tid; e < C * NSP; e += NT) rd[e] = DX[e];
                 }
-                for (int e = tid; e < H * NSP; e += NT) {
-                    const int hh = e >> 4, s = e & 15;
-                    rc[e] = w * AS[((hh >> 2) * NSP + s) * 4 + (hh & 3)];
+                __syncthreads();
+                // ---- dL/dpre_L = (sum of the 8 partials) * relu'(x_L) ---------------------------------------------------------
+                for (int e = tid; e < dlast * NSP; e += NT) {
+                    float g = 0.0f;
+    #pragma unroll
+                    for (int wv = 0; wv < NWV; ++wv) g += SC[wv * SCW + e];
+                    G1[e] = in[e] > 0.0f ? g : 0.0f;
                 }
-                for (int e = tid; e < C * NSP; e += NT) rd[e] = DX[e];
+                __syncthreads();
             }
-            __syncthreads();
-            // ---- dL/dpre_L = (sum of the 8 partials) * relu'(x_L) ---------------------------------------------------------
-            for (int e = tid; e < dlast * NSP; e += NT) {
-                float g = 0.0f;
-#pragma unroll
-                for (int wv = 0; wv < NWV; ++wv) g += SC[wv * SCW + e];
-                G1[e] = in[e] > 0.0f ? g : 0.0f;
-            }
-            __syncthreads();
             // ---- hidden layers backwards ----------------------------------------------------------------------------------
             float* gpre = G1;
             float* gx = G0;
@@ -1335,11 +1413,33 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                 if (tt < ntile) {
                     const int jt = tt / nit, it = tt - jt * nit;
                     const f32x4 v = slot == 0 ? dw0[q] : dw1[q];
+                    // DIRECT: layer 0 was processed with its columns padded to K; the gradient goes back with the real row stride
+                    const int Kreal = (DIRECT != 0 && l == 0) ? a.d0 : K;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) gp[a.gW_off[l] + (16 * jt + 4 * lk + r) * K + 16 * it + li] = v[r];
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * it + li < Kreal) gp[a.gW_off[l] + (16 * jt + 4 * lk + r) * Kreal + 16 * it + li] = v[r];
                 }
             }
             if (tid < N) gp[a.gb_off[l] + tid] = slot == 0 ? db0 : db1;
+        }
+        if constexpr (DIRECT != 0) {      // the heads' gradients: [H][dlast] each
+            const int nit = dlast >> 4, ntile = (H >> 4) * nit;
+#pragma unroll
+            for (int q = 0; q < TL_DWT; ++q) {
+                const int tt = wave + NWV * q;
+                if (tt < ntile) {
+                    const int jt = tt / nit, it = tt - jt * nit;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        gp[a.gWo_off + (16 * jt + 4 * lk + r) * dlast + 16 * it + li] = dwo[q][r];
+                        if constexpr (GATED != 0) gp[a.gWg_off + (16 * jt + 4 * lk + r) * dlast + 16 * it + li] = dwg[q][r];
+                    }
+                }
+            }
+            if (tid < H) {
+                gp[a.gbo_off + tid] = dbo;
+                if constexpr (GATED != 0) gp[a.gbg_off + tid] = dbg;
+            }
         }
     }
 }
@@ -1828,8 +1928,14 @@ bool tiled_adj_res(const NcdeProblem* p) {
     return res;
 }
 size_t tiled_adj_lds_base(const NcdeProblem* p) {
-    const int pk = tiled_adj_pk(p), D = tiled_dmax(p);
+    const int pk = p->field_input != NCDE_INPUT_MATMUL ? 1 : tiled_adj_pk(p);      // direct modes run the PK = 1 instantiation
+    int D = tiled_dmax(p);
     const int scw = std::max(16 * (16 * pk + 4), 16 * pk * 16);
+    if (p->field_input != NCDE_INPUT_MATMUL) {      // direct modes: the field input and its cotangent carry H + C (padded) rows
+        const int d0p = (p->layer_in[0] + 15) & ~15, U = std::max(p->hidden, d0p);
+        D = std::max(D, d0p);
+        return sizeof(float) * (size_t)(2 * U * 16 + 2 * p->hidden * 16 + (p->n_layers + 2) * D * 16 + p->channels * 16 + TL_ADJ_NW * scw);
+    }
     return sizeof(float) * (size_t)(4 * p->hidden * 16 + (p->n_layers + 2) * D * 16 + p->channels * 16 + TL_ADJ_NW * scw);
 }
 // hidden matrices resident, output tiles streamed (RES = 2): small square hidden stacks that do not qualify for RES = 1
@@ -1843,7 +1949,7 @@ bool tiled_adj_res2(const NcdeProblem* p) {
 // x_L in the sweep's LDS, and the caller did not ask for plain fp32-input MFMA
 bool tiled_adj_bf(const NcdeProblem* p) {
     const int pk = tiled_adj_pk(p);
-    return !(p->flags & NCDE_FLAG_FP32_MFMA) && pk >= 2 && !tiled_adj_res(p) &&
+    return !(p->flags & NCDE_FLAG_FP32_MFMA) && pk >= 2 && !tiled_adj_res(p) && p->field_input == NCDE_INPUT_MATMUL &&
            tiled_adj_lds_base(p) + (size_t)pk * 16 * 16 * 6 <= (size_t)kLdsLimit;
 }
 size_t tiled_adj_lds(const NcdeProblem* p) {
@@ -1851,10 +1957,12 @@ size_t tiled_adj_lds(const NcdeProblem* p) {
 }
 
 bool tiled_adj_ok(const NcdeProblem* p) {
-    if (tiled_adj_pk(p) == 0 || p->hidden * 16 > 2048 || p->channels > 80) return false;
+    const bool direct = p->field_input != NCDE_INPUT_MATMUL;
+    if ((!direct && tiled_adj_pk(p) == 0) || p->hidden * 16 > 2048 || p->channels > 80) return false;
     int l1 = -1;
+    if (direct && (p->hidden / 16) * (p->layer_out[p->n_layers - 1] / 16) > 64) return false;      // direct heads: [H][dlast] tiles
     for (int l = 0; l < p->n_layers; ++l) {
-        if (p->layer_out[l] > 64 * TL_ADJ_NW || (p->layer_out[l] / 16) * (p->layer_in[l] / 16) > 64) return false;
+        if (p->layer_out[l] > 64 * TL_ADJ_NW || (p->layer_out[l] / 16) * ((p->layer_in[l] + 15) / 16) > 64) return false;
         for (int q = 0; q < l; ++q)
             if ((p->layer_W[l] == p->layer_W[q]) != (p->layer_b[l] == p->layer_b[q])) return false;
         if (l >= 1 && p->layer_W[l] != p->layer_W[0]) {   // at most two distinct matrices: layer 0's and ONE other
@@ -1889,6 +1997,21 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
     t.n_st = (p->batch + 15) / 16;
     t.gstride = y.gWo_off;
     const bool bf = tiled_adj_bf(p);
+    if (p->field_input != NCDE_INPUT_MATMUL) {      // direct modes: no records, no pass B; partials carry every parameter
+        t.nrt = 1; t.parts = 1;
+        t.gstride = y.theta_size;
+        t.window = p->output == NCDE_OUT_TIMES ? std::max(p->n_steps_fwd, p->n_steps_adj) : p->n_knots - 1;
+        t.n_sc = t.window * S;
+        long long off = 64;
+        t.recA = t.recB = t.recC = t.recD = off;
+        t.gpartA = off; off += (long long)t.n_st * t.gstride;
+        t.gpartB = off;
+        t.carry = off; off += 2LL * t.n_st * p->hidden * 16;
+        t.pack = off; off += (long long)p->layer_out[0] * ((p->layer_in[0] + 15) & ~15);      // layer 0, columns padded
+        t.pack_bf = off;
+        t.total = off + 64;
+        return t;
+    }
     const long long recA_tile = bf ? dlast * 24 : dlast * 16;      // floats per (stage, sample tile) of record A
     const long long per_step = (long long)S * t.n_st * (2 * recA_tile + (p->hidden + p->channels) * 16) * (long long)sizeof(float);
     const int steps = p->output == NCDE_OUT_TIMES ? std::max(p->n_steps_fwd, p->n_steps_adj) : p->n_knots - 1;
@@ -1924,13 +2047,14 @@ bool ncde_tiled_supported(const NcdeProblem* p, int pass) {
     auto aligned = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     if (p->field_kind == NCDE_FIELD_GRU) return false;
     if (p->field_input != NCDE_INPUT_MATMUL) {
-        // evaluate / derivative inputs: the FORWARD only (one sample tile per workgroup; layer 0 is re-laid out with its H + C
-        // columns padded to a multiple of 16, so its own alignment does not matter); the backward stays on the variant kernels
-        if (pass != 0 || p->layer_in[0] != p->hidden + p->channels) return false;
+        // evaluate / derivative inputs (one sample tile per workgroup; layer 0 is re-laid out with its H + C columns padded to a
+        // multiple of 16, so its own alignment does not matter)
+        if (p->layer_in[0] != p->hidden + p->channels) return false;
         for (int l = 0; l < p->n_layers; ++l)
             if (p->layer_out[l] % 16 || (l > 0 && (p->layer_in[l] % 16 || !aligned(p->layer_W[l]))) || !aligned(p->layer_b[l])) return false;
         if (!aligned(p->Wo) || !aligned(p->bo)) return false;
         if (p->field_kind == NCDE_FIELD_MINIMAL && (!aligned(p->Wg) || !aligned(p->bg))) return false;
+        if (pass != 0) return tiled_adj_ok(p);
         return tiled_fwd_lds(p, 1) <= (size_t)kLdsLimit && p->hidden * 16 <= TL_EMAX * TL_THREADS;
     }
     // field variants: the minimal-gated field with the matmul input (a second head on the same activations)
@@ -1956,6 +2080,8 @@ bool ncde_tiled_preferred(const NcdeProblem* p, int pass) {
 const char* ncde_tiled_kernel_name(const NcdeProblem* p, int pass) {
     if (!ncde_tiled_supported(p, pass)) return nullptr;
     const bool gated = p->field_kind == NCDE_FIELD_MINIMAL;
+    if (pass >= 1 && p->field_input != NCDE_INPUT_MATMUL)
+        return pass == 1 ? (gated ? "ncde_adj_tiled<gated,direct>" : "ncde_adj_tiled<direct>") : (gated ? "ncde_adj_tiled<gated,direct,discrete>" : "ncde_adj_tiled<direct,discrete>");
     if (pass >= 1 && tiled_adj_bf(p)) {      // split-bf16 records: the pair kernel is pass B
         if (pass == 1) return gated ? "ncde_adj_tiled<gated,bf16>+ncde_dwo_pair" : "ncde_adj_tiled<bf16>+ncde_dwo_pair";
         return gated ? "ncde_adj_tiled<gated,discrete,bf16>+ncde_dwo_pair" : "ncde_adj_tiled<discrete,bf16>+ncde_dwo_pair";
@@ -2039,6 +2165,22 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     a.recA = w + t.recA; a.recB = w + t.recB; a.recC = w + t.recC; a.recD = w + t.recD;
     a.gpart = w + t.gpartA;
     a.gstride = t.gstride;
+    if (p->field_input != NCDE_INPUT_MATMUL) {      // evaluate / derivative inputs: one launch of the direct-mode sweep + the reduction
+        const int d0p = (p->layer_in[0] + 15) & ~15, n0 = p->layer_out[0];
+        hipLaunchKernelGGL(ncde_pad_columns, dim3((n0 * d0p + 255) / 256), dim3(256), 0, st, a.W[0], w + t.pack, n0, p->layer_in[0], d0p);
+        a.W[0] = w + t.pack;
+        a.din[0] = d0p;
+        a.carry = w + t.carry;
+        const bool g1 = p->field_kind == NCDE_FIELD_MINIMAL;
+        void (*fd)(KArgs) = g1 ? ncde_adj_tiled<1, TL_ADJ_NW, 0, 1, 0, 1> : ncde_adj_tiled<1, TL_ADJ_NW, 0, 0, 0, 1>;
+        if (hipFuncSetAttribute((const void*)fd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess) return NCDE_ERR_HIP;
+        const int n_rs = p->output == NCDE_OUT_TIMES ? (discrete ? p->n_steps_fwd : p->n_steps_adj) : p->n_knots - 1;
+        a.win_hi = n_rs; a.win_lo = 0; a.resume = 0;
+        hipLaunchKernelGGL(fd, dim3(t.n_st), dim3(64 * TL_ADJ_NW), tiled_adj_lds(p), st, a);
+        if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
+        if (main_kernel_only) return NCDE_OK;
+        return launch_reduce_partials(p, y, g, (const float*)a.gpart, t.n_st, st);
+    }
     tiled_pack_launch(p, &a, w + t.pack, false, st);
     if (tiled_adj_bf(p) && p->field_kind != NCDE_FIELD_MINIMAL) {
         const int dl = p->layer_out[p->n_layers - 1];
