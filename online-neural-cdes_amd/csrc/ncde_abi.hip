@@ -160,7 +160,7 @@ int launch_forward(const NcdeProblem* p, const Layout& y, int family, float* out
     fill_kargs(p, y, &a);
     a.out = out;
     a.stages = stages;
-    HIP_TRY(hipFuncSetAttribute((const void*)ncde_fwd_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)y.lds_fwd));
+    HIP_TRY(ncde_lds_optin((const void*)ncde_fwd_generic, y.lds_fwd));
     hipLaunchKernelGGL(ncde_fwd_generic, dim3(y.n_wg), dim3(256), y.lds_fwd, st, a);
     HIP_TRY(hipGetLastError());
     return NCDE_OK;
@@ -192,7 +192,7 @@ int launch_adjoint(const NcdeProblem* p, const Layout& y, int family, const floa
     if (discrete) { a.stages = const_cast<float*>(src); a.discrete = 1; }
     else a.z_out = src;
     a.gpart = (float*)ws;
-    HIP_TRY(hipFuncSetAttribute((const void*)ncde_adj_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)y.lds_adj));
+    HIP_TRY(ncde_lds_optin((const void*)ncde_adj_generic, y.lds_adj));
     hipLaunchKernelGGL(ncde_adj_generic, dim3(y.n_wg), dim3(256), y.lds_adj, st, a);
     HIP_TRY(hipGetLastError());
     if (main_kernel_only) return NCDE_OK;

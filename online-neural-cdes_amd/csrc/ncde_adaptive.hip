@@ -801,7 +801,7 @@ int ncde_dp_solve(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdapti
     const long long BH = (long long)p->batch * p->hidden;
     const int egrid = (int)((BH + 255) / 256);
     const int tgrid = (w.theta1 + 255) / 256;
-    DP_TRY(hipFuncSetAttribute((const void*)ncde_dp_stage, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DP_TRY(ncde_lds_optin((const void*)ncde_dp_stage, lds));
     hipLaunchKernelGGL(ncde_dp_init, dim3(egrid), dim3(256), 0, st, d);
     DP_TRY(hipGetLastError());
     DpCtrl hc;

@@ -2554,7 +2554,7 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
         a.out = (float*)ws + (size_t)y.n_wg * y.theta_size + 64;
     }
     const size_t lds = v1 ? e->adj_lds(p->interp) : (v3 ? e->adj3_lds(p->interp) : e->adj2_lds(p->interp));
-    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NCDE_ERR_HIP;
+    if (ncde_lds_optin((const void*)fn, lds) != hipSuccess) return NCDE_ERR_HIP;
     hipLaunchKernelGGL(fn, dim3(y.n_wg), dim3(v1 ? 64 * e->nw : 512), lds, st, a);
     if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
     if (main_kernel_only) return NCDE_OK;

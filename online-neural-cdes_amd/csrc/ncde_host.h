@@ -1,5 +1,8 @@
 // Host-side helpers shared by ncde_abi.hip and ncde_fast.hip: parameter-gradient layout, K4 launch.
 #pragma once
+#include <mutex>
+#include <map>
+#include <utility>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -16,6 +19,22 @@ struct ReduceSegs {
 extern "C" __global__ void ncde_reduce_partials(const float* gpart, int n_part, int theta_size, ReduceSegs segs);
 
 constexpr int kLdsLimit = 160 * 1024;
+
+// Raise a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) only when a launch needs more than what was
+// already granted for this (device, kernel) -- not a hipFuncSetAttribute call in front of every launch.  (Granting a flat 160 KB
+// would fail for kernels that also hold static __shared__ arrays.)
+inline hipError_t ncde_lds_optin(const void* fn, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> granted;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t& have = granted[{dev, fn}];
+    if (bytes <= have) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
 inline int hru4(int x) { return (x + 3) & ~3; }
 inline int hru16(int x) { return (x + 15) & ~15; }
 

@@ -11,6 +11,7 @@
 #include <cmath>
 
 #include "ncde_hip.h"
+#include "ncde_host.h"
 
 namespace {
 
@@ -639,7 +640,7 @@ int ncde_prepare_linear(const float* x, int B, int L, int C, int rectilinear_tim
     (void)T;
     const size_t lds = sizeof(float) * ((size_t)L * C * (rect >= 0 ? 2 : 3) + 64 * (size_t)C);
     if (lds <= 64 * 1024 && C <= 256) {   // the series fits LDS: staged, coalesced, scan-parallel variant
-        if (hipFuncSetAttribute((const void*)ncde_linear_coeffs_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (ncde_lds_optin((const void*)ncde_linear_coeffs_lds_kernel, lds) != hipSuccess)
             return NCDE_ERR_HIP;
         hipLaunchKernelGGL(ncde_linear_coeffs_lds_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, x, B, L, C, rect, out);
     } else {
@@ -669,7 +670,7 @@ int ncde_prepare_cubic(const float* x, int B, int L, int C, float* out, void* wo
         while (nsmp > 1 && lds_of(nsmp) > budget) --nsmp;
         if (lds_of(nsmp) <= (size_t)150 * 1024) {
             const size_t lds = lds_of(nsmp);
-            if (hipFuncSetAttribute((const void*)ncde_cubic_coeffs_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            if (ncde_lds_optin((const void*)ncde_cubic_coeffs_lds_kernel, lds) != hipSuccess)
                 return NCDE_ERR_HIP;
             hipLaunchKernelGGL(ncde_cubic_coeffs_lds_kernel, dim3((unsigned)((B + nsmp - 1) / nsmp)), dim3(CUBIC_NT), lds, (hipStream_t)stream, x, B, L, C,
                                nsmp, sstride, out, ws, diag, ws_d);

@@ -2144,7 +2144,7 @@ int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws
         if (p->field_kind == NCDE_FIELD_MINIMAL) fn = small ? ncde_fwd_tiled<1, TL_NW, 4, 1, 0, 0, 1> : ncde_fwd_tiled<1, TL_NW, 16, 1, 0, 0, 1>;
         else fn = small ? ncde_fwd_tiled<1, TL_NW, 4, 0, 0, 0, 1> : ncde_fwd_tiled<1, TL_NW, 16, 0, 0, 0, 1>;
     }
-    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NCDE_ERR_HIP;
+    if (ncde_lds_optin((const void*)fn, lds) != hipSuccess) return NCDE_ERR_HIP;
     const int nwg = (p->batch + ns * 16 - 1) / (ns * 16);
     hipLaunchKernelGGL(fn, dim3(nwg), dim3(TL_THREADS), lds, st, a);
     return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
@@ -2173,7 +2173,7 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
         a.carry = w + t.carry;
         const bool g1 = p->field_kind == NCDE_FIELD_MINIMAL;
         void (*fd)(KArgs) = g1 ? ncde_adj_tiled<1, TL_ADJ_NW, 0, 1, 0, 1> : ncde_adj_tiled<1, TL_ADJ_NW, 0, 0, 0, 1>;
-        if (hipFuncSetAttribute((const void*)fd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess) return NCDE_ERR_HIP;
+        if (ncde_lds_optin((const void*)fd, tiled_adj_lds(p)) != hipSuccess) return NCDE_ERR_HIP;
         const int n_rs = p->output == NCDE_OUT_TIMES ? (discrete ? p->n_steps_fwd : p->n_steps_adj) : p->n_knots - 1;
         a.win_hi = n_rs; a.win_lo = 0; a.resume = 0;
         hipLaunchKernelGGL(fd, dim3(t.n_st), dim3(64 * TL_ADJ_NW), tiled_adj_lds(p), st, a);
@@ -2227,14 +2227,7 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     }
     const dim3 gridB(p->hidden * p->channels / 16 / t.nrt, t.parts);
     const size_t lds = tiled_adj_lds(p);
-    static const void* attr_done[32] = {};   // set once per kernel, not per launch
-    bool seen = false;
-    for (const void* q : attr_done) seen = seen || q == (const void*)fa;
-    if (!seen) {
-        if (hipFuncSetAttribute((const void*)fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess) return NCDE_ERR_HIP;
-        for (const void*& q : attr_done)
-            if (!q) { q = (const void*)fa; break; }
-    }
+    if (ncde_lds_optin((const void*)fa, lds) != hipSuccess) return NCDE_ERR_HIP;
     a.carry = w + t.carry;
     float* gB = w + t.gpartB;
     float* gB2 = gB + (long long)t.parts * t.theta_o;

@@ -888,7 +888,7 @@ int ncde_variant_forward(const NcdeProblem* p, float* out, float* stages, hipStr
     a.stages = stages;
     for (int l = 0; l < NCDE_MAX_LAYERS; ++l) a.wres[l] = v.res_fwd.w[l];
     a.wres_o = v.res_fwd.o; a.wres_g = v.res_fwd.g; a.wres_r = v.res_fwd.r;
-    if (hipFuncSetAttribute((const void*)ncde_fwd_variant, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds_fwd) != hipSuccess) return NCDE_ERR_HIP;
+    if (ncde_lds_optin((const void*)ncde_fwd_variant, v.lds_fwd) != hipSuccess) return NCDE_ERR_HIP;
     hipLaunchKernelGGL(ncde_fwd_variant, dim3(y.n_wg), dim3(VR_THREADS), v.lds_fwd, st, a);
     return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
 }
@@ -907,7 +907,7 @@ int ncde_variant_adjoint(const NcdeProblem* p, const float* src, const float* gr
     a.gacc_in_lds = v.gacc_in_lds;
     for (int l = 0; l < NCDE_MAX_LAYERS; ++l) a.wres[l] = v.res_adj.w[l];
     a.wres_o = v.res_adj.o; a.wres_g = v.res_adj.g; a.wres_r = v.res_adj.r;
-    if (hipFuncSetAttribute((const void*)ncde_adj_variant, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds_adj) != hipSuccess) return NCDE_ERR_HIP;
+    if (ncde_lds_optin((const void*)ncde_adj_variant, v.lds_adj) != hipSuccess) return NCDE_ERR_HIP;
     hipLaunchKernelGGL(ncde_adj_variant, dim3(y.n_wg), dim3(VR_THREADS), v.lds_adj, st, a);
     if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
     if (main_kernel_only) return NCDE_OK;
