@@ -929,7 +929,9 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     // general time axis (a.plan): reverse step n = n_rsteps .. 1 is plan step rstep = n_rsteps - n of the adjoint table
     // (continuous adjoint) or the transpose of forward step m = n - 1 (discrete backward) -- as in ncde_variant.hip, whose
     // plan mode is pinned to the reference
-    const bool planned = a.plan != nullptr;
+    // (the all-resident variant, RES = 1, is the latency-critical one -- cfg4: +6 % with the plan's extra live state -- and runs
+    // the default axis only: the host sends planned problems to RES = 2 / streamed kernels)
+    const bool planned = RES != 1 && a.plan != nullptr;
     const int pw_ = plan_step_words(S);
     const int* pfwd = planned ? a.plan + plan_off_fwd() : nullptr;
     const int* pout = planned ? a.plan + plan_off_out(S, a.n_steps_fwd) : nullptr;
@@ -1923,7 +1925,8 @@ int tiled_adj_pk(const NcdeProblem* p) {
 // small square models: every weight fragment register-resident (see ncde_adj_tiled, RES)
 bool tiled_adj_res(const NcdeProblem* p) {
     const int pk = tiled_adj_pk(p);
-    bool res = p->field_kind != NCDE_FIELD_MINIMAL && pk >= 1 && pk <= 4 && p->hidden == 16 * pk && p->hidden * p->channels / 16 <= 2 * TL_ADJ_NW;
+    bool res = p->field_kind != NCDE_FIELD_MINIMAL && pk >= 1 && pk <= 4 && p->hidden == 16 * pk && p->hidden * p->channels / 16 <= 2 * TL_ADJ_NW &&
+               p->output != NCDE_OUT_TIMES;      // default time axis only (see ncde_adj_tiled)
     for (int l = 0; l < p->n_layers; ++l) res = res && p->layer_out[l] == 16 * pk && p->layer_in[l] == 16 * pk;
     return res;
 }
