@@ -510,7 +510,8 @@ def test_fast_kernels_vs_oracle(shape, interp, method, seq, gpu_lib):
         assert np.array_equal(againd["dz0"], isod["dz0"]) and all(np.array_equal(againd["grads"][k], isod["grads"][k]) for k in isod["grads"])
 
 
-@pytest.mark.parametrize("shape", [(80, 128, 128, 3), (8, 48, 64, 2), (4, 16, 32, 1)])
+@pytest.mark.parametrize("shape", [(80, 128, 128, 3), (8, 48, 64, 2), (4, 16, 32, 1), (16, 64, 64, 2)])      # the last: four row tiles per wave in pass B,
+                                                                                                                # resident hidden fragments (RESH / RES = 2)
 @pytest.mark.parametrize("interp,method,seq", [("linear", "rk4", False), ("cubic", "midpoint", True), ("linear", "euler", True)])
 def test_tiled_family_vs_oracle(shape, interp, method, seq, gpu_lib):
     """The batch-tiled (large-hidden) family: every sample-tile count NS, ragged batch, against the oracle and,
@@ -556,13 +557,14 @@ def test_tiled_family_vs_oracle(shape, interp, method, seq, gpu_lib):
         assert e <= TIGHT_G, ("tiled discrete backward (fp32 MFMA) on the oracle's stage record", k, e)
 
 
-@pytest.mark.parametrize("shape,gated", [((80, 128, 128, 3), False), ((8, 48, 64, 2), False), ((20, 32, 32, 3), True)])
+@pytest.mark.parametrize("shape,gated", [((80, 128, 128, 3), False), ((8, 48, 64, 2), False), ((20, 32, 32, 3), True),
+                                         ((8, 32, 128, 2), True)])      # the last: gated heads of 128 columns = one pair-kernel pass per head
 @pytest.mark.parametrize("interp,method,seq", [("linear", "rk4", False), ("cubic", "midpoint", True)])
 def test_tiled_backward_time_windows(shape, gated, interp, method, seq, gpu_lib, monkeypatch):
     """The batch-tiled backward keeps its per-stage records for a WINDOW of steps only (workspace O(B H W), not O(B H T)):
     forcing windows of one / a few steps (NCDE_TILED_WINDOW_MB) must reproduce the single-window result -- bit for bit for
     dL/dz0 and the hidden-layer gradients (the carried (y, a) and the hidden-layer partial are exact hand-overs), to summation
-    order (1e-6) for the head gradients (pass B adds one partial per window instead of running one long accumulation) -- for
+    order (2e-6) for the head gradients (pass B adds one partial per window instead of running one long accumulation) -- for
     the continuous adjoint and the exact discrete backward; the workspace query shrinks accordingly."""
     import ctypes
     import gpu_util
@@ -590,7 +592,7 @@ def test_tiled_backward_time_windows(shape, gated, interp, method, seq, gpu_lib,
             assert np.array_equal(g_["dz0"], r_["dz0"])
             for k in r_["grads"]:
                 if k in ("Wo", "bo", "Wg", "bg"):
-                    assert gu.relerr(g_["grads"][k], r_["grads"][k]) <= 1e-6, (steps, k)
+                    assert gu.relerr(g_["grads"][k], r_["grads"][k]) <= 2e-6, (steps, k)      # summation order only (one partial per window)
                 else:
                     assert np.array_equal(g_["grads"][k], r_["grads"][k]), (steps, k)
 
