@@ -785,9 +785,9 @@ def test_general_time_axis_on_the_batch_tiled_family_vs_oracle(kind, interp, met
     assert np.sum(per <= E2E_G) >= B - 2, np.sort(per)[-4:]
 
 
-@pytest.mark.parametrize("kind", ["original", "minimal"])
+@pytest.mark.parametrize("kind,nl", [("original", 3), ("minimal", 3), ("original", 1)])
 @pytest.mark.parametrize("mode,interp,method", [("evaluate", "linear", "rk4"), ("derivative", "cubic", "midpoint"), ("evaluate", "cubic", "euler")])
-def test_evaluate_derivative_inputs_on_the_batch_tiled_forward(kind, mode, interp, method, gpu_lib):
+def test_evaluate_derivative_inputs_on_the_batch_tiled_family(kind, nl, mode, interp, method, gpu_lib):
     """The evaluate / derivative input modes (field input [z, X(t)] / [z, dX/dt]; H-row heads) where every width is a multiple
     of 16 and C of 4: forward and backward run on the batch-tiled family (layer 0 re-laid out with its H + C columns zero-padded;
     the heads' VJP and parameter gradients inside the sweep, no gradient pass).  Against the oracle (variant fields pinned to the
@@ -796,11 +796,12 @@ def test_evaluate_derivative_inputs_on_the_batch_tiled_forward(kind, mode, inter
     import gpu_util
     import ncde_oracle as orc
     from ncde_amd import _lib
-    B, L, C, H, HH, nl = 37, 7, 8, 32, 48, 3
+    B, L, C, H, HH = 37, 7, 8, 32, 48
     coeffs = gu.data.make_cubic_coeffs(B, L, C - 1, seed=61) if interp == "cubic" else gu.data.make_rectilinear_coeffs(B, L, C - 1, missing=0.3, seed=61)
-    p = gu.data.make_variant_weights(H, HH, C, seed=29, kind=kind, mode=mode)
+    pfull = gu.data.make_variant_weights(H, HH, C, seed=29, kind=kind, mode=mode)
+    p = {k: v for k, v in pfull.items() if nl > 1 or k not in ("W1", "b1")}      # a single inner layer: no shared second matrix
     z0 = (gu.data.normal(47, B * H, stream=2).reshape(B, H) * 0.5).astype(np.float32)
-    field = orc.Field.variant(p, H, C, nl, kind, mode)
+    field = orc.Field.variant(pfull, H, C, nl, kind, mode)
     ctl = orc.Control(coeffs, interp)
     names = [n for n in ("W0", "b0", "W1", "b1", "Wg", "bg", "Wo", "bo") if n in p]
     layers = [("W0", "b0")] + [("W1", "b1")] * (nl - 1)
