@@ -57,8 +57,8 @@ typedef enum NcdeOutput { NCDE_OUT_INTERVAL = 0, NCDE_OUT_KNOTS = 1, NCDE_OUT_TI
 #define NCDE_FLAG_AUTO 0u
 #define NCDE_FLAG_FORCE_GENERIC 1u  /* never use a shape-specialised kernel */
 #define NCDE_FLAG_FORCE_FAST 2u     /* fail with NCDE_ERR_UNSUPPORTED if no specialised kernel fits */
-#define NCDE_FLAG_FP32_MFMA 4u      /* specialised kernels: plain fp32-input MFMA instead of the (default, fp32-equivalent)
-                                       3-way split-bf16 MFMA GEMMs */
+#define NCDE_FLAG_FP32_MFMA 4u      /* specialised and batch-tiled kernels: plain fp32-input MFMA (and fp32 records) instead of the
+                                       (default, fp32-equivalent) 3-way split-bf16 MFMA GEMMs */
 #define NCDE_FLAG_ADJOINT_V1 8u     /* specialised adjoint: single-role kernel instead of the (default) chain+gradient
                                        wave-specialised one */
 #define NCDE_FLAG_ADJOINT_V2 16u    /* specialised adjoint: chain+gradient kernel with an fp32-MFMA chain (default: split-bf16 chain) */
