@@ -838,6 +838,12 @@ def test_evaluate_derivative_inputs_on_the_batch_tiled_family(kind, nl, mode, in
     assert gu.relerr(rt["z_out"], zt) <= TIGHT_Z and gu.relerr(rt["dz0"], dzt) <= E2E_G
     for n_, g_ in zip(names, gpt):
         assert gu.relerr(rt["grads"][n_], g_) <= E2E_G, ("times", n_)
+    bdzt, bgpt = orc.solve_discrete_backward_times(ctl, field, z0, tout, gt, method, 0.5)
+    rtd = gpu_util.run_times_case({"coeffs": coeffs, "z0": z0, "t_out": tout, "grad_out": gt}, {"kind": interp, "method": method, "step_size": 0.5, "dims": {"nl": nl}},
+                                  adjoint=False, kind=kind, mode=mode, params=p)
+    assert gu.relerr(rtd["dz0"], bdzt) <= E2E_G
+    for n_, g_ in zip(names, bgpt):
+        assert gu.relerr(rtd["grads"][n_], g_) <= E2E_G, ("times, discrete", n_)
 
 
 def test_variant_gradient_partial_in_global_memory_is_reproducible(gpu_lib):
