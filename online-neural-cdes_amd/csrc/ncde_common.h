@@ -61,6 +61,9 @@ struct KArgs {
     // variant family: LDS-resident copies of weight matrices (float offset into the dynamic LDS, -1 = streamed from L2);
     // a resident matrix [N][K] is stored with row stride K + 1, column K holding the bias
     int wres[NCDE_MAX_LAYERS], wres_o, wres_g, wres_r;
+    // batch-tiled direct modes: LDS-resident row-major copies of the small matrices, [N][K] with row stride K + 4, the bias behind
+    // (float offset into the dynamic LDS, 0 = streamed from L2)
+    int tres[NCDE_MAX_LAYERS], tres_o, tres_g;
 };
 
 // ---- time plan (built on the host by ncde_time_plan_build, csrc/ncde_timeplan.hip; layout in 4-byte words) -------------

@@ -101,15 +101,18 @@ __host__ __device__ __forceinline__ int tl_panel_k(int nkb) { return (nkb % 8 ==
 // ACT: 0 relu (hidden layers), 1 tanh, 2 sigmoid (the heads of the evaluate / derivative input modes, which are plain
 // H-row dense layers)
 template <int NS, int PK, int NWV, int ACT = 0>
+// ld = row stride of W in floats (0: K; a resident LDS copy is stored with K + 4 so that the 16 rows of a fragment load spread
+// over the banks)
 __device__ __forceinline__ void tl_dense_relu_pk(const float* __restrict__ W, const float* __restrict__ bias, int N, int K,
-                                                 const float* in, float* out, int wave, int lane, unsigned* xb = nullptr) {
+                                                 const float* in, float* out, int wave, int lane, unsigned* xb = nullptr, int ld = 0) {
     constexpr int NSP = NS * 16;
     const int li = lane & 15, lk = lane >> 4;
     const int npan = (K >> 4) / PK;
     const int ntile = ((N >> 4) - wave + NWV - 1) / NWV;       // row tiles wave, wave+8, ...
     if (ntile <= 0) return;
     const int nq = ntile * npan;
-    auto wrow_of = [&](int q) { return W + (long long)(16 * (wave + NWV * (q / npan)) + li) * K + 4 * lk; };
+    const int ldw = ld ? ld : K;
+    auto wrow_of = [&](int q) { return W + (long long)(16 * (wave + NWV * (q / npan)) + li) * ldw + 4 * lk; };
     Panel<PK> Pn = tl_load_panel<PK>(wrow_of(0), 0);
     f32x4 acc[NS];
     for (int q = 0; q < nq; ++q) {
@@ -150,13 +153,46 @@ __device__ __forceinline__ void tl_dense_relu_pk(const float* __restrict__ W, co
 }
 template <int NS, int NWV, int ACT = 0>
 __device__ __forceinline__ void tl_dense_relu(const float* __restrict__ W, const float* __restrict__ bias, int N, int K,
-                                              const float* in, float* out, int wave, int lane, unsigned* xb = nullptr) {
+                                              const float* in, float* out, int wave, int lane, unsigned* xb = nullptr, int ld = 0) {
     switch (tl_panel_k(K >> 4)) {
-        case 8: tl_dense_relu_pk<NS, 8, NWV, ACT>(W, bias, N, K, in, out, wave, lane, xb); break;
-        case 4: tl_dense_relu_pk<NS, 4, NWV, ACT>(W, bias, N, K, in, out, wave, lane, xb); break;
-        case 2: tl_dense_relu_pk<NS, 2, NWV, ACT>(W, bias, N, K, in, out, wave, lane, xb); break;
-        default: tl_dense_relu_pk<NS, 1, NWV, ACT>(W, bias, N, K, in, out, wave, lane, xb); break;
+        case 8: tl_dense_relu_pk<NS, 8, NWV, ACT>(W, bias, N, K, in, out, wave, lane, xb, ld); break;
+        case 4: tl_dense_relu_pk<NS, 4, NWV, ACT>(W, bias, N, K, in, out, wave, lane, xb, ld); break;
+        case 2: tl_dense_relu_pk<NS, 2, NWV, ACT>(W, bias, N, K, in, out, wave, lane, xb, ld); break;
+        default: tl_dense_relu_pk<NS, 1, NWV, ACT>(W, bias, N, K, in, out, wave, lane, xb, ld); break;
     }
+}
+
+// Direct modes, small models: the matrices the host marked (KArgs.tres*) are copied once into LDS -- [N][K] row-major with
+// row stride K + 4 and the bias behind -- so the dense phases of a stage (each otherwise starting with an exposed L2 round trip
+// for its first fragment) read them from there.  Returns nothing; TlW hands the right pointers to the layer calls.
+struct TlW {
+    const float* W;
+    const float* b;
+    int ld;
+};
+__device__ __forceinline__ TlW tl_wref(const float* lds, int off, const float* W, const float* b, int N, int K) {
+    TlW r;
+    if (off) { r.W = lds + off; r.b = lds + off + N * (K + 4); r.ld = K + 4; }
+    else { r.W = W; r.b = b; r.ld = 0; }
+    return r;
+}
+template <int NT>
+__device__ __forceinline__ void tl_fill_resident(const KArgs& a, float* lds, int tid) {
+    auto fill = [&](const float* W, const float* b, int N, int K, int off) {
+        for (int e = tid; e < N * K; e += NT) {
+            const int r = e / K, c = e - r * K;
+            lds[off + r * (K + 4) + c] = W[e];
+        }
+        for (int r = tid; r < N; r += NT) lds[off + N * (K + 4) + r] = b[r];
+    };
+    for (int l = 0; l < a.n_layers; ++l) {
+        bool first = a.tres[l] != 0;
+        for (int q = 0; q < l; ++q) first = first && a.tres[q] != a.tres[l];
+        if (first) fill(a.W[l], a.b[l], a.dout[l], a.din[l], a.tres[l]);
+    }
+    const int dlast = a.dout[a.n_layers - 1];
+    if (a.tres_o) fill(a.Wo, a.bo, a.H, dlast, a.tres_o);
+    if (a.tres_g) fill(a.Wg, a.bg, a.H, dlast, a.tres_g);
 }
 
 // control input of the evaluate / derivative modes for the tile's samples -> rows row0 .. row0 + C - 1 of the activation array
@@ -526,6 +562,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
     unsigned* XB = reinterpret_cast<unsigned*>(DX + a.C * NSP);   // BF: x_L as three bf16 pieces, B-operand order
     if constexpr (DIRECT != 0) {
         for (int e = HS + tid; e < US; e += NT) YS[e] = 0.0f;      // rows H + C .. of the padded input stay zero
+        tl_fill_resident<NT>(a, lds, tid);                           // small matrices -> LDS (visible after the first barrier below)
     }
 
     // state slice of this thread: element e = tid + q * NT of the [H/4][NSP][4] arrays
@@ -614,16 +651,22 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                             }
                         }
                     }
-                } else
-                tl_dense_relu<NS, NWV>(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane,
-                                       (BF != 0 && l == a.n_layers - 1) ? XB : nullptr);
+                } else {
+                    const TlW wr_ = tl_wref(lds, DIRECT != 0 ? a.tres[l] : 0, a.W[l], a.b[l], a.dout[l], a.din[l]);
+                    tl_dense_relu<NS, NWV>(wr_.W, wr_.b, a.dout[l], a.din[l], in, outb, wave, lane,
+                                           (BF != 0 && l == a.n_layers - 1) ? XB : nullptr, wr_.ld);
+                }
                 __syncthreads();
                 in = outb;
             }
             float* KG = in == ACT0 ? ACT1 : ACT0;      // direct gated head: the free ping-pong buffer takes sigmoid(Wg x_L + bg)
             if constexpr (DIRECT != 0) {
-                tl_dense_relu<NS, NWV, 1>(a.Wo, a.bo, H, dlast, in, KO, wave, lane);
-                if constexpr (GATED != 0) tl_dense_relu<NS, NWV, 2>(a.Wg, a.bg, H, dlast, in, KG, wave, lane);
+                const TlW wo_ = tl_wref(lds, a.tres_o, a.Wo, a.bo, H, dlast);
+                tl_dense_relu<NS, NWV, 1>(wo_.W, wo_.b, H, dlast, in, KO, wave, lane, nullptr, wo_.ld);
+                if constexpr (GATED != 0) {
+                    const TlW wg_ = tl_wref(lds, a.tres_g, a.Wg, a.bg, H, dlast);
+                    tl_dense_relu<NS, NWV, 2>(wg_.W, wg_.b, H, dlast, in, KG, wave, lane, nullptr, wg_.ld);
+                }
             } else
             if constexpr (BF != 0) {
                 switch (nkb_o) {
@@ -821,29 +864,30 @@ __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, c
 template <int NWV>
 __device__ __forceinline__ void tl_hidden_bwd(const float* __restrict__ W, int N, int K, const float* gpre, const float* xin,
                                               bool mask, float* out, int wave, int lane, const float* __restrict__ W2 = nullptr,
-                                              const float* gpre2 = nullptr) {
+                                              const float* gpre2 = nullptr, int ld = 0) {
     constexpr int NSP = 16;
     const int li = lane & 15, lk = lane >> 4;
     const int nkb = N >> 4;
+    const int ldw = ld ? ld : K;      // row stride of W (and W2): K, or K + 4 for a resident LDS copy
     for (int it = wave; it < (K >> 4); it += NWV) {
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* wcol = W + (long long)(4 * lk) * K + 16 * it + li;
+        const float* wcol = W + (long long)(4 * lk) * ldw + 16 * it + li;
 #pragma unroll 4
         for (int kb = 0; kb < nkb; ++kb) {
             float av[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) av[e] = wcol[(long long)(16 * kb + e) * K];
+            for (int e = 0; e < 4; ++e) av[e] = wcol[(long long)(16 * kb + e) * ldw];
             const f32x4 Bv = *reinterpret_cast<const f32x4*>(gpre + ((4 * kb + lk) * NSP + li) * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = mfma16(av[e], Bv[e], acc);
         }
         if (W2) {
-            const float* wcol2 = W2 + (long long)(4 * lk) * K + 16 * it + li;
+            const float* wcol2 = W2 + (long long)(4 * lk) * ldw + 16 * it + li;
 #pragma unroll 4
             for (int kb = 0; kb < nkb; ++kb) {
                 float av[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) av[e] = wcol2[(long long)(16 * kb + e) * K];
+                for (int e = 0; e < 4; ++e) av[e] = wcol2[(long long)(16 * kb + e) * ldw];
                 const f32x4 Bv = *reinterpret_cast<const f32x4*>(gpre2 + ((4 * kb + lk) * NSP + li) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc = mfma16(av[e], Bv[e], acc);
@@ -971,6 +1015,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     }
     if constexpr (DIRECT != 0) {
         for (int e = HS + tid; e < US; e += NT) YS[e] = 0.0f;      // rows H + C .. of the padded field input stay zero
+        tl_fill_resident<NT>(a, lds, tid);                           // small matrices -> LDS (a barrier follows before the first stage)
     }
     // hidden-layer parameter gradients: at most two distinct (W, b) pairs (layer 0, and ONE matrix shared by the rest)
     f32x4 dw0[TL_DWT], dw1[TL_DWT];
@@ -1167,7 +1212,8 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                         }
                     }
                 } else {
-                    tl_dense_relu<1, NWV>(a.W[l], a.b[l], a.dout[l], a.din[l], in, outb, wave, lane, (BF != 0 && l == L - 1) ? XBA : nullptr);
+                    const TlW wr_ = tl_wref(lds, DIRECT != 0 ? a.tres[l] : 0, a.W[l], a.b[l], a.dout[l], a.din[l]);
+                    tl_dense_relu<1, NWV>(wr_.W, wr_.b, a.dout[l], a.din[l], in, outb, wave, lane, (BF != 0 && l == L - 1) ? XBA : nullptr, wr_.ld);
                 }
                 __syncthreads();
                 in = outb;
@@ -1176,8 +1222,10 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                 // ---- direct heads: m = tanh(Wo x_L + bo) (x sigmoid(Wg x_L + bg)) IS dz/dt; cotangents of the two pre-activations ----
                 float* DPT = G0;      // dL/dPt  [H][16]
                 float* SG = SC;       // sigmoid(Pg), then dL/dPg (the per-wave scratch area is free in this mode)
-                tl_dense_relu<1, NWV, 1>(a.Wo, a.bo, H, dlast, in, KOY, wave, lane);
-                if constexpr (GATED != 0) tl_dense_relu<1, NWV, 2>(a.Wg, a.bg, H, dlast, in, SG, wave, lane);
+                const TlW wo_ = tl_wref(lds, a.tres_o, a.Wo, a.bo, H, dlast);
+                const TlW wg_ = tl_wref(lds, GATED != 0 ? a.tres_g : 0, a.Wg, a.bg, H, dlast);      // resident together with Wo or not at all
+                tl_dense_relu<1, NWV, 1>(wo_.W, wo_.b, H, dlast, in, KOY, wave, lane, nullptr, wo_.ld);
+                if constexpr (GATED != 0) tl_dense_relu<1, NWV, 2>(wg_.W, wg_.b, H, dlast, in, SG, wave, lane, nullptr, wg_.ld);
                 __syncthreads();
                 for (int e = tid; e < HS; e += NT) {
                     const float th = KOY[e], dm = AS[e];
@@ -1206,7 +1254,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                     }
                 }
                 // dL/dpre_L = (Wo^T dPt + Wg^T dPg) relu'(x_L)
-                tl_hidden_bwd<NWV>(a.Wo, H, dlast, DPT, in, true, G1, wave, lane, GATED != 0 ? a.Wg : nullptr, GATED != 0 ? SG : nullptr);
+                tl_hidden_bwd<NWV>(wo_.W, H, dlast, DPT, in, true, G1, wave, lane, GATED != 0 ? wg_.W : nullptr, GATED != 0 ? SG : nullptr, wo_.ld);
                 __syncthreads();
             } else {
                 // ---- output layer: f, dP, per-wave partial of dL/dx_L -----------------------------------------------------
@@ -1306,7 +1354,8 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                         *reinterpret_cast<f32x4*>((l == 0 ? KOA : gx) + o) = acc;
                     }
                 } else {
-                    tl_hidden_bwd<NWV>(a.W[l], N, K, gpre, xin, l > 0, l == 0 ? KOA : gx, wave, lane);
+                    const TlW wr_ = tl_wref(lds, DIRECT != 0 ? a.tres[l] : 0, a.W[l], a.b[l], N, K);
+                    tl_hidden_bwd<NWV>(wr_.W, N, K, gpre, xin, l > 0, l == 0 ? KOA : gx, wave, lane, nullptr, nullptr, wr_.ld);
                 }
                 __syncthreads();
                 float* tmp = gpre; gpre = gx; gx = tmp;
@@ -1875,6 +1924,35 @@ int64_t tiled_pack_floats(const NcdeProblem* p, bool bf) {
     const int64_t n = (int64_t)p->hidden * p->channels * dl * (p->field_kind == NCDE_FIELD_MINIMAL ? 2 : 1);
     return bf ? n + n / 2 : n;
 }
+// Direct modes: which matrices get an LDS-resident copy behind the kernel's own `base` bytes of LDS (tl_fill_resident): the inner
+// layers (a shared one once) as far as they fit, then the heads (both or neither).  Fills a->tres*, returns the LDS bytes to launch with.
+size_t tiled_direct_residency(const NcdeProblem* p, KArgs* a, size_t base) {
+    for (int l = 0; l < NCDE_MAX_LAYERS; ++l) a->tres[l] = 0;
+    a->tres_o = a->tres_g = 0;
+    if (getenv("NCDE_TILED_NO_RESIDENT")) return base;
+    size_t off = (base + 15) / 16 * 4;      // floats, 16-byte aligned
+    auto need = [](int N, int K) { return ((size_t)N * (K + 4) + N + 3) & ~(size_t)3; };
+    auto fits = [&](size_t n) { return (off + n) * sizeof(float) <= (size_t)kLdsLimit; };
+    for (int l = 0; l < p->n_layers; ++l) {
+        int shared = -1;
+        for (int q = 0; q < l; ++q)
+            if (a->W[q] == a->W[l]) shared = q;
+        if (shared >= 0) { a->tres[l] = a->tres[shared]; continue; }
+        const size_t n = need(a->dout[l], a->din[l]);
+        if (!fits(n)) continue;
+        a->tres[l] = (int)off;
+        off += n;
+    }
+    const int dl = p->layer_out[p->n_layers - 1];
+    const bool gated = p->field_kind != NCDE_FIELD_ORIGINAL;
+    const size_t nh = need(p->hidden, dl);
+    if (fits(nh * (gated ? 2 : 1))) {
+        a->tres_o = (int)off; off += nh;
+        if (gated) { a->tres_g = (int)off; off += nh; }
+    }
+    return off * sizeof(float);
+}
+
 // Packs Wo (and Wg) into `dst` and hands the copies to the kernels.
 void tiled_pack_launch(const NcdeProblem* p, KArgs* a, float* dst, bool bf, hipStream_t st) {
     const int dl = p->layer_out[p->n_layers - 1];
@@ -2124,7 +2202,7 @@ int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws
         a.din[0] = d0p;
     } else if (tiled_pack_floats(p, bf) > 0) tiled_pack_launch(p, &a, (float*)ws + 64, bf, st);
     const int ns = direct ? 1 : tiled_fwd_ns(p);
-    const size_t lds = tiled_fwd_lds(p, ns);
+    const size_t lds = direct ? tiled_direct_residency(p, &a, tiled_fwd_lds(p, ns)) : tiled_fwd_lds(p, ns);
     const bool small = p->hidden * ns * 16 <= 4 * TL_THREADS;   // state slice of <= 4 elements per thread: fewer live registers
     void (*fn)(KArgs) = ns == 4 ? (small ? ncde_fwd_tiled<4, TL_NW, 4> : ncde_fwd_tiled<4, TL_NW, 16>)
                                 : (ns == 2 ? (small ? ncde_fwd_tiled<2, TL_NW, 4> : ncde_fwd_tiled<2, TL_NW, 16>)
@@ -2176,10 +2254,11 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
         a.carry = w + t.carry;
         const bool g1 = p->field_kind == NCDE_FIELD_MINIMAL;
         void (*fd)(KArgs) = g1 ? ncde_adj_tiled<1, TL_ADJ_NW, 0, 1, 0, 1> : ncde_adj_tiled<1, TL_ADJ_NW, 0, 0, 0, 1>;
-        if (ncde_lds_optin((const void*)fd, tiled_adj_lds(p)) != hipSuccess) return NCDE_ERR_HIP;
+        const size_t ldsd = tiled_direct_residency(p, &a, tiled_adj_lds(p));      // + LDS-resident copies of the small matrices
+        if (ncde_lds_optin((const void*)fd, ldsd) != hipSuccess) return NCDE_ERR_HIP;
         const int n_rs = p->output == NCDE_OUT_TIMES ? (discrete ? p->n_steps_fwd : p->n_steps_adj) : p->n_knots - 1;
         a.win_hi = n_rs; a.win_lo = 0; a.resume = 0;
-        hipLaunchKernelGGL(fd, dim3(t.n_st), dim3(64 * TL_ADJ_NW), tiled_adj_lds(p), st, a);
+        hipLaunchKernelGGL(fd, dim3(t.n_st), dim3(64 * TL_ADJ_NW), ldsd, st, a);
         if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
         if (main_kernel_only) return NCDE_OK;
         return launch_reduce_partials(p, y, g, (const float*)a.gpart, t.n_st, st);
