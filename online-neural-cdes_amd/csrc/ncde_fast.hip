@@ -13,42 +13,17 @@
 //
 // Reference semantics: see ncde_generic.hip (same stage tables, same knot-index rule).
 #include "ncde_fast.h"
+#include "ncde_fast4.h"
 
 #include <cstring>
 #include <type_traits>
 
 #include "ncde_common.h"
 #include "ncde_bf3.h"
+#include "ncde_fastdefs.h"
 #include "ncde_host.h"
 
 namespace {
-
-template <int METHOD>
-struct Combine {
-    // Butcher bookkeeping; returns the next stage input (or the new state after the last stage).
-    static __device__ __forceinline__ float apply(int j, float k, float& y0, float& k1, float& k2) {
-        if constexpr (METHOD == NCDE_RK4_38) {
-            if (j == 0) { k1 = k; return y0 + k * 0.333333343267440796f; }
-            if (j == 1) { k2 = k; return y0 + (k - k1 * 0.333333343267440796f); }
-            if (j == 2) { const float ys = y0 + ((k1 - k2) + k); k2 = k2 + k; return ys; }
-            y0 = y0 + ((k1 + 3.0f * k2) + k) * 0.125f;
-            return y0;
-        } else if constexpr (METHOD == NCDE_MIDPOINT) {
-            if (j == 0) return y0 + k * 0.5f;
-            y0 = y0 + k;
-            return y0;
-        } else {
-            y0 = y0 + k;
-            return y0;
-        }
-    }
-};
-
-// DS instructions of one wave are executed by the LDS in issue order, so a ds_read that follows a ds_write
-// of the same wave (any lanes) sees the data without an s_waitcnt; only the COMPILER must keep the order.
-__device__ __forceinline__ void wave_lds_order() { asm volatile("" ::: "memory"); }
-
-template <int METHOD> constexpr int kStages = METHOD == NCDE_RK4_38 ? 4 : (METHOD == NCDE_MIDPOINT ? 2 : 1);
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -299,13 +274,6 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_fwd_fast(KArgs a) {
 // forward, split-bf16 variant: fp32-equivalent GEMMs on the bf16 matrix cores
 // ------------------------------------------------------------------------------------------------
 // (the split-bf16 arithmetic itself lives in ncde_bf3.h, shared with the batch-tiled family)
-// relu on the bit pattern: max_i32(bits, 0) is 0 for every negative float (and -0.0) and the identity otherwise -- ONE
-// VALU op, no canonicalisation of the MFMA result (v_max_f32 / v_med3_f32 get a v_max x,x,x in front).
-__device__ __forceinline__ float relu_bits(float x) {
-    const int b = __builtin_bit_cast(int, x);
-    return __builtin_bit_cast(float, b > 0 ? b : 0);
-}
-
 // NLT = number of layers known at compile time (0 = runtime): with the layer loop unrolled the whole stage is ONE basic
 // block, so the scheduler can issue the hi-piece MFMAs of layer l+1 under the mid / lo split of layer l.
 template <int H, int HH, int C, int NW, int INTERP, int METHOD, int PROF = 0, int NLT = 0>
@@ -2470,6 +2438,14 @@ const FastEntry* find_entry(const NcdeProblem* p) {
     return nullptr;
 }
 
+// the decoupled-chain adjoint (ncde_fast4.hip) is the default wherever it is instantiated
+bool use_v4(const NcdeProblem* p, const FastEntry* e, bool discrete) {
+    if (e->shape.H != 32 || e->shape.HH != 32) return false;
+    if (p->flags & (NCDE_FLAG_ADJOINT_V1 | NCDE_FLAG_ADJOINT_V2 | NCDE_FLAG_ADJOINT_V3 | 0x200u)) return false;
+    if (discrete && (p->flags & NCDE_FLAG_DEBUG_PROFILE)) return false;
+    return ncde_fast4_pick(p->n_layers, p->channels, p->interp, p->method, discrete, (p->flags & NCDE_FLAG_DEBUG_PROFILE) != 0) != nullptr;
+}
+
 }  // namespace
 
 bool ncde_fast_supported(const NcdeProblem* p, int pass) {
@@ -2484,6 +2460,8 @@ const char* ncde_fast_kernel_name(const NcdeProblem* p, int pass) {
     if (!ncde_fast_supported(p, pass)) return nullptr;
     const FastEntry* e = find_entry(p);
     if (pass == 0) return ((p->flags & NCDE_FLAG_FP32_MFMA) == 0 && e->fwd_bf3) ? e->fwd_bf3_name : e->fwd_name;
+    if (use_v4(p, e, pass == 2)) return pass == 2 ? "ncde_adj_fast4<H32,HH32,C20,NL3,y-waves+cotangent-waves(bf16x3),discrete>"
+                                                  : "ncde_adj_fast4<H32,HH32,C20,NL3,y-waves+cotangent-waves(bf16x3)>";
     if (pass == 2) return e->adj3_disc_name;
     if (p->flags & NCDE_FLAG_ADJOINT_V1) return e->adj_name;
     if ((p->flags & NCDE_FLAG_ADJOINT_V2) && e->adj2) return e->adj2_name;
@@ -2542,6 +2520,17 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     if (discrete) { a.stages = const_cast<float*>(z_out); a.discrete = 1; }
     else a.z_out = z_out;
     a.gpart = (float*)ws;
+    if (use_v4(p, e, discrete)) {
+        const bool prof = (p->flags & NCDE_FLAG_DEBUG_PROFILE) != 0;
+        NcdeFast4Kernel k4 = ncde_fast4_pick(p->n_layers, p->channels, p->interp, p->method, discrete, prof);
+        if (prof) a.out = (float*)ws + (size_t)y.n_wg * y.theta_size + 64;
+        const size_t lds4 = ncde_fast4_lds_bytes(p->n_layers, p->channels, p->interp);
+        if (ncde_lds_optin((const void*)k4, lds4) != hipSuccess) return NCDE_ERR_HIP;
+        hipLaunchKernelGGL(k4, dim3(y.n_wg), dim3(512), lds4, st, a);
+        if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
+        if (main_kernel_only) return NCDE_OK;
+        return launch_reduce_partials(p, y, g, (const float*)ws, y.n_wg, st);
+    }
     if (p->flags & 0x200u) {  // development: per-stage chain values of workgroup 0 -> tail of the workspace
         if (!(e->shape.H == 32 && e->shape.C == 20 && p->interp == NCDE_INTERP_CUBIC && p->method == NCDE_MIDPOINT)) return NCDE_ERR_UNSUPPORTED;
         fn = !v1 ? ncde_adj_fast2<32, 32, 20, 3, NCDE_INTERP_CUBIC, NCDE_MIDPOINT, 2> : ncde_adj_fast<32, 32, 20, 3, 4, NCDE_INTERP_CUBIC, NCDE_MIDPOINT, 2>;

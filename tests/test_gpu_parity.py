@@ -204,8 +204,8 @@ CFG2_FULL_BATCH_G = TOL_DTHETA
 
 
 def test_full_size_cfg2_adjoint_and_discrete_backward_vs_oracle(gpu_lib):
-    """BASELINE configs 2/3 at the benchmarked size (B = 4096 launched, T = 399): `ncde_adj_fast3` and
-    `ncde_adj_fast3<discrete>` (adjoint.py:37-145 / autograd through solvers.py:94-119) against the oracle on a 32-sample
+    """BASELINE configs 2/3 at the benchmarked size (B = 4096 launched, T = 399): `ncde_adj_fast4` and
+    `ncde_adj_fast4<discrete>` (adjoint.py:37-145 / autograd through solvers.py:94-119) against the oracle on a 32-sample
     sub-batch that straddles tile boundaries, bit-exact sample independence of z and dL/dz0 between the big batch and the
     sub-batch, and the full-batch parameter gradients of the continuous adjoint against the oracle on all 4096 samples."""
     import gpu_util
@@ -214,8 +214,8 @@ def test_full_size_cfg2_adjoint_and_discrete_backward_vs_oracle(gpu_lib):
     big, names = _cfg2_case(B)
     torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
     rb = gpu_util.run_case(big)                               # forward + continuous adjoint, the benchmarked kernels
-    assert rb["kernels"][0].startswith("ncde_fwd_fast_bf3") and rb["kernels"][1].startswith("ncde_adj_fast3"), rb["kernels"]
-    assert "discrete" in rb["kernels"][2] and rb["kernels"][2].startswith("ncde_adj_fast3"), rb["kernels"]
+    assert rb["kernels"][0].startswith("ncde_fwd_fast_bf3") and rb["kernels"][1].startswith("ncde_adj_fast4"), rb["kernels"]
+    assert "discrete" in rb["kernels"][2] and rb["kernels"][2].startswith("ncde_adj_fast4"), rb["kernels"]
     rbd = gpu_util.run_case(big, adjoint=False)               # recording forward + exact discrete backward
     sel = slice(2039, 2071)                                   # tiles 127..129
     sub = dict(big, coeffs=big["coeffs"][sel].copy(), z0=big["z0"][sel].copy(), expect={"grad_out": big["expect"]["grad_out"][sel].copy()})
@@ -489,8 +489,10 @@ def test_fast_kernels_vs_oracle(shape, interp, method, seq, gpu_lib):
     iso = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_AUTO)
     for k, e in _grad_errors(case, iso).items():
         assert e <= TIGHT_G, ("adjoint kernel on oracle z_out", res["kernels"][1], k, e)
-    if res["kernels"][1].startswith("ncde_adj_fast3"):       # also the other specialised adjoint variants
-        for fl, nm in ((_lib.FLAG_ADJOINT_V1, "single-role"), (_lib.FLAG_ADJOINT_V2, "chain+grad fp32 chain")):
+    if H == 32:
+        assert res["kernels"][1].startswith("ncde_adj_fast4"), res["kernels"]      # default: decoupled y / cotangent waves
+        for fl, nm in ((_lib.FLAG_ADJOINT_V1, "single-role"), (_lib.FLAG_ADJOINT_V2, "chain+grad fp32 chain"),
+                       (_lib.FLAG_ADJOINT_V3, "chain+grad split-bf16 chain")):      # also the other specialised adjoint variants
             iso1 = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=fl)
             for k, e in _grad_errors(case, iso1).items():
                 assert e <= TIGHT_G, (nm + " adjoint kernel on oracle z_out", k, e)
@@ -505,9 +507,31 @@ def test_fast_kernels_vs_oracle(shape, interp, method, seq, gpu_lib):
     for k, e in _grad_errors(case, isod, "bp_").items():
         assert e <= TIGHT_G, ("discrete backward kernel on the oracle's stage record", res["kernels"][2], k, e)
     if H == 32:
-        assert res["kernels"][2].startswith("ncde_adj_fast3") and "discrete" in res["kernels"][2], res["kernels"]
+        assert res["kernels"][2].startswith("ncde_adj_fast4") and "discrete" in res["kernels"][2], res["kernels"]
         againd = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_AUTO, stages=case["stage_record"])
         assert np.array_equal(againd["dz0"], isod["dz0"]) and all(np.array_equal(againd["grads"][k], isod["grads"][k]) for k in isod["grads"])
+
+
+@pytest.mark.parametrize("interp,method", [("cubic", "midpoint"), ("linear", "rk4"), ("cubic", "euler")])
+def test_decoupled_adjoint_hand_offs_under_repetition(interp, method, gpu_lib):
+    """ncde_adj_fast4 hands data between its y waves and cotangent waves through LDS flags (t blocks, reduction partials):
+    ten launches of the continuous adjoint and of the discrete backward on the oracle's z, ragged two-workgroup batch, must be
+    bit-identical and within the tight tolerance.  (cubic + midpoint was the combination that exposed a timing-dependent
+    failure of a stage-weight-dependent control flow during development.)"""
+    import gpu_util
+    from ncde_amd import _lib
+    case = _seeded_case(interp, method, False, B=21, L=5, C=20, H=32, HH=32, nl=3, seed=177)
+    ex = case["expect"]
+    for kw, pre in (({}, ""), ({"stages": case["stage_record"]}, "bp_")):
+        first = None
+        for _ in range(10):
+            iso = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_AUTO, **kw)
+            for k, e in _grad_errors(case, iso, pre).items():
+                assert e <= TIGHT_G, (interp, method, pre, k, e)
+            if first is None:
+                first = iso
+            else:
+                assert np.array_equal(first["dz0"], iso["dz0"]) and all(np.array_equal(first["grads"][k], iso["grads"][k]) for k in iso["grads"])
 
 
 @pytest.mark.parametrize("shape", [(80, 128, 128, 3), (8, 48, 64, 2), (4, 16, 32, 1), (16, 64, 64, 2)])      # the last: four row tiles per wave in pass B,

@@ -34,7 +34,7 @@ for flags, label in ((4, "fp32-mfma plain"), (0x104, "fp32-mfma instrumented"), 
 
 # ---- adjoint ----
 theta = 32*32+32+32*32+32+640*32+640
-for flags, label in ((8, "adj v1 plain"), (16, "adj v2 plain"), (0, "adj v3 plain"), (0x100, "adj v3 instrumented")):
+for flags, label in ((32, "adj v3 plain"), (0x120, "adj v3 instrumented"), (0, "adj v4 plain"), (0x100, "adj v4 instrumented")):
     p = solver.build_problem(coeffs, "linear", z0, spec, "rk4", _lib.OUT_INTERVAL, flags)
     ws = torch.zeros(int(lib.ncde_workspace_bytes(ctypes.byref(p), 1)), dtype=torch.uint8, device="cuda")
     out = torch.randn(B, 2, 32, device="cuda"); gout = torch.randn(B, 2, 32, device="cuda")
@@ -46,12 +46,16 @@ for flags, label in ((8, "adj v1 plain"), (16, "adj v2 plain"), (0, "adj v3 plai
     ms = ctypes.c_float()
     _lib.check(lib.ncde_time_kernel(ctypes.byref(p), 1, out.data_ptr(), gout.data_ptr(), ctypes.byref(g), ws.data_ptr(), ws.numel(), None, 3, ctypes.byref(ms)), "time")
     print(label, "ms/launch", ms.value)
-    if flags:
+    if flags & 0x100:
         nwg = B // 16
         off = (nwg * theta + 64) * 4
         cyc = ws[off: off + nwg * 8 * 6 * 8].view(torch.int64).view(-1, 8, 6).cpu().numpy().astype(np.float64)
         per = cyc.mean(axis=0) / (398 * 4)
-        print("chain rows 0-3: recompute | out tiles | wait barrier A | reduce+hidden bwd+vy | rk+exchange(+barrier B)")
-        print("grad  rows 4-7: dw_hidden(prev) | wait group0 | dxl0+dWo blocks | wait group1 | dxl1+red | A+dWo rest+B")
+        if flags & 32:
+            print("chain rows 0-3: recompute | out tiles | wait barrier A | reduce+hidden bwd+vy | rk+exchange(+barrier B)")
+            print("grad  rows 4-7: dw_hidden(prev) | wait group0 | dxl0+dWo blocks | wait group1 | dxl1+red | A+dWo rest+B")
+        else:
+            print("Y rows 0-3: hidden+masks+images | out tiles + t blocks | rk + stores | barrier E | - | -")
+            print("A rows 4-7: dP, Wo^T dP, dWo blocks | reduction hand-off | sum + hidden bwd + dW + vy | rk | barrier E | -")
         print(np.array2string(per[:, :6], precision=0))
         print("total", per[:, :6].sum(axis=1))
