@@ -15,7 +15,7 @@ OUT_INTERVAL, OUT_KNOTS, OUT_TIMES = 0, 1, 2
 FIELD_KIND = {"original": 0, "minimal": 1, "gru": 2}
 FIELD_INPUT = {"matmul": 0, "evaluate": 1, "derivative": 2}
 FLAG_AUTO, FLAG_FORCE_GENERIC, FLAG_FORCE_FAST, FLAG_FP32_MFMA, FLAG_ADJOINT_V1, FLAG_ADJOINT_V2 = 0, 1, 2, 4, 8, 16
-FLAG_ADJOINT_V3 = 32
+FLAG_ADJOINT_V4 = 32
 FLAG_TILED_NS1, FLAG_TILED_NS2, FLAG_TILED_NS4, FLAG_FORCE_TILED = 0x1000, 0x2000, 0x4000, 0x8000
 
 _c_float_p = ctypes.c_void_p  # device pointers are passed as integers

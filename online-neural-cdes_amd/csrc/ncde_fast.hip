@@ -2438,10 +2438,10 @@ const FastEntry* find_entry(const NcdeProblem* p) {
     return nullptr;
 }
 
-// the decoupled-chain adjoint (ncde_fast4.hip) is the default wherever it is instantiated
+// the decoupled-chain adjoint (ncde_fast4.hip): selectable (NCDE_FLAG_ADJOINT_V4), not the default -- measured slower
 bool use_v4(const NcdeProblem* p, const FastEntry* e, bool discrete) {
     if (e->shape.H != 32 || e->shape.HH != 32) return false;
-    if (p->flags & (NCDE_FLAG_ADJOINT_V1 | NCDE_FLAG_ADJOINT_V2 | NCDE_FLAG_ADJOINT_V3 | 0x200u)) return false;
+    if (!(p->flags & NCDE_FLAG_ADJOINT_V4) || (p->flags & (NCDE_FLAG_ADJOINT_V1 | NCDE_FLAG_ADJOINT_V2 | 0x200u))) return false;
     if (discrete && (p->flags & NCDE_FLAG_DEBUG_PROFILE)) return false;
     return ncde_fast4_pick(p->n_layers, p->channels, p->interp, p->method, discrete, (p->flags & NCDE_FLAG_DEBUG_PROFILE) != 0) != nullptr;
 }

@@ -56,8 +56,14 @@ struct F4Lds {   // offsets in 4-byte words
 };
 
 template <int NL, int C, int INTERP, int METHOD, int PROF = 0, int DISC = 0>
+#ifndef F4_YB
+#define F4_YB 2
+#endif
 #ifndef F4_LB
 #define F4_LB 2
+#endif
+#ifdef F4_NV
+__attribute__((amdgpu_num_vgpr(F4_NV)))
 #endif
 __global__ __launch_bounds__(512, F4_LB) void ncde_adj_fast4(KArgs a) {
     unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
@@ -71,6 +77,8 @@ __global__ __launch_bounds__(512, F4_LB) void ncde_adj_fast4(KArgs a) {
     constexpr int H = 32, HH = 32, NW = 4, HT = 2;
     constexpr int CP = L::CP, CQ = L::CQ, NB = 2, NTILE = L::NTILE, DXW = L::DXW, XROWS = L::XROWS;
     constexpr int S = kStages<METHOD>;
+    constexpr int YB = CQ >= 3 ? F4_YB : 0;                // dWo blocks cq >= CQ - YB are accumulated by the Y wave (register balance: §fast4)
+    constexpr int AB = CQ - YB;
     constexpr int NTY = 64 * NW;                       // threads of the Y role (they stage the control path)
     constexpr int EPT = (16 * DXW + NTY - 1) / NTY;
     static_assert(NL >= 1 && NL <= 3, "mask word holds three layers");
@@ -153,6 +161,21 @@ __global__ __launch_bounds__(512, F4_LB) void ncde_adj_fast4(KArgs a) {
     }
 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // write-out of one row tile of a dWo block: D tile lane (unit n = s, g) register r <-> row 4g + r of row tile nb <->
+    // (h = 4 (pw NB + nb) + g, c = 4 blk + r); bias: lane (row s of the tile, g) holds the sum over samples 4g..4g+3
+    auto write_dwo_tiles = [&](float* gp, int blk, int nb, const f32x4* acc, float bsum) {
+        const int h = 4 * (pw * NB + nb) + g;
+#pragma unroll
+        for (int ut = 0; ut < HT; ++ut)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * blk + r < C) gp[a.gWo_off + (h * C + 4 * blk + r) * HH + 16 * ut + s] = acc[ut][r];
+        float v = bsum;
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        const int hrow = 4 * (pw * NB + nb) + (s >> 2), crow = 4 * blk + (s & 3);
+        if (g == 0 && crow < C) gp[a.gbo_off + hrow * C + crow] = v;
+    };
     if (is_y) {
         // =================================================================================================
         // Y wave: forward stage of reverse stage sc = it + 1
@@ -217,6 +240,17 @@ __global__ __launch_bounds__(512, F4_LB) void ncde_adj_fast4(KArgs a) {
             stage_load(p_hi - 1);
             stage_store(p_hi - 1);
         }
+        f32x4 gWoY[YB > 0 ? YB : 1][NB][HT];
+        float gboY[YB > 0 ? YB : 1][NB];
+#pragma unroll
+        for (int i = 0; i < (YB > 0 ? YB : 1); ++i)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                gboY[i][nb] = 0.0f;
+#pragma unroll
+                for (int ut = 0; ut < HT; ++ut) gWoY[i][nb][ut] = zero4;
+            }
+        float wprev = 0.0f;     // quadrature weight of the stage whose dP blocks come back in this interval
         const int last_row = a.n_out - 1;
         float y0[NB], ky1[NB], ky2[NB], zreg[8];
         f32x4 znext[2];     // DISC: the next stage input, fetched a stage ahead; KNOTS: the stored state of the next knot
@@ -246,9 +280,13 @@ __global__ __launch_bounds__(512, F4_LB) void ncde_adj_fast4(KArgs a) {
         int n = a.T - 1, j = 0;
         if constexpr (PROF != 0) tlast = __builtin_readcyclecounter();
         for (int it = 0; it <= NS; ++it) {
-            if (it < NS) {
-                const int sc = it + 1;
-                const int par = sc & 1;
+            const bool fwd = it < NS;       // forward stage sc = it + 1
+            const int sc = it + 1;
+            const int par = sc & 1;
+            float t = 0.0f, frac = 0.0f;
+            int idx = 0;
+            Split3 xb;
+            if (fwd) {
                 if (j == 0) {
                     if (n - 3 >= 0) stage_load(n - 3);
                     if constexpr (DISC == 0) {
@@ -261,17 +299,15 @@ __global__ __launch_bounds__(512, F4_LB) void ncde_adj_fast4(KArgs a) {
                         }
                     }
                 }
-                const float t = DISC != 0 ? (float)(n - 1) + stage_offset(METHOD, S - 1 - j) : -(-(float)n + stage_offset(METHOD, j));
-                const int idx = piece_index(t, a.n_pieces);
-                const float frac = t - (float)idx;
+                t = DISC != 0 ? (float)(n - 1) + stage_offset(METHOD, S - 1 - j) : -(-(float)n + stage_offset(METHOD, j));
+                idx = piece_index(t, a.n_pieces);
+                frac = t - (float)idx;
                 if constexpr (DISC != 0) {
                     const int lin = (n - 1) * S + (S - 1 - j);
                     if (lin >= 1) rec_fetch(lin - 1);
                 }
-                const float* dxp = dxs + (idx % 3) * 16 * DXW + s * DXW;
                 // ---- hidden layers (split-bf16); x[l][4t+r] <-> unit 8g + 4t + r ---------------------------------------
                 float x[NL][8];
-                Split3 xb;
                 {
                     f32x4 acc[HT];
                     xb = split8(zreg);
@@ -320,13 +356,27 @@ __global__ __launch_bounds__(512, F4_LB) void ncde_adj_fast4(KArgs a) {
                         }
                 }
                 NCDE_TICK(0)
-                // ---- output tiles: P, r = 1/(exp(2P)+1), f, t = 4 dX r (1 - r) -> LDS block ------------------------------
-                float kout[NB];
-                float sdx = 0.0f;
+            }
+            const float* dxp = dxs + (idx % 3) * 16 * DXW + s * DXW;
+            f32x4 bx[HT];       // w * x_L of stage it as the fp32 B operand of the dWo tiles this wave accumulates
+            if constexpr (YB > 0) {
+                const float* xp = ximg + (it & 1) * XROWS * 16;
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) kout[nb] = 0.0f;
+                for (int ut = 0; ut < HT; ++ut) {
+                    bx[ut] = *reinterpret_cast<const f32x4*>(xp + (H + (NL - 1) * HH + 16 * ut + s) * 16 + 4 * g);
 #pragma unroll
-                for (int cq = 0; cq < CQ; ++cq) {
+                    for (int q = 0; q < 4; ++q) bx[ut][q] *= wprev;
+                }
+            }
+            // ---- output tiles: P, r = 1/(exp(2P)+1), f, t = 4 dX r (1 - r) -> LDS block; dP blocks of stage it coming back ----
+            float kout[NB];
+            float sdx = 0.0f;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) kout[nb] = 0.0f;
+#pragma unroll
+            for (int cq = 0; cq < CQ; ++cq) {
+                f32x4 tv[NB];
+                if (fwd) {
                     f32x4 o[NB];
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
@@ -351,7 +401,6 @@ __global__ __launch_bounds__(512, F4_LB) void ncde_adj_fast4(KArgs a) {
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sdx += dx[r];
-                    f32x4 tv[NB];
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -360,16 +409,40 @@ __global__ __launch_bounds__(512, F4_LB) void ncde_adj_fast4(KArgs a) {
                             if constexpr (DISC == 0) kout[nb] = fmaf(rr, dx[r], kout[nb]);
                             tv[nb][r] = (4.0f * dx[r]) * fmaf(-rr, rr, rr);
                         }
-                    // the pair's A wave must have taken block cq of the previous stage out of the buffer
-                    {
-                        const int want = (sc - 1) * 8 + cq + 1;
-                        while (__builtin_amdgcn_readfirstlane(vflags[4 + pw]) < want) __builtin_amdgcn_s_sleep(1);
-                        wave_lds_order();
-                    }
-                    float* rb = rbuf + ((pw * CQ + cq) * 2) * 256 + lane * 4;
-                    *reinterpret_cast<f32x4*>(rb) = tv[0];
-                    *reinterpret_cast<f32x4*>(rb + 256) = tv[1];
                 }
+                // the pair's A wave must be done with block cq of stage it (its t values taken; for cq >= AB its dP tile put back)
+                {
+                    const int want = it * 8 + cq + 1;
+                    while (__builtin_amdgcn_readfirstlane(vflags[4 + pw]) < want) __builtin_amdgcn_s_sleep(1);
+                    wave_lds_order();
+                }
+                float* slot = rbuf + (pw * CQ + cq) * 512;
+                if constexpr (YB > 0) {
+                    if (cq >= AB && it >= 1) {     // dWo of block cq, stage it: the tile is [row][sample], samples are K (fp32 MFMA)
+                        f32x4 av[NB];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) av[nb] = *reinterpret_cast<const f32x4*>(slot + (nb * 16 + s) * 16 + 4 * g);
+                        wave_lds_order();
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            gboY[cq >= AB ? cq - AB : 0][nb] += wprev * ((av[nb][0] + av[nb][1]) + (av[nb][2] + av[nb][3]));
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                for (int ut = 0; ut < HT; ++ut)
+                                    gWoY[cq >= AB ? cq - AB : 0][nb][ut] = mfma16(av[nb][q], bx[ut][q], gWoY[cq >= AB ? cq - AB : 0][nb][ut]);
+                        }
+                    }
+                }
+                if (fwd) {
+                    *reinterpret_cast<f32x4*>(slot + lane * 4) = tv[0];
+                    *reinterpret_cast<f32x4*>(slot + 256 + lane * 4) = tv[1];
+                }
+#ifdef F4_YSB
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+            if (fwd) {
                 NCDE_TICK(1)
                 if constexpr (DISC == 0) {
                     float ys[NB];
@@ -388,6 +461,7 @@ __global__ __launch_bounds__(512, F4_LB) void ncde_adj_fast4(KArgs a) {
                     }
                 }
                 if (j == S - 1 && n - 3 >= 0) stage_store(n - 3);
+                wprev = DISC != 0 ? 1.0f : stage_weight(METHOD, j);
                 NCDE_TICK(2)
             }
             __syncthreads();   // E: stage sc + 1 of y done, stage sc of a done
@@ -416,6 +490,13 @@ __global__ __launch_bounds__(512, F4_LB) void ncde_adj_fast4(KArgs a) {
                 for (int k = 0; k < 6; ++k) dst[k] = prof[k];
             }
         }
+        if constexpr (YB > 0) {
+            float* gp = a.gpart + (long long)blockIdx.x * a.theta_size;
+#pragma unroll
+            for (int i = 0; i < YB; ++i)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) write_dwo_tiles(gp, AB + i, nb, gWoY[i][nb], gboY[i][nb]);
+        }
     } else {
         // =================================================================================================
         // A wave: cotangent chain + parameter gradients of reverse stage sc = it
@@ -439,15 +520,17 @@ __global__ __launch_bounds__(512, F4_LB) void ncde_adj_fast4(KArgs a) {
                 wtMid[cq][tt] = sp.mid;
                 *reinterpret_cast<u32x4*>(my_lo + ((cq * HT + tt) * 64 + lane) * 4) = sp.lo;
             }
-        f32x16 gWo[CQ];
+        f32x4 gWo[AB][NB][HT];               // dWo of block cq < AB: row tile nb x unit tile ut, fp32 MFMA accumulators (samples are K)
         f32x4 gW1 = zero4, gW0 = zero4;      // one 16x16 tile of dW1 / dW0 per pair: tile (tr, tc) = (pw >> 1, pw & 1)
-        float gbo[CQ], gb1 = 0.0f, gb0 = 0.0f;
+        float gbo[AB][NB], gb1 = 0.0f, gb0 = 0.0f;
 #pragma unroll
-        for (int i = 0; i < CQ; ++i) {
-            gbo[i] = 0.0f;
+        for (int i = 0; i < AB; ++i)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) gWo[i][q] = 0.0f;
-        }
+            for (int nb = 0; nb < NB; ++nb) {
+                gbo[i][nb] = 0.0f;
+#pragma unroll
+                for (int ut = 0; ut < HT; ++ut) gWo[i][nb][ut] = zero4;
+            }
         const int last_row = a.n_out - 1;
         float a0[NB], ka1[NB], ka2[NB], ka3[NB], as_[NB], gk[NB];
 #pragma unroll
@@ -461,7 +544,6 @@ __global__ __launch_bounds__(512, F4_LB) void ncde_adj_fast4(KArgs a) {
         const int tr = pw >> 1, tc = pw & 1;
         float* my_scr = scr + pw * 512;
         float* my_gs = gscr + pw * 256;
-        const int i32 = lane & 31, kg = lane >> 5;
         __syncthreads();
 
         int n = a.T - 1, j = 0;
@@ -480,15 +562,12 @@ __global__ __launch_bounds__(512, F4_LB) void ncde_adj_fast4(KArgs a) {
                         gk[nb] = (need && valid) ? a.grad_out[((long long)bs * a.n_out + row) * H + 4 * (pw * NB + nb) + g] : 0.0f;
                 }
                 const unsigned m = masks[(par * NW + pw) * 64 + lane];
-                Split3 Bs;          // w * x_L as the B operand of the dWo blocks: lane (unit i32, kg) holds samples 8kg..8kg+7
-                {
-                    const float* xl = xi + (H + (NL - 1) * HH + i32) * 16 + 8 * kg;
-                    const f32x4 b0v = *reinterpret_cast<const f32x4*>(xl);
-                    const f32x4 b1v = *reinterpret_cast<const f32x4*>(xl + 4);
-                    float bv[8];
+                f32x4 bx[HT];       // w * x_L as the fp32 B operand of the dWo tiles: lane (unit 16 ut + s, kk = g) holds samples 4g..4g+3
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { bv[q] = wq * b0v[q]; bv[4 + q] = wq * b1v[q]; }
-                    Bs = split8(bv);
+                for (int ut = 0; ut < HT; ++ut) {
+                    bx[ut] = *reinterpret_cast<const f32x4*>(xi + (H + (NL - 1) * HH + 16 * ut + s) * 16 + 4 * g);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bx[ut][q] *= wq;
                 }
                 f32x4 accJ[HT];
 #pragma unroll
@@ -498,8 +577,10 @@ __global__ __launch_bounds__(512, F4_LB) void ncde_adj_fast4(KArgs a) {
                     const float* rb = rbuf + ((pw * CQ + cq) * 2) * 256 + lane * 4;
                     const f32x4 t0 = *reinterpret_cast<const f32x4*>(rb);
                     const f32x4 t1 = *reinterpret_cast<const f32x4*>(rb + 256);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the block is in registers before it is released
-                    if (lane == 0) vflags[4 + pw] = sc * 8 + cq + 1;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the block is in registers before its slot is released
+                    if (cq < AB) {
+                        if (lane == 0) vflags[4 + pw] = sc * 8 + cq + 1;
+                    }
                     float dP[8];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { dP[r] = as_[0] * t0[r]; dP[4 + r] = as_[1] * t1[r]; }
@@ -512,27 +593,32 @@ __global__ __launch_bounds__(512, F4_LB) void ncde_adj_fast4(KArgs a) {
                         As.lo = *reinterpret_cast<const u32x4*>(my_lo + ((cq * HT + tt) * 64 + lane) * 4);
                         accJ[tt] = mfma_split(As, gb, accJ[tt]);
                     }
-                    {   // dWo block cq: 32 rows x 32 units x 16 samples = 6 split-bf16 32x32x16 MFMAs
+                    if (cq < AB) {   // dWo block cq: dP through the wave-private patch to come back with the samples as K; plain fp32
+                        // MFMA (16 per block: no second split of dP, no split of x_L -- issue slots, not the matrix pipe, bound the stage)
 #pragma unroll
                         for (int jj = 0; jj < 8; ++jj) my_scr[((jj >> 2) * 16 + 4 * g + (jj & 3)) * 16 + s] = dP[jj];
                         wave_lds_order();
-                        const f32x4 a0v = *reinterpret_cast<const f32x4*>(my_scr + i32 * 16 + 8 * kg);
-                        const f32x4 a1v = *reinterpret_cast<const f32x4*>(my_scr + i32 * 16 + 8 * kg + 4);
-                        wave_lds_order();
-                        float av[8];
+                        f32x4 av[NB];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) { av[q] = a0v[q]; av[4 + q] = a1v[q]; }
-                        gbo[cq] += wq * (((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7])));
-                        const Split3 As = split8(av);
-                        f32x16 c = gWo[cq];
-                        c = mfma_bf32(As.lo, Bs.hi, c);
-                        c = mfma_bf32(As.hi, Bs.lo, c);
-                        c = mfma_bf32(As.mid, Bs.mid, c);
-                        c = mfma_bf32(As.mid, Bs.hi, c);
-                        c = mfma_bf32(As.hi, Bs.mid, c);
-                        c = mfma_bf32(As.hi, Bs.hi, c);
-                        gWo[cq] = c;
+                        for (int nb = 0; nb < NB; ++nb) av[nb] = *reinterpret_cast<const f32x4*>(my_scr + (nb * 16 + s) * 16 + 4 * g);
+                        wave_lds_order();
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            gbo[cq < AB ? cq : 0][nb] += wq * ((av[nb][0] + av[nb][1]) + (av[nb][2] + av[nb][3]));
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                for (int ut = 0; ut < HT; ++ut)
+                                    gWo[cq < AB ? cq : 0][nb][ut] = mfma16(av[nb][q], bx[ut][q], gWo[cq < AB ? cq : 0][nb][ut]);
+                        }
+                    } else {         // blocks the Y wave accumulates: the [row][sample] tile goes back into the slot the t values came from
+                        float* slot = rbuf + (pw * CQ + cq) * 512;
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) slot[((jj >> 2) * 16 + 4 * g + (jj & 3)) * 16 + s] = dP[jj];
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if (lane == 0) vflags[4 + pw] = sc * 8 + cq + 1;
                     }
+                    __builtin_amdgcn_sched_barrier(0);   // one block at a time: hoisting the next blocks' loads costs registers the role does not have
                 }
                 NCDE_TICK(0)
                 // ---- dL/dx_L: sum of the four pairs' partials (the patch of the dP blocks is free now) ---------------------
@@ -665,20 +751,9 @@ __global__ __launch_bounds__(512, F4_LB) void ncde_adj_fast4(KArgs a) {
         // ---- write-out of this workgroup's parameter-gradient partial ------------------------------------------
         float* gp = a.gpart + (long long)blockIdx.x * a.theta_size;
 #pragma unroll
-        for (int blk = 0; blk < CQ; ++blk) {
+        for (int blk = 0; blk < AB; ++blk)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int nb = q >> 3;                                   // block row >> 4 = tile within the block = nb
-                const int gr = 2 * ((q >> 2) & 1) + (lane >> 5), rr = q & 3;
-                const int h = 4 * (pw * NB + nb) + gr, c = 4 * blk + rr;
-                if (c < C) gp[a.gWo_off + (h * C + c) * HH + (lane & 31)] = gWo[blk][q];
-            }
-            float v = gbo[blk];
-            v += __shfl_xor(v, 32, 64);
-            const int nb = i32 >> 4, rowt = i32 & 15;
-            const int hrow = 4 * (pw * NB + nb) + (rowt >> 2), crow = 4 * blk + (rowt & 3);
-            if (lane < 32 && crow < C) gp[a.gbo_off + hrow * C + crow] = v;
-        }
+            for (int nb = 0; nb < NB; ++nb) write_dwo_tiles(gp, blk, nb, gWo[blk][nb], gbo[blk][nb]);
         if constexpr (NL > 1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) gp[a.gW_off[1] + (16 * tr + 4 * g + r) * HH + 16 * tc + s] = gW1[r];

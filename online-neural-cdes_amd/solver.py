@@ -60,7 +60,8 @@ def _time_mode(X, t):
     """-> _lib.OUT_INTERVAL / OUT_KNOTS.  Tagged tensors from X.interval / X.grid_points avoid a device sync."""
     kind = getattr(t, "_ncde_kind", None)
     owner = getattr(t, "_ncde_owner", None)      # a weakref: a recycled id() of a dead control can never match
-    if kind is not None and owner is not None and owner() is X and t.numel() == (X.n_knots if kind == "knots" else 2):
+    if X._default_grid and kind is not None and owner is not None and owner() is X and \
+            t.numel() == (X.n_knots if kind == "knots" else 2):     # a control on a user knot grid always takes the time plan
         return _lib.OUT_KNOTS if kind == "knots" else _lib.OUT_INTERVAL
     tv = torch.as_tensor(t).detach().cpu().double()
     assert tv.dim() == 1, "t must be one dimensional"

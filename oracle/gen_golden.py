@@ -461,9 +461,76 @@ def gen_g10():
         json.dump(report, f, indent=1)
 
 
+
+def gen_g12():
+    """dopri5 with adjoint=False -- the way the reference's shipped "interpolation" experiment grid runs it
+    (experiments/configurations/configurations.json5:187-191 -> NeuralCDE(solver='dopri5', adjoint=False), options
+    {'min_step': 0.5}, src/ncde/ncde.py:130-134): autograd through the taped adaptive solve, including the gradient of the FIRST
+    step size (misc.py:33-74).  Goldens = the reference's z and gradients; the oracle's hand-written reverse sweep
+    (ncde_oracle.dopri5_discrete_backward) is asserted against them here."""
+    report = []
+
+    def one(name, coeffs, interp, func, ofield, names, z0, seq, kw, pdict, dims, field_kind):
+        c = torch.from_numpy(coeffs)
+        X = torchcde.LinearInterpolation(c) if interp == "linear" else torchcde.NaturalCubicSpline(c)
+        t = X.grid_points if seq else X.interval
+        gout = grad_out_like((coeffs.shape[0], len(t), z0.shape[1]), seed=23)
+        z0t = torch.from_numpy(z0).clone().requires_grad_(True)
+        for q in func.parameters():
+            q.grad = None
+        func.nfe = 0
+        out = torchcde.cdeint(X, func, z0t, t, adjoint=False, **{**kw, "options": dict(kw.get("options", {}))})
+        nfe = func.nfe
+        (out * torch.from_numpy(gout)).sum().backward()
+        z_ref, dz0_ref, gp_ref = out.detach(), z0t.grad.detach(), [q.grad.detach().clone() for q in func.parameters()]
+        st = {}
+        z_or, dz0_or, gp_or = orc.dopri5_discrete_backward(orc.Control(coeffs, interp), ofield, z0, t, gout, kw.get("rtol", 1e-4), kw.get("atol", 1e-6),
+                                                           kw.get("options"), stats=st)
+        e = {"z": relerr(z_or, z_ref), "dz0": relerr(dz0_or, dz0_ref), "dtheta": max(relerr(a, b) for a, b in zip(gp_or, gp_ref))}
+        print(f"{name:34s} oracle-vs-ref: " + " ".join(f"{k} {v:.2e}" for k, v in e.items()),
+              f"nfe {st['nfe']}/{nfe} steps +{st['accepted']}/-{st['rejected']} first dt {st['first_step']:.4g} differentiable: {st['delta_active']}")
+        assert st["nfe"] == nfe and e["z"] <= 2e-6 and max(e["dz0"], e["dtheta"]) <= 5e-6, "oracle does not reproduce the reference"
+        rec = {"z_out": z_ref.numpy(), "bp_dz0": dz0_ref.numpy(), "grad_out": gout, "coeffs": coeffs, "z0": z0}
+        for n, g in zip(names, gp_ref):
+            rec["bp_d" + n] = g.numpy()
+        for k, v in pdict.items():
+            rec["p_" + k] = v
+        meta = {"name": name, "kind": interp, "method": "dopri5", "sequence": bool(seq), "field": field_kind, "dims": dims, "param_names": names,
+                "rtol": kw.get("rtol", 1e-4), "atol": kw.get("atol", 1e-6), "options": kw.get("options", {}), "nfe_fwd": nfe,
+                "steps_fwd": [st["accepted"], st["rejected"]], "first_step": st["first_step"], "first_step_differentiable": st["delta_active"],
+                "oracle_vs_ref": e, "trace_fwd": [[a_, b_, int(c_)] for a_, b_, c_, _ in st["trace"]]}
+        rec["meta"] = np.array(json.dumps(meta))
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+        report.append(meta)
+
+    B, L, C, H, HH, nl = 12, 8, 5, 16, 24, 3
+    names = ["W0", "b0", "W1", "b1", "Wo", "bo"]
+    p = data.make_field_weights(H, HH, C, seed=6)
+    rw = data.make_readin_weights(H, C, 1, seed=6)
+    kw = {"method": "dopri5", "rtol": 1e-3, "atol": 1e-5, "options": {"min_step": 0.5}}      # src/ncde/ncde.py:130-134
+    dims = {"C": C, "H": H, "HH": HH, "nl": nl}
+    rect = data.make_rectilinear_coeffs(B, L, C - 1, missing=0.3, seed=71)
+    cub = data.make_cubic_coeffs(B, 2 * L, C - 1, seed=72)
+    lin = data.linear_interpolation_coeffs(data.synthetic_series(B, 2 * L, C - 1, missing=0.3, seed=73))
+    for nm, coeffs, interp, seq, k in (
+            ("g12_ncde_dopri5_rect_final", rect, "linear", False, kw), ("g12_ncde_dopri5_rect_seq", rect, "linear", True, kw),
+            ("g12_ncde_dopri5_linear_final", lin, "linear", False, kw),
+            ("g12_ncde_dopri5_cubic_final", cub, "cubic", False, kw), ("g12_ncde_dopri5_cubic_seq", cub, "cubic", True, kw),
+            ("g12_adaptive_cubic_final", cub, "cubic", False, {"method": "dopri5", "rtol": 1e-5, "atol": 1e-7}),
+            ("g12_first_step_given_rect_seq", rect, "linear", True, {"method": "dopri5", "rtol": 1e-3, "atol": 1e-5, "options": {"min_step": 0.5, "first_step": 0.3}})):
+        z0 = z0_from(coeffs[:, 0, :C], rw)
+        func = ref_field_original(p, C, H, HH, nl)
+        one(nm, coeffs, interp, func, orc.Field.original(p, H, C, nl), names, z0, seq, k, p, dims, "original")
+    with open(os.path.join(GOLD, "MANIFEST_dopri5_taped.json"), "w") as f:
+        json.dump(report, f, indent=1)
+
+
 def main():
     if "--only-g10" in sys.argv:
         gen_g10()
+        return
+    if "--only-g12" in sys.argv:
+        gen_g12()
         return
     if "--only-g11" in sys.argv:
         gen_g11()
@@ -578,6 +645,7 @@ def main():
     gen_g9()
     gen_g11()
     gen_g10()
+    gen_g12()
 
     # ---- G5: full-size cfg2 forward z_T (inputs regenerated by tests from the generator) ---------
     if "--no-full" not in sys.argv:

@@ -748,6 +748,9 @@ class Dopri5:
         self.c_error, self.mid = _DP_C_ERROR.to(dt_), _DP_C_MID.to(dt_)
         self.n_accept = self.n_reject = 0
         self.trace = []        # (t0, dt, accepted, error_ratio) per attempt
+        self.tape = None       # set to [] to record every ACCEPTED step (dopri5_discrete_backward)
+        self.init_info = None  # what _select_initial_step computed (for the gradient of the first step size)
+        self.out_steps = []    # per output time i >= 1: (index of the accepted step it was interpolated in, x)
 
     def _f(self, t, y, perturb=0):
         t = t.to(y.dtype)
@@ -772,12 +775,15 @@ class Dopri5:
             h1 = torch.max(torch.tensor(1e-6, dtype=dtype), h0 * 1e-3)
         else:
             h1 = (0.01 / max(d1, d2)) ** (1. / float(4 + 1))
+        self.init_info = {"t0": t0, "f0": f0, "scale": scale, "d0": d0, "d1": d1, "d2": d2, "h0": h0, "h1": h1, "y1": y1, "f1": f1,
+                          "h0_const": bool(d0 < 1e-5 or d1 < 1e-5), "h1_const": bool(d1 <= 1e-15 and d2 <= 1e-15)}
         return torch.min(100 * h0, h1).to(torch.float64)
 
     def _rk_step(self, y0, f0, t0, dt, t1):
         t0, dt, t1 = t0.to(y0.dtype), dt.to(y0.dtype), t1.to(y0.dtype)
         k = torch.empty(*f0.shape, 7, dtype=y0.dtype)
         k[..., 0] = f0
+        self._stage_times = []
         for i, (alpha_i, beta_i) in enumerate(zip(self.alpha, self.beta)):
             if alpha_i == 1.:
                 ti, perturb = t1, -1
@@ -785,6 +791,7 @@ class Dopri5:
                 ti, perturb = t0 + alpha_i * dt, 0
             yi = y0 + k[..., :i + 1].matmul(beta_i * dt).view_as(f0)
             k[..., i + 1] = self._f(ti, yi, perturb)
+            self._stage_times.append(torch.nextafter(ti, torch.tensor(-math.inf)) if perturb < 0 else ti)
         y1 = yi                                 # c_sol = (beta[-1], 0): the last stage input IS the solution
         return y1, k[..., -1], k.matmul(dt * self.c_error), k
 
@@ -823,6 +830,8 @@ class Dopri5:
             c = dtf * (fb - 4 * fa) - 11 * y0 - 5 * y1 + 16 * y_mid
             interp = [y0, dtf * fa, c, b, a]
             t_next, y_next, f_next = t1, y1, f1
+            if self.tape is not None:
+                self.tape.append({"t0": t0, "dt": dt, "y0": y0, "k": k, "ts": list(self._stage_times), "attempt": len(self.trace) - 1})
         else:
             self.n_reject += 1
             t_next, y_next, f_next = t0, y0, f0
@@ -844,6 +853,7 @@ class Dopri5:
             coeffs, t0, t1 = st[5], st[2], st[3]
             assert (t0 <= t[i]) & (t[i] <= t1)
             x = ((t[i] - t0) / (t1 - t0)).to(coeffs[0].dtype)
+            self.out_steps.append((self.n_accept - 1, x))
             total = coeffs[0] + x * coeffs[1]
             xp = x
             for cf in coeffs[2:]:
@@ -953,3 +963,168 @@ def dopri5_adjoint(control, field, t, z_out, grad_out, rtol, atol, options=None,
     if stats is not None:
         stats.update(nfe=nfe[0], **acc)
     return a, g
+
+
+def dopri5_discrete_backward(control, field, z0, t, grad_out, rtol, atol, options=None, stats=None):
+    """cdeint(..., method='dopri5', adjoint=False): reverse-mode through the taped adaptive solve, by hand.  What the reference's
+    autograd differentiates (rk_common.py:216-305 under torchdiffeq.odeint):
+      * every ACCEPTED step -- the six stage evaluations (rk_common.py:41-86), with FSAL: k1 of a step IS k7 of the previous one;
+      * the 4th-order dense output that produces the solution at the requested times (interp.py:4-61, rk_common.py:307-313);
+      * NOT the step-size controller: _optimal_step_size is @torch.no_grad() (misc.py:84-97), so every dt but the first is a constant;
+      * the FIRST step size: _select_initial_step (misc.py:33-74) is differentiable in (y0, theta), and it reaches the solution
+        through step 1 itself (y_i = y0 + dt sum beta k, the fit's dt terms), through every later step's start time
+        t0_m = t[0] + dt_1 + (constants) -- the dense-output abscissa x = (t - t0)/(t1 - t0) of every output, and, for a control whose
+        derivative depends on t (cubic), every stage time -- provided the first attempt was accepted (otherwise dt_2 is a constant).
+    Returns (dL/dz0, [dL/dtheta]) for L = sum(z_out * grad_out); stats gets the forward's nfe / step counts."""
+    z0, grad_out = torch.as_tensor(z0), torch.as_tensor(grad_out)
+    t = torch.as_tensor(t).to(torch.float64)
+    params = field.unique_params()
+    nfe = [0]
+
+    def func(tt, y):
+        nfe[0] += 1
+        return field.g(y, control.field_input(tt, field.mode))
+
+    sv = Dopri5(func, z0, rtol, atol, **(options or {}))
+    sv.tape = []
+    sol = sv.integrate(t).permute(1, 0, 2).contiguous()
+    tape, M = sv.tape, len(sv.tape)
+    outs = [[] for _ in range(M)]
+    for j, (m, x) in enumerate(sv.out_steps):
+        outs[m].append((j + 1, x))
+    dtype = z0.dtype
+    beta, alpha, mid = sv.beta, sv.alpha, sv.mid
+    gth = [torch.zeros_like(p) for p in params]
+
+    def vjp(tt, y, c):
+        """cotangent c of k = f(tt, y) -> (ybar, tbar); theta-bar accumulates"""
+        cin = control.field_input(tt, field.mode)
+        _, saved = field.g(y, cin, save=True)
+        dy, dp = field.g_vjp(saved, cin, c)
+        for q, v in zip(gth, dp):
+            q += v
+        tb = 0.0
+        if control.kind == "cubic":
+            if field.mode != "matmul":
+                raise NotImplementedError("time gradient of the field input only for the matmul mode")
+            mth = saved["th"] if field.kind == "original" else saved["sg"] * saved["th"]
+            ddx = (c.unsqueeze(-1) * mth.view(-1, field.H, field.C)).sum(1)
+            tb = float((ddx * control.second_derivative(tt)).sum())
+        return dy, tb
+
+    # is dt_1 a differentiable function of (y0, theta)?  (no first_step option, and the very first attempt was accepted)
+    delta_active = sv.first_step is None and M > 0 and tape[0]["attempt"] == 0
+    Yb1 = torch.zeros_like(z0)           # cotangent of the step's y1 (= the next step's y0)
+    Kb_next = torch.zeros_like(z0)       # cotangent of the step's k7 coming from its use as the next step's k1 (FSAL)
+    Tbar, dtbar1 = 0.0, 0.0              # d/d(t0 of the steps m >= 2) summed; d/d(dt_1) of step 1's own arithmetic
+    for m in range(M - 1, -1, -1):
+        st = tape[m]
+        y0, k, dt64 = st["y0"], st["k"], st["dt"]
+        dtf = dt64.to(dtype)
+        Kb = [torch.zeros_like(y0) for _ in range(7)]
+        Kb[6] = Kb[6] + Kb_next
+        yb0 = torch.zeros_like(y0)
+        yb1 = Yb1.clone()
+        dtb, tb0 = 0.0, 0.0
+        k1, k7 = k[..., 0], k[..., 6]
+        if outs[m]:
+            y1 = y0 + k[..., :6].matmul(beta[5] * dtf)
+            y_mid = y0 + k.matmul(dtf * mid)
+            ca = 2 * dtf * (k7 - k1) - 8 * (y1 + y0) + 16 * y_mid
+            cb = dtf * (5 * k1 - 3 * k7) + 18 * y0 + 14 * y1 - 32 * y_mid
+            cc = dtf * (k7 - 4 * k1) - 11 * y0 - 5 * y1 + 16 * y_mid
+            cd = dtf * k1
+            ab, bb, cbb, db, eb = (torch.zeros_like(y0) for _ in range(5))
+            for j, x in outs[m]:
+                g = grad_out[:, j]
+                x2 = x * x
+                x3 = x2 * x
+                x4 = x3 * x
+                eb += g
+                db += x * g
+                cbb += x2 * g
+                bb += x3 * g
+                ab += x4 * g
+                xbar = float((g * (cd + 2 * x * cc + 3 * x2 * cb + 4 * x3 * ca)).double().sum())
+                if m >= 1:
+                    Tbar += xbar * (-1.0 / float(dt64))            # x = (t - t0)/dt_m, t0 moves with dt_1
+                else:
+                    dtbar1 += xbar * (-float(x) / float(dt64))     # x = (t - t[0])/dt_1
+            ymb = 16 * ab - 32 * bb + 16 * cbb
+            yb0 += -8 * ab + 18 * bb - 11 * cbb + eb + ymb
+            yb1 += -8 * ab + 14 * bb - 5 * cbb
+            Kb[0] += dtf * (-2 * ab + 5 * bb - 4 * cbb + db)
+            Kb[6] += dtf * (2 * ab - 3 * bb + cbb)
+            dtb += float((ab * 2 * (k7 - k1) + bb * (5 * k1 - 3 * k7) + cbb * (k7 - 4 * k1) + db * k1).double().sum())
+            for j in range(7):
+                Kb[j] += (dtf * mid[j]) * ymb
+            dtb += float((ymb * k.matmul(mid)).double().sum())
+        for i in range(6, 0, -1):          # stage i: k[..., i] = f(ts[i-1], y0 + k[..., :i] @ (beta[i-1] dt))
+            yi = y0 + k[..., :i].matmul(beta[i - 1] * dtf)
+            dy, tbi = vjp(st["ts"][i - 1], yi, Kb[i])
+            ybi = dy + yb1 if i == 6 else dy
+            yb0 += ybi
+            for jj in range(i):
+                Kb[jj] += (beta[i - 1][jj] * dtf) * ybi
+            dtb += float((ybi * k[..., :i].matmul(beta[i - 1])).double().sum()) + float(alpha[i - 1]) * tbi
+            tb0 += tbi
+        if m >= 1:
+            Tbar += tb0
+        else:
+            dtbar1 += dtb
+        Yb1, Kb_next = yb0, Kb[0]
+    dz0 = Yb1 + grad_out[:, 0]             # the solution at t[0] is z0 itself
+    f0b = Kb_next                          # cotangent of f0 = f(t[0], y0)
+    t0f = t[0].to(dtype)
+    if delta_active:
+        ii = sv.init_info
+        dbar = dtbar1 + Tbar               # dL/d(dt_1)
+        h0, h1, d0, d1, d2, scale, f0, f1, y1p = (ii[k_] for k_ in ("h0", "h1", "d0", "d1", "d2", "scale", "f0", "f1", "y1"))
+        n_el = z0.numel()
+        h0b = h1b = 0.0
+        if float(100 * h0) <= float(h1):
+            h0b = 100.0 * dbar
+        else:
+            h1b = dbar
+        d1b = d2b = 0.0
+        if h1b != 0.0 and not ii["h1_const"]:
+            mx = max(float(d1), float(d2))
+            mxb = -0.2 * float(h1) / mx * h1b
+            if float(d1) >= float(d2):
+                d1b += mxb
+            else:
+                d2b += mxb
+        elif h1b != 0.0:
+            h0b += 1e-3 * h1b if float(h0 * 1e-3) > 1e-6 else 0.0
+        scb = torch.zeros_like(z0)
+        if d2b != 0.0:
+            n2 = float(d2) * float(h0)                      # d2 = rms((f1 - f0)/scale) / h0
+            h0b += -float(d2) / float(h0) * d2b
+            q = (f1 - f0) / scale
+            qb = (d2b / float(h0)) * q / (n_el * n2)
+            f1b = qb / scale
+            f0b = f0b - qb / scale
+            scb = scb - qb * q / scale
+            dy1, tbp = vjp(ii["t0"] + h0, y1p, f1b)
+            dz0 = dz0 + dy1
+            f0b = f0b + float(h0) * dy1
+            h0b += float((dy1 * f0).double().sum()) + tbp
+        if h0b != 0.0 and not ii["h0_const"]:
+            d0b = 0.01 / float(d1) * h0b
+            d1b += -float(h0) / float(d1) * h0b
+            q0 = z0 / scale
+            q0b = d0b * q0 / (n_el * float(d0))
+            dz0 = dz0 + q0b / scale
+            scb = scb - q0b * q0 / scale
+        if d1b != 0.0:
+            q1 = f0 / scale
+            q1b = d1b * q1 / (n_el * float(d1))
+            f0b = f0b + q1b / scale
+            scb = scb - q1b * q1 / scale
+        dz0 = dz0 + scb * float(sv.rtol) * torch.sign(z0)
+    dy0, _ = vjp(t0f, z0, f0b)
+    dz0 = dz0 + dy0
+    if stats is not None:
+        stats.update(nfe=nfe[0], accepted=sv.n_accept, rejected=sv.n_reject, trace=sv.trace, delta_active=bool(delta_active),
+                     first_step=float(tape[0]["dt"]) if M else None)
+    return sol, dz0, gth

@@ -106,7 +106,8 @@ def kernel_names(case, flags=_lib.FLAG_AUTO, device="cuda"):
     return tuple((lib.ncde_kernel_name(ctypes.byref(p), k) or b"?").decode() for k in (0, 1, 2))
 
 
-def run_times_case(f, meta, adjoint=True, flags=_lib.FLAG_AUTO, device="cuda", kind="original", mode="matmul", params=None):
+def run_times_case(f, meta, adjoint=True, flags=_lib.FLAG_AUTO, device="cuda", kind="original", mode="matmul", params=None,
+                   tagged=None):
     """A general-time-axis case (golden g11 layout: coeffs, [knots], t_out, z0, p_*, grad_out) through cdeint."""
     coeffs = torch.from_numpy(f["coeffs"]).to(device)
     kn = torch.from_numpy(f["knots"]).to(device) if "knots" in f else None
@@ -116,6 +117,8 @@ def run_times_case(f, meta, adjoint=True, flags=_lib.FLAG_AUTO, device="cuda", k
     func = CaseField(params, [("W0", "b0")] + [("W1", "b1")] * (nl - 1), device, kind, mode)
     z0 = torch.from_numpy(f["z0"]).to(device).requires_grad_(True)
     t = torch.from_numpy(f["t_out"]).to(device)
+    if tagged is not None:          # the control's own (tagged) tensors instead of a plain tensor with the same values
+        t = X.interval if tagged == "interval" else X.grid_points
     out = ncde_amd.cdeint(X, func, z0, t, adjoint=adjoint, vector_field_type=mode, method=meta["method"],
                           options={"step_size": meta["step_size"]}, kernel_flags=flags)
     nfe_fwd = func.nfe

@@ -204,8 +204,8 @@ CFG2_FULL_BATCH_G = TOL_DTHETA
 
 
 def test_full_size_cfg2_adjoint_and_discrete_backward_vs_oracle(gpu_lib):
-    """BASELINE configs 2/3 at the benchmarked size (B = 4096 launched, T = 399): `ncde_adj_fast4` and
-    `ncde_adj_fast4<discrete>` (adjoint.py:37-145 / autograd through solvers.py:94-119) against the oracle on a 32-sample
+    """BASELINE configs 2/3 at the benchmarked size (B = 4096 launched, T = 399): `ncde_adj_fast3` and
+    `ncde_adj_fast3<discrete>` (adjoint.py:37-145 / autograd through solvers.py:94-119) against the oracle on a 32-sample
     sub-batch that straddles tile boundaries, bit-exact sample independence of z and dL/dz0 between the big batch and the
     sub-batch, and the full-batch parameter gradients of the continuous adjoint against the oracle on all 4096 samples."""
     import gpu_util
@@ -214,8 +214,8 @@ def test_full_size_cfg2_adjoint_and_discrete_backward_vs_oracle(gpu_lib):
     big, names = _cfg2_case(B)
     torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
     rb = gpu_util.run_case(big)                               # forward + continuous adjoint, the benchmarked kernels
-    assert rb["kernels"][0].startswith("ncde_fwd_fast_bf3") and rb["kernels"][1].startswith("ncde_adj_fast4"), rb["kernels"]
-    assert "discrete" in rb["kernels"][2] and rb["kernels"][2].startswith("ncde_adj_fast4"), rb["kernels"]
+    assert rb["kernels"][0].startswith("ncde_fwd_fast_bf3") and rb["kernels"][1].startswith("ncde_adj_fast3"), rb["kernels"]
+    assert "discrete" in rb["kernels"][2] and rb["kernels"][2].startswith("ncde_adj_fast3"), rb["kernels"]
     rbd = gpu_util.run_case(big, adjoint=False)               # recording forward + exact discrete backward
     sel = slice(2039, 2071)                                   # tiles 127..129
     sub = dict(big, coeffs=big["coeffs"][sel].copy(), z0=big["z0"][sel].copy(), expect={"grad_out": big["expect"]["grad_out"][sel].copy()})
@@ -490,9 +490,9 @@ def test_fast_kernels_vs_oracle(shape, interp, method, seq, gpu_lib):
     for k, e in _grad_errors(case, iso).items():
         assert e <= TIGHT_G, ("adjoint kernel on oracle z_out", res["kernels"][1], k, e)
     if H == 32:
-        assert res["kernels"][1].startswith("ncde_adj_fast4"), res["kernels"]      # default: decoupled y / cotangent waves
+        assert res["kernels"][1].startswith("ncde_adj_fast3"), res["kernels"]      # default: chain + gradient waves, split-bf16 chain
         for fl, nm in ((_lib.FLAG_ADJOINT_V1, "single-role"), (_lib.FLAG_ADJOINT_V2, "chain+grad fp32 chain"),
-                       (_lib.FLAG_ADJOINT_V3, "chain+grad split-bf16 chain")):      # also the other specialised adjoint variants
+                       (_lib.FLAG_ADJOINT_V4, "decoupled y / cotangent waves")):      # also the other specialised adjoint variants
             iso1 = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=fl)
             for k, e in _grad_errors(case, iso1).items():
                 assert e <= TIGHT_G, (nm + " adjoint kernel on oracle z_out", k, e)
@@ -507,14 +507,18 @@ def test_fast_kernels_vs_oracle(shape, interp, method, seq, gpu_lib):
     for k, e in _grad_errors(case, isod, "bp_").items():
         assert e <= TIGHT_G, ("discrete backward kernel on the oracle's stage record", res["kernels"][2], k, e)
     if H == 32:
-        assert res["kernels"][2].startswith("ncde_adj_fast4") and "discrete" in res["kernels"][2], res["kernels"]
+        assert res["kernels"][2].startswith("ncde_adj_fast3") and "discrete" in res["kernels"][2], res["kernels"]
+        iso4 = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_ADJOINT_V4, stages=case["stage_record"])
+        for k, e in _grad_errors(case, iso4, "bp_").items():
+            assert e <= TIGHT_G, ("decoupled-waves discrete backward on the oracle's stage record", k, e)
         againd = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_AUTO, stages=case["stage_record"])
         assert np.array_equal(againd["dz0"], isod["dz0"]) and all(np.array_equal(againd["grads"][k], isod["grads"][k]) for k in isod["grads"])
 
 
 @pytest.mark.parametrize("interp,method", [("cubic", "midpoint"), ("linear", "rk4"), ("cubic", "euler")])
 def test_decoupled_adjoint_hand_offs_under_repetition(interp, method, gpu_lib):
-    """ncde_adj_fast4 hands data between its y waves and cotangent waves through LDS flags (t blocks, reduction partials):
+    """ncde_adj_fast4 (NCDE_FLAG_ADJOINT_V4) hands data between its y waves and cotangent waves through LDS flags (t blocks, dP tiles coming
+    back, reduction partials):
     ten launches of the continuous adjoint and of the discrete backward on the oracle's z, ragged two-workgroup batch, must be
     bit-identical and within the tight tolerance.  (cubic + midpoint was the combination that exposed a timing-dependent
     failure of a stage-weight-dependent control flow during development.)"""
@@ -525,7 +529,7 @@ def test_decoupled_adjoint_hand_offs_under_repetition(interp, method, gpu_lib):
     for kw, pre in (({}, ""), ({"stages": case["stage_record"]}, "bp_")):
         first = None
         for _ in range(10):
-            iso = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_AUTO, **kw)
+            iso = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_ADJOINT_V4, **kw)
             for k, e in _grad_errors(case, iso, pre).items():
                 assert e <= TIGHT_G, (interp, method, pre, k, e)
             if first is None:
@@ -749,6 +753,30 @@ def test_general_time_axis_matches_reference_golden(name, gpu_lib):
     assert gu.relerr(resd["dz0"], f["bp_dz0"]) <= E2E_G
     for pname in m["param_names"]:
         assert gu.relerr(resd["grads"][pname], f["bp_d" + pname]) <= E2E_G, pname
+
+
+def test_user_knot_grid_with_the_controls_own_time_tensors(gpu_lib):
+    """`t = X.interval` of a control built on a user knot grid (golden g11_knots_interval_rk4: the reference on exactly that
+    call): the tagged-tensor shortcut of `_time_mode` must not route it to the default-axis kernels."""
+    import json
+    import os
+    import gpu_util
+    f = dict(np.load(os.path.join(gu.GOLD, "g11_knots_interval_rk4.npz")))
+    m = json.loads(str(f["meta"]))
+    res = gpu_util.run_times_case(f, m, adjoint=True, tagged="interval")
+    assert gu.relerr(res["z_out"], f["z_out"]) <= TIGHT_Z
+    assert gu.relerr(res["dz0"], f["dz0"]) <= E2E_G
+    for pname in m["param_names"]:
+        assert gu.relerr(res["grads"][pname], f["d" + pname]) <= E2E_G, pname
+    plain = gpu_util.run_times_case(f, m, adjoint=True)
+    assert np.array_equal(plain["z_out"], res["z_out"])
+    # every knot of the user grid as output (X.grid_points, tagged) == the same values as a plain tensor
+    f2 = dict(f)
+    f2["t_out"] = f["knots"]
+    f2["grad_out"] = np.ones((f["z0"].shape[0], f["knots"].shape[0], f["z0"].shape[1]), dtype=np.float32)
+    a = gpu_util.run_times_case(f2, m, adjoint=True, tagged="knots")
+    b = gpu_util.run_times_case(f2, m, adjoint=True)
+    assert np.array_equal(a["z_out"], b["z_out"]) and np.array_equal(a["dz0"], b["dz0"])
 
 
 @pytest.mark.parametrize("kind,interp,method,step", [("original", "linear", "rk4", 0.5), ("original", "cubic", "midpoint", 0.4),

@@ -352,6 +352,8 @@ def test_time_mode_detection():
     assert solver._time_mode(X, torch.tensor([0.0, 2.5])) is None        # -> general time axis (time plan)
     Xk = ncde_amd.LinearInterpolation(torch.zeros(2, 5, 3), t=torch.tensor([0.0, 1.0, 2.0, 3.0, 4.5]))
     assert solver._time_mode(Xk, torch.tensor([0.0, 4.0])) is None       # user knot grid: always the plan
+    assert solver._time_mode(Xk, Xk.interval) is None                     # ... also for the control's own tagged tensors
+    assert solver._time_mode(Xk, Xk.grid_points) is None
 
 
 def test_host_coefficient_mirrors_match_reference_golden():

@@ -152,6 +152,26 @@ def test_oracle_dopri5_matches_reference_golden(name):
         assert gu.relerr(g, f["d" + pname]) <= tol, pname
 
 
+DOPRI5_TAPED_CASES = ["g12_ncde_dopri5_rect_final", "g12_ncde_dopri5_rect_seq", "g12_ncde_dopri5_linear_final", "g12_ncde_dopri5_cubic_final",
+                      "g12_ncde_dopri5_cubic_seq", "g12_adaptive_cubic_final", "g12_first_step_given_rect_seq"]
+
+
+@pytest.mark.parametrize("name", DOPRI5_TAPED_CASES)
+def test_oracle_dopri5_taped_backward_matches_reference_golden(name):
+    """dopri5 with adjoint=False (goldens g12 = the imported reference's autograd through its taped adaptive solve -- the setting of
+    the shipped "interpolation" experiment grid, configurations.json5:187-191): the oracle's hand-written reverse sweep over the
+    accepted steps, dense output and first-step-size gradient included, reproduces z bit-level and every gradient to fp32 round-off."""
+    f, m, field, ctl, t = load_dopri5_case(name)
+    st = {}
+    z, dz0, gp = orc.dopri5_discrete_backward(ctl, field, f["z0"], t, f["grad_out"], m["rtol"], m["atol"], m["options"] or None, stats=st)
+    assert st["nfe"] == m["nfe_fwd"] and [st["accepted"], st["rejected"]] == m["steps_fwd"]
+    assert st["delta_active"] == m["first_step_differentiable"]
+    assert gu.relerr(z, f["z_out"]) <= TOL_Z
+    assert gu.relerr(dz0, f["bp_dz0"]) <= TOL_G
+    for pname, g in zip(m["param_names"], gp):
+        assert gu.relerr(g, f["bp_d" + pname]) <= TOL_G, pname
+
+
 @pytest.mark.parametrize("name", gu.SOLVE_CASES)
 def test_cpu_cabi_restatement_matches_reference_golden(name):
     """oracle/ncde_cpu.cpp -- the scalar C++ / OpenMP restatement behind the SAME C-ABI as the HIP library --

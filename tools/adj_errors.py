@@ -11,13 +11,13 @@ B = int(sys.argv[4]) if len(sys.argv) > 4 else 21
 L = int(sys.argv[5]) if len(sys.argv) > 5 else 9
 case = tg._seeded_case(interp, method, seq, B=B, L=L, C=20, H=32, HH=32, nl=3, seed=120)
 ex = case["expect"]
-for fl, nm in ((_lib.FLAG_ADJOINT_V3, "v3"), (0, "v4")):
+for fl, nm in ((0, "v3"), (_lib.FLAG_ADJOINT_V4, "v4")):
     iso = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=fl)
     print(nm, {k: float("%.3g" % e) for k, e in tg._grad_errors(case, iso).items()})
     isod = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=fl, stages=case["stage_record"])
     print(nm, "disc", {k: float("%.3g" % e) for k, e in tg._grad_errors(case, isod, "bp_").items()})
 if os.environ.get("DUMP"):
-    iso = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=0)
+    iso = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_ADJOINT_V4)
     np.set_printoptions(linewidth=250, precision=3, suppress=True)
     d = iso["dz0"] - ex["dz0"]
     print("dz0 err by h (max over samples):"); print(np.abs(d).max(axis=0))

@@ -34,7 +34,7 @@ for flags, label in ((4, "fp32-mfma plain"), (0x104, "fp32-mfma instrumented"), 
 
 # ---- adjoint ----
 theta = 32*32+32+32*32+32+640*32+640
-for flags, label in ((32, "adj v3 plain"), (0x120, "adj v3 instrumented"), (0, "adj v4 plain"), (0x100, "adj v4 instrumented")):
+for flags, label in ((0, "adj v3 plain"), (0x100, "adj v3 instrumented"), (32, "adj v4 plain"), (0x120, "adj v4 instrumented")):
     p = solver.build_problem(coeffs, "linear", z0, spec, "rk4", _lib.OUT_INTERVAL, flags)
     ws = torch.zeros(int(lib.ncde_workspace_bytes(ctypes.byref(p), 1)), dtype=torch.uint8, device="cuda")
     out = torch.randn(B, 2, 32, device="cuda"); gout = torch.randn(B, 2, 32, device="cuda")
@@ -51,7 +51,7 @@ for flags, label in ((32, "adj v3 plain"), (0x120, "adj v3 instrumented"), (0, "
         off = (nwg * theta + 64) * 4
         cyc = ws[off: off + nwg * 8 * 6 * 8].view(torch.int64).view(-1, 8, 6).cpu().numpy().astype(np.float64)
         per = cyc.mean(axis=0) / (398 * 4)
-        if flags & 32:
+        if not flags & 32:
             print("chain rows 0-3: recompute | out tiles | wait barrier A | reduce+hidden bwd+vy | rk+exchange(+barrier B)")
             print("grad  rows 4-7: dw_hidden(prev) | wait group0 | dxl0+dWo blocks | wait group1 | dxl1+red | A+dWo rest+B")
         else:

@@ -5,7 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
 import gpu_util
 import test_gpu_parity as tg
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+from ncde_amd import _lib
+FLAGS = _lib.FLAG_ADJOINT_V4 if "v4" in sys.argv else 0
+N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8
 bad = 0
 for interp in ("linear", "cubic"):
     for method in ("rk4", "midpoint", "euler"):
@@ -19,7 +21,7 @@ for interp in ("linear", "cubic"):
                     errs = []
                     same = True
                     for _ in range(N):
-                        iso = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=0, **kw)
+                        iso = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=FLAGS, **kw)
                         errs.append(max(tg._grad_errors(case, iso, "bp_" if disc else "").values()))
                         if first is None:
                             first = iso
