@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NCDE_ABI_VERSION 3 /* version-1 structs (no trailing field_kind .. br members) and version-2 structs (no trailing
+#define NCDE_ABI_VERSION 4 /* version-1 structs (no trailing field_kind .. br members) and version-2 structs (no trailing
                               time_plan .. members) are still accepted */
 #define NCDE_MAX_LAYERS 8
 
@@ -197,6 +197,15 @@ typedef struct NcdeAdaptiveOptions {
     int32_t trace_capacity; /* diagnostics: number of attempts `trace` has room for (0 = none) */
     double* trace;          /* HOST buffer of trace_capacity x 4 doubles, filled after the solve with one row per attempt:
                                t0, dt, accepted (0/1), error ratio -- the step sequence, for comparison with the reference's */
+    /* ---- read only when the problem's abi_version >= 4 ----
+     * Replay of a recorded step sequence (verification): attempt i (counted over the whole call, all output intervals of an adjoint
+     * solve included) takes dt = replay[2 i] and is accepted iff replay[2 i + 1] != 0 instead of what the controller would decide;
+     * attempts beyond replay_count run free.  With the reference's own sequence (tests/golden/g10, g12: `trace_fwd` / `trace_bwd`)
+     * the solve does the reference's arithmetic step for step, so the comparison with its outputs is tight instead of
+     * solver-tolerance level. */
+    int32_t replay_count;
+    int32_t reserved_;
+    const double* replay;   /* HOST, replay_count x 2 doubles */
 } NcdeAdaptiveOptions;
 
 typedef struct NcdeAdaptiveStats {
@@ -205,12 +214,30 @@ typedef struct NcdeAdaptiveStats {
     int32_t reserved_;
 } NcdeAdaptiveStats;
 
-int64_t ncde_dopri5_workspace_bytes(const NcdeProblem* p, const NcdeTimeSpec* ts, int pass /* 0 forward, 1 adjoint */);
+int64_t ncde_dopri5_workspace_bytes(const NcdeProblem* p, const NcdeTimeSpec* ts, int pass /* 0 forward, 1 adjoint, 2 taped backward */);
 int ncde_dopri5_forward(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt, float* out, void* workspace,
                         size_t workspace_bytes, void* stream, NcdeAdaptiveStats* stats);
 int ncde_dopri5_adjoint(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt, const float* z_out,
                         const float* grad_out, const NcdeGrads* grads, void* workspace, size_t workspace_bytes, void* stream,
                         NcdeAdaptiveStats* stats);
+
+/* dopri5 with adjoint=False -- how the reference's shipped "interpolation" experiments run it (experiments/configurations/
+ * configurations.json5:187-191 -> torchdiffeq.odeint under autograd, torchcde/solver.py:224-225).  Replaces the autograd tape of
+ * RKAdaptiveStepsizeODESolver (rk_common.py:216-305): ncde_dopri5_forward_record is ncde_dopri5_forward that also keeps, per ACCEPTED
+ * step, (t0, dt, the state at its start, the outputs interpolated in it) in a caller-owned device record; ncde_dopri5_backward is the
+ * exact reverse-mode sweep over that record -- six stage VJPs per step with FSAL, the transpose of the 4th-order dense output
+ * (interp.py:4-61), and the gradient of the FIRST step size through _select_initial_step (misc.py:33-74; every later step size is a
+ * constant because _optimal_step_size is @torch.no_grad(), misc.py:84-97).  The backward is stream-ordered (one persistent launch
+ * + two small ones + the partial reduction); the forward synchronises like ncde_dopri5_forward.
+ * Record size: ncde_dopri5_record_bytes() is enough for every solve with options.min_step > 0; without a minimum step it is a
+ * default that a solve with very many steps can exceed (NCDE_ERR_WORKSPACE: pass a larger record).  Workspace of the backward:
+ * ncde_dopri5_workspace_bytes(p, ts, 2). */
+int64_t ncde_dopri5_record_bytes(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt);
+int ncde_dopri5_forward_record(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt, float* out, void* record,
+                               size_t record_bytes, void* workspace, size_t workspace_bytes, void* stream, NcdeAdaptiveStats* stats);
+int ncde_dopri5_backward(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt, const void* record,
+                         size_t record_bytes, const float* grad_out, const NcdeGrads* grads, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 int ncde_version(void);
 const char* ncde_last_error_string(void);

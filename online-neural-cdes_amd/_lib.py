@@ -6,7 +6,7 @@ raises.  Build it with ``python __graft_entry__.py`` (or ``make -C online-neural
 import ctypes
 import os
 
-NCDE_ABI_VERSION = 3
+NCDE_ABI_VERSION = 4
 NCDE_MAX_LAYERS = 8
 
 INTERP = {"linear": 0, "cubic": 1}
@@ -81,7 +81,8 @@ class NcdeTimePlanInfo(ctypes.Structure):
 
 class NcdeAdaptiveOptions(ctypes.Structure):
     _fields_ = [(n, ctypes.c_double) for n in ("rtol", "atol", "min_step", "max_step", "first_step", "safety", "ifactor", "dfactor")] + \
-               [("max_num_steps", ctypes.c_int32), ("trace_capacity", ctypes.c_int32), ("trace", ctypes.POINTER(ctypes.c_double))]
+               [("max_num_steps", ctypes.c_int32), ("trace_capacity", ctypes.c_int32), ("trace", ctypes.POINTER(ctypes.c_double)),
+                ("replay_count", ctypes.c_int32), ("reserved_", ctypes.c_int32), ("replay", ctypes.POINTER(ctypes.c_double))]
 
 
 class NcdeAdaptiveStats(ctypes.Structure):
@@ -108,6 +109,7 @@ EXPORTS = (
     "ncde_prepare_workspace_bytes", "ncde_prepare_linear", "ncde_prepare_cubic",
     "ncde_stage_record_bytes", "ncde_forward_record", "ncde_backward",
     "ncde_time_plan_build", "ncde_dopri5_workspace_bytes", "ncde_dopri5_forward", "ncde_dopri5_adjoint",
+    "ncde_dopri5_record_bytes", "ncde_dopri5_forward_record", "ncde_dopri5_backward",
 )
 
 _LIB = None
@@ -183,6 +185,12 @@ def lib():
     h.ncde_dopri5_forward.restype = ctypes.c_int
     h.ncde_dopri5_adjoint.argtypes = [P, TS, AO, vp, vp, G, vp, sz, vp, AS]
     h.ncde_dopri5_adjoint.restype = ctypes.c_int
+    h.ncde_dopri5_record_bytes.argtypes = [P, TS, AO]
+    h.ncde_dopri5_record_bytes.restype = ctypes.c_int64
+    h.ncde_dopri5_forward_record.argtypes = [P, TS, AO, vp, vp, sz, vp, sz, vp, AS]
+    h.ncde_dopri5_forward_record.restype = ctypes.c_int
+    h.ncde_dopri5_backward.argtypes = [P, TS, AO, vp, sz, vp, G, vp, sz, vp]
+    h.ncde_dopri5_backward.restype = ctypes.c_int
     if h.ncde_version() != NCDE_ABI_VERSION:
         raise NcdeError("libncde_hip.so ABI %d != binding %d" % (h.ncde_version(), NCDE_ABI_VERSION))
     _LIB = h

@@ -240,7 +240,44 @@ int64_t ncde_dopri5_workspace_bytes(const NcdeProblem* p, const NcdeTimeSpec* ts
     o.rtol = 1e-4;
     const int rc = dopri5_prepare(p, ts, &o, pass != 0, &q_);
     if (rc != NCDE_OK) return rc;
-    return ncde_dp_workspace_bytes(&q_, ts->n_t, pass != 0);
+    return ncde_dp_workspace_bytes(&q_, ts->n_t, pass);
+}
+
+int64_t ncde_dopri5_record_bytes(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt) {
+    NcdeProblem q_;
+    if (!opt) return fail(NCDE_ERR_INVALID, "options are NULL");
+    const int rc = dopri5_prepare(p, ts, opt, 0, &q_);
+    if (rc != NCDE_OK) return rc;
+    return ncde_dp_record_bytes(&q_, ts, opt);
+}
+
+int ncde_dopri5_forward_record(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt, float* out, void* record,
+                               size_t record_bytes, void* workspace, size_t workspace_bytes, void* stream, NcdeAdaptiveStats* stats) {
+    NcdeProblem q_;
+    if (!opt) return fail(NCDE_ERR_INVALID, "options are NULL");
+    int rc = dopri5_prepare(p, ts, opt, 0, &q_);
+    if (rc != NCDE_OK) return rc;
+    if (!out || !workspace || !record) return fail(NCDE_ERR_INVALID, "out / workspace / record is NULL");
+    char msg[256] = "";
+    const bool v4 = p->abi_version >= 4;
+    rc = ncde_dp_solve(&q_, ts, opt, 0, out, nullptr, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream, stats, msg, sizeof(msg),
+                       record, record_bytes, v4 ? opt->replay : nullptr, v4 ? opt->replay_count : 0);
+    if (rc != NCDE_OK) return fail(rc, "%s", msg);
+    return NCDE_OK;
+}
+
+int ncde_dopri5_backward(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt, const void* record,
+                         size_t record_bytes, const float* grad_out, const NcdeGrads* grads, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+    NcdeProblem q_;
+    if (!opt) return fail(NCDE_ERR_INVALID, "options are NULL");
+    int rc = dopri5_prepare(p, ts, opt, 1, &q_);
+    if (rc != NCDE_OK) return rc;
+    if (!record || !grad_out || !grads || !grads->grad_z0 || !workspace) return fail(NCDE_ERR_INVALID, "NULL record/grad_out/grads/workspace");
+    char msg[256] = "";
+    rc = ncde_dp_tape_backward_run(&q_, ts, opt, record, record_bytes, grad_out, grads, workspace, workspace_bytes, (hipStream_t)stream, msg, sizeof(msg));
+    if (rc != NCDE_OK) return fail(rc, "%s", msg);
+    return NCDE_OK;
 }
 
 int ncde_dopri5_forward(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt, float* out, void* workspace,
@@ -251,7 +288,9 @@ int ncde_dopri5_forward(const NcdeProblem* p, const NcdeTimeSpec* ts, const Ncde
     if (rc != NCDE_OK) return rc;
     if (!out || !workspace) return fail(NCDE_ERR_INVALID, "out / workspace is NULL");
     char msg[256] = "";
-    rc = ncde_dp_solve(&q_, ts, opt, 0, out, nullptr, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream, stats, msg, sizeof(msg));
+    const bool v4 = p->abi_version >= 4;      // the replay members of the options exist from ABI version 4 on
+    rc = ncde_dp_solve(&q_, ts, opt, 0, out, nullptr, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream, stats, msg, sizeof(msg),
+                       nullptr, 0, v4 ? opt->replay : nullptr, v4 ? opt->replay_count : 0);
     if (rc != NCDE_OK) return fail(rc, "%s", msg);
     return NCDE_OK;
 }
@@ -265,7 +304,9 @@ int ncde_dopri5_adjoint(const NcdeProblem* p, const NcdeTimeSpec* ts, const Ncde
     if (rc != NCDE_OK) return rc;
     if (!z_out || !grad_out || !grads || !grads->grad_z0 || !workspace) return fail(NCDE_ERR_INVALID, "NULL z_out/grad_out/grads/workspace");
     char msg[256] = "";
-    rc = ncde_dp_solve(&q_, ts, opt, 1, nullptr, z_out, grad_out, grads, workspace, workspace_bytes, (hipStream_t)stream, stats, msg, sizeof(msg));
+    const bool v4 = p->abi_version >= 4;
+    rc = ncde_dp_solve(&q_, ts, opt, 1, nullptr, z_out, grad_out, grads, workspace, workspace_bytes, (hipStream_t)stream, stats, msg, sizeof(msg),
+                       nullptr, 0, v4 ? opt->replay : nullptr, v4 ? opt->replay_count : 0);
     if (rc != NCDE_OK) return fail(rc, "%s", msg);
     return NCDE_OK;
 }

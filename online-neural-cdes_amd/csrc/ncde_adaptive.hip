@@ -46,9 +46,35 @@ struct DpCtrl {
     StageDesc st[7];                 // st[0]: the f0 / probe evaluation; st[1..6]: stages 2..7 of the attempt
 };
 
+// Record of a taped forward solve (adjoint=False): the accepted steps, what the reverse sweep of ncde_dp_tape_* needs.
+struct DpTapeHeader {
+    int magic, cap, n_steps, delta_active;   // delta_active: dt of step 1 came from _select_initial_step and attempt 1 was accepted
+    int h0_const, h1_const, n_t, overflow;
+    float h0, h1, d0, d1, d2, pad_[3];
+    double t_start;
+    double pad2_[23];
+};
+static_assert(sizeof(DpTapeHeader) == 256, "tape header is 256 bytes");
+struct DpStepRec {
+    double t0, dt;
+    int j_begin, j_end, attempt, pad_;
+};
+constexpr int DP_TAPE_MAGIC = 0x44503554;
+
 struct DpArgs {
     KArgs a;
     DpCtrl* ctrl;
+    // taped solve: record of the accepted steps (forward writes, the reverse sweep reads)
+    DpTapeHeader* tape;
+    DpStepRec* tape_steps;
+    float* tape_x;           // [n_t] dense-output abscissae
+    float* tape_y;           // [cap][B][H] state at the start of every accepted step
+    int tape_cap;
+    // reverse sweep of the taped solve
+    float* KF;  float* KBR;  // [n_wg][7][HS] stage derivatives / their cotangents, per workgroup
+    float* DZ0; float* F0B; float* SCB;   // [B][H]
+    double* PN2;             // [n_wg][4]
+    float* gz0;
     int adj, n_wg, n_t, n_knots, theta1;   // theta1 = theta_size + 1 (the vjp_t slot)
     const double* t_out;     // [n_t] device
     const float* knots;      // [n_knots] device or NULL
@@ -61,6 +87,8 @@ struct DpArgs {
     double* PN;              // [n_wg][4] per-workgroup partial sums of squares
     double* TR;              // [trace_cap][4] diagnostics: t0, dt, accepted, error ratio per attempt
     int trace_cap;
+    const double* replay;    // [replay_n][2] forced (dt, accepted) per attempt (verification), device
+    int replay_n;
     float* out;              // forward: [B][n_t][H]
     const float* z_out;      // adjoint
     const float* grad_out;
@@ -493,8 +521,14 @@ extern "C" __global__ __launch_bounds__(256) void ncde_dp_control(DpArgs d) {
             if (d0f < 1e-5f || d1f < 1e-5f) h0 = 1e-6f;
             else h0 = 0.01f * d0f / d1f;
             c->h0 = h0;
+            if (d.tape) {
+                d.tape->h0 = h0; d.tape->d0 = d0f; d.tape->d1 = d1f;
+                d.tape->h0_const = (d0f < 1e-5f || d1f < 1e-5f) ? 1 : 0;
+                d.tape->t_start = c->t0;
+            }
             if (d.first_step > 0.0) {      // options['first_step']: no probe evaluation (rk_common.py:160-164)
                 c->dt = d.first_step;
+                if (c->n_attempts < d.replay_n) c->dt = d.replay[2 * c->n_attempts];
                 dp_plan_attempt(c, d);
                 c->phase = DP_STEP;
             } else {
@@ -520,6 +554,11 @@ extern "C" __global__ __launch_bounds__(256) void ncde_dp_control(DpArgs d) {
             else h1 = powf(0.01f / fmaxf(d1f, d2f), 1.0f / 5.0f);
             c->nfe += 1;
             c->dt = (double)fminf(100.0f * h0, h1);
+            if (c->n_attempts < d.replay_n) c->dt = d.replay[2 * c->n_attempts];
+            if (d.tape) {
+                d.tape->h1 = h1; d.tape->d2 = d2f;
+                d.tape->h1_const = (d1f <= 1e-15f && d2f <= 1e-15f) ? 1 : 0;
+            }
             dp_plan_attempt(c, d);
             c->phase = DP_STEP;
             c->accepted_now = 0;
@@ -538,6 +577,7 @@ extern "C" __global__ __launch_bounds__(256) void ncde_dp_control(DpArgs d) {
         bool accept = ratiof <= 1.0f;
         if (dt > d.max_step) accept = false;
         if (dt <= d.min_step) accept = true;
+        if (c->n_attempts < d.replay_n) accept = d.replay[2 * c->n_attempts + 1] != 0.0;           // replay of a recorded sequence
         if (!(ratio == ratio) || !(fabs(ratio) <= 1.79e308)) { c->error = 2; accept = false; }      // non-finite state
         c->nfe += 6;
         if (c->n_attempts < d.trace_cap) {
@@ -556,6 +596,7 @@ extern "C" __global__ __launch_bounds__(256) void ncde_dp_control(DpArgs d) {
             dt_next = dt * factor;
         }
         dt_next = fmin(fmax(dt_next, d.min_step), d.max_step);
+        if (c->n_attempts < d.replay_n) dt_next = d.replay[2 * c->n_attempts];      // (n_attempts already counts this attempt)
         int finish = 0;
         c->dtf_commit = c->dtf;
         if (accept) {
@@ -566,10 +607,23 @@ extern "C" __global__ __launch_bounds__(256) void ncde_dp_control(DpArgs d) {
                 c->j_begin = j;
                 while (j < d.n_t && !(d.t_out[j] > t1)) {
                     d.XOUT[j] = (float)((d.t_out[j] - t0) / (t1 - t0));
+                    if (d.tape) d.tape_x[j] = d.XOUT[j];
                     ++j;
                 }
                 c->j_end = c->j_out = j;
                 if (j >= d.n_t) finish = 1;
+                if (d.tape) {          // tape of the accepted steps
+                    const int m = c->n_accept - 1;
+                    if (m < d.tape_cap) {
+                        DpStepRec* r = d.tape_steps + m;
+                        r->t0 = t0; r->dt = dt; r->j_begin = c->j_begin; r->j_end = c->j_end; r->attempt = c->n_attempts - 1;
+                        d.tape->n_steps = m + 1;
+                        if (m == 0) d.tape->delta_active = (c->n_attempts == 1 && !(d.first_step > 0.0)) ? 1 : 0;
+                    } else {
+                        d.tape->overflow = 1;
+                        c->error = 4;
+                    }
+                }
             } else if (!(c->t_goal > t1)) {
                 finish = 1;
                 sh_x = (float)((c->t_goal - t0) / (t1 - t0));
@@ -635,6 +689,7 @@ extern "C" __global__ __launch_bounds__(256) void ncde_dp_commit(DpArgs d) {
     const float y0 = d.Y0[g], y1 = d.YC[g];
     const float f0 = d.KY[g], f1 = d.KY[6 * n + g];
     if (!d.adj) {
+        if (d.tape_y && c->n_accept - 1 < d.tape_cap) d.tape_y[(long long)(c->n_accept - 1) * n + g] = y0;
         if (c->j_end > c->j_begin) {
             float ym = 0.0f;
             for (int j = 0; j < 7; ++j) ym += d.KY[j * n + g] * (dtc * kMid[j]);
@@ -659,6 +714,397 @@ extern "C" __global__ __launch_bounds__(256) void ncde_dp_commit(DpArgs d) {
         d.A0[g] = a1;
         d.KY[g] = f1;
         d.KA[g] = fa1;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// reverse sweep of a TAPED solve: cdeint(..., method='dopri5', adjoint=False) -- the way the reference's shipped "interpolation"
+// experiments run dopri5 (experiments/configurations/configurations.json5:187-191).  What autograd differentiates there
+// (rk_common.py:216-305 under torchdiffeq.odeint): the six stage evaluations of every ACCEPTED step with FSAL (k1 of a step is k7
+// of the previous one), the 4th-order dense output at the requested times (interp.py:4-61), and -- _optimal_step_size being
+// @torch.no_grad() (misc.py:84-97) -- of all step sizes only the FIRST, _select_initial_step(y0, f0, f(t0 + h0, y0 + h0 f0))
+// (misc.py:33-74), which moves the start time of every later step (dense-output abscissae, stage times of a cubic control).
+// Samples couple only through that one scalar, so the sweep over the recorded steps is ONE persistent launch, one workgroup per
+// 16-sample tile, no grid-wide synchronisation inside: per step the stage derivatives are recomputed from the recorded state
+// (7 evaluations), then six stage VJPs in reverse; the scalar partials d/d(t0), d/d(dt_1) are reduced afterwards and pushed
+// through the initial-step rule by two small launches (ncde_dp_tape_finish).  Oracle: ncde_oracle.dopri5_discrete_backward.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int DP_NE = 8;      // elements of an [H <= 128][16] tile array per thread (GEN_THREADS = 256)
+
+struct TapeLds {
+    float *YS, *AS, *KOY, *KOA, *X, *G0, *G1, *PW2, *DX, *D2X, *SC, *Y0s, *YB1, *KBN, *GL;
+    int total;
+};
+__device__ TapeLds tape_lds(float* lds, int HS, int DS, int L, int Cp, int theta1, int gacc_in_lds) {
+    TapeLds t;
+    t.YS = lds; t.AS = t.YS + HS; t.KOY = t.AS + HS; t.KOA = t.KOY + HS;
+    t.X = t.KOA + HS; t.G0 = t.X + (L > 0 ? L : 1) * DS; t.G1 = t.G0 + DS; t.PW2 = t.G1 + DS;
+    t.DX = t.PW2 + 2 * DS; t.D2X = t.DX + Cp * 16; t.SC = t.D2X + Cp * 16;
+    t.Y0s = t.SC + GEN_NW * 16 * 17; t.YB1 = t.Y0s + HS; t.KBN = t.YB1 + HS; t.GL = t.KBN + HS;
+    t.total = (int)(t.GL - lds) + (gacc_in_lds ? theta1 : 0);
+    return t;
+}
+// block-wide sum of a double over GEN_THREADS threads; every thread gets the total
+__device__ double tape_block_sum(double v, double* sh) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    sh[tid] = v;
+    __syncthreads();
+    for (int off = GEN_THREADS / 2; off > 0; off >>= 1) {
+        if (tid < off) sh[tid] += sh[tid + off];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+}  // namespace
+
+extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_dp_tape_backward(DpArgs d) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ StageDesc sdesc[7];
+    __shared__ double sh_dt;
+    __shared__ int sh_jb, sh_je;
+    __shared__ double shred[GEN_THREADS];
+    const KArgs& a = d.a;
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x * NCDE_TILE;
+    const int H = a.H, Hp = ru16(H), Cp = ru4(a.C), L = a.n_layers;
+    int Dp = Hp;
+    for (int l = 0; l < L; ++l) Dp = max(Dp, ru16(a.dout[l]));
+    const int HS = Hp * 16, DS = Dp * 16;
+    const TapeLds t = tape_lds(lds, HS, DS, L, Cp, d.theta1, d.gacc_in_lds);
+    for (int e = tid; e < t.total; e += GEN_THREADS) lds[e] = 0.0f;
+    float* gacc = d.gacc_in_lds ? t.GL : d.GP + (long long)blockIdx.x * d.theta1;
+    if (!d.gacc_in_lds)
+        for (int e = tid; e < d.theta1; e += GEN_THREADS) gacc[e] = 0.0f;
+    float* KF = d.KF + (long long)blockIdx.x * 7 * HS;
+    float* KB = d.KBR + (long long)blockIdx.x * 7 * HS;
+    const bool cubic = a.interp == NCDE_INTERP_CUBIC;
+    const long long BH = (long long)a.B * H;
+    const int M = d.tape->n_steps;
+    double Tpart = 0.0, D1part = 0.0;      // per-thread partials of dL/d(t0 of the steps >= 2) and dL/d(dt_1)
+    __syncthreads();
+
+    for (int m = M - 1; m >= 0; --m) {
+        if (tid == 0) {
+            const DpStepRec r = d.tape_steps[m];
+            const double t1 = r.t0 + r.dt;
+            const float t0f = (float)r.t0, dtf = (float)r.dt, t1f = (float)t1;
+            sh_dt = r.dt;
+            sh_jb = r.j_begin;
+            sh_je = r.j_end;
+            // k1 of the step: f0 = f(t[0], y0) for the first step, else the previous step's last stage, evaluated one ulp before its t1
+            sdesc[0] = dp_stage_desc(m == 0 ? t0f : nextafterf(t0f, -INFINITY), d.knots, d.n_knots);
+            for (int i = 0; i < 6; ++i) {
+                const float ti = kAlpha[i] == 1.0f ? nextafterf(t1f, -INFINITY) : t0f + kAlpha[i] * dtf;
+                sdesc[i + 1] = dp_stage_desc(ti, d.knots, d.n_knots);
+            }
+        }
+        __syncthreads();
+        const double dt64 = sh_dt;
+        const float dtf = (float)dt64;
+        const int jb = sh_jb, je = sh_je;
+        // ---- recompute the stage derivatives of the step ------------------------------------------------------------
+        for (int e = tid; e < HS; e += GEN_THREADS) {
+            const int h = e >> 4, sidx = e & 15, b = b0 + sidx;
+            t.Y0s[e] = (h < H && b < a.B) ? d.tape_y[(long long)m * BH + (long long)b * H + h] : 0.0f;
+        }
+        load_dx(a, b0, sdesc[0], t.DX, Cp, tid);
+        __syncthreads();
+        gen_stage_forward(a, t.Y0s, t.X, t.G0, t.DX, t.KOY, Hp, Cp, tid);
+        for (int e = tid; e < HS; e += GEN_THREADS) KF[e] = t.KOY[e];
+        for (int i = 1; i <= 6; ++i) {
+            for (int e = tid; e < HS; e += GEN_THREADS) {
+                const int h = e >> 4, sidx = e & 15, b = b0 + sidx;
+                float acc = 0.0f;
+                for (int j = 0; j < i; ++j) acc += KF[j * HS + e] * (kBeta[i - 1][j] * dtf);
+                t.YS[e] = (h < H && b < a.B) ? t.Y0s[e] + acc : 0.0f;
+            }
+            load_dx(a, b0, sdesc[i], t.DX, Cp, tid);
+            __syncthreads();
+            gen_stage_forward(a, t.YS, t.X, t.G0, t.DX, t.KOY, Hp, Cp, tid);
+            for (int e = tid; e < HS; e += GEN_THREADS) KF[i * HS + e] = t.KOY[e];
+        }
+        // ---- cotangents: FSAL, dense output, interpolation fit ------------------------------------------------------
+        float yb0[DP_NE], yb1[DP_NE];
+#pragma unroll
+        for (int q = 0; q < DP_NE; ++q) {
+            const int e = tid + q * GEN_THREADS;
+            yb0[q] = 0.0f;
+            yb1[q] = 0.0f;
+            if (e < HS) {
+                yb1[q] = t.YB1[e];
+                for (int j = 0; j < 6; ++j) KB[j * HS + e] = 0.0f;
+                KB[6 * HS + e] = t.KBN[e];
+            }
+        }
+        if (je > jb) {
+#pragma unroll
+            for (int q = 0; q < DP_NE; ++q) {
+                const int e = tid + q * GEN_THREADS;
+                const int h = e >> 4, sidx = e & 15, b = b0 + sidx;
+                if (e < HS && h < H && b < a.B) {
+                    const float y0 = t.Y0s[e], y1 = t.YS[e];      // YS still holds the input of the last stage = the step's solution
+                    const float k1 = KF[e], k7 = KF[6 * HS + e];
+                    float ym = 0.0f, kmid = 0.0f;
+                    for (int j = 0; j < 7; ++j) {
+                        ym += KF[j * HS + e] * (dtf * kMid[j]);
+                        kmid += KF[j * HS + e] * kMid[j];
+                    }
+                    ym = y0 + ym;
+                    const float ca = 2.0f * dtf * (k7 - k1) - 8.0f * (y1 + y0) + 16.0f * ym;
+                    const float cb = dtf * (5.0f * k1 - 3.0f * k7) + 18.0f * y0 + 14.0f * y1 - 32.0f * ym;
+                    const float cc = dtf * (k7 - 4.0f * k1) - 11.0f * y0 - 5.0f * y1 + 16.0f * ym;
+                    const float cd = dtf * k1;
+                    float ab = 0.f, bb = 0.f, cbb = 0.f, db = 0.f, eb = 0.f;
+                    for (int j = jb; j < je; ++j) {
+                        const float x = d.tape_x[j];
+                        const float g = d.grad_out[((long long)b * d.n_t + j) * H + h];
+                        const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+                        eb += g; db += x * g; cbb += x2 * g; bb += x3 * g; ab += x4 * g;
+                        const double xbar = (double)(g * (cd + 2.0f * x * cc + 3.0f * x2 * cb + 4.0f * x3 * ca));
+                        if (m >= 1) Tpart += xbar * (-1.0 / dt64);             // x = (t - t0) / dt_m, t0 moves with dt_1
+                        else D1part += xbar * (-(double)x / dt64);            // x = (t - t[0]) / dt_1
+                    }
+                    const float ymb = 16.0f * ab - 32.0f * bb + 16.0f * cbb;
+                    yb0[q] += -8.0f * ab + 18.0f * bb - 11.0f * cbb + eb + ymb;
+                    yb1[q] += -8.0f * ab + 14.0f * bb - 5.0f * cbb;
+                    KB[e] += dtf * (-2.0f * ab + 5.0f * bb - 4.0f * cbb + db);
+                    KB[6 * HS + e] += dtf * (2.0f * ab - 3.0f * bb + cbb);
+                    for (int j = 0; j < 7; ++j) KB[j * HS + e] += (dtf * kMid[j]) * ymb;
+                    if (m == 0)
+                        D1part += (double)(ab * 2.0f * (k7 - k1) + bb * (5.0f * k1 - 3.0f * k7) + cbb * (k7 - 4.0f * k1) + db * k1) + (double)(ymb * kmid);
+                }
+            }
+        }
+        // ---- the six stages in reverse: k_{i+1} = f(t_i, y_i), y_i = y0 + dt sum_j beta_ij k_j -------------------------
+        for (int i = 6; i >= 1; --i) {
+            for (int e = tid; e < HS; e += GEN_THREADS) {
+                const int h = e >> 4, sidx = e & 15, b = b0 + sidx;
+                const bool ok = h < H && b < a.B;
+                float acc = 0.0f;
+                for (int j = 0; j < i; ++j) acc += KF[j * HS + e] * (kBeta[i - 1][j] * dtf);
+                t.YS[e] = ok ? t.Y0s[e] + acc : 0.0f;
+                t.AS[e] = ok ? KB[i * HS + e] : 0.0f;
+            }
+            load_dx(a, b0, sdesc[i], t.DX, Cp, tid);
+            if (cubic) dp_load_d2x(a, b0, sdesc[i], t.D2X, Cp, tid);
+            __syncthreads();
+            gen_stage_vjp(a, t.YS, t.AS, t.DX, cubic ? t.D2X : nullptr, t.X, t.G0, t.G1, t.PW2, t.SC, t.KOY, t.KOA, gacc, 1.0f, Hp, Cp, DS, tid);
+            __syncthreads();
+            const float tbi = cubic ? gacc[a.theta_size] : 0.0f;     // dL/d(t_i), summed over the tile
+            __syncthreads();
+            if (tid == 0) {
+                if (cubic) gacc[a.theta_size] = 0.0f;
+                if (m >= 1) Tpart += (double)tbi;                   // t_i = t0 + alpha_i dt, t0 = t[0] + dt_1 + constants
+                else D1part += (double)kAlpha[i - 1] * (double)tbi;
+            }
+#pragma unroll
+            for (int q = 0; q < DP_NE; ++q) {
+                const int e = tid + q * GEN_THREADS;
+                if (e < HS) {
+                    const float ybi = t.KOA[e] + (i == 6 ? yb1[q] : 0.0f);
+                    yb0[q] += ybi;
+                    float sbk = 0.0f;
+                    for (int j = 0; j < i; ++j) {
+                        KB[j * HS + e] += (kBeta[i - 1][j] * dtf) * ybi;
+                        sbk += kBeta[i - 1][j] * KF[j * HS + e];
+                    }
+                    if (m == 0) D1part += (double)(ybi * sbk);
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < DP_NE; ++q) {
+            const int e = tid + q * GEN_THREADS;
+            if (e < HS) {
+                t.YB1[e] = yb0[q];
+                t.KBN[e] = KB[e];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- hand-over to the finish launches -----------------------------------------------------------------------------
+    for (int e = tid; e < HS; e += GEN_THREADS) {
+        const int h = e >> 4, sidx = e & 15, b = b0 + sidx;
+        if (h < H && b < a.B) {
+            const long long g = (long long)b * H + h;
+            d.DZ0[g] = t.YB1[e] + d.grad_out[((long long)b * d.n_t) * H + h];      // the solution at t[0] is z0 itself
+            d.F0B[g] = t.KBN[e];
+            d.SCB[g] = 0.0f;
+        }
+    }
+    const double Tsum = tape_block_sum(Tpart, shred), Dsum = tape_block_sum(D1part, shred);
+    if (tid == 0) {
+        d.PN2[(long long)blockIdx.x * 4 + 0] = Tsum;
+        d.PN2[(long long)blockIdx.x * 4 + 1] = Dsum;
+        d.PN2[(long long)blockIdx.x * 4 + 2] = 0.0;
+        d.PN2[(long long)blockIdx.x * 4 + 3] = 0.0;
+    }
+    if (d.gacc_in_lds) {
+        float* dst = d.GP + (long long)blockIdx.x * d.theta1;
+        for (int e = tid; e < d.theta1; e += GEN_THREADS) dst[e] = t.GL[e];
+    }
+}
+
+// phase 1: dL/d(dt_1) through the probe evaluation f(t0 + h0, y0 + h0 f0) of the initial-step rule; phase 2: through d0, d1 and
+// the scale, and the VJP of f0 = f(t[0], y0) with everything that landed on it (misc.py:33-74; oracle: dopri5_discrete_backward)
+extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_dp_tape_finish(DpArgs d, int phase) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ StageDesc sd0, sd1;
+    __shared__ double shred[GEN_THREADS];
+    const KArgs& a = d.a;
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x * NCDE_TILE;
+    const int H = a.H, Hp = ru16(H), Cp = ru4(a.C), L = a.n_layers;
+    int Dp = Hp;
+    for (int l = 0; l < L; ++l) Dp = max(Dp, ru16(a.dout[l]));
+    const int HS = Hp * 16, DS = Dp * 16;
+    const TapeLds t = tape_lds(lds, HS, DS, L, Cp, d.theta1, d.gacc_in_lds);
+    for (int e = tid; e < t.total; e += GEN_THREADS) lds[e] = 0.0f;
+    float* gpart = d.GP + (long long)blockIdx.x * d.theta1;
+    float* gacc = d.gacc_in_lds ? t.GL : gpart;
+    const bool cubic = a.interp == NCDE_INTERP_CUBIC;
+    const DpTapeHeader hd = *d.tape;
+    const bool active = hd.delta_active != 0;
+    const float rtolf = (float)d.rtol, atolf = (float)d.atol;
+    const double n_el = (double)a.B * (double)H;
+    // batch-wide scalars (every workgroup forms them itself: n_wg doubles)
+    double p0 = 0.0, p2 = 0.0, p3 = 0.0;
+    for (int w = tid; w < d.n_wg; w += GEN_THREADS) {
+        p0 += d.PN2[(long long)w * 4 + 0] + d.PN2[(long long)w * 4 + 1];
+        p2 += d.PN2[(long long)w * 4 + 2];
+        p3 += d.PN2[(long long)w * 4 + 3];
+    }
+    const double dbar = tape_block_sum(p0, shred);                 // dL/d(dt_1)
+    const double s2 = tape_block_sum(p2, shred), s3 = tape_block_sum(p3, shred);
+    const double h0 = hd.h0, h1 = hd.h1, d0 = hd.d0, d1 = hd.d1, d2 = hd.d2;
+    double h0b = 0.0, h1b = 0.0, d1b = 0.0, d2b = 0.0;
+    if (active) {
+        if ((float)(100.0f * hd.h0) <= hd.h1) h0b = 100.0 * dbar;
+        else h1b = dbar;
+        if (h1b != 0.0 && !hd.h1_const) {
+            const double mx = fmax(d1, d2);
+            const double mxb = -0.2 * h1 / mx * h1b;
+            if (d1 >= d2) d1b += mxb;
+            else d2b += mxb;
+        } else if (h1b != 0.0) {
+            if (hd.h0 * 1e-3f > 1e-6f) h0b += 1e-3 * h1b;
+        }
+    }
+    if (tid == 0) {
+        const float t0f = (float)hd.t_start;
+        sd0 = dp_stage_desc(t0f, d.knots, d.n_knots);
+        sd1 = dp_stage_desc(t0f + hd.h0, d.knots, d.n_knots);
+    }
+    __syncthreads();
+    // y0 and f0 = f(t[0], y0) for the tile
+    for (int e = tid; e < HS; e += GEN_THREADS) {
+        const int h = e >> 4, sidx = e & 15, b = b0 + sidx;
+        t.Y0s[e] = (h < H && b < a.B) ? a.z0[(long long)b * H + h] : 0.0f;
+    }
+    load_dx(a, b0, sd0, t.DX, Cp, tid);
+    __syncthreads();
+    gen_stage_forward(a, t.Y0s, t.X, t.G0, t.DX, t.KOY, Hp, Cp, tid);
+    for (int e = tid; e < HS; e += GEN_THREADS) t.YB1[e] = t.KOY[e];       // f0
+    __syncthreads();
+    if (phase == 1) {
+        if (!(active && d2b != 0.0)) return;
+        const double n2 = d2 * h0;
+        for (int e = tid; e < HS; e += GEN_THREADS) {
+            const int h = e >> 4, sidx = e & 15, b = b0 + sidx;
+            t.YS[e] = (h < H && b < a.B) ? t.Y0s[e] + hd.h0 * t.YB1[e] : 0.0f;     // y1' = y0 + h0 f0
+        }
+        load_dx(a, b0, sd1, t.DX, Cp, tid);
+        __syncthreads();
+        gen_stage_forward(a, t.YS, t.X, t.G0, t.DX, t.KOY, Hp, Cp, tid);          // f1' = f(t0 + h0, y1')
+        for (int e = tid; e < HS; e += GEN_THREADS) {
+            const int h = e >> 4, sidx = e & 15, b = b0 + sidx;
+            float f1b = 0.0f;
+            if (h < H && b < a.B) {
+                const long long g = (long long)b * H + h;
+                const float scale = atolf + fabsf(t.Y0s[e]) * rtolf;
+                const float q = (t.KOY[e] - t.YB1[e]) / scale;
+                const float qb = (float)((d2b / h0) * (double)q / (n_el * n2));
+                f1b = qb / scale;
+                d.F0B[g] -= qb / scale;
+                d.SCB[g] -= qb * q / scale;
+            }
+            t.AS[e] = f1b;
+        }
+        if (cubic) dp_load_d2x(a, b0, sd1, t.D2X, Cp, tid);
+        __syncthreads();
+        gen_stage_vjp(a, t.YS, t.AS, t.DX, cubic ? t.D2X : nullptr, t.X, t.G0, t.G1, t.PW2, t.SC, t.KOY, t.KOA, gacc, 1.0f, Hp, Cp, DS, tid);
+        __syncthreads();
+        double part = 0.0;
+        for (int e = tid; e < HS; e += GEN_THREADS) {
+            const int h = e >> 4, sidx = e & 15, b = b0 + sidx;
+            if (h < H && b < a.B) {
+                const long long g = (long long)b * H + h;
+                const float dy1 = t.KOA[e];
+                d.DZ0[g] += dy1;
+                d.F0B[g] += hd.h0 * dy1;
+                part += (double)(dy1 * t.YB1[e]);
+            }
+        }
+        const double psum = tape_block_sum(part, shred);
+        if (tid == 0) {
+            d.PN2[(long long)blockIdx.x * 4 + 2] = psum;
+            d.PN2[(long long)blockIdx.x * 4 + 3] = cubic ? (double)gacc[a.theta_size] : 0.0;
+        }
+    } else {
+        double d0b = 0.0;
+        if (active) {
+            if (d2b != 0.0) h0b += -d2 / h0 * d2b + s2 + s3;
+            if (h0b != 0.0 && !hd.h0_const) {
+                d0b = 0.01 / d1 * h0b;
+                d1b += -h0 / d1 * h0b;
+            }
+        }
+        for (int e = tid; e < HS; e += GEN_THREADS) {
+            const int h = e >> 4, sidx = e & 15, b = b0 + sidx;
+            float f0b = 0.0f;
+            if (h < H && b < a.B) {
+                const long long g = (long long)b * H + h;
+                const float y0 = t.Y0s[e];
+                const float scale = atolf + fabsf(y0) * rtolf;
+                f0b = d.F0B[g];
+                float scb = d.SCB[g], dz = d.DZ0[g];
+                if (d0b != 0.0) {
+                    const float q0 = y0 / scale;
+                    const float q0b = (float)(d0b * (double)q0 / (n_el * d0));
+                    dz += q0b / scale;
+                    scb -= q0b * q0 / scale;
+                }
+                if (d1b != 0.0) {
+                    const float q1 = t.YB1[e] / scale;
+                    const float q1b = (float)(d1b * (double)q1 / (n_el * d1));
+                    f0b += q1b / scale;
+                    scb -= q1b * q1 / scale;
+                }
+                dz += scb * rtolf * (y0 > 0.0f ? 1.0f : (y0 < 0.0f ? -1.0f : 0.0f));
+                d.DZ0[g] = dz;
+            }
+            t.AS[e] = f0b;
+        }
+        __syncthreads();
+        gen_stage_vjp(a, t.Y0s, t.AS, t.DX, nullptr, t.X, t.G0, t.G1, t.PW2, t.SC, t.KOY, t.KOA, gacc, 1.0f, Hp, Cp, DS, tid);
+        __syncthreads();
+        for (int e = tid; e < HS; e += GEN_THREADS) {
+            const int h = e >> 4, sidx = e & 15, b = b0 + sidx;
+            if (h < H && b < a.B) {
+                const long long g = (long long)b * H + h;
+                d.gz0[g] = d.DZ0[g] + t.KOA[e];
+            }
+        }
+    }
+    if (d.gacc_in_lds) {       // this launch's parameter part on top of the partial the sweep left
+        __syncthreads();
+        for (int e = tid; e < d.theta1; e += GEN_THREADS) gpart[e] += t.GL[e];
     }
 }
 
@@ -691,7 +1137,7 @@ DpPlan dp_plan(const NcdeProblem* p, const Layout& y, int n_t, bool adj) {
     w.off_yc = take(4 * BH);
     w.off_ky = take(4 * 7 * BH);
     w.off_pn = take(sizeof(double) * 4 * w.n_wg);
-    w.off_tr = take(sizeof(double) * 4 * kTraceCap);
+    w.off_tr = take(sizeof(double) * 4 * kTraceCap + sizeof(double) * 2 * kTraceCap);      // trace rows, then the replay list
     if (adj) {
         w.off_a0 = take(4 * BH);
         w.off_ac = take(4 * BH);
@@ -707,9 +1153,68 @@ DpPlan dp_plan(const NcdeProblem* p, const Layout& y, int n_t, bool adj) {
 
 }  // namespace
 
+namespace {
+// device record of a taped solve: header | steps[cap] | x[n_t] | y[cap][B][H]
+struct TapeLayout {
+    size_t off_steps, off_x, off_y, total;
+    int cap;
+};
+TapeLayout tape_layout(const NcdeProblem* p, int n_t, int cap) {
+    TapeLayout t{};
+    const size_t BH = (size_t)p->batch * p->hidden;
+    t.cap = cap;
+    t.off_steps = sizeof(DpTapeHeader);
+    t.off_x = al256(t.off_steps + sizeof(DpStepRec) * (size_t)cap);
+    t.off_y = al256(t.off_x + sizeof(float) * (size_t)n_t);
+    t.total = t.off_y + 4 * BH * (size_t)cap;
+    return t;
+}
+// accepted steps a solve can take: every step but the first is >= min_step long and starts before t[-1]
+int tape_default_cap(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* op) {
+    const double span = ts->t[ts->n_t - 1] - ts->t[0];
+    if (op->min_step > 0.0) return (int)std::min(1.0e6, std::ceil(span / op->min_step)) + 4;
+    return 4 * p->n_knots + 4 * ts->n_t + 1024;       // no lower bound on the step: a generous default; a larger record may be passed
+}
+// the largest capacity a record of `bytes` holds
+int tape_cap_of(const NcdeProblem* p, int n_t, size_t bytes) {
+    int lo = 0, hi = 1 << 24;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tape_layout(p, n_t, mid).total <= bytes) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+struct TapeWs {
+    size_t off_knots, off_kf, off_kb, off_dz0, off_f0b, off_scb, off_gp, off_pn2, total;
+};
+TapeWs tape_ws(const NcdeProblem* p, const Layout& y) {
+    TapeWs w{};
+    size_t o = 0;
+    const size_t BH = (size_t)p->batch * p->hidden;
+    auto take = [&](size_t bytes) { const size_t at = o; o = al256(o + bytes); return at; };
+    w.off_knots = take(sizeof(float) * p->n_knots);
+    w.off_kf = take(4 * (size_t)y.n_wg * 7 * y.HS);
+    w.off_kb = take(4 * (size_t)y.n_wg * 7 * y.HS);
+    w.off_dz0 = take(4 * BH);
+    w.off_f0b = take(4 * BH);
+    w.off_scb = take(4 * BH);
+    w.off_gp = take(4 * (size_t)y.n_wg * (y.theta_size + 1));
+    w.off_pn2 = take(sizeof(double) * 4 * y.n_wg);
+    w.total = o;
+    return w;
+}
+}  // namespace
+
 int64_t ncde_dp_workspace_bytes(const NcdeProblem* p, int n_t, int adj) {
     const Layout y = make_layout(p);
+    if (adj == 2) return (int64_t)tape_ws(p, y).total;      // reverse sweep of a taped solve
     return (int64_t)dp_plan(p, y, n_t, adj != 0).total;
+}
+
+int64_t ncde_dp_record_bytes(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* op) {
+    return (int64_t)tape_layout(p, ts->n_t, tape_default_cap(p, ts, op)).total;
 }
 
 bool ncde_dp_supported(const NcdeProblem* p, int adj, char* why, size_t n) {
@@ -727,7 +1232,7 @@ bool ncde_dp_supported(const NcdeProblem* p, int adj, char* why, size_t n) {
 // Runs the solve to completion (this call synchronises: the number of attempts is data dependent).
 int ncde_dp_solve(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* op, int adj, float* out, const float* z_out,
                   const float* grad_out, const NcdeGrads* g, void* ws, size_t ws_bytes, hipStream_t st, NcdeAdaptiveStats* stats,
-                  char* err, size_t errn) {
+                  char* err, size_t errn, void* record, size_t record_bytes, const double* replay, int replay_n) {
     const Layout y = make_layout(p);
     const int n_t = ts->n_t;
     const DpPlan w = dp_plan(p, y, n_t, adj != 0);
@@ -754,6 +1259,24 @@ int ncde_dp_solve(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdapti
         d.G0T = (float*)(base + w.off_g0t); d.GCT = (float*)(base + w.off_gct);
     }
     d.out = out; d.z_out = z_out; d.grad_out = grad_out;
+    if (record) {      // taped forward (adjoint=False): keep what the reverse sweep needs of every accepted step
+        if (adj) { snprintf(err, errn, "a record is kept by the forward solve only"); return NCDE_ERR_INVALID; }
+        const int cap = tape_cap_of(p, n_t, record_bytes);
+        if (cap < 1) { snprintf(err, errn, "record of %zu B holds no step (ncde_dopri5_record_bytes)", record_bytes); return NCDE_ERR_WORKSPACE; }
+        const TapeLayout tl = tape_layout(p, n_t, cap);
+        char* rb = (char*)record;
+        d.tape = (DpTapeHeader*)rb;
+        d.tape_steps = (DpStepRec*)(rb + tl.off_steps);
+        d.tape_x = (float*)(rb + tl.off_x);
+        d.tape_y = (float*)(rb + tl.off_y);
+        d.tape_cap = cap;
+        DpTapeHeader hh;
+        memset(&hh, 0, sizeof(hh));
+        hh.magic = DP_TAPE_MAGIC; hh.cap = cap; hh.n_t = n_t;
+        hipError_t e0 = hipMemcpyAsync(rb, &hh, sizeof(hh), hipMemcpyHostToDevice, st);
+        if (e0 == hipSuccess) e0 = hipStreamSynchronize(st);      // hh is a local
+        if (e0 != hipSuccess) { snprintf(err, errn, "record header upload failed: %s", hipGetErrorString(e0)); return NCDE_ERR_HIP; }
+    }
     d.rtol = op->rtol; d.atol = op->atol; d.min_step = op->min_step; d.max_step = op->max_step > 0.0 ? op->max_step : INFINITY;
     d.first_step = op->first_step;
     d.safety = op->safety > 0.0 ? op->safety : 0.9;
@@ -791,6 +1314,14 @@ int ncde_dp_solve(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdapti
     } while (0)
 
     DP_TRY(hipMemcpyAsync(base + w.off_t, ts->t, sizeof(double) * n_t, hipMemcpyHostToDevice, st));
+    if (replay && replay_n > 0) {
+        if (replay_n > kTraceCap) { snprintf(err, errn, "replay of %d attempts: at most %d", replay_n, kTraceCap); return NCDE_ERR_INVALID; }
+        double* rdev = (double*)(base + w.off_tr) + 4 * (size_t)kTraceCap;
+        DP_TRY(hipMemcpyAsync(rdev, replay, sizeof(double) * 2 * replay_n, hipMemcpyHostToDevice, st));
+        DP_TRY(hipStreamSynchronize(st));
+        d.replay = rdev;
+        d.replay_n = replay_n;
+    }
     std::vector<float> kf;
     if (ts->knots) {
         kf.resize(p->n_knots);
@@ -830,11 +1361,95 @@ int ncde_dp_solve(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdapti
     if (hc.error == 1) { snprintf(err, errn, "underflow in dt %g", hc.dt); return NCDE_ERR_INVALID; }
     if (hc.error == 2) { snprintf(err, errn, "non-finite values in state `y`"); return NCDE_ERR_INVALID; }
     if (hc.error == 3) { snprintf(err, errn, "max_num_steps exceeded (%d)", d.max_num_steps); return NCDE_ERR_INVALID; }
+    if (hc.error == 4) { snprintf(err, errn, "the record holds %d accepted steps and the solve needs more: pass a larger record", d.tape_cap); return NCDE_ERR_WORKSPACE; }
     if (adj) {
         // dL/dz0 = a at the start time; dL/dtheta = the parameter part, scattered into the caller's buffers
         DP_TRY(hipMemcpyAsync(g->grad_z0, d.A0, sizeof(float) * BH, hipMemcpyDeviceToDevice, st));
         const int rc = launch_reduce_partials(p, y, g, d.G0T, 1, st);      // one "partial" of theta_size floats: a pure scatter
         if (rc != NCDE_OK) { snprintf(err, errn, "NcdeGrads: NULL destination for a parameter gradient"); return rc; }
+    }
+    return NCDE_OK;
+#undef DP_TRY
+}
+
+// Reverse sweep of a taped solve: dL/dz0 and dL/dtheta from the record of ncde_dp_solve(..., record).  Stream-ordered, no
+// synchronisation except for the (tiny) knot upload when the control has a user knot grid.
+int ncde_dp_tape_backward_run(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* op, const void* record, size_t record_bytes,
+                              const float* grad_out, const NcdeGrads* g, void* ws, size_t ws_bytes, hipStream_t st, char* err, size_t errn) {
+    const Layout y = make_layout(p);
+    const int n_t = ts->n_t;
+    const TapeWs w = tape_ws(p, y);
+    if (ws_bytes < w.total) { snprintf(err, errn, "workspace %zu B < %zu B", ws_bytes, w.total); return NCDE_ERR_WORKSPACE; }
+    const int cap = tape_cap_of(p, n_t, record_bytes);
+    if (cap < 1) { snprintf(err, errn, "record of %zu B holds no step", record_bytes); return NCDE_ERR_WORKSPACE; }
+    const TapeLayout tl = tape_layout(p, n_t, cap);
+    char* base = (char*)ws;
+    char* rb = (char*)const_cast<void*>(record);
+    DpArgs d;
+    memset(&d, 0, sizeof(d));
+    fill_kargs(p, y, &d.a);
+    d.a.n_out = n_t;
+    d.n_wg = y.n_wg; d.n_t = n_t; d.n_knots = p->n_knots; d.theta1 = y.theta_size + 1;
+    d.tape = (DpTapeHeader*)rb;
+    d.tape_steps = (DpStepRec*)(rb + tl.off_steps);
+    d.tape_x = (float*)(rb + tl.off_x);
+    d.tape_y = (float*)(rb + tl.off_y);
+    d.tape_cap = cap;
+    d.knots = ts->knots ? (const float*)(base + w.off_knots) : nullptr;
+    d.KF = (float*)(base + w.off_kf); d.KBR = (float*)(base + w.off_kb);
+    d.DZ0 = (float*)(base + w.off_dz0); d.F0B = (float*)(base + w.off_f0b); d.SCB = (float*)(base + w.off_scb);
+    d.GP = (float*)(base + w.off_gp); d.PN2 = (double*)(base + w.off_pn2);
+    d.grad_out = grad_out; d.gz0 = g->grad_z0;
+    d.rtol = op->rtol; d.atol = op->atol;
+#define DP_TRY(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) { snprintf(err, errn, "%s failed: %s", #expr, hipGetErrorString(e_)); return NCDE_ERR_HIP; } \
+    } while (0)
+    std::vector<float> kf;
+    if (ts->knots) {
+        kf.resize(p->n_knots);
+        for (int i = 0; i < p->n_knots; ++i) kf[i] = (float)ts->knots[i];
+        DP_TRY(hipMemcpyAsync(base + w.off_knots, kf.data(), sizeof(float) * p->n_knots, hipMemcpyHostToDevice, st));
+        DP_TRY(hipStreamSynchronize(st));
+    }
+    DpTapeHeader hh;
+    DP_TRY(hipMemcpyAsync(&hh, rb, sizeof(hh), hipMemcpyDeviceToHost, st));
+    DP_TRY(hipStreamSynchronize(st));
+    if (hh.magic != DP_TAPE_MAGIC || hh.n_t != n_t || hh.n_steps < 1 || hh.n_steps > cap || hh.overflow) {
+        snprintf(err, errn, "not the record of a finished taped solve of this problem (magic %x, n_t %d, steps %d / %d)", hh.magic, hh.n_t, hh.n_steps, cap);
+        return NCDE_ERR_INVALID;
+    }
+    size_t lds = sizeof(float) * (size_t)(7 * y.HS + ((y.L > 0 ? y.L : 1) + 4) * y.DS + 2 * y.Cp * 16 + 4 * 16 * 17);
+    const size_t red_bytes = 4 * 256 * sizeof(double);
+    d.gacc_in_lds = lds + sizeof(float) * (size_t)d.theta1 + red_bytes <= (size_t)kLdsLimit;
+    if (d.gacc_in_lds) lds += sizeof(float) * (size_t)d.theta1;
+    DP_TRY(ncde_lds_optin((const void*)ncde_dp_tape_backward, lds));
+    DP_TRY(ncde_lds_optin((const void*)ncde_dp_tape_finish, lds));
+    hipLaunchKernelGGL(ncde_dp_tape_backward, dim3(y.n_wg), dim3(GEN_THREADS), lds, st, d);
+    if (hh.delta_active) hipLaunchKernelGGL(ncde_dp_tape_finish, dim3(y.n_wg), dim3(GEN_THREADS), lds, st, d, 1);
+    hipLaunchKernelGGL(ncde_dp_tape_finish, dim3(y.n_wg), dim3(GEN_THREADS), lds, st, d, 2);
+    DP_TRY(hipGetLastError());
+    // per-workgroup partials have stride theta_size + 1 (the time slot): compact sum via the common reduction on a strided view
+    {
+        ReduceSegs segs{};
+        int n = 0;
+        for (int l = 0; l < p->n_layers; ++l) {
+            bool firstW = true, firstB = true;
+            for (int q = 0; q < l; ++q) {
+                if (p->layer_W[q] == p->layer_W[l]) firstW = false;
+                if (p->layer_b[q] == p->layer_b[l]) firstB = false;
+            }
+            if (firstW) { segs.off[n] = y.gW_off[l]; segs.len[n] = p->layer_out[l] * p->layer_in[l]; segs.dst[n] = g->grad_layer_W[l]; ++n; }
+            if (firstB) { segs.off[n] = y.gb_off[l]; segs.len[n] = p->layer_out[l]; segs.dst[n] = g->grad_layer_b[l]; ++n; }
+        }
+        segs.off[n] = y.gWo_off; segs.len[n] = y.rows * y.dlast; segs.dst[n] = g->grad_Wo; ++n;
+        segs.off[n] = y.gbo_off; segs.len[n] = y.rows; segs.dst[n] = g->grad_bo; ++n;
+        segs.n = n;
+        for (int i = 0; i < n; ++i)
+            if (!segs.dst[i]) { snprintf(err, errn, "NcdeGrads: NULL destination for a parameter gradient"); return NCDE_ERR_INVALID; }
+        hipLaunchKernelGGL(ncde_reduce_partials, dim3((d.theta1 + 255) / 256), dim3(256), 0, st, d.GP, y.n_wg, d.theta1, segs);
+        DP_TRY(hipGetLastError());
     }
     return NCDE_OK;
 #undef DP_TRY

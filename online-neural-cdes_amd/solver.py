@@ -278,6 +278,11 @@ class _AdaptiveSpec:
             self.trace = np.zeros((int(options["_trace"]), 4), dtype=np.float64)
             o.trace_capacity = self.trace.shape[0]
             o.trace = self.trace.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        self.replay = None
+        if options.get("_replay") is not None:      # verification (tests): force a recorded step sequence, rows of (dt, accepted)
+            self.replay = np.ascontiguousarray(np.asarray(options["_replay"], dtype=np.float64).reshape(-1, 2))
+            o.replay_count = self.replay.shape[0]
+            o.replay = self.replay.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
         self.opt = o
 
 
@@ -345,7 +350,68 @@ class _FusedDopri5(torch.autograd.Function):
         return (grad_z0 if ctx.needs_input_grad[0] else None, None, None, *grads)
 
 
-_DOPRI5_OPTIONS = ("min_step", "max_step", "first_step", "safety", "ifactor", "dfactor", "max_num_steps", "_trace")
+class _FusedDopri5Taped(torch.autograd.Function):
+    """method='dopri5' with adjoint=False (torchdiffeq.odeint under autograd, torchcde/solver.py:224-225): forward =
+    ncde_dopri5_forward_record (the adaptive solve keeping a record of its accepted steps), backward = ncde_dopri5_backward
+    (reverse-mode sweep over that record incl. the gradient of the first step size).  The backward evaluates no vector field
+    the reference would count: func.nfe grows by the forward's evaluations only, as under autograd."""
+
+    @staticmethod
+    def forward(ctx, z0, coeffs, cfg, *params):
+        spec, ad = cfg["spec"], cfg["adaptive"]
+        z0c = z0.detach().contiguous()
+        p = build_problem(coeffs, cfg["interp"], z0c, spec, "rk4", _lib.OUT_INTERVAL, cfg["flags"])
+        out = torch.empty(z0.shape[0], len(ad.tv), z0.shape[1], dtype=torch.float32, device=z0.device)
+        lib = _lib.lib()
+        stats = _lib.NcdeAdaptiveStats()
+        with torch.cuda.device(z0.device):
+            need = _lib.check(lib.ncde_dopri5_workspace_bytes(ctypes.byref(p), ctypes.byref(ad.ts), 0), "ncde_dopri5_workspace_bytes")
+            ws = torch.empty(int(need), dtype=torch.uint8, device=z0.device)
+            rbytes = _lib.check(lib.ncde_dopri5_record_bytes(ctypes.byref(p), ctypes.byref(ad.ts), ctypes.byref(ad.opt)), "ncde_dopri5_record_bytes")
+            rec = torch.empty(int(rbytes), dtype=torch.uint8, device=z0.device)
+            rc = lib.ncde_dopri5_forward_record(ctypes.byref(p), ctypes.byref(ad.ts), ctypes.byref(ad.opt), out.data_ptr(), rec.data_ptr(),
+                                                rec.numel(), ws.data_ptr(), ws.numel(), _stream_ptr(), ctypes.byref(stats))
+        if rc == -1:
+            raise AssertionError(lib.ncde_last_error_string().decode())      # the reference asserts (rk_common.py:232-233, 195)
+        _lib.check(rc, "ncde_dopri5_forward_record")
+        cfg["stats_forward"] = (stats.nfe, stats.n_accepted, stats.n_rejected)
+        if ad.trace is not None and cfg["func"] is not None:
+            cfg["func"].dopri5_trace = ad.trace[:stats.n_accepted + stats.n_rejected].copy()
+        if cfg["func"] is not None and hasattr(cfg["func"], "nfe"):
+            cfg["func"].nfe += stats.nfe
+        ctx.cfg, ctx.coeffs, ctx.z0_shape = cfg, coeffs, z0.shape
+        ctx.save_for_backward(z0c, rec, *params)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        cfg = ctx.cfg
+        z0c, rec, *params = ctx.saved_tensors
+        spec, ad = cfg["spec"], cfg["adaptive"]
+        dev = z0c.device
+        grad_out = grad_out.contiguous().float()
+        p = build_problem(ctx.coeffs, cfg["interp"], z0c, spec, "rk4", _lib.OUT_INTERVAL, cfg["flags"])
+        uniq = spec.unique_params()
+        gbuf = {id(q): torch.empty_like(q, memory_format=torch.contiguous_format) for q in uniq}
+        g = _lib.NcdeGrads()
+        grad_z0 = torch.empty(ctx.z0_shape, dtype=torch.float32, device=dev)
+        g.grad_z0 = grad_z0.data_ptr()
+        for i, (w, b) in enumerate(spec.layers):
+            g.grad_layer_W[i], g.grad_layer_b[i] = gbuf[id(w)].data_ptr(), gbuf[id(b)].data_ptr()
+        g.grad_Wo, g.grad_bo = gbuf[id(spec.Wo)].data_ptr(), gbuf[id(spec.bo)].data_ptr()
+        lib = _lib.lib()
+        with torch.cuda.device(dev):
+            need = _lib.check(lib.ncde_dopri5_workspace_bytes(ctypes.byref(p), ctypes.byref(ad.ts), 2), "ncde_dopri5_workspace_bytes")
+            ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+            rc = lib.ncde_dopri5_backward(ctypes.byref(p), ctypes.byref(ad.ts), ctypes.byref(ad.opt), rec.data_ptr(), rec.numel(),
+                                          grad_out.data_ptr(), ctypes.byref(g), ws.data_ptr(), ws.numel(), _stream_ptr())
+        _lib.check(rc, "ncde_dopri5_backward")
+        grads = [gbuf[id(q)] if needs else None for q, needs in zip(params, ctx.needs_input_grad[3:])]
+        return (grad_z0 if ctx.needs_input_grad[0] else None, None, None, *grads)
+
+
+_DOPRI5_OPTIONS = ("min_step", "max_step", "first_step", "safety", "ifactor", "dfactor", "max_num_steps", "_trace", "_replay")
 
 
 def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
@@ -383,9 +449,6 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
         raise NotImplementedError("X must be ncde_amd.LinearInterpolation or ncde_amd.NaturalCubicSpline")
     adaptive = method == "dopri5"
     if adaptive:
-        if not adjoint:
-            raise NotImplementedError("method='dopri5' with adjoint=False (autograd through the adaptive solver, including its "
-                                      "data-dependent first step) is not implemented; use adjoint=True or a fixed-step method")
         for k in list(options):
             if k not in _DOPRI5_OPTIONS and k != "norm":
                 warnings.warn("cdeint: Unexpected arguments {}".format({k: options.pop(k)}))
@@ -456,7 +519,7 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
                "adaptive": _AdaptiveSpec(X, t, rtol, atol, ad_options),
                "adaptive_backward": _AdaptiveSpec(X, t, rtol if adjoint_rtol is None else adjoint_rtol,
                                                   atol if adjoint_atol is None else adjoint_atol, bopt)}
-        out = _FusedDopri5.apply(z0, coeffs.detach(), cfg, *uniq)
+        out = (_FusedDopri5 if adjoint else _FusedDopri5Taped).apply(z0, coeffs.detach(), cfg, *uniq)
         if len(batch_shape) != 1:
             out = out.reshape(*batch_shape, out.shape[-2], out.shape[-1])
         return out

@@ -409,7 +409,9 @@ def gen_g10():
                 "rtol": okw["rtol"], "atol": okw["atol"], "options": okw.get("options", {}), "nfe_fwd": nfe_fwd, "nfe_bwd": nfe_all - nfe_fwd,
                 "steps_fwd": [sf["accepted"], sf["rejected"]], "steps_bwd": [sb["accepted"], sb["rejected"]],
                 "accept_margin_fwd": margin_f, "accept_margin_bwd": margin_b, "oracle_vs_ref": e,
-                "hand_vjp_same_step_sequence": bool(same_seq), "trace_fwd": [[a_, b_, int(c_)] for a_, b_, c_, _ in sf["trace"]]}
+                "hand_vjp_same_step_sequence": bool(same_seq), "trace_fwd": [[a_, b_, int(c_)] for a_, b_, c_, _ in sf["trace"]],
+                # the reference's own reverse step sequence (the autograd-VJP run reproduces it: same nfe, bit-level gradients)
+                "trace_bwd": [[a_, b_, int(c_)] for a_, b_, c_, _ in sa["trace"]]}
         rec["meta"] = np.array(json.dumps(meta))
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
         report.append(meta)
