@@ -11,4 +11,4 @@ from .solver import FieldSpec, cdeint  # noqa: F401
 from .vector_fields import GRUGatedVectorField, MinimalGatedVectorField, MLPField, OriginalVectorField  # noqa: F401
 from .ncde import NeuralCDE  # noqa: F401
 from .coefficients import linear_interpolation_coeffs, natural_cubic_coeffs, natural_cubic_spline_coeffs  # noqa: F401
-from .losses import MaskedTemporalLoss, masked_mean  # noqa: F401
+from .losses import MaskedTemporalLoss, RMSELoss, TemporalLossWrapper, masked_mean  # noqa: F401

@@ -611,6 +611,7 @@ extern "C" __global__ __launch_bounds__(256) void ncde_dp_control(DpArgs d) {
                     ++j;
                 }
                 c->j_end = c->j_out = j;
+                if (j > c->j_begin) c->steps_this_solve = 0;      // the reference counts attempts per _advance(next_t) (rk_common.py:196-203)
                 if (j >= d.n_t) finish = 1;
                 if (d.tape) {          // tape of the accepted steps
                     const int m = c->n_accept - 1;
@@ -1292,11 +1293,14 @@ int ncde_dp_solve(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdapti
                 if (p->layer_W[q] == p->layer_W[l]) firstW = false;
                 if (p->layer_b[q] == p->layer_b[l]) firstB = false;
             }
-            if (firstW) { d.seg_off[n] = y.gW_off[l]; d.seg_len[n] = p->layer_out[l] * p->layer_in[l]; ++n; }
-            if (firstB) { d.seg_off[n] = y.gb_off[l]; d.seg_len[n] = p->layer_out[l]; ++n; }
+            // a NULL destination = the tensor is not among the adjoint's parameters (requires_grad False, or left out of
+            // adjoint_params): the reference's augmented state does not contain it (adjoint.py:176-189), so it has no say in
+            // the mixed error norm either
+            if (firstW && (!adj || g->grad_layer_W[l])) { d.seg_off[n] = y.gW_off[l]; d.seg_len[n] = p->layer_out[l] * p->layer_in[l]; ++n; }
+            if (firstB && (!adj || g->grad_layer_b[l])) { d.seg_off[n] = y.gb_off[l]; d.seg_len[n] = p->layer_out[l]; ++n; }
         }
-        d.seg_off[n] = y.gWo_off; d.seg_len[n] = y.rows * y.dlast; ++n;
-        d.seg_off[n] = y.gbo_off; d.seg_len[n] = y.rows; ++n;
+        if (!adj || g->grad_Wo) { d.seg_off[n] = y.gWo_off; d.seg_len[n] = y.rows * y.dlast; ++n; }
+        if (!adj || g->grad_bo) { d.seg_off[n] = y.gbo_off; d.seg_len[n] = y.rows; ++n; }
         d.nseg = n;
     }
     // LDS plans
@@ -1365,8 +1369,25 @@ int ncde_dp_solve(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdapti
     if (adj) {
         // dL/dz0 = a at the start time; dL/dtheta = the parameter part, scattered into the caller's buffers
         DP_TRY(hipMemcpyAsync(g->grad_z0, d.A0, sizeof(float) * BH, hipMemcpyDeviceToDevice, st));
-        const int rc = launch_reduce_partials(p, y, g, d.G0T, 1, st);      // one "partial" of theta_size floats: a pure scatter
-        if (rc != NCDE_OK) { snprintf(err, errn, "NcdeGrads: NULL destination for a parameter gradient"); return rc; }
+        // one "partial" of theta_size floats: a pure scatter into the destinations that exist
+        ReduceSegs segs{};
+        int n = 0;
+        for (int l = 0; l < p->n_layers; ++l) {
+            bool firstW = true, firstB = true;
+            for (int q = 0; q < l; ++q) {
+                if (p->layer_W[q] == p->layer_W[l]) firstW = false;
+                if (p->layer_b[q] == p->layer_b[l]) firstB = false;
+            }
+            if (firstW && g->grad_layer_W[l]) { segs.off[n] = y.gW_off[l]; segs.len[n] = p->layer_out[l] * p->layer_in[l]; segs.dst[n] = g->grad_layer_W[l]; ++n; }
+            if (firstB && g->grad_layer_b[l]) { segs.off[n] = y.gb_off[l]; segs.len[n] = p->layer_out[l]; segs.dst[n] = g->grad_layer_b[l]; ++n; }
+        }
+        if (g->grad_Wo) { segs.off[n] = y.gWo_off; segs.len[n] = y.rows * y.dlast; segs.dst[n] = g->grad_Wo; ++n; }
+        if (g->grad_bo) { segs.off[n] = y.gbo_off; segs.len[n] = y.rows; segs.dst[n] = g->grad_bo; ++n; }
+        segs.n = n;
+        if (n > 0) {
+            hipLaunchKernelGGL(ncde_reduce_partials, dim3((y.theta_size + 255) / 256), dim3(256), 0, st, (const float*)d.G0T, 1, y.theta_size, segs);
+            DP_TRY(hipGetLastError());
+        }
     }
     return NCDE_OK;
 #undef DP_TRY

@@ -84,6 +84,12 @@ __host__ __device__ __forceinline__ int plan_step_words(int S) { return 3 + 3 * 
 __host__ __device__ __forceinline__ int plan_off_fwd() { return NCDE_PLAN_HEADER; }
 __host__ __device__ __forceinline__ int plan_off_out(int S, int n_fwd) { return NCDE_PLAN_HEADER + n_fwd * plan_step_words(S); }
 __host__ __device__ __forceinline__ int plan_off_adj(int S, int n_fwd, int n_out) { return plan_off_out(S, n_fwd) + 2 * n_out; }
+// A planned kernel walks the table with offsets computed from the CALLER's counts: refuse (leave the outputs untouched) a table
+// whose own header says something else -- a stale plan, or one built for another method, would otherwise index out of bounds.
+__device__ __forceinline__ bool plan_header_ok(const KArgs& a, int S) {
+    const int* h = a.plan;
+    return h[0] == NCDE_PLAN_MAGIC && h[1] == S && h[2] == a.n_steps_fwd && h[3] == a.n_steps_adj && h[4] == a.n_out;
+}
 __device__ __forceinline__ StageDesc plan_stage(const int* step, int j) {
     StageDesc d;
     d.idx = step[3 + 3 * j];

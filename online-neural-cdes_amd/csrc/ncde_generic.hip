@@ -51,6 +51,7 @@ extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_fwd_generic(KArgs
     const int S = n_stages(a.method);
     int cur_idx = -1;
     const bool planned = a.plan != nullptr;
+    if (planned && !plan_header_ok(a, S)) return;      // (uniform: before the first barrier)
     const int n_steps = planned ? a.n_steps_fwd : a.T - 1;
     const int* pout = planned ? a.plan + plan_off_out(S, a.n_steps_fwd) : nullptr;
     for (int n = 0; n < n_steps; ++n) {
@@ -139,6 +140,7 @@ extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_adj_generic(KArgs
     const int S = n_stages(a.method);
     const bool disc = a.discrete != 0;
     const bool planned = a.plan != nullptr;
+    if (planned && !plan_header_ok(a, S)) return;      // (uniform: before the first barrier)
     const int pw_ = plan_step_words(S);
     const int* pfwd = planned ? a.plan + plan_off_fwd() : nullptr;
     const int* pout = planned ? a.plan + plan_off_out(S, a.n_steps_fwd) : nullptr;

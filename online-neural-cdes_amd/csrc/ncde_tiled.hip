@@ -601,6 +601,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
     // general time axis (a.plan != NULL; csrc/ncde_timeplan.hip): per-step dt, per-stage (piece, offset, knot spacing), and the
     // output rows each step emits -- same semantics as the generic / variant kernels, whose plan mode is pinned to the reference
     const bool planned = a.plan != nullptr;
+    if (planned && !plan_header_ok(a, S)) return;      // (uniform: before the first barrier)
     const int n_steps = planned ? a.n_steps_fwd : a.T - 1;
     const int* pout = planned ? a.plan + plan_off_out(S, a.n_steps_fwd) : nullptr;
     for (int n = 0; n < n_steps; ++n) {
@@ -976,6 +977,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     // (the all-resident variant, RES = 1, is the latency-critical one -- cfg4: +6 % with the plan's extra live state -- and runs
     // the default axis only: the host sends planned problems to RES = 2 / streamed kernels)
     const bool planned = RES != 1 && a.plan != nullptr;
+    if (planned && !plan_header_ok(a, S)) return;      // (uniform: before the first barrier)
     const int pw_ = plan_step_words(S);
     const int* pfwd = planned ? a.plan + plan_off_fwd() : nullptr;
     const int* pout = planned ? a.plan + plan_off_out(S, a.n_steps_fwd) : nullptr;

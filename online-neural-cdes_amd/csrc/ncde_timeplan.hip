@@ -107,6 +107,14 @@ int build(const NcdeProblem* p, const NcdeTimeSpec* ts, int* w, size_t cap_words
         for (int i = 1; i < p->n_knots; ++i)
             if (!((float)ts->knots[i] > (float)ts->knots[i - 1])) { snprintf(err, errn, "knot grid must be strictly increasing"); return NCDE_ERR_INVALID; }
 
+    {   // the table is indexed with 32-bit word offsets (and built in host memory): refuse grids it cannot describe
+        const double est = (ts->t[nt - 1] - ts->t[0]) / ts->step_size + (double)nt + 2.0;      // steps per direction, roughly
+        const double cap = 2147483647.0 / (double)pw / 2.0 - 16.0;
+        if (!(est < cap)) {
+            snprintf(err, errn, "step_size %g over [%g, %g]: about %.3g steps, more than a time plan can hold (%.3g)", ts->step_size, ts->t[0], ts->t[nt - 1], est, cap);
+            return NCDE_ERR_INVALID;
+        }
+    }
     const std::vector<T> grid = fixed_grid<T>(t[0], t[nt - 1], step);
     if (grid.size() < 2 || !(grid.front() == t[0])) { snprintf(err, errn, "degenerate time grid"); return NCDE_ERR_INVALID; }
     const int n_fwd = (int)grid.size() - 1;

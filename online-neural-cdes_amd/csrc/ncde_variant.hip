@@ -263,6 +263,7 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_fwd_variant(KArgs 
     const int dlast = L ? a.dout[L - 1] : d0;
     const int ncq = Cp >> 2, ngrp = matmul ? (Hp >> 2) : (Hp >> 4), per_grp = matmul ? ncq : 1;
     const bool planned = a.plan != nullptr;
+    if (planned && !plan_header_ok(a, S)) return;      // (uniform: before the first barrier)
     const int n_steps = planned ? a.n_steps_fwd : a.T - 1;
     const int* pout = planned ? a.plan + plan_off_out(S, a.n_steps_fwd) : nullptr;
     for (int n = 0; n < n_steps; ++n) {
@@ -513,6 +514,7 @@ extern "C" __global__ __launch_bounds__(VR_THREADS) void ncde_adj_variant(KArgs 
     const int S = n_stages(a.method);
     const bool disc = a.discrete != 0;
     const bool planned = a.plan != nullptr;
+    if (planned && !plan_header_ok(a, S)) return;      // (uniform: before the first barrier)
     const int pw_ = plan_step_words(S);
     const int* pfwd = planned ? a.plan + plan_off_fwd() : nullptr;
     const int* pout = planned ? a.plan + plan_off_out(S, a.n_steps_fwd) : nullptr;

@@ -21,8 +21,11 @@ def masked_mean(preds, labels, kind="mse"):
     if kind not in _POINTWISE:
         raise ValueError("kind must be one of %s" % sorted(_POINTWISE))
     valid = labels == labels                          # NaN != NaN
-    y = torch.where(valid, labels, torch.zeros((), dtype=labels.dtype, device=labels.device))
-    per = _POINTWISE[kind](preds, y) * valid.to(preds.dtype)
+    zero_y = torch.zeros((), dtype=labels.dtype, device=labels.device)
+    zero_p = torch.zeros((), dtype=preds.dtype, device=preds.device)
+    y = torch.where(valid, labels, zero_y)
+    p = torch.where(valid, preds, zero_p)             # a non-finite prediction at a masked position must not poison the mean (0 * inf)
+    per = torch.where(valid, _POINTWISE[kind](p, y), zero_p)
     return per.sum() / valid.sum().clamp_min(1).to(preds.dtype)
 
 
@@ -39,3 +42,42 @@ class MaskedTemporalLoss(torch.nn.Module):
         if self.kind == "rmse":
             return torch.sqrt(masked_mean(preds, labels, "mse") + self.eps)
         return masked_mean(preds, labels, self.kind)
+
+
+class RMSELoss(torch.nn.Module):
+    """sqrt(mse + eps) -- the reference's criterion of that name (experiments/ingredients/metrics.py:49-58)."""
+
+    def __init__(self, eps=1e-6):
+        super().__init__()
+        self.mse = torch.nn.MSELoss()
+        self.eps = eps
+
+    def forward(self, yhat, y):
+        return torch.sqrt(self.mse(yhat, y) + self.eps)
+
+
+class TemporalLossWrapper(torch.nn.Module):
+    """The reference's wrapper (metrics.py:26-46): ``criterion`` applied to the positions whose label is not NaN.  The criteria the
+    reference pairs it with (MSELoss, L1Loss, BCEWithLogitsLoss with mean reduction, RMSELoss) run on the stream-ordered masked
+    formulation above; any other criterion falls back to the reference's boolean gather (one host synchronisation per call).
+    Difference kept on purpose: with NO valid position the fast path returns 0 where a mean over an empty gather is NaN."""
+
+    def __init__(self, criterion):
+        super().__init__()
+        assert isinstance(criterion, torch.nn.Module)
+        self.criterion = criterion
+        kinds = ((RMSELoss, "rmse"), (torch.nn.MSELoss, "mse"), (torch.nn.L1Loss, "l1"), (torch.nn.BCEWithLogitsLoss, "bce_logits"))
+        self._kind = None
+        for cls, kind in kinds:
+            plain = getattr(criterion, "reduction", "mean") == "mean" and getattr(criterion, "weight", None) is None and \
+                getattr(criterion, "pos_weight", None) is None
+            if type(criterion) is cls and plain:
+                self._kind = kind
+
+    def forward(self, preds, labels):
+        if self._kind == "rmse":
+            return torch.sqrt(masked_mean(preds, labels, "mse") + self.criterion.eps)
+        if self._kind is not None:
+            return masked_mean(preds, labels, self._kind)
+        mask = ~torch.isnan(labels)
+        return self.criterion(preds[mask], labels[mask])

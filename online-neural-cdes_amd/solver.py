@@ -329,9 +329,14 @@ class _FusedDopri5(torch.autograd.Function):
         g = _lib.NcdeGrads()
         grad_z0 = torch.empty(ctx.z0_shape, dtype=torch.float32, device=dev)
         g.grad_z0 = grad_z0.data_ptr()
+        # the adjoint's parameters (adjoint.py:176-189): those that require a gradient and, if given, are listed in adjoint_params; the
+        # others get a NULL destination = they are not part of the augmented state, hence not of the mixed error norm
+        keep = cfg["adjoint_param_ids"]
+        live = {id(q) for q, needs in zip(params, ctx.needs_input_grad[3:]) if needs and (keep is None or id(q) in keep)}
+        ptr = lambda q: gbuf[id(q)].data_ptr() if id(q) in live else None      # noqa: E731
         for i, (w, b) in enumerate(spec.layers):
-            g.grad_layer_W[i], g.grad_layer_b[i] = gbuf[id(w)].data_ptr(), gbuf[id(b)].data_ptr()
-        g.grad_Wo, g.grad_bo = gbuf[id(spec.Wo)].data_ptr(), gbuf[id(spec.bo)].data_ptr()
+            g.grad_layer_W[i], g.grad_layer_b[i] = ptr(w), ptr(b)
+        g.grad_Wo, g.grad_bo = ptr(spec.Wo), ptr(spec.bo)
         lib = _lib.lib()
         stats = _lib.NcdeAdaptiveStats()
         with torch.cuda.device(dev):
@@ -345,8 +350,7 @@ class _FusedDopri5(torch.autograd.Function):
         cfg["stats_backward"] = (stats.nfe, stats.n_accepted, stats.n_rejected)
         if cfg["func"] is not None and hasattr(cfg["func"], "nfe"):
             cfg["func"].nfe += stats.nfe
-        keep = cfg["adjoint_param_ids"]
-        grads = [gbuf[id(q)] if needs and (keep is None or id(q) in keep) else None for q, needs in zip(params, ctx.needs_input_grad[3:])]
+        grads = [gbuf[id(q)] if id(q) in live else None for q in params]
         return (grad_z0 if ctx.needs_input_grad[0] else None, None, None, *grads)
 
 

@@ -393,3 +393,20 @@ def test_masked_temporal_loss_ignores_finished_series():
     assert float(ncde_amd.masked_mean(preds, torch.full_like(labels, float("nan")))) == 0.0
     with pytest.raises(ValueError):
         ncde_amd.MaskedTemporalLoss("hinge")
+    # a non-finite prediction at a masked position is discarded, as the reference's boolean gather does (0 * inf would poison the mean)
+    bad = preds.detach().clone()
+    bad[0, 3, 1] = float("inf")
+    bad[0, 2, 0] = float("nan")
+    assert torch.allclose(ncde_amd.masked_mean(bad, labels), torch.nn.functional.mse_loss(keep_p, keep_y))
+    # the reference's class names (metrics.py:26-58): same values as its gather for the criteria it is used with, and for any other one
+    for crit in (torch.nn.MSELoss(), torch.nn.L1Loss(), torch.nn.BCEWithLogitsLoss(), ncde_amd.RMSELoss(), torch.nn.SmoothL1Loss()):
+        got = ncde_amd.TemporalLossWrapper(crit)(preds, labels)
+        assert torch.allclose(got, crit(keep_p, keep_y)), type(crit).__name__
+
+
+def test_time_plan_refuses_a_grid_it_cannot_index():
+    """ncde_time_plan_build: a step so small that the step tables would not fit 32-bit word offsets is an error, not an overflow
+    (ADVICE round 2)."""
+    X = ncde_amd.LinearInterpolation(torch.zeros(2, 5, 3))
+    with pytest.raises((ValueError, AssertionError, ncde_amd._lib.NcdeError), match="more than a time plan can hold"):
+        solver._time_plan(X, torch.tensor([0.0, 4.0]), "rk4", 1e-9, "cpu")
