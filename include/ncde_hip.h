@@ -291,6 +291,12 @@ int ncde_time_kernel(const NcdeProblem* p, int pass, float* out, const float* gr
 int64_t ncde_prepare_workspace_bytes(int kind, int B, int L, int C);
 int ncde_prepare_linear(const float* x, int B, int L, int C, int rectilinear_time_index, float* out, void* stream);
 int ncde_prepare_cubic(const float* x, int B, int L, int C, float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* The same builders with the observations on a USER time grid (the t= argument of torchcde.linear_interpolation_coeffs /
+ * natural_cubic_coeffs: interpolation_linear.py:131-180, interpolation_cubic.py:56-165): t = DEVICE pointer to L strictly
+ * increasing fp32 times, NULL = the integer grid.  Linear: the grid enters the interior-gap fill only (ignored by the rectilinear
+ * preparation, whose output the caller pairs with a grid of 2L-1 times).  Cubic: non-uniform natural spline. */
+int ncde_prepare_linear_grid(const float* x, const float* t, int B, int L, int C, int rectilinear_time_index, float* out, void* stream);
+int ncde_prepare_cubic_grid(const float* x, const float* t, int B, int L, int C, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

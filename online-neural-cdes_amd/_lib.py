@@ -106,7 +106,7 @@ class NcdeGrads(ctypes.Structure):
 EXPORTS = (
     "ncde_version", "ncde_last_error_string", "ncde_num_outputs", "ncde_workspace_bytes",
     "ncde_kernel_name", "ncde_forward", "ncde_adjoint", "ncde_time_kernel",
-    "ncde_prepare_workspace_bytes", "ncde_prepare_linear", "ncde_prepare_cubic",
+    "ncde_prepare_workspace_bytes", "ncde_prepare_linear", "ncde_prepare_cubic", "ncde_prepare_linear_grid", "ncde_prepare_cubic_grid",
     "ncde_stage_record_bytes", "ncde_forward_record", "ncde_backward",
     "ncde_time_plan_build", "ncde_dopri5_workspace_bytes", "ncde_dopri5_forward", "ncde_dopri5_adjoint",
     "ncde_dopri5_record_bytes", "ncde_dopri5_forward_record", "ncde_dopri5_backward",
@@ -176,6 +176,10 @@ def lib():
     h.ncde_prepare_linear.restype = ctypes.c_int
     h.ncde_prepare_cubic.argtypes = [vp, i32, i32, i32, vp, vp, sz, vp]
     h.ncde_prepare_cubic.restype = ctypes.c_int
+    h.ncde_prepare_linear_grid.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    h.ncde_prepare_linear_grid.restype = ctypes.c_int
+    h.ncde_prepare_cubic_grid.argtypes = [vp, vp, i32, i32, i32, vp, vp, sz, vp]
+    h.ncde_prepare_cubic_grid.restype = ctypes.c_int
     h.ncde_time_plan_build.argtypes = [P, ctypes.POINTER(NcdeTimeSpec), vp, sz, ctypes.POINTER(NcdeTimePlanInfo)]
     h.ncde_time_plan_build.restype = ctypes.c_int
     TS, AO, AS = ctypes.POINTER(NcdeTimeSpec), ctypes.POINTER(NcdeAdaptiveOptions), ctypes.POINTER(NcdeAdaptiveStats)

@@ -20,7 +20,9 @@ namespace {
 // rect >= 0: rectilinear preparation first (forward fill, every row twice, time channel advanced one slot).
 // One series (one sample, one channel); xs / os are strided views (global memory or an LDS copy).
 // mode 0: linear knots, NaN filled (L rows out);  1: rectilinear value channel (2L-1 rows out);  2: rectilinear time channel
-__device__ void linear_series(const float* xs, long long sx, float* os, long long so, int L, int mode) {
+// tg: the user time grid the observations sit on (interpolation_linear.py:131-180 with t=...), NULL = the integer grid; it only
+// enters the ratio of the interior-gap fill (the rectilinear preparation leaves no interior gap).
+__device__ void linear_series(const float* xs, long long sx, float* os, long long so, int L, int mode, const float* tg = nullptr) {
     if (mode == 2) {  // time channel: t_0, t_1, t_1, t_2, t_2, ... (advanced by one slot)
         const int T = 2 * L - 1;
         for (int i = 0; i < L; ++i) {
@@ -55,7 +57,7 @@ __device__ void linear_series(const float* xs, long long sx, float* os, long lon
             for (int k = 0; k < i; ++k) os[k * so] = v;
         } else {
             for (int k = prev + 1; k < i; ++k) {
-                const float ratio = ((float)k - (float)prev) / ((float)i - (float)prev);
+                const float ratio = tg ? (tg[k] - tg[prev]) / (tg[i] - tg[prev]) : ((float)k - (float)prev) / ((float)i - (float)prev);
                 os[k * so] = prev_v + ratio * (v - prev_v);
             }
         }
@@ -72,12 +74,12 @@ __device__ void linear_series(const float* xs, long long sx, float* os, long lon
 
 // v1: one thread per series straight on global memory (any size; coalescing limited to C*4-byte runs)
 __global__ __launch_bounds__(256) void ncde_linear_coeffs_kernel(const float* __restrict__ x, int B, int L, int C, int rect,
-                                                                  float* __restrict__ out) {
+                                                                  float* __restrict__ out, const float* __restrict__ tg) {
     const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (tid >= (long long)B * C) return;
     const int b = (int)(tid / C), c = (int)(tid - (long long)b * C);
     const int T = rect >= 0 ? 2 * L - 1 : L;
-    linear_series(x + (long long)b * L * C + c, C, out + (long long)b * T * C + c, C, L, rect < 0 ? 0 : (c == rect ? 2 : 1));
+    linear_series(x + (long long)b * L * C + c, C, out + (long long)b * T * C + c, C, L, rect < 0 ? 0 : (c == rect ? 2 : 1), tg);
 }
 
 // v2: one workgroup per sample, the whole [L][C] series staged in LDS: fully coalesced loads and stores, and the
@@ -102,7 +104,7 @@ __device__ __forceinline__ int wave_suffix_min(int v, int lane) {
 }
 
 __global__ __launch_bounds__(256) void ncde_linear_coeffs_lds_kernel(const float* __restrict__ x, int B, int L, int C, int rect,
-                                                                     float* __restrict__ out) {
+                                                                     float* __restrict__ out, const float* __restrict__ tg) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int T = rect >= 0 ? 2 * L - 1 : L;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256) void ncde_linear_coeffs_lds_kernel(const float
                 else if (q >= L) v = xin[p * C + cc];                              // trailing gap
                 else {
                     const float pv = xin[p * C + cc], qv = xin[q * C + cc];
-                    const float ratio = ((float)i - (float)p) / ((float)q - (float)p);
+                    const float ratio = tg ? (tg[i] - tg[p]) / (tg[q] - tg[p]) : ((float)i - (float)p) / ((float)q - (float)p);
                     v = pv + ratio * (qv - pv);
                 }
                 dst[e] = v;
@@ -256,7 +258,9 @@ __global__ __launch_bounds__(256) void ncde_linear_coeffs_lds_kernel(const float
 // Series with missing values (interpolation_cubic.py:77-165): ends filled from the first / last observation, spline
 // through the observed knots only (non-uniform spacing, so the swept diagonal is per series: wd), then every unit
 // interval [time, time+1) gets the piece that covers it, re-expanded around `time` (offset = t_knot - time).
-__device__ void cubic_series_missing(const float* xs, float* os, float* wb, float* wd, int L, int C, int first, int last) {
+// tg: user time grid (interpolation_cubic.py:56-165 with t=...), NULL = integer grid: knot spacing and the re-expansion offsets.
+__device__ void cubic_series_missing(const float* xs, float* os, float* wb, float* wd, int L, int C, int first, int last,
+                                     const float* tg = nullptr) {
     const long long sC = C;
     auto val = [&](int i) { return i < first ? xs[first * sC] : (i > last ? xs[last * sC] : xs[i * sC]); };
     // forward sweep over the knots: knot p is processed when the next knot q is known (r_p = 1/(t_q - t_p))
@@ -265,7 +269,7 @@ __device__ void cubic_series_missing(const float* xs, float* os, float* wb, floa
     for (int q = 1; q < L; ++q) {
         const float xq = val(q);
         if (isnan(xq)) continue;
-        const float td = (float)q - (float)p;
+        const float td = tg ? tg[q] - tg[p] : (float)q - (float)p;
         const float r = 1.0f / td, r2 = r * r;
         const float three = 3.0f * (xq - xp);
         const float scaled = three * r2;
@@ -297,14 +301,14 @@ __device__ void cubic_series_missing(const float* xs, float* os, float* wb, floa
     for (int i = L - 2; i >= 0; --i) {
         const float xi = val(i);
         if (isnan(xi)) continue;
-        const float td = (float)q - (float)i;
+        const float td = tg ? tg[q] - tg[i] : (float)q - (float)i;
         const float r = 1.0f / td, r2 = r * r;
         const float kd = (wb[i * sC] - r * kd_next) / wd[i * sC];
         const float three = 3.0f * (xq - xi), six = 2.0f * three;
         const float two_c = ((six * r - 4.0f * kd) - 2.0f * kd_next) * r;
         const float three_d = (-six * r + 3.0f * (kd + kd_next)) * r2;
         for (int time = q - 1; time >= i; --time) {
-            const float off = (float)i - (float)time;
+            const float off = tg ? tg[i] - tg[time] : (float)i - (float)time;
             const float a_in = (0.5f * two_c - three_d * off / 3.0f) * off;
             float* o = os + (long long)time * 4 * C;
             o[0] = xi + (a_in - kd) * off;
@@ -318,7 +322,8 @@ __device__ void cubic_series_missing(const float* xs, float* os, float* wb, floa
 
 // one (sample, channel) series straight on global memory: any size, missing values included
 __device__ void cubic_series_global(const float* __restrict__ x, int L, int C, float* __restrict__ out, float* __restrict__ ws,
-                                    const float* __restrict__ diag_swept, float* __restrict__ ws_d, int b, int c) {
+                                    const float* __restrict__ diag_swept, float* __restrict__ ws_d, int b, int c,
+                                    const float* __restrict__ tg = nullptr) {
     const float* xs = x + (long long)b * L * C + c;
     float* os = out + (long long)b * (L - 1) * 4 * C + c;
     // missing values?  (NaN anywhere in the series)
@@ -339,14 +344,14 @@ __device__ void cubic_series_global(const float* __restrict__ x, int L, int C, f
     if (L == 2) {
         const float x0 = xs[first * (long long)C], x1 = xs[last * (long long)C];   // ends filled from the observations
         os[0] = x0;
-        os[C] = x1 - x0;
+        os[C] = tg ? (x1 - x0) / (tg[1] - tg[0]) : x1 - x0;
         os[2 * C] = 0.0f;
         os[3 * C] = 0.0f;
         return;
     }
     float* wb = ws + (long long)b * L * C + c;
-    if (n_obs < L) {
-        cubic_series_missing(xs, os, wb, ws_d + (long long)b * L * C + c, L, C, first, last);
+    if (n_obs < L || tg) {      // a user grid is non-uniform spacing: the same sweep as for missing values (every point a knot)
+        cubic_series_missing(xs, os, wb, ws_d + (long long)b * L * C + c, L, C, first, last, tg);
         return;
     }
     // rhs_i = 3 (x_i - x_{i-1}) + 3 (x_{i+1} - x_i) with unit knot spacing; Thomas forward sweep
@@ -388,13 +393,14 @@ __device__ void cubic_series_global(const float* __restrict__ x, int L, int C, f
 
 __global__ __launch_bounds__(64) void ncde_cubic_coeffs_kernel(const float* __restrict__ x, int B, int L, int C,
                                                                  float* __restrict__ out, float* __restrict__ ws,
-                                                                 const float* __restrict__ diag_swept, float* __restrict__ ws_d) {
+                                                                 const float* __restrict__ diag_swept, float* __restrict__ ws_d,
+                                                                 const float* __restrict__ tg) {
     // one wave per workgroup: the serial recurrences are latency-bound, so many small workgroups (all CUs, many waves in
     // flight) beat few large ones -- 32768 series at cfg4 are only 128 workgroups of 256
     const long long tid = (long long)blockIdx.x * 64 + threadIdx.x;
     if (tid >= (long long)B * C) return;
     const int b = (int)(tid / C), c = (int)(tid - (long long)b * C);
-    cubic_series_global(x, L, C, out, ws, diag_swept, ws_d, b, c);
+    cubic_series_global(x, L, C, out, ws, diag_swept, ws_d, b, c, tg);
 }
 
 // LDS-staged variant for complete series (no missing values): one wave = NSMP whole samples (lane <-> (sample, channel)).
@@ -632,8 +638,9 @@ int64_t ncde_prepare_workspace_bytes(int kind, int B, int L, int C) {
     return 256;
 }
 
-int ncde_prepare_linear(const float* x, int B, int L, int C, int rectilinear_time_index, float* out, void* stream) {
+int ncde_prepare_linear_grid(const float* x, const float* t, int B, int L, int C, int rectilinear_time_index, float* out, void* stream) {
     if (!x || !out || B < 1 || L < 2 || C < 1 || rectilinear_time_index >= C) return NCDE_ERR_INVALID;
+    const float* tg = rectilinear_time_index < 0 ? t : nullptr;      // the rectilinear preparation leaves no gap the grid could enter
     const long long n = (long long)B * C;
     const int rect = rectilinear_time_index < 0 ? -1 : rectilinear_time_index;
     const int T = rect >= 0 ? 2 * L - 1 : L;
@@ -642,14 +649,18 @@ int ncde_prepare_linear(const float* x, int B, int L, int C, int rectilinear_tim
     if (lds <= 64 * 1024 && C <= 256) {   // the series fits LDS: staged, coalesced, scan-parallel variant
         if (ncde_lds_optin((const void*)ncde_linear_coeffs_lds_kernel, lds) != hipSuccess)
             return NCDE_ERR_HIP;
-        hipLaunchKernelGGL(ncde_linear_coeffs_lds_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, x, B, L, C, rect, out);
+        hipLaunchKernelGGL(ncde_linear_coeffs_lds_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, x, B, L, C, rect, out, tg);
     } else {
-        hipLaunchKernelGGL(ncde_linear_coeffs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, B, L, C, rect, out);
+        hipLaunchKernelGGL(ncde_linear_coeffs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, B, L, C, rect, out, tg);
     }
     return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
 }
 
-int ncde_prepare_cubic(const float* x, int B, int L, int C, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+int ncde_prepare_linear(const float* x, int B, int L, int C, int rectilinear_time_index, float* out, void* stream) {
+    return ncde_prepare_linear_grid(x, nullptr, B, L, C, rectilinear_time_index, out, stream);
+}
+
+int ncde_prepare_cubic_grid(const float* x, const float* t, int B, int L, int C, float* out, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !out || !workspace || B < 1 || L < 2 || C < 1) return NCDE_ERR_INVALID;
     if ((int64_t)workspace_bytes < ncde_prepare_workspace_bytes(NCDE_INTERP_CUBIC, B, L, C)) return NCDE_ERR_WORKSPACE;
     float* ws = (float*)workspace;
@@ -658,7 +669,7 @@ int ncde_prepare_cubic(const float* x, int B, int L, int C, float* out, void* wo
     hipLaunchKernelGGL(ncde_cubic_diag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, L, diag);
     const long long n = (long long)B * C;
     // LDS-staged variant: NSMP whole samples per wave (lane <-> (sample, channel)), as many as fit 64 lanes and the LDS budget
-    if (C <= 64) {
+    if (C <= 64 && !t) {      // (constant-coefficient system: the default grid only)
         const int LC = L * C;
         int sstride = LC + ((C - (LC % 32)) % 32 + 32) % 32;      // stride == C (mod 32): the lanes of one time step fall on distinct banks
         sstride = (sstride + 3) & ~3;
@@ -678,8 +689,12 @@ int ncde_prepare_cubic(const float* x, int B, int L, int C, float* out, void* wo
         }
     }
     hipLaunchKernelGGL(ncde_cubic_coeffs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, x, B, L, C, out,
-                       ws, diag, ws_d);
+                       ws, diag, ws_d, t);
     return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
+}
+
+int ncde_prepare_cubic(const float* x, int B, int L, int C, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    return ncde_prepare_cubic_grid(x, nullptr, B, L, C, out, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -272,6 +272,18 @@ def gen_g8():
           "cubic", relerr(data.natural_cubic_coeffs(xc), cub_ref))
     np.savez_compressed(os.path.join(GOLD, "g8_coeffs.npz"), x_missing=xr, linear=lin_ref, rectilinear=rect_ref,
                         x_clean=xc, cubic=cub_ref, cubic_len2=cub2_ref, cubic_missing=cubm_ref)
+    # the same builders with the observations on a USER time grid (the t= argument; interpolation_linear.py:131-180,
+    # interpolation_cubic.py:56-165): irregular increasing times
+    tg = np.cumsum(0.3 + 1.4 * data.uniform01(8, L, stream=3)).astype(np.float32)
+    tt = torch.from_numpy(tg)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lin_t = torchcde.linear_interpolation_coeffs(torch.from_numpy(xr.copy()), t=tt).numpy()
+        cub_t = torchcde.natural_cubic_coeffs(torch.from_numpy(xc), t=tt).numpy()
+        cub2_t = torchcde.natural_cubic_coeffs(torch.from_numpy(xc[:, :2].copy()), t=tt[:2]).numpy()
+        cubm_t = torchcde.natural_cubic_coeffs(torch.from_numpy(xr.copy()), t=tt).numpy()
+    np.savez_compressed(os.path.join(GOLD, "g8_coeffs_user_grid.npz"), t=tg, x_missing=xr, x_clean=xc, linear=lin_t, cubic=cub_t,
+                        cubic_len2=cub2_t, cubic_missing=cubm_t)
 
 
 def gen_g11():

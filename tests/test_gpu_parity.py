@@ -726,6 +726,33 @@ def test_gpu_coefficient_builders_match_reference(gpu_lib):
     assert np.array_equal(got, gu.data.natural_cubic_coeffs(x4))
 
 
+def test_gpu_coefficient_builders_on_a_user_time_grid(gpu_lib):
+    """linear_interpolation_coeffs(x, t=...) / natural_cubic_coeffs(x, t=...) (interpolation_linear.py:131-180, interpolation_cubic.py:56-165):
+    goldens = the reference's builders on an irregular grid.  Linear: the grid enters the interior-gap fill; cubic: the non-uniform
+    natural spline, with and without missing values; and the result feeds cdeint on the same knots (g11's user-grid path)."""
+    import os
+    import ncde_amd
+    f = np.load(os.path.join(gu.GOLD, "g8_coeffs_user_grid.npz"))
+    t = torch.from_numpy(f["t"]).cuda()
+    xm, xc = torch.from_numpy(f["x_missing"]).cuda(), torch.from_numpy(f["x_clean"]).cuda()
+    assert gu.relerr(ncde_amd.linear_interpolation_coeffs(xm, t=t).cpu().numpy(), f["linear"]) <= 1e-6
+    got = ncde_amd.natural_cubic_coeffs(xc, t=t).cpu().numpy()
+    assert gu.relerr(got, f["cubic"]) <= 2e-6, gu.relerr(got, f["cubic"])
+    assert np.allclose(ncde_amd.natural_cubic_coeffs(xc[:, :2].contiguous(), t=t[:2]).cpu().numpy(), f["cubic_len2"], rtol=1e-6, atol=1e-7)
+    gotm = ncde_amd.natural_cubic_coeffs(xm, t=t).cpu().numpy()
+    assert gu.relerr(gotm, f["cubic_missing"]) <= 2e-6, gu.relerr(gotm, f["cubic_missing"])
+    # the reference's argument checks (misc.py:70-100)
+    with pytest.raises(ValueError, match="monotonically increasing"):
+        ncde_amd.natural_cubic_coeffs(xc, t=t.flip(0))
+    with pytest.raises(ValueError, match="time dimension"):
+        ncde_amd.linear_interpolation_coeffs(xm, t=t[:-1])
+    # a control built here on the user grid goes straight into cdeint on that grid
+    X = ncde_amd.NaturalCubicSpline(ncde_amd.natural_cubic_coeffs(xc, t=t), t=t)
+    func = ncde_amd.OriginalVectorField(xc.shape[-1], 8, 16, 2).cuda()
+    z = ncde_amd.cdeint(X, func, torch.zeros(xc.shape[0], 8, device="cuda"), X.interval, method="rk4", options={"step_size": 0.5})
+    assert torch.isfinite(z).all()
+
+
 TIMES_CASES = ["g11_times_rk4_half", "g11_times_midpoint_third", "g11_knots_rk4", "g11_knots_cubic_euler",
                "g11_knots_interval_rk4", "g11_times_f64_rk4", "g11_times_cubic_rk4_ragged"]
 
