@@ -72,7 +72,11 @@ typedef enum NcdeOutput { NCDE_OUT_INTERVAL = 0, NCDE_OUT_KNOTS = 1, NCDE_OUT_TI
                                           specialised, then batch-tiled wherever its shape constraints hold, then generic).
                                           Its backward keeps per-stage records for a WINDOW of steps only (sweep W steps, fold
                                           them into the output-layer gradient, reuse the record): workspace O(B H W), W sized to
-                                          a 192 MB record budget (environment variable NCDE_TILED_WINDOW_MB overrides) */
+                                          a 192 MB record budget (NCDE_FLAG_TILED_WINDOW_STEPS(n) overrides) */
+
+#define NCDE_FLAG_TILED_WINDOW_STEPS(n) (((uint32_t)(n) & 0xFFu) << 16) /* batch-tiled backward: n (1..255) solver steps per time window
+                                          instead of what the record budget allows (0 = budget).  The library reads no environment
+                                          variable on any call path; development switches exist only in builds with -DNCDE_DEV_KNOBS */
 
 typedef struct NcdeProblem {
     int32_t abi_version;  /* = NCDE_ABI_VERSION */

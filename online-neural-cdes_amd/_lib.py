@@ -16,6 +16,10 @@ FIELD_KIND = {"original": 0, "minimal": 1, "gru": 2}
 FIELD_INPUT = {"matmul": 0, "evaluate": 1, "derivative": 2}
 FLAG_AUTO, FLAG_FORCE_GENERIC, FLAG_FORCE_FAST, FLAG_FP32_MFMA, FLAG_ADJOINT_V1, FLAG_ADJOINT_V2 = 0, 1, 2, 4, 8, 16
 FLAG_ADJOINT_V4 = 32
+
+
+def FLAG_TILED_WINDOW_STEPS(n):
+    return (int(n) & 0xFF) << 16
 FLAG_TILED_NS1, FLAG_TILED_NS2, FLAG_TILED_NS4, FLAG_FORCE_TILED = 0x1000, 0x2000, 0x4000, 0x8000
 
 _c_float_p = ctypes.c_void_p  # device pointers are passed as integers

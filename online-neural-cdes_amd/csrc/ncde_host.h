@@ -20,6 +20,17 @@ extern "C" __global__ void ncde_reduce_partials(const float* gpart, int n_part, 
 
 constexpr int kLdsLimit = 160 * 1024;
 
+// Development switches are environment variables ONLY in builds with -DNCDE_DEV_KNOBS; the shipped library is stateless and
+// reads nothing but its arguments.
+inline const char* ncde_dev_env(const char* name) {
+#ifdef NCDE_DEV_KNOBS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 // Raise a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) only when a launch needs more than what was
 // already granted for this (device, kernel) -- not a hipFuncSetAttribute call in front of every launch.  (Granting a flat 160 KB
 // would fail for kernels that also hold static __shared__ arrays.)

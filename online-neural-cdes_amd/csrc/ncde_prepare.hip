@@ -676,7 +676,7 @@ int ncde_prepare_cubic_grid(const float* x, const float* t, int B, int L, int C,
         int nsmp = 64 / C;
         auto lds_of = [&](int ns) { return sizeof(float) * ((size_t)2 * ns * sstride + 2 * ((L + 3) & ~3)); };
         // the recurrences are latency chains: prefer several resident workgroups per CU (<= 28 KB each: measured best at cfg4 size) over full waves
-        const char* ev = getenv("NCDE_CUBIC_LDS_KB");      // development knob
+        const char* ev = ncde_dev_env("NCDE_CUBIC_LDS_KB");
         const size_t budget = (size_t)(ev && atoi(ev) > 0 ? atoi(ev) : 28) * 1024;
         while (nsmp > 1 && lds_of(nsmp) > budget) --nsmp;
         if (lds_of(nsmp) <= (size_t)150 * 1024) {

@@ -1931,7 +1931,7 @@ int64_t tiled_pack_floats(const NcdeProblem* p, bool bf) {
 size_t tiled_direct_residency(const NcdeProblem* p, KArgs* a, size_t base) {
     for (int l = 0; l < NCDE_MAX_LAYERS; ++l) a->tres[l] = 0;
     a->tres_o = a->tres_g = 0;
-    if (getenv("NCDE_TILED_NO_RESIDENT")) return base;
+    if (ncde_dev_env("NCDE_TILED_NO_RESIDENT")) return base;
     size_t off = (base + 15) / 16 * 4;      // floats, 16-byte aligned
     auto need = [](int N, int K) { return ((size_t)N * (K + 4) + N + 3) & ~(size_t)3; };
     auto fits = [&](size_t n) { return (off + n) * sizeof(float) <= (size_t)kLdsLimit; };
@@ -2024,7 +2024,7 @@ size_t tiled_adj_lds_base(const NcdeProblem* p) {
 // hidden matrices resident, output tiles streamed (RES = 2): small square hidden stacks that do not qualify for RES = 1
 bool tiled_adj_res2(const NcdeProblem* p) {
     const int pk = tiled_adj_pk(p);
-    bool ok = !tiled_adj_res(p) && pk >= 1 && pk <= 4 && p->hidden == 16 * pk && getenv("NCDE_TILED_NO_RES2") == nullptr;
+    bool ok = !tiled_adj_res(p) && pk >= 1 && pk <= 4 && p->hidden == 16 * pk && ncde_dev_env("NCDE_TILED_NO_RES2") == nullptr;
     for (int l = 0; l < p->n_layers; ++l) ok = ok && p->layer_out[l] == 16 * pk && p->layer_in[l] == 16 * pk;
     return ok;
 }
@@ -2065,9 +2065,9 @@ struct TiledAdjPlan {
 // Record budget of one time window.  The continuous adjoint exists to be O(1) in memory (torchcde README: "slower but more
 // memory efficient"), so the per-stage records pass B consumes are kept for a WINDOW of steps only: the sweep (pass A) runs W
 // steps, the output-layer gradient pass (pass B) folds those W steps into its accumulators, and the record is reused.  The
-// default budget is sized to stay resident in the 256 MB Infinity Cache between the two passes (NCDE_TILED_WINDOW_MB overrides).
+// default budget is sized to stay resident in the 256 MB Infinity Cache between the two passes (NCDE_FLAG_TILED_WINDOW_STEPS(n) overrides).
 long long tiled_window_budget_bytes() {
-    const char* e = getenv("NCDE_TILED_WINDOW_MB");      // read per call: tests shrink it to force several windows
+    const char* e = ncde_dev_env("NCDE_TILED_WINDOW_MB");
     if (e && atof(e) > 0.0) return (long long)(atof(e) * (double)(1LL << 20));
     return 192LL << 20;
 }
@@ -2099,6 +2099,8 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
     const long long per_step = (long long)S * t.n_st * (2 * recA_tile + (p->hidden + p->channels) * 16) * (long long)sizeof(float);
     const int steps = p->output == NCDE_OUT_TIMES ? std::max(p->n_steps_fwd, p->n_steps_adj) : p->n_knots - 1;
     t.window = (int)std::max<long long>(1, std::min<long long>(steps, tiled_window_budget_bytes() / per_step));
+    const int forced = (int)((p->flags >> 16) & 0xFFu);      // NCDE_FLAG_TILED_WINDOW_STEPS(n)
+    if (forced > 0) t.window = (int)std::min<long long>(steps, forced);
     t.n_sc = t.window * S;
     const long long tiles = (long long)t.n_sc * t.n_st;
     long long off = 64;
@@ -2215,7 +2217,7 @@ int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws
         if (p->field_kind == NCDE_FIELD_MINIMAL) fn = small ? ncde_fwd_tiled<1, TL_NW, 4, 1, 1> : ncde_fwd_tiled<1, TL_NW, 16, 1, 1>;
         else fn = small ? ncde_fwd_tiled<1, TL_NW, 4, 0, 1> : ncde_fwd_tiled<1, TL_NW, 16, 0, 1>;
         // small square hidden stack (H = every width = 32 or 64): hidden fragments resident
-        bool sq = (p->hidden == 32 || p->hidden == 64) && getenv("NCDE_TILED_NO_RES2") == nullptr;
+        bool sq = (p->hidden == 32 || p->hidden == 64) && ncde_dev_env("NCDE_TILED_NO_RES2") == nullptr;
         for (int l = 0; l < p->n_layers; ++l) sq = sq && p->layer_out[l] == p->hidden && p->layer_in[l] == p->hidden;
         if (sq) {
             const bool g = p->field_kind == NCDE_FIELD_MINIMAL;

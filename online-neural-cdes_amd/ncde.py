@@ -69,34 +69,33 @@ class NeuralCDE(nn.Module):
     def nfe(self):
         return getattr(self.func, "nfe", None)
 
-    def _setup_h0(self, inputs):
-        if not self.static_dim:
-            spline = self.spline(inputs)
-            if self.use_initial:
-                h0 = self.initial_linear(spline.evaluate(0))
-            else:
-                h0 = torch.zeros(inputs.size(0), self.hidden_dim, device=inputs.device, dtype=inputs.dtype)
+    def _control_and_start(self, inputs):
+        """(control path X, z(t0)) from the module input: coefficients, or (static features, coefficients) when static_dim is set.
+        The read-in layer sees [static features,] [X(t0)] -- whichever of the two the configuration provides (reference semantics:
+        src/ncde/ncde.py:170-198) -- and with neither, z(t0) = 0."""
+        if self.static_dim:
+            if not (isinstance(inputs, (tuple, list)) and len(inputs) == 2):
+                raise AssertionError("Inputs must be a 2-tuple of (static_data, temporal_data)")
+            static, coeffs = inputs
         else:
-            assert len(inputs) == 2, "Inputs must be a 2-tuple of (static_data, temporal_data)"
-            static, spline = inputs[0], self.spline(inputs[1])
-            if self.use_initial:
-                h0 = self.initial_linear(torch.cat((static, spline.evaluate(0)), dim=-1))
-            else:
-                h0 = self.initial_linear(static)
-        return spline, h0
+            static, coeffs = None, inputs
+        X = self.spline(coeffs)
+        feats = ([static] if static is not None else []) + ([X.evaluate(0)] if self.use_initial else [])
+        if not feats:
+            return X, coeffs.new_zeros(coeffs.size(0), self.hidden_dim)
+        return X, self.initial_linear(feats[0] if len(feats) == 1 else torch.cat(feats, dim=-1))
 
-    def _make_outputs(self, hidden):
-        if self.return_sequences:
-            outputs = self.final_linear(hidden)
-            if self.interpolation == "rectilinear" and self.return_filtered_rectilinear:
-                outputs = outputs[:, ::2]
-            return outputs
-        return self.final_linear(hidden[:, -1, :])
+    def _readout(self, z):
+        """z: the solution [B, n_times, H].  Final time only, or every time; on a rectilinear path every other knot is the lagged
+        copy the rectilinear preparation inserted, dropped unless asked for (src/ncde/ncde.py:200-212)."""
+        if not self.return_sequences:
+            return self.final_linear(z[:, -1])
+        y = self.final_linear(z)
+        return y[:, ::2] if (self.interpolation == "rectilinear" and self.return_filtered_rectilinear) else y
 
     def forward(self, inputs):
-        spline, h0 = self._setup_h0(inputs)
-        times = spline.grid_points if self.return_sequences else spline.interval
-        hidden = cdeint(spline, self.func, h0, t=times, adjoint=self.adjoint,
-                        vector_field_type=self.vector_field_type, method=self.solver, atol=self.atol,
-                        rtol=self.rtol, options=dict(self.cdeint_options), kernel_flags=self.kernel_flags)
-        return self._make_outputs(hidden)
+        X, z0 = self._control_and_start(inputs)
+        z = cdeint(X, self.func, z0, t=X.grid_points if self.return_sequences else X.interval, adjoint=self.adjoint,
+                   vector_field_type=self.vector_field_type, method=self.solver, atol=self.atol, rtol=self.rtol,
+                   options=dict(self.cdeint_options), kernel_flags=self.kernel_flags)
+        return self._readout(z)

@@ -160,9 +160,20 @@ def _stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_ARENA = {}      # (device index, stream) -> one byte tensor, grown on demand and reused by every solve on that stream
+
+
 def _workspace(p, pass_, device):
-    need = _lib.check(_lib.lib().ncde_workspace_bytes(ctypes.byref(p), pass_), "ncde_workspace_bytes")
-    return torch.empty(max(int(need), 256), dtype=torch.uint8, device=device)
+    """Scratch for one C-ABI call: a per-(device, stream) arena instead of an allocation per call.  The kernels are stream-ordered
+    and a workspace is dead when its call's kernels are, so consecutive calls on ONE stream may share it; another stream gets its own."""
+    need = max(int(_lib.check(_lib.lib().ncde_workspace_bytes(ctypes.byref(p), pass_), "ncde_workspace_bytes")), 256)
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    buf = _ARENA.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(need + need // 8, dtype=torch.uint8, device=dev)
+        _ARENA[key] = buf
+    return buf[:need]
 
 
 def _check_tensor(x, name):

@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
 
 B, L, C, H, HH, NL, OUT = 64, 12, 20, 32, 32, 3, 1
 STEPS = 3
+SHAPE = {"B": B, "L": L}      # the workers of the cfg2-shaped case get (1024, 200) through their arguments
 
 
 def _free_port():
@@ -36,6 +37,7 @@ def _make_model(adjoint, seq):
 
 
 def _data(lo, hi, seq):
+    B, L = SHAPE["B"], SHAPE["L"]
     x = gu.data.make_rectilinear_coeffs(B, L, C - 1, missing=0.3, seed=21)
     n = L if seq else 1
     y = (ncde_amd.data.uniform01(3, B * n, stream=2) > 0.5).astype(np.float32).reshape(B, n, 1)
@@ -58,7 +60,10 @@ def _train(model, x, y):
     return flat, first, bucket
 
 
-def _worker(rank, world, port, out_dir, adjoint, seq):
+def _worker(rank, world, port, out_dir, adjoint, seq, shape=None):
+    if shape:
+        SHAPE.update(shape)
+    B = SHAPE["B"]
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     r, _, w = D.init_process_group("gloo")
@@ -86,7 +91,7 @@ def test_two_rank_neuralcde_data_parallel_on_one_gpu(adjoint, seq, tmp_path, gpu
     assert torch.equal(r0["params"], r1["params"])           # replicas stay bit-identical
     assert torch.equal(r0["grad"], r1["grad"])
     # a single process on the full batch: mean loss over 64 samples == average of the two 32-sample mean-loss gradients
-    x, y = _data(0, B, seq)
+    x, y = _data(0, SHAPE["B"], seq)
     flat, grad, _ = _train(_make_model(adjoint, seq), x, y)
     scale = float(grad.abs().max())
     eg = float((grad - r0["grad"]).abs().max()) / scale
@@ -96,3 +101,23 @@ def test_two_rank_neuralcde_data_parallel_on_one_gpu(adjoint, seq, tmp_path, gpu
     # Adam divides by sqrt(v): an element whose gradient is small by cancellation turns fp32 summation noise into an update
     # difference of up to ~lr * (relative error of that element); lr = 1e-2, 3 steps
     assert ep <= 1e-3, ep
+
+
+def test_two_rank_data_parallel_at_the_benchmarked_shape(tmp_path, gpu_lib):
+    """The same two-rank run at BASELINE cfg2/cfg3's per-sample shape (200 observations -> 399 rectilinear knots, C = 20, H = HH = 32),
+    512 samples per rank: the flat-bucket all-reduce runs with the kernels the benchmark times (ncde_fwd_fast_bf3 / ncde_adj_fast3),
+    replicas stay bit-identical and the first-step gradient equals the single-process one on the 1024-sample batch."""
+    shape = {"B": 1024, "L": 200}
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), True, False, shape), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    assert torch.equal(r0["params"], r1["params"]) and torch.equal(r0["grad"], r1["grad"])
+    SHAPE.update(shape)
+    try:
+        x, y = _data(0, 1024, False)
+        flat, grad, _ = _train(_make_model(True, False), x, y)
+    finally:
+        SHAPE.update({"B": B, "L": L})
+    eg = float((grad - r0["grad"]).abs().max()) / float(grad.abs().max())
+    assert eg <= 2e-5, eg

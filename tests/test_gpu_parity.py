@@ -588,9 +588,9 @@ def test_tiled_family_vs_oracle(shape, interp, method, seq, gpu_lib):
 @pytest.mark.parametrize("shape,gated", [((80, 128, 128, 3), False), ((8, 48, 64, 2), False), ((20, 32, 32, 3), True),
                                          ((8, 32, 128, 2), True)])      # the last: gated heads of 128 columns = one pair-kernel pass per head
 @pytest.mark.parametrize("interp,method,seq", [("linear", "rk4", False), ("cubic", "midpoint", True)])
-def test_tiled_backward_time_windows(shape, gated, interp, method, seq, gpu_lib, monkeypatch):
+def test_tiled_backward_time_windows(shape, gated, interp, method, seq, gpu_lib):
     """The batch-tiled backward keeps its per-stage records for a WINDOW of steps only (workspace O(B H W), not O(B H T)):
-    forcing windows of one / a few steps (NCDE_TILED_WINDOW_MB) must reproduce the single-window result -- bit for bit for
+    forcing windows of one / a few steps (NCDE_FLAG_TILED_WINDOW_STEPS) must reproduce the single-window result -- bit for bit for
     dL/dz0 and the hidden-layer gradients (the carried (y, a) and the hidden-layer partial are exact hand-overs), to summation
     order (2e-6) for the head gradients (pass B adds one partial per window instead of running one long accumulation) -- for
     the continuous adjoint and the exact discrete backward; the workspace query shrinks accordingly."""
@@ -600,7 +600,6 @@ def test_tiled_backward_time_windows(shape, gated, interp, method, seq, gpu_lib,
     C, H, HH, nl = shape
     case = _seeded_case(interp, method, seq, B=37, L=7, C=C, H=H, HH=HH, nl=nl, seed=900 + C, kind="minimal" if gated else "original")
     FT = 0x8000
-    monkeypatch.delenv("NCDE_TILED_WINDOW_MB", raising=False)
     ref = gpu_util.run_adjoint_direct(case, case["expect"]["z_out"], flags=FT)
     refd = gpu_util.run_adjoint_direct(case, case["expect"]["z_out"], flags=FT, stages=case["stage_record"])
     coeffs = torch.from_numpy(case["coeffs"]).cuda()
@@ -611,11 +610,12 @@ def test_tiled_backward_time_windows(shape, gated, interp, method, seq, gpu_lib,
     n_steps = case["coeffs"].shape[1] - 1 + (interp == "cubic")
     per_step_mb = S * 3 * (2 * HH + H + C) * 16 * 4 / 2 ** 20          # 3 sample tiles of 16
     for steps in (1, 5):
-        monkeypatch.setenv("NCDE_TILED_WINDOW_MB", repr(per_step_mb * steps * 1.001))
+        FW = FT | (steps << 16)                      # NCDE_FLAG_TILED_WINDOW_STEPS(steps)
+        p.flags = FW
         small = _lib.lib().ncde_workspace_bytes(ctypes.byref(p), 1)
         assert small < full and full - small >= (n_steps - steps - 1) * per_step_mb * 2 ** 20 * 0.99
-        got = gpu_util.run_adjoint_direct(case, case["expect"]["z_out"], flags=FT)
-        gotd = gpu_util.run_adjoint_direct(case, case["expect"]["z_out"], flags=FT, stages=case["stage_record"])
+        got = gpu_util.run_adjoint_direct(case, case["expect"]["z_out"], flags=FW)
+        gotd = gpu_util.run_adjoint_direct(case, case["expect"]["z_out"], flags=FW, stages=case["stage_record"])
         for g_, r_ in ((got, ref), (gotd, refd)):
             assert np.array_equal(g_["dz0"], r_["dz0"])
             for k in r_["grads"]:
@@ -840,15 +840,9 @@ def test_general_time_axis_on_the_batch_tiled_family_vs_oracle(kind, interp, met
     if interp == "linear":
         g["knots"] = kn
     names = [n for n in ("W0", "b0", "W1", "b1", "Wg", "bg", "Wo", "bo") if n in p]
-    os_ = __import__("os")
-    for window_mb in (None, "0.05"):                       # default budget, then a few steps per window
-        if window_mb:
-            os_.environ["NCDE_TILED_WINDOW_MB"] = window_mb
-        try:
-            res = gpu_util.run_times_case(g, meta, adjoint=True, kind=kind, mode="matmul", params=p)
-            resd = gpu_util.run_times_case(g, meta, adjoint=False, kind=kind, mode="matmul", params=p)
-        finally:
-            os_.environ.pop("NCDE_TILED_WINDOW_MB", None)
+    for wflags in (0, 3 << 16):                            # default budget, then NCDE_FLAG_TILED_WINDOW_STEPS(3)
+        res = gpu_util.run_times_case(g, meta, adjoint=True, kind=kind, mode="matmul", params=p, flags=wflags)
+        resd = gpu_util.run_times_case(g, meta, adjoint=False, kind=kind, mode="matmul", params=p, flags=wflags)
         assert gu.relerr(res["z_out"], z) <= TIGHT_Z, gu.relerr(res["z_out"], z)
         assert gu.relerr(res["dz0"], dz0) <= E2E_G, gu.relerr(res["dz0"], dz0)
         for n_, g_ in zip(names, gp):
