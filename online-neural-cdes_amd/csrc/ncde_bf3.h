@@ -50,7 +50,94 @@ __device__ __forceinline__ f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// ---- 2-way split-fp16 ("h2") -------------------------------------------------------------------------------------------------
+// x = h1 + 2^-11 h2 with h1 = rne_f16(x) (11 significant bits) and h2 = rne_f16((x - h1) * 2^11) (the next 11, signed): the
+// representation error is <= 2^-24 |x| -- one fp32 half-ulp -- as long as h1 is a NORMAL fp16 number, i.e. 6.1e-5 <= |x| < 65520;
+// below that range the error is absolute (<= 2^-36), above it the conversion overflows.  A product a*b is the three partial products
+// of weight >= 2^-11 (h1*h1; h1*h2 and h2*h1, which share one accumulator scaled by 2^11); the dropped h2*h2 term is <= 2^-24 |ab|,
+// of either sign.  3 MFMAs instead of the 3-way split-bf16's 6, ~24 VALU per 8 values instead of 44 (v_cvt_pk_f16_f32, v_pk_mul_f32,
+// v_cvt_f32_f16, v_pk_fma_f32), 8 registers per operand fragment instead of 12.
+// The fp16 range is the price: kernels that use this split keep a sticky flag (`mx`) and report a RANGE FAULT for their sample tile
+// when an operand overflowed fp16 (|x| >= 65520) or was not finite; the host re-executes faulted tiles with the split-bf16
+// kernel (same arithmetic contract, any magnitude).  Cotangent-side operands, whose scale is arbitrary, are brought into range
+// by a per-workgroup power-of-two factor first (ncde_adj_fast3).
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define NCDE_H2_SCALE 2048.0f
+#define NCDE_H2_INV 4.8828125e-4f
+
+struct Split2h {
+    u32x4 hi, lo;  // 8 fp16 each: element j in dword j>>1, even j in the low half; lo holds (x - hi) * 2^11
+};
+
+// Range tracking: `mx` is a sticky NaN flag.  The scaled residual r = (x - h1) * 2^11 is -/+inf when h1 overflowed and NaN when x is
+// NaN, so fma(r, 0, mx) turns mx into NaN exactly when an operand left the fp16 range (one v_pk_fma_f32 per pair, on values the
+// split computes anyway).
+__device__ __forceinline__ Split2h split8h(const float* v, f32x2& mx) {
+    Split2h o;
+    h16x2 h[4];  // (a __builtin_bit_cast applied directly to an element of an ext-vector reads element 0: keep the pairs as scalars)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x2 x = {v[2 * q], v[2 * q + 1]};
+        h[q] = __builtin_convertvector(x, h16x2);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x2 r;
+        r[0] = __builtin_fmaf((float)h[q][0], -NCDE_H2_SCALE, v[2 * q] * NCDE_H2_SCALE);  // exact: (x - h1) * 2^11
+        r[1] = __builtin_fmaf((float)h[q][1], -NCDE_H2_SCALE, v[2 * q + 1] * NCDE_H2_SCALE);
+        mx = __builtin_elementwise_fma(r, (f32x2){0.0f, 0.0f}, mx);
+        const h16x2 l = __builtin_convertvector(r, h16x2);
+        const unsigned hq = __builtin_bit_cast(unsigned, h[q]);
+        const unsigned lq = __builtin_bit_cast(unsigned, l);
+        o.hi[q] = hq;
+        o.lo[q] = lq;
+    }
+    return o;
+}
+__device__ __forceinline__ bool h2_range_fault(f32x2 mx) {
+    const float t = mx[0] + mx[1];
+    return t != t;
+}
+
+__device__ __forceinline__ f32x4 mfma_h(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+}
+
+// main += A.hi B.hi;  cross += A.hi B.lo + A.lo B.hi  (cross carries the factor 2^11: result = main + 2^-11 cross).
+// The cross products first: they need only... the hi piece of the weights and BOTH pieces of the fresh B operand are formed before
+// the first MFMA anyway (24 VALU), and alternating accumulators keeps dependent MFMAs apart.
+__device__ __forceinline__ void mfma_split2(const Split2h& A, const Split2h& B, f32x4& main, f32x4& cross) {
+    main = mfma_h(A.hi, B.hi, main);
+    cross = mfma_h(A.lo, B.hi, cross);
+    cross = mfma_h(A.hi, B.lo, cross);
+}
+__device__ __forceinline__ f32x4 h2_combine(f32x4 main, f32x4 cross) {  // two v_pk_fma_f32
+    const f32x2 k = {NCDE_H2_INV, NCDE_H2_INV};
+    const f32x2 lo = __builtin_elementwise_fma((f32x2){cross[0], cross[1]}, k, (f32x2){main[0], main[1]});
+    const f32x2 hi = __builtin_elementwise_fma((f32x2){cross[2], cross[3]}, k, (f32x2){main[2], main[3]});
+    return (f32x4){lo[0], lo[1], hi[0], hi[1]};
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16 mfma_h32(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+}
+
+// Power-of-two factor that brings a cotangent of largest magnitude m into the fp16 sweet spot: keep `cur` while 4 <= m * cur < 64,
+// otherwise 2^(4 - floor(log2 m)).  A pure function of (m, cur): every wave of a workgroup evaluates it on the same inputs.
+__device__ __forceinline__ float h2_pick_scale(float m, float cur) {
+    if (!(m > 0.0f) || !(m < 3.0e38f)) return cur;  // zero / infinite / NaN cotangent: nothing to normalise
+    const float v = m * cur;
+    if (v >= 4.0f && v < 64.0f) return cur;
+    int k = 4 - (int)((__builtin_bit_cast(unsigned, m) >> 23) & 255u) + 127;
+    k = k < -96 ? -96 : (k > 96 ? 96 : k);
+    return __builtin_bit_cast(float, (unsigned)(k + 127) << 23);
+}
+__device__ __forceinline__ float h2_inv_scale(float sig) {  // exact reciprocal of a power of two
+    return __builtin_bit_cast(float, (254u - ((__builtin_bit_cast(unsigned, sig) >> 23) & 255u)) << 23);
+}
 __device__ __forceinline__ f32x16 mfma_bf32(u32x4 a, u32x4 b, f32x16 c) {  // 32x32x16: lane (i=lane&31, kg=lane>>5) holds k = 8kg..8kg+7
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -67,5 +154,54 @@ __device__ __forceinline__ f32x4 mfma_split(const Split3& A, const Split3& B, f3
     c = mfma_bf(A.hi, B.lo, c);
     return c;
 }
+
+// One interface over both splits, so a kernel is written once and instantiated per precision scheme:
+//   SplitOps<0>: 3-way split-bf16 (any magnitude), SplitOps<1>: 2-way split-fp16 (|x| < 65504; weights and forward activations).
+template <int HP>
+struct SplitOps;
+template <>
+struct SplitOps<0> {
+    typedef Split3 T;
+    static constexpr int NP = 3;
+    // LDS image of one operand fragment: [NP pieces][64 lanes][4 dwords]
+    static __device__ __forceinline__ void store(unsigned* img, int lane, const T& v) {
+        *reinterpret_cast<u32x4*>(img + (0 * 64 + lane) * 4) = v.hi;
+        *reinterpret_cast<u32x4*>(img + (1 * 64 + lane) * 4) = v.mid;
+        *reinterpret_cast<u32x4*>(img + (2 * 64 + lane) * 4) = v.lo;
+    }
+    static __device__ __forceinline__ T load(const unsigned* img, int lane) {
+        T v;
+        v.hi = *reinterpret_cast<const u32x4*>(img + (0 * 64 + lane) * 4);
+        v.mid = *reinterpret_cast<const u32x4*>(img + (1 * 64 + lane) * 4);
+        v.lo = *reinterpret_cast<const u32x4*>(img + (2 * 64 + lane) * 4);
+        return v;
+    }
+    struct Acc { f32x4 m; };
+    static __device__ __forceinline__ T split(const float* v, f32x2&) { return split8(v); }
+    static __device__ __forceinline__ Acc init(f32x4 bias) { return Acc{bias}; }
+    static __device__ __forceinline__ void mac(const T& A, const T& B, Acc& c) { c.m = mfma_split(A, B, c.m); }
+    static __device__ __forceinline__ f32x4 finish(const Acc& c) { return c.m; }
+};
+template <>
+struct SplitOps<1> {
+    typedef Split2h T;
+    static constexpr int NP = 2;
+    static __device__ __forceinline__ void store(unsigned* img, int lane, const T& v) {
+        *reinterpret_cast<u32x4*>(img + (0 * 64 + lane) * 4) = v.hi;
+        *reinterpret_cast<u32x4*>(img + (1 * 64 + lane) * 4) = v.lo;
+    }
+    static __device__ __forceinline__ T load(const unsigned* img, int lane) {
+        T v;
+        v.hi = *reinterpret_cast<const u32x4*>(img + (0 * 64 + lane) * 4);
+        v.lo = *reinterpret_cast<const u32x4*>(img + (1 * 64 + lane) * 4);
+        return v;
+    }
+    struct Acc { f32x4 m, x; };
+    static __device__ __forceinline__ T split(const float* v, f32x2& mx) { return split8h(v, mx); }
+    static __device__ __forceinline__ Acc init(f32x4 bias) { return Acc{bias, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}}; }
+    static __device__ __forceinline__ void mac(const T& A, const T& B, Acc& c) { mfma_split2(A, B, c.m, c.x); }
+    static __device__ __forceinline__ f32x4 finish(const Acc& c) { return h2_combine(c.m, c.x); }
+};
+
 
 }  // namespace

@@ -56,6 +56,9 @@ struct KArgs {
     int n_steps_fwd, n_steps_adj;
     // batch-tiled family: fragment-ordered copies of the output layer and of the gate head (ncde_pack_panels)
     const float* Wo_pk;
+    // split-fp16 kernels (ncde_fast.hip): range-fault word per workgroup; only_faulted = re-execute the faulted ones, skip the rest
+    int* fault;
+    int only_faulted;
     const float* Wg_pk;
     const unsigned* Wo_bf;   // split-bf16 copy (backward sweep: beside the fp32 copy, which feeds the transposed products)
     // variant family: LDS-resident copies of weight matrices (float offset into the dynamic LDS, -1 = streamed from L2);

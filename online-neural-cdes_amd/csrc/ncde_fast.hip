@@ -14,6 +14,15 @@
 // Reference semantics: see ncde_generic.hip (same stage tables, same knot-index rule).
 #include "ncde_fast.h"
 #include "ncde_fast4.h"
+#ifndef NCDE_H2_PK
+#define NCDE_H2_PK 1
+#endif
+#ifndef NCDE_H2_DW_LATE
+#define NCDE_H2_DW_LATE 1
+#endif
+#ifndef NCDE_H2_DWO_EARLY
+#define NCDE_H2_DWO_EARLY 0
+#endif
 
 #include <cstring>
 #include <type_traits>
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_fwd_fast(KArgs a) {
 // (the split-bf16 arithmetic itself lives in ncde_bf3.h, shared with the batch-tiled family)
 // NLT = number of layers known at compile time (0 = runtime): with the layer loop unrolled the whole stage is ONE basic
 // block, so the scheduler can issue the hi-piece MFMAs of layer l+1 under the mid / lo split of layer l.
-template <int H, int HH, int C, int NW, int INTERP, int METHOD, int PROF = 0, int NLT = 0>
+template <int H, int HH, int C, int NW, int INTERP, int METHOD, int PROF = 0, int NLT = 0, int HP = 0>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs a) {
     unsigned long long prof[4] = {0, 0, 0, 0}, tlast = 0;
 #define NCDE_TICK(k)                                                \
@@ -294,6 +303,13 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
     static_assert(H % (4 * NW) == 0 && HH % 32 == 0 && H % 32 == 0, "shape not tileable");
     __shared__ __attribute__((aligned(16))) float zx[2][H * 16];
     __shared__ __attribute__((aligned(16))) float dxs[3][16 * DXW];
+    __shared__ int fault_s;
+    // split-fp16 instances speculate on the fp16 range and report a fault per sample tile; the split-bf16 instance, launched behind
+    // them with only_faulted set, re-executes exactly those tiles (ncde_bf3.h)
+    if constexpr (HP == 0) {
+        if (a.only_faulted && a.fault[blockIdx.x] == 0) return;
+    }
+    f32x2 mx = {0.0f, 0.0f};      // sticky range-fault flag of the split-fp16 operands (ncde_bf3.h)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -303,7 +319,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
     const bool valid = bs < a.B;
 
     // ---- weights -> split bf16 A operands in registers ------------------------------------------------
-    Split3 w0[HT][KC0], w1[HT][KC], wo[NB][CQ][KC];
+    typedef SplitOps<HP> SO;
+    typedef typename SO::T SpT;
+    SpT w0[HT][KC0], w1[HT][KC], wo[NB][CQ][KC];
     f32x4 bias0[HT], bias1[HT], biaso[NB][CQ];
     const bool has_inner = a.n_layers > 1;
 #pragma unroll
@@ -315,13 +333,13 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
         for (int c = 0; c < KC0; ++c) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) tmp[j] = a.W[0][unitA * H + 32 * c + 8 * g + j];
-            w0[t][c] = split8(tmp);
+            w0[t][c] = SO::split(tmp, mx);
         }
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) tmp[j] = has_inner ? a.W[1][unitA * HH + 32 * c + 8 * g + j] : 0.0f;
-            w1[t][c] = split8(tmp);
+            w1[t][c] = SO::split(tmp, mx);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -341,7 +359,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
             for (int c = 0; c < KC; ++c) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) tmp[j] = cA < C ? NCDE_TANH_PRESCALE * a.Wo[(hA * C + cA) * HH + 32 * c + 8 * g + j] : 0.0f;
-                wo[nb][cq][c] = split8(tmp);
+                wo[nb][cq][c] = SO::split(tmp, mx);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -424,39 +442,39 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
                 }
             }
             // ---- hidden layers ---------------------------------------------------------------------------
-            f32x4 acc[HT];
+            typename SO::Acc acc[HT];
             float hv[KC][8];
-            Split3 xb[KC];
+            SpT xb[KC];
+            auto activate = [&]() {
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt) {
+                    const f32x4 pre = SO::finish(acc[tt]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hv[tt >> 1][4 * (tt & 1) + r] = relu_bits(pre[r]);
+                }
+#pragma unroll
+                for (int c = 0; c < KC; ++c) xb[c] = SO::split(hv[c], mx);
+            };
             {
-                Split3 zb[KC0];
+                SpT zb[KC0];
 #pragma unroll
-                for (int c = 0; c < KC0; ++c) zb[c] = split8(zreg[c]);
+                for (int c = 0; c < KC0; ++c) zb[c] = SO::split(zreg[c], mx);
 #pragma unroll
-                for (int tt = 0; tt < HT; ++tt) acc[tt] = bias0[tt];
+                for (int tt = 0; tt < HT; ++tt) acc[tt] = SO::init(bias0[tt]);
 #pragma unroll
                 for (int c = 0; c < KC0; ++c)
 #pragma unroll
-                    for (int tt = 0; tt < HT; ++tt) acc[tt] = mfma_split(w0[tt][c], zb[c], acc[tt]);
+                    for (int tt = 0; tt < HT; ++tt) SO::mac(w0[tt][c], zb[c], acc[tt]);
             }
-#pragma unroll
-            for (int tt = 0; tt < HT; ++tt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) hv[tt >> 1][4 * (tt & 1) + r] = relu_bits(acc[tt][r]);
-#pragma unroll
-            for (int c = 0; c < KC; ++c) xb[c] = split8(hv[c]);
+            activate();
             auto inner_layer = [&]() {
 #pragma unroll
-                for (int tt = 0; tt < HT; ++tt) acc[tt] = bias1[tt];
+                for (int tt = 0; tt < HT; ++tt) acc[tt] = SO::init(bias1[tt]);
 #pragma unroll
                 for (int c = 0; c < KC; ++c)
 #pragma unroll
-                    for (int tt = 0; tt < HT; ++tt) acc[tt] = mfma_split(w1[tt][c], xb[c], acc[tt]);
-#pragma unroll
-                for (int tt = 0; tt < HT; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) hv[tt >> 1][4 * (tt & 1) + r] = relu_bits(acc[tt][r]);
-#pragma unroll
-                for (int c = 0; c < KC; ++c) xb[c] = split8(hv[c]);
+                    for (int tt = 0; tt < HT; ++tt) SO::mac(w1[tt][c], xb[c], acc[tt]);
+                activate();
             };
             if constexpr (NLT > 0) {
 #pragma unroll
@@ -467,17 +485,24 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
             NCDE_TICK(0)
             // ---- output layer tiles owned by this wave: tanh + channel contraction -----------------------
             float kout[NB];
+            f32x2 kout2[NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) kout[nb] = 0.0f;
+            for (int nb = 0; nb < NB; ++nb) {
+                kout[nb] = 0.0f;
+                kout2[nb] = (f32x2){0.0f, 0.0f};
+            }
 #pragma unroll
             for (int cq = 0; cq < CQ; ++cq) {
+                typename SO::Acc oa[NB];
                 f32x4 o[NB];
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) o[nb] = biaso[nb][cq];
+                for (int nb = 0; nb < NB; ++nb) oa[nb] = SO::init(biaso[nb][cq]);
 #pragma unroll
                 for (int c = 0; c < KC; ++c)
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) o[nb] = mfma_split(wo[nb][cq][c], xb[c], o[nb]);
+                    for (int nb = 0; nb < NB; ++nb) SO::mac(wo[nb][cq][c], xb[c], oa[nb]);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) o[nb] = SO::finish(oa[nb]);
                 f32x4 dx;
                 if constexpr (INTERP == NCDE_INTERP_LINEAR) {
                     dx = *reinterpret_cast<const f32x4*>(dxp + 4 * cq);
@@ -491,10 +516,27 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
                         dx[r] = cb[r] + inner * frac;
                     }
                 }
+                if constexpr (HP != 0 && NCDE_H2_PK != 0) {   // the same arithmetic on pairs (v_pk_add / v_pk_fma): even and odd channels accumulate apart
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
+                    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) kout[nb] = fmaf(tanh_prescaled(o[nb][r]), dx[r], kout[nb]);
+                        for (int q = 0; q < 2; ++q) {
+                            const f32x2 e = {__builtin_amdgcn_exp2f(o[nb][2 * q]), __builtin_amdgcn_exp2f(o[nb][2 * q + 1])};
+                            const f32x2 d = e + 1.0f;
+                            const f32x2 rr = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+                            const f32x2 th = __builtin_elementwise_fma((f32x2){-2.0f, -2.0f}, rr, (f32x2){1.0f, 1.0f});
+                            kout2[nb] = __builtin_elementwise_fma(th, (f32x2){dx[2 * q], dx[2 * q + 1]}, kout2[nb]);
+                        }
+                } else {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) kout[nb] = fmaf(tanh_prescaled(o[nb][r]), dx[r], kout[nb]);
+                }
+            }
+            if constexpr (HP != 0 && NCDE_H2_PK != 0) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) kout[nb] = kout2[nb][0] + kout2[nb][1];
             }
             NCDE_TICK(1)
             float ys[NB];
@@ -526,6 +568,15 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
         if (lane == 0) {
             unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.gpart) + ((long long)blockIdx.x * NW + wave) * 4;
             dst[0] = prof[0]; dst[1] = prof[1]; dst[2] = prof[2]; dst[3] = prof[3];
+        }
+    }
+    if constexpr (HP != 0) {
+        if (a.fault != nullptr) {
+            if (tid == 0) fault_s = 0;
+            __syncthreads();
+            if (__builtin_amdgcn_ballot_w64(h2_range_fault(mx)) != 0 && lane == 0) fault_s = 1;
+            __syncthreads();
+            if (tid == 0) a.fault[blockIdx.x] = fault_s;
         }
     }
 #undef NCDE_TICK
@@ -1631,7 +1682,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
 //     partial per tile group right behind the chain wave and this stage's dWo blocks in its shadow; only the
 //     hidden-layer dW/db lag one stage (x images double-buffered by stage parity);
 //   * the lo pieces of the output-layer weights and the split W1^T / W0^T A-operands live in LDS images.
-template <int NL, int C, int INTERP, int METHOD, int PROF = 0, int DISC = 0>
+template <int NL, int C, int INTERP, int METHOD, int PROF = 0, int DISC = 0, int HP = 0>
 __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
     unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
 #define NCDE_TICK(k)                                                \
@@ -1649,6 +1700,15 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
     constexpr int NTILE = NB * CQ, NBLK = NTILE / 2;   // tile tau = cq*NB + nb (publication order); block = one cq
     constexpr int XROWS = H + NL * HH;
     constexpr int NFLAG = NTILE + 2;
+    // HP = 1: 2-way split-fp16 GEMMs (ncde_bf3.h) -- the forward-side operands as they are, the cotangent-side ones in units of a
+    // per-workgroup power of two `sig` that follows max |a| over the tile from step to step; the workgroup reports a range fault
+    // (a.fault) when any operand left the fp16 range, and the HP = 0 instance re-executes exactly those workgroups (only_faulted).
+    typedef SplitOps<HP> SO;
+    typedef typename SO::T SpT;
+    constexpr int NP = SO::NP;
+    if constexpr (HP == 0) {
+        if (a.only_faulted && a.fault[blockIdx.x] == 0) return;
+    }
     static_assert(NB == 2 && NTILE % 2 == 0, "one 32-row dWo block per cq");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* zx = lds;                                   // [2][H*16]
@@ -1657,13 +1717,20 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
     float* boL = red + NW * HH * 16;                   // [NW][NB*CQ][4 g][4 r]   (nb-major)
     float* tiles = boL + NW * NTILE * 16;              // [NW][NTILE][16][16]     raw dP of the current stage
     float* ximg = tiles + NW * NTILE * 256;            // [2][XROWS][16]          by stage parity (chain wave 0)
-    float* dpimg = ximg + 2 * XROWS * 16;              // [NL][HH][16]            (chain wave 0)
-    int* flags = reinterpret_cast<int*>(dpimg + NL * HH * 16);        // [NW][NFLAG]
+    float* dpimg = ximg + 2 * XROWS * 16;              // [NDP][NL][HH][16]       (chain wave 0); NDP = 2 (by stage parity) when the
+                                                       // gradient waves consume it behind barrier A of the NEXT stage (HP = 1)
+    constexpr int NDP = (HP != 0 && NCDE_H2_DW_LATE != 0) ? 2 : 1;
+    int* flags = reinterpret_cast<int*>(dpimg + NDP * NL * HH * 16);  // [NW][NFLAG]
     float* biasL = reinterpret_cast<float*>(flags + NW * NFLAG);      // [2][HT][4 g][4 r]: b[8g + 4t + r]
-    unsigned* w1T3 = reinterpret_cast<unsigned*>(biasL + 2 * HT * 16);  // [HT][3][64][4]  split W1^T A operands
-    unsigned* w0T3 = w1T3 + HT * 3 * 256;                             // [NW][3][64][4]   split W0^T (own state rows)
-    unsigned* woLo = w0T3 + NW * 3 * 256;                             // [NW][NB][CQ][64][4] lo pieces of the Wo A operands
-    unsigned* w1S3 = woLo + NW * NB * CQ * 256;                       // [2 layers][HT][3][64][4]  split W0 / W1 (forward) A operands
+    unsigned* w1T3 = reinterpret_cast<unsigned*>(biasL + 2 * HT * 16);  // [HT][NP][64][4]  split W1^T A operands
+    unsigned* w0T3 = w1T3 + HT * NP * 256;                            // [NW][NP][64][4]   split W0^T (own state rows)
+    unsigned* woLo = w0T3 + NW * NP * 256;                            // [NW][NB][CQ][64][4] lo pieces: of the chain waves' Wo A operands
+                                                                      // (HP = 0) / of the gradient waves' Wo^T A operands (HP = 1)
+    unsigned* w1S3 = woLo + NW * NB * CQ * 256;                       // [2 layers][HT][NP][64][4]  split W0 / W1 (forward) A operands
+    float* amax = reinterpret_cast<float*>(w1S3 + 2 * HT * NP * 256); // [NW] max |a| of each chain wave's state rows; [NW] = fault word
+    int* fault_s = reinterpret_cast<int*>(amax + NW);
+    f32x2 mx = {0.0f, 0.0f};      // sticky range-fault flag of the split-fp16 operands (ncde_bf3.h)
+    float sig = 1.0f;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1680,6 +1747,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
     const float* boLw = boL + pw * NTILE * 16;
 
     for (int e = tid; e < NW * NFLAG; e += 512) flags[e] = 0;
+    if (tid == 0) *fault_s = 0;
     for (int e = tid; e < NW * NTILE * 16; e += 512) {
         const int r = e & 3, gg = (e >> 2) & 3, rest = e >> 4;
         const int t2 = rest % NTILE, wv = rest / NTILE;
@@ -1697,10 +1765,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         float tmp[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) tmp[jj] = a.W[1][(8 * (l >> 4) + jj) * HH + unit_out];
-        const Split3 sp = split8(tmp);
-        *reinterpret_cast<u32x4*>(w1T3 + ((t * 3 + 0) * 64 + l) * 4) = sp.hi;
-        *reinterpret_cast<u32x4*>(w1T3 + ((t * 3 + 1) * 64 + l) * 4) = sp.mid;
-        *reinterpret_cast<u32x4*>(w1T3 + ((t * 3 + 2) * 64 + l) * 4) = sp.lo;
+        SO::store(w1T3 + t * NP * 256, l, SO::split(tmp, mx));
     } else if (tid >= 64 * HT + 64 * NW && tid < 64 * HT + 64 * NW + 64 * HT) {  // split W0 and W1 (forward), shared by all chain waves
         const int l = tid & 63, t = (tid >> 6) - HT - NW;
         const int unitA = 8 * ((l & 15) >> 2) + 4 * t + (l & 3);
@@ -1709,10 +1774,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
             float tmp[8];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) tmp[jj] = a.W[layer][unitA * HH + 8 * (l >> 4) + jj];   // H == HH
-            const Split3 sp = split8(tmp);
-            *reinterpret_cast<u32x4*>(w1S3 + (((layer * HT + t) * 3 + 0) * 64 + l) * 4) = sp.hi;
-            *reinterpret_cast<u32x4*>(w1S3 + (((layer * HT + t) * 3 + 1) * 64 + l) * 4) = sp.mid;
-            *reinterpret_cast<u32x4*>(w1S3 + (((layer * HT + t) * 3 + 2) * 64 + l) * 4) = sp.lo;
+            SO::store(w1S3 + (layer * HT + t) * NP * 256, l, SO::split(tmp, mx));
         }
     } else if (tid < 64 * HT + 64 * NW) {  // split W0^T rows of the state entries pair wv owns
         const int l = tid & 63, wv = (tid >> 6) - HT;
@@ -1721,23 +1783,25 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         float tmp[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) tmp[jj] = r_own < NB ? a.W[0][(8 * (l >> 4) + jj) * H + hrow] : 0.0f;
-        const Split3 sp = split8(tmp);
-        *reinterpret_cast<u32x4*>(w0T3 + ((wv * 3 + 0) * 64 + l) * 4) = sp.hi;
-        *reinterpret_cast<u32x4*>(w0T3 + ((wv * 3 + 1) * 64 + l) * 4) = sp.mid;
-        *reinterpret_cast<u32x4*>(w0T3 + ((wv * 3 + 2) * 64 + l) * 4) = sp.lo;
+        SO::store(w0T3 + wv * NP * 256, l, SO::split(tmp, mx));
     }
 
     if (is_chain) {
         // =================================================================================================
         // chain wave
         // =================================================================================================
-        u32x4 woHi[NB][CQ], woMid[NB][CQ];
+        u32x4 woHi[NB][CQ], woMid[NB][CQ];      // HP = 1: (hi, lo), both in registers
         unsigned* my_woLo = woLo + pw * NB * CQ * 256;
-        auto fwd_weights = [&](int layer, int tt) {
-            Split3 As;
-            As.hi = *reinterpret_cast<const u32x4*>(w1S3 + (((layer * HT + tt) * 3 + 0) * 64 + lane) * 4);
-            As.mid = *reinterpret_cast<const u32x4*>(w1S3 + (((layer * HT + tt) * 3 + 1) * 64 + lane) * 4);
-            As.lo = *reinterpret_cast<const u32x4*>(w1S3 + (((layer * HT + tt) * 3 + 2) * 64 + lane) * 4);
+        auto fwd_weights = [&](int layer, int tt) { return SO::load(w1S3 + (layer * HT + tt) * NP * 256, lane); };
+        auto wo_operand = [&](int nb, int cq) {
+            SpT As;
+            As.hi = woHi[nb][cq];
+            if constexpr (HP != 0) {
+                As.lo = woMid[nb][cq];
+            } else {
+                As.mid = woMid[nb][cq];
+                As.lo = *reinterpret_cast<const u32x4*>(my_woLo + ((nb * CQ + cq) * 64 + lane) * 4);
+            }
             return As;
         };
 #pragma unroll
@@ -1748,10 +1812,14 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                 float tmp[8];
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) tmp[jj] = cA < C ? NCDE_TANH_PRESCALE * a.Wo[(hA * C + cA) * HH + 8 * g + jj] : 0.0f;
-                const Split3 sp = split8(tmp);
+                const SpT sp = SO::split(tmp, mx);
                 woHi[nb][cq] = sp.hi;
-                woMid[nb][cq] = sp.mid;
-                *reinterpret_cast<u32x4*>(my_woLo + ((nb * CQ + cq) * 64 + lane) * 4) = sp.lo;
+                if constexpr (HP != 0) {
+                    woMid[nb][cq] = sp.lo;
+                } else {
+                    woMid[nb][cq] = sp.mid;
+                    *reinterpret_cast<u32x4*>(my_woLo + ((nb * CQ + cq) * 64 + lane) * 4) = sp.lo;
+                }
             }
         // control-path staging (reverse order), by the 256 chain threads
         const float* eptr[EPT];
@@ -1819,7 +1887,20 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
             ky1[nb] = ky2[nb] = ka1[nb] = ka2[nb] = 0.0f;
         }
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        // max |a| over this wave's state rows -> amax[pw] (read by every wave behind the next barrier)
+        auto publish_amax = [&](const float* av) {
+            if constexpr (HP != 0) {
+                float m = __builtin_fmaxf(__builtin_fabsf(av[0]), __builtin_fabsf(av[1]));
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off, 64));
+                if (lane == 0) amax[pw] = m;
+            }
+        };
+        static_assert(NB == 2, "publish_amax reads two entries");
+        publish_amax(a0);
         __syncthreads();
+        if constexpr (HP != 0) sig = h2_pick_scale(__builtin_fmaxf(__builtin_fmaxf(amax[0], amax[1]), __builtin_fmaxf(amax[2], amax[3])), 1.0f);
+        float isig = h2_inv_scale(sig);
 
         int zpar = 0, sc = 0;
         if constexpr (PROF != 0) tlast = __builtin_readcyclecounter();
@@ -1840,27 +1921,37 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                 const float* dxp = dxs + (idx % 3) * 16 * DXW + s * DXW;
                 // ---- forward recompute (split-bf16); x[l][4t+r] <-> unit 8g + 4t + r -----------------------------------
                 float x[NL][8];
-                Split3 xb;
+                SpT xb;
                 {
-                    f32x4 acc[HT];
-                    xb = split8(zreg);
+                    typename SO::Acc acc[HT];
+                    xb = SO::split(zreg, mx);
 #pragma unroll
-                    for (int tt = 0; tt < HT; ++tt) acc[tt] = mfma_split(fwd_weights(0, tt), xb, *reinterpret_cast<const f32x4*>(biasL + (tt * 4 + g) * 4));
+                    for (int tt = 0; tt < HT; ++tt) {
+                        acc[tt] = SO::init(*reinterpret_cast<const f32x4*>(biasL + (tt * 4 + g) * 4));
+                        SO::mac(fwd_weights(0, tt), xb, acc[tt]);
+                    }
 #pragma unroll
-                    for (int tt = 0; tt < HT; ++tt)
+                    for (int tt = 0; tt < HT; ++tt) {
+                        const f32x4 pre = SO::finish(acc[tt]);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) x[0][4 * tt + r] = relu_bits(acc[tt][r]);
+                        for (int r = 0; r < 4; ++r) x[0][4 * tt + r] = relu_bits(pre[r]);
+                    }
 #pragma unroll
                     for (int l = 1; l < NL; ++l) {
-                        xb = split8(x[l - 1]);
+                        xb = SO::split(x[l - 1], mx);
 #pragma unroll
-                        for (int tt = 0; tt < HT; ++tt) acc[tt] = mfma_split(fwd_weights(1, tt), xb, *reinterpret_cast<const f32x4*>(biasL + ((HT + tt) * 4 + g) * 4));
+                        for (int tt = 0; tt < HT; ++tt) {
+                            acc[tt] = SO::init(*reinterpret_cast<const f32x4*>(biasL + ((HT + tt) * 4 + g) * 4));
+                            SO::mac(fwd_weights(1, tt), xb, acc[tt]);
+                        }
 #pragma unroll
-                        for (int tt = 0; tt < HT; ++tt)
+                        for (int tt = 0; tt < HT; ++tt) {
+                            const f32x4 pre = SO::finish(acc[tt]);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) x[l][4 * tt + r] = relu_bits(acc[tt][r]);
+                            for (int r = 0; r < 4; ++r) x[l][4 * tt + r] = relu_bits(pre[r]);
+                        }
                     }
-                    xb = split8(x[NL - 1]);
+                    xb = SO::split(x[NL - 1], mx);
                 }
                 NCDE_TICK(0)
                 if (wq != 0.0f) {  // [unit][sample] images for the gradient waves: the chain waves hold identical copies, wave pw
@@ -1883,19 +1974,21 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                 }
                 // ---- output tiles: P, r = 1/(exp(2P)+1), f, dP -> LDS tile + flag -----------------------------------
                 float kout[NB];
+                f32x2 kout2[NB];
                 float sdx = 0.0f;
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) kout[nb] = 0.0f;
+                for (int nb = 0; nb < NB; ++nb) {
+                    kout[nb] = 0.0f;
+                    kout2[nb] = (f32x2){0.0f, 0.0f};
+                }
 #pragma unroll
                 for (int cq = 0; cq < CQ; ++cq) {
                     f32x4 o[NB];
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
-                        Split3 As;
-                        As.hi = woHi[nb][cq];
-                        As.mid = woMid[nb][cq];
-                        As.lo = *reinterpret_cast<const u32x4*>(my_woLo + ((nb * CQ + cq) * 64 + lane) * 4);
-                        o[nb] = mfma_split(As, xb, *reinterpret_cast<const f32x4*>(boLw + ((nb * CQ + cq) * 4 + g) * 4));
+                        typename SO::Acc oa = SO::init(*reinterpret_cast<const f32x4*>(boLw + ((nb * CQ + cq) * 4 + g) * 4));
+                        SO::mac(wo_operand(nb, cq), xb, oa);
+                        o[nb] = SO::finish(oa);
                     }
                     f32x4 dx;
                     if constexpr (INTERP == NCDE_INTERP_LINEAR) {
@@ -1916,18 +2009,36 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                     for (int nb = 0; nb < NB; ++nb) {
                         const int tau = cq * NB + nb;
                         float* tl = my_tiles + tau * 256;
-                        const float a4 = 4.0f * as_[nb];
+                        const float a4 = (4.0f * sig) * as_[nb];     // dP, and everything downstream of it, in units of sig
+                        if constexpr (HP != 0 && NCDE_H2_PK != 0) {   // on pairs (v_pk_add / v_pk_fma / v_pk_mul): even and odd channels accumulate apart
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float rr = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[nb][r]) + 1.0f);
-                            if constexpr (DISC == 0) kout[nb] = fmaf(rr, dx[r], kout[nb]);
-                            tl[(4 * g + r) * 16 + s] = (a4 * dx[r]) * fmaf(-rr, rr, rr);
+                            for (int q = 0; q < 2; ++q) {
+                                const f32x2 e = {__builtin_amdgcn_exp2f(o[nb][2 * q]), __builtin_amdgcn_exp2f(o[nb][2 * q + 1])};
+                                const f32x2 d = e + 1.0f;
+                                const f32x2 rr = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+                                const f32x2 dx2 = {dx[2 * q], dx[2 * q + 1]};
+                                if constexpr (DISC == 0) kout2[nb] = __builtin_elementwise_fma(rr, dx2, kout2[nb]);
+                                const f32x2 t2 = (dx2 * a4) * __builtin_elementwise_fma(-rr, rr, rr);
+                                tl[(4 * g + 2 * q) * 16 + s] = t2[0];
+                                tl[(4 * g + 2 * q + 1) * 16 + s] = t2[1];
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float rr = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[nb][r]) + 1.0f);
+                                if constexpr (DISC == 0) kout[nb] = fmaf(rr, dx[r], kout[nb]);
+                                tl[(4 * g + r) * 16 + s] = (a4 * dx[r]) * fmaf(-rr, rr, rr);
+                            }
                         }
                         if (nb == NB - 1) {      // one publication per block (= cq, both tiles): the gradient wave polls odd tiles only
                             wave_lds_order();
                             my_flags[tau] = sc;
                         }
                     }
+                }
+                if constexpr (HP != 0 && NCDE_H2_PK != 0) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) kout[nb] = kout2[nb][0] + kout2[nb][1];
                 }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) kout[nb] = fmaf(-2.0f, kout[nb], sdx);
@@ -1947,35 +2058,36 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                 for (int l = NL - 1; l >= 1; --l) {
                     if (wq != 0.0f && pw == l % NW) {      // one image per chain wave (all hold the same gpre)
 #pragma unroll
-                        for (int jj = 0; jj < 8; ++jj) dpimg[(l * HH + 8 * g + jj) * 16 + s] = gpre[jj];
+                        for (int jj = 0; jj < 8; ++jj) dpimg[(NDP - 1) * par * NL * HH * 16 + (l * HH + 8 * g + jj) * 16 + s] = gpre[jj];
                     }
-                    const Split3 gb = split8(gpre);
-                    f32x4 acc[HT];
+                    const SpT gb = SO::split(gpre, mx);
+                    typename SO::Acc acc[HT];
 #pragma unroll
                     for (int tt = 0; tt < HT; ++tt) {
-                        Split3 As;
-                        As.hi = *reinterpret_cast<const u32x4*>(w1T3 + ((tt * 3 + 0) * 64 + lane) * 4);
-                        As.mid = *reinterpret_cast<const u32x4*>(w1T3 + ((tt * 3 + 1) * 64 + lane) * 4);
-                        As.lo = *reinterpret_cast<const u32x4*>(w1T3 + ((tt * 3 + 2) * 64 + lane) * 4);
-                        acc[tt] = mfma_split(As, gb, zero4);
+                        acc[tt] = SO::init(zero4);
+                        SO::mac(SO::load(w1T3 + tt * NP * 256, lane), gb, acc[tt]);
                     }
 #pragma unroll
-                    for (int tt = 0; tt < HT; ++tt)
+                    for (int tt = 0; tt < HT; ++tt) {
+                        const f32x4 gq = SO::finish(acc[tt]);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) gpre[4 * tt + r] = x[l - 1][4 * tt + r] > 0.0f ? acc[tt][r] : 0.0f;
+                        for (int r = 0; r < 4; ++r) gpre[4 * tt + r] = x[l - 1][4 * tt + r] > 0.0f ? gq[r] : 0.0f;
+                    }
                 }
                 if (wq != 0.0f && pw == 0) {
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) dpimg[(8 * g + jj) * 16 + s] = gpre[jj];
+                    for (int jj = 0; jj < 8; ++jj) dpimg[(NDP - 1) * par * NL * HH * 16 + (8 * g + jj) * 16 + s] = gpre[jj];
                 }
                 f32x4 vy;
                 {
-                    const Split3 gb = split8(gpre);
-                    Split3 As;
-                    As.hi = *reinterpret_cast<const u32x4*>(w0T3 + ((pw * 3 + 0) * 64 + lane) * 4);
-                    As.mid = *reinterpret_cast<const u32x4*>(w0T3 + ((pw * 3 + 1) * 64 + lane) * 4);
-                    As.lo = *reinterpret_cast<const u32x4*>(w0T3 + ((pw * 3 + 2) * 64 + lane) * 4);
-                    vy = mfma_split(As, gb, zero4);
+                    const SpT gb = SO::split(gpre, mx);
+                    typename SO::Acc va = SO::init(zero4);
+                    SO::mac(SO::load(w0T3 + pw * NP * 256, lane), gb, va);
+                    vy = SO::finish(va);
+                    if constexpr (HP != 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vy[r] *= isig;
+                    }
                 }
                 NCDE_TICK(3)
                 float ys[NB];
@@ -2009,8 +2121,15 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) as_[nb] = METHOD == NCDE_RK4_38 ? a0[nb] * 0.125f : a0[nb];
                         if (n - 3 >= 0) stage_store(n - 3);
+                        publish_amax(a0);
                     }
                     __syncthreads();  // barrier B
+                    if constexpr (HP != 0) {
+                        if (j == S - 1) {
+                            sig = h2_pick_scale(__builtin_fmaxf(__builtin_fmaxf(amax[0], amax[1]), __builtin_fmaxf(amax[2], amax[3])), sig);
+                            isig = h2_inv_scale(sig);
+                        }
+                    }
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) zreg[jj] = valid ? znext[jj >> 2][jj & 3] : 0.0f;
                     NCDE_TICK(4)
@@ -2039,6 +2158,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                         }
                     }
                     if (n - 3 >= 0) stage_store(n - 3);
+                    publish_amax(as_);      // as_ = a at the step's lower end (+ dL/dz of that knot)
                 }
                 if (j == S - 1 && a.output == NCDE_OUT_KNOTS) {
 #pragma unroll
@@ -2052,6 +2172,12 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) zreg[jj] = zw[(8 * g + jj) * 16 + s];
                     zpar ^= 1;
+                }
+                if constexpr (HP != 0) {
+                    if (j == S - 1) {
+                        sig = h2_pick_scale(__builtin_fmaxf(__builtin_fmaxf(amax[0], amax[1]), __builtin_fmaxf(amax[2], amax[3])), sig);
+                        isig = h2_inv_scale(sig);
+                    }
                 }
                 NCDE_TICK(4)
             }
@@ -2070,7 +2196,13 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         // =================================================================================================
         // gradient wave
         // =================================================================================================
-        float woT[NTILE][HT][4];  // fp32 A operands of the dL/dx_L GEMM: output row i <-> unit 8(i>>2)+4t'+(i&3)
+        // A operands of the dL/dx_L GEMM, output row i <-> unit 8(i>>2)+4t'+(i&3).  HP = 0: fp32 (v_mfma_f32_16x16x4_f32), one
+        // value per (tile, t', r).  HP = 1: split-fp16, K = the 32 rows of a block (= one cq): k = 8 kg + jj <-> tile nb = k >> 4,
+        // row 4 g' + r = k & 15 of that tile; hi pieces in 40 registers, lo pieces in this pair's LDS image.
+        float woT[HP ? 1 : NTILE][HT][4];
+        u32x4 woT2h[HP ? NBLK : 1][HT];
+        unsigned* my_woTlo = woLo + pw * NBLK * HT * 256;
+        static_assert(NBLK * HT == NB * CQ, "the lo-piece image reuses the chain waves' region");
 #pragma unroll
         for (int tau = 0; tau < NTILE; ++tau) {
             const int cq = tau / NB, nb = tau - cq * NB;
@@ -2078,10 +2210,23 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
 #pragma unroll
             for (int tp = 0; tp < HT; ++tp) {
                 const int jrow = 8 * (s >> 2) + 4 * tp + (s & 3);
+                if constexpr (HP == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = 4 * cq + r;
-                    woT[tau][tp][r] = c < C ? a.Wo[(h * C + c) * HH + jrow] : 0.0f;
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 4 * cq + r;
+                        woT[tau][tp][r] = c < C ? a.Wo[(h * C + c) * HH + jrow] : 0.0f;
+                    }
+                } else if (nb == 0) {
+                    float tmp[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int kk = 8 * g + jj;
+                        const int hh = 4 * (pw * NB + (kk >> 4)) + ((kk & 15) >> 2), c = 4 * cq + (kk & 3);
+                        tmp[jj] = c < C ? a.Wo[(hh * C + c) * HH + jrow] : 0.0f;
+                    }
+                    const Split2h sp = split8h(tmp, mx);
+                    woT2h[cq][tp] = sp.hi;
+                    *reinterpret_cast<u32x4*>(my_woTlo + ((cq * HT + tp) * 64 + lane) * 4) = sp.lo;
                 }
             }
         }
@@ -2098,6 +2243,8 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
             for (int q = 0; q < 16; ++q) gWo[i][q] = 0.0f;
         }
         __syncthreads();
+        if constexpr (HP != 0) sig = h2_pick_scale(__builtin_fmaxf(__builtin_fmaxf(amax[0], amax[1]), __builtin_fmaxf(amax[2], amax[3])), 1.0f);
+        float acc_sig = sig;        // the units the gradient accumulators are in
 
         const int tr = pw >> 1, tc = pw & 1;
         auto wait_flag = [&](int slot, int want) {
@@ -2105,7 +2252,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
             wave_lds_order();
         };
         // dWo of 2-tile block `blk` (= one cq): 32 rows x 32 units x 16 samples = 6 split-bf16 32x32x16 MFMAs
-        auto dwo_block = [&](const Split3& Bs, float w, int blk) {
+        auto dwo_block = [&](const SpT& Bs, float w, int blk) {
             const int i32 = lane & 31, kg = lane >> 5;
             const float* tl = my_tiles + (2 * blk + (i32 >> 4)) * 256 + (i32 & 15) * 16 + 8 * kg;
             const f32x4 a0v = *reinterpret_cast<const f32x4*>(tl);
@@ -2114,14 +2261,31 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) { av[q] = a0v[q]; av[4 + q] = a1v[q]; }
             gbo[blk] += w * (((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7])));
-            const Split3 As = split8(av);
+            const SpT As = SO::split(av, mx);
             f32x16 c = gWo[blk];
-            c = mfma_bf32(As.lo, Bs.hi, c);
-            c = mfma_bf32(As.hi, Bs.lo, c);
-            c = mfma_bf32(As.mid, Bs.mid, c);
-            c = mfma_bf32(As.mid, Bs.hi, c);
-            c = mfma_bf32(As.hi, Bs.mid, c);
-            c = mfma_bf32(As.hi, Bs.hi, c);
+            if constexpr (HP == 0) {
+                c = mfma_bf32(As.lo, Bs.hi, c);
+                c = mfma_bf32(As.hi, Bs.lo, c);
+                c = mfma_bf32(As.mid, Bs.mid, c);
+                c = mfma_bf32(As.mid, Bs.hi, c);
+                c = mfma_bf32(As.hi, Bs.mid, c);
+                c = mfma_bf32(As.hi, Bs.hi, c);
+            } else {
+                // the cross products are folded into the accumulator block by block: a second set of 5 x 16 accumulator
+                // registers does not fit beside gWo and the W_o^T operands
+                f32x16 cx;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) cx[q] = 0.0f;
+                cx = mfma_h32(As.lo, Bs.hi, cx);
+                cx = mfma_h32(As.hi, Bs.lo, cx);
+                c = mfma_h32(As.hi, Bs.hi, c);
+#pragma unroll
+                for (int q = 0; q < 16; q += 2) {
+                    const f32x2 f = __builtin_elementwise_fma((f32x2){cx[q], cx[q + 1]}, (f32x2){NCDE_H2_INV, NCDE_H2_INV}, (f32x2){c[q], c[q + 1]});
+                    c[q] = f[0];
+                    c[q + 1] = f[1];
+                }
+            }
             gWo[blk] = c;
         };
         auto x3_split = [&](int par, float w) {
@@ -2132,11 +2296,13 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
             float bv[8];
 #pragma unroll
             for (int q = 0; q < 4; ++q) { bv[q] = w * b0v[q]; bv[4 + q] = w * b1v[q]; }
-            return split8(bv);
+            return SO::split(bv, mx);
         };
         // hidden-layer dW/db of the stage whose x images have parity `par` (fp32 MFMA, samples are K)
+        const float* dpimg_all = dpimg;
         auto dw_hidden = [&](int par, float w) {
             const float* xi = ximg + par * XROWS * 16;
+            const float* dpimg = dpimg_all + (NDP - 1) * par * NL * HH * 16;
 #pragma unroll
             for (int l = NL - 1; l >= 1; --l) {
                 const f32x4 av = *reinterpret_cast<const f32x4*>(dpimg + (l * HH + 16 * tr + s) * 16 + 4 * g);
@@ -2151,20 +2317,56 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) gW0 = mfma16(av[q], w * bv[q], gW0);
         };
-        f32x4 accJ[HT];
+        f32x4 accJ[HT], accJx[HT];
         auto dxl_tiles = [&](auto t_lo_c, auto t_hi_c) {
             constexpr int t_lo = decltype(t_lo_c)::value, t_hi = decltype(t_hi_c)::value;
-            float bq[t_hi - t_lo][4];
+            if constexpr (HP != 0) {        // one block: B = dP of the 32 rows of this block for sample s, k = 8g + jj
+                static_assert(t_hi - t_lo == 2, "a block is two tiles");
+                float bv[8];
+                const float* tl = my_tiles + (t_lo + (g >> 1)) * 256 + (8 * (g & 1)) * 16 + s;
 #pragma unroll
-            for (int tau = t_lo; tau < t_hi; ++tau)
+                for (int jj = 0; jj < 8; ++jj) bv[jj] = tl[jj * 16];
+                const Split2h Bq = split8h(bv, mx);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bq[tau - t_lo][r] = my_tiles[tau * 256 + (4 * g + r) * 16 + s];
+                for (int tt = 0; tt < HT; ++tt) {
+                    Split2h Aw;
+                    Aw.hi = woT2h[t_lo / 2][tt];
+                    Aw.lo = *reinterpret_cast<const u32x4*>(my_woTlo + (((t_lo / 2) * HT + tt) * 64 + lane) * 4);
+                    mfma_split2(Aw, Bq, accJ[tt], accJx[tt]);
+                }
+            } else {
+                float bq[t_hi - t_lo][4];
 #pragma unroll
-            for (int tau = t_lo; tau < t_hi; ++tau)
+                for (int tau = t_lo; tau < t_hi; ++tau)
 #pragma unroll
-                for (int tt = 0; tt < HT; ++tt)
+                    for (int r = 0; r < 4; ++r) bq[tau - t_lo][r] = my_tiles[tau * 256 + (4 * g + r) * 16 + s];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) accJ[tt] = mfma16(woT[tau][tt][r], bq[tau - t_lo][r], accJ[tt]);
+                for (int tau = t_lo; tau < t_hi; ++tau)
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) accJ[tt] = mfma16(woT[tau][tt][r], bq[tau - t_lo][r], accJ[tt]);
+            }
+        };
+        // the cotangent scale moved at the last step boundary: bring the accumulators along (after the last contribution in the
+        // old units -- dw_hidden of the previous stage -- and before the first in the new ones)
+        auto rescale_acc = [&]() {
+            if constexpr (HP != 0) {
+                if (sig != acc_sig) {
+                    const float ratio = sig * h2_inv_scale(acc_sig);
+#pragma unroll
+                    for (int i = 0; i < NBLK; ++i) {
+                        gbo[i] *= ratio;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) gWo[i][q] *= ratio;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { gW1[r] *= ratio; gW0[r] *= ratio; }
+                    gb1 *= ratio;
+                    gb0 *= ratio;
+                    acc_sig = sig;
+                }
+            }
         };
         int sc = 0;
         float wprev = 0.0f;
@@ -2176,14 +2378,15 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                 const int par = sc & 1;
                 const float wq = DISC != 0 ? 1.0f : stage_weight(METHOD, j);
                 // hidden-layer dW/db of the previous stage, under the chain wave's forward recompute
-                if (wprev != 0.0f) dw_hidden(par ^ 1, wprev);
+                if (NDP == 1 && wprev != 0.0f) dw_hidden(par ^ 1, wprev);
                 NCDE_TICK(0)
 #pragma unroll
-                for (int tt = 0; tt < HT; ++tt) accJ[tt] = zero4;
+                for (int tt = 0; tt < HT; ++tt) accJ[tt] = accJx[tt] = zero4;
+                if constexpr (NDP == 1) rescale_acc();
                 // Per block (= one cq, two tiles, published together): poll, dL/dx_L (16 fp32 MFMAs, on the stage's
                 // critical path).  One dWo block of this stage is slotted in behind block 1 (more would make the wave
                 // fall behind the chain wave); only the LAST block's dL/dx_L trails the chain wave into barrier A.
-                Split3 Bs;
+                SpT Bs;
                 bool have_bs = false;
 #pragma unroll
                 for (int blk = 0; blk < NBLK; ++blk) {
@@ -2196,7 +2399,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                     else if (blk == 3) { if constexpr (NBLK > 3) dxl_tiles(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{}); }
                     else if (blk == 4) { if constexpr (NBLK > 4) dxl_tiles(std::integral_constant<int, 8>{}, std::integral_constant<int, 10>{}); }
                     static_assert(NBLK <= 5, "extend the block dispatch");
-                    if (wq != 0.0f && blk == 1) {
+                    if (wq != 0.0f && blk == 1 && (HP == 0 || NCDE_H2_DWO_EARLY != 0)) {
                         if (!have_bs) {
                             while (__builtin_amdgcn_readfirstlane(*xflag) != sc) __builtin_amdgcn_s_sleep(1);
                             wave_lds_order();
@@ -2208,11 +2411,17 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                 }
                 NCDE_TICK(3)
 #pragma unroll
-                for (int tt = 0; tt < HT; ++tt)
+                for (int tt = 0; tt < HT; ++tt) {
+                    if constexpr (HP != 0) accJ[tt] = h2_combine(accJ[tt], accJx[tt]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) red[pw * HH * 16 + (8 * g + 4 * tt + r) * 16 + s] = accJ[tt][r];
+                }
                 NCDE_TICK(4)
                 __syncthreads();  // barrier A
+                if constexpr (NDP == 2) {   // under the chain waves' hidden-layer backward
+                    if (wprev != 0.0f) dw_hidden(par ^ 1, wprev);
+                    rescale_acc();
+                }
                 if (wq != 0.0f) {
                     if (!have_bs) {
                         while (__builtin_amdgcn_readfirstlane(*xflag) != sc) __builtin_amdgcn_s_sleep(1);
@@ -2221,10 +2430,13 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                     }
 #pragma unroll
                     for (int blk = 0; blk < NBLK; ++blk)
-                        if (blk >= 1) dwo_block(Bs, wq, blk);
+                        if (blk >= 1 || (HP != 0 && NCDE_H2_DWO_EARLY == 0)) dwo_block(Bs, wq, blk);
 
                 }
                 __syncthreads();  // barrier B
+                if constexpr (HP != 0) {
+                    if (j == S - 1) sig = h2_pick_scale(__builtin_fmaxf(__builtin_fmaxf(amax[0], amax[1]), __builtin_fmaxf(amax[2], amax[3])), sig);
+                }
                 NCDE_TICK(5)
                 wprev = wq;
             }
@@ -2238,6 +2450,19 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         }
         // ---- write-out of this workgroup's parameter-gradient partial ------------------------------------------
         float* gp = a.gpart + (long long)blockIdx.x * a.theta_size;
+        if constexpr (HP != 0) {
+            const float un = h2_inv_scale(acc_sig);
+#pragma unroll
+            for (int i = 0; i < NBLK; ++i) {
+                gbo[i] *= un;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) gWo[i][q] *= un;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { gW1[r] *= un; gW0[r] *= un; }
+            gb1 *= un;
+            gb0 *= un;
+        }
 #pragma unroll
         for (int blk = 0; blk < NBLK; ++blk) {
 #pragma unroll
@@ -2269,6 +2494,13 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
             }
         }
     }
+    if constexpr (HP != 0) {
+        if (a.fault != nullptr) {
+            if (__builtin_amdgcn_ballot_w64(h2_range_fault(mx)) != 0 && lane == 0) *fault_s = 1;
+            __syncthreads();
+            if (tid == 0) a.fault[blockIdx.x] = *fault_s;
+        }
+    }
 #undef NCDE_TICK
 }
 
@@ -2295,10 +2527,10 @@ FwdFn pick_fwd(int interp, int method) {
     return nullptr;
 }
 
-template <int H, int HH, int C, int NW>
-FwdFn pick_fwd_bf3(int interp, int method, int n_layers) {
+template <int H, int HH, int C, int NW, int HP>
+FwdFn pick_fwd_split(int interp, int method, int n_layers) {
 #define NCDE_PICK(I, M) \
-    if (interp == I && method == M) return n_layers == 3 ? ncde_fwd_fast_bf3<H, HH, C, NW, I, M, 0, 3> : ncde_fwd_fast_bf3<H, HH, C, NW, I, M>;
+    if (interp == I && method == M) return n_layers == 3 ? ncde_fwd_fast_bf3<H, HH, C, NW, I, M, 0, 3, HP> : ncde_fwd_fast_bf3<H, HH, C, NW, I, M, 0, 0, HP>;
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_RK4_38)
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_MIDPOINT)
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_EULER)
@@ -2307,6 +2539,10 @@ FwdFn pick_fwd_bf3(int interp, int method, int n_layers) {
     NCDE_PICK(NCDE_INTERP_CUBIC, NCDE_EULER)
 #undef NCDE_PICK
     return nullptr;
+}
+template <int H, int HH, int C, int NW>
+FwdFn pick_fwd_bf3(int interp, int method, int n_layers, int hp) {
+    return hp ? pick_fwd_split<H, HH, C, NW, 1>(interp, method, n_layers) : pick_fwd_split<H, HH, C, NW, 0>(interp, method, n_layers);
 }
 
 template <int H, int HH, int C, int NL, int NW>
@@ -2347,9 +2583,9 @@ size_t adj2_lds_bytes(int interp) {
 }
 
 template <int NL, int C>
-FwdFn pick_adj3(int interp, int method) {
+FwdFn pick_adj3(int interp, int method, int hp) {
 #define NCDE_PICK(I, M) \
-    if (interp == I && method == M) return ncde_adj_fast3<NL, C, I, M>;
+    if (interp == I && method == M) return hp ? ncde_adj_fast3<NL, C, I, M, 0, 0, 1> : ncde_adj_fast3<NL, C, I, M>;
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_RK4_38)
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_MIDPOINT)
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_EULER)
@@ -2361,9 +2597,9 @@ FwdFn pick_adj3(int interp, int method) {
 }
 
 template <int NL, int C>
-FwdFn pick_adj3_disc(int interp, int method) {
+FwdFn pick_adj3_disc(int interp, int method, int hp) {
 #define NCDE_PICK(I, M) \
-    if (interp == I && method == M) return ncde_adj_fast3<NL, C, I, M, 0, 1>;
+    if (interp == I && method == M) return hp ? ncde_adj_fast3<NL, C, I, M, 0, 1, 1> : ncde_adj_fast3<NL, C, I, M, 0, 1>;
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_RK4_38)
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_MIDPOINT)
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_EULER)
@@ -2375,12 +2611,13 @@ FwdFn pick_adj3_disc(int interp, int method) {
 }
 
 template <int NL, int C>
-size_t adj3_lds_bytes(int interp) {
+size_t adj3_lds_bytes(int interp, int hp) {
     constexpr int H = 32, HH = 32, NW = 4, HT = 2, CP = (C + 3) & ~3, CQ = CP / 4, NB = 2, NTILE = NB * CQ;
     const int DXW = interp == NCDE_INTERP_LINEAR ? CP : 3 * CP;
+    const int NP = hp ? 2 : 3;
     return sizeof(float) * (size_t)(2 * H * 16 + 3 * 16 * DXW + NW * HH * 16 + NW * NTILE * 16 + NW * NTILE * 256 +
-                                    2 * (H + NL * HH) * 16 + NL * HH * 16 + NW * (NTILE + 2) + 2 * HT * 16 +
-                                    HT * 3 * 256 + NW * 3 * 256 + NW * NB * CQ * 256 + 2 * HT * 3 * 256);
+                                    2 * (H + NL * HH) * 16 + ((hp && NCDE_H2_DW_LATE) ? 2 : 1) * NL * HH * 16 + NW * (NTILE + 2) + 2 * HT * 16 +
+                                    HT * NP * 256 + NW * NP * 256 + NW * NB * CQ * 256 + 2 * HT * NP * 256 + NW + 4);
 }
 
 template <int H, int HH, int C, int NL, int NW>
@@ -2396,7 +2633,7 @@ struct FastEntry {
     int nw;
     FwdFn (*fwd)(int, int);
     const char* fwd_name;
-    FwdFn (*fwd_bf3)(int, int, int);  // split-bf16 variant (default); NCDE_FLAG_FP32_MFMA selects `fwd`
+    FwdFn (*fwd_bf3)(int, int, int, int);  // split-bf16 variant (default); NCDE_FLAG_FP32_MFMA selects `fwd`
     const char* fwd_bf3_name;
     int nw_bf3;
     int adj_layers;                 // n_layers the adjoint instantiation is built for (0 = none)
@@ -2406,10 +2643,10 @@ struct FastEntry {
     FwdFn (*adj2)(int, int);        // wave-specialised variant, fp32 chain (NCDE_FLAG_ADJOINT_V2)
     size_t (*adj2_lds)(int);
     const char* adj2_name;
-    FwdFn (*adj3)(int, int);        // wave-specialised variant, split-bf16 chain (default)
-    size_t (*adj3_lds)(int);
+    FwdFn (*adj3)(int, int, int);   // wave-specialised variant, split GEMMs (default); last argument: 1 = split-fp16, 0 = split-bf16
+    size_t (*adj3_lds)(int, int);
     const char* adj3_name;
-    FwdFn (*adj3_disc)(int, int);   // same kernel transposing the discretised solve (ncde_backward)
+    FwdFn (*adj3_disc)(int, int, int);   // same kernel transposing the discretised solve (ncde_backward)
     const char* adj3_disc_name;
 };
 
@@ -2468,13 +2705,16 @@ const char* ncde_fast_kernel_name(const NcdeProblem* p, int pass) {
     return e->adj3 ? e->adj3_name : (e->adj2 ? e->adj2_name : e->adj_name);
 }
 
+// range-fault words of the split-fp16 kernels, one per workgroup, at the tail of the workspace
+static int64_t fault_bytes(const Layout& y) { return ((int64_t)y.n_wg * 4 + 255) & ~(int64_t)255; }
+
 int64_t ncde_fast_workspace_bytes(const NcdeProblem* p, int pass) {
     if (!ncde_fast_supported(p, pass)) return NCDE_ERR_UNSUPPORTED;
     const Layout y = make_layout(p);
-    if (pass == 0) return (p->flags & NCDE_FLAG_DEBUG_PROFILE) ? 256 + (int64_t)y.n_wg * 8 * 4 * 8 : 256;
+    if (pass == 0) return ((p->flags & NCDE_FLAG_DEBUG_PROFILE) ? 256 + (int64_t)y.n_wg * 8 * 4 * 8 : 256) + fault_bytes(y);
     return (int64_t)sizeof(float) * (int64_t)y.n_wg * (int64_t)y.theta_size + 256 +
            ((p->flags & NCDE_FLAG_DEBUG_PROFILE) ? (int64_t)y.n_wg * 8 * 6 * 8 + 256 : 0) +
-           ((p->flags & 0x200u) ? (int64_t)p->n_knots * 4 * 5 * 64 * 4 + 256 : 0);
+           ((p->flags & 0x200u) ? (int64_t)p->n_knots * 4 * 5 * 64 * 4 + 256 : 0) + fault_bytes(y);
 }
 
 int ncde_fast_forward(const NcdeProblem* p, float* out, float* stages, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -2489,15 +2729,22 @@ int ncde_fast_forward(const NcdeProblem* p, float* out, float* stages, void* ws,
     a.out = out;
     a.stages = stages;
     const bool bf3 = (p->flags & NCDE_FLAG_FP32_MFMA) == 0 && e->fwd_bf3 != nullptr;
-    if (bf3) fn = e->fwd_bf3(p->interp, p->method, p->n_layers);
+    const int hp = (bf3 && (p->flags & NCDE_FLAG_SPLIT_FP16)) ? 1 : 0;
+    if (bf3) fn = e->fwd_bf3(p->interp, p->method, p->n_layers, hp);
+    a.fault = hp ? reinterpret_cast<int*>(static_cast<char*>(ws) + ncde_fast_workspace_bytes(p, 0) - fault_bytes(y)) : nullptr;
     if (p->flags & NCDE_FLAG_DEBUG_PROFILE) {  // phase-cycle counters -> workspace [n_wg][NW][4] u64
         if (!(e->shape.H == 32 && e->shape.C == 20 && p->interp == NCDE_INTERP_LINEAR && p->method == NCDE_RK4_38)) return NCDE_ERR_UNSUPPORTED;
-        fn = bf3 ? (p->n_layers == 3 ? ncde_fwd_fast_bf3<32, 32, 20, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1, 3>
+        fn = bf3 ? (p->n_layers == 3 ? (hp ? ncde_fwd_fast_bf3<32, 32, 20, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1, 3, 1>
+                                           : ncde_fwd_fast_bf3<32, 32, 20, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1, 3>)
                                      : ncde_fwd_fast_bf3<32, 32, 20, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>)
                  : ncde_fwd_fast<32, 32, 20, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>;
         a.gpart = (float*)ws;
     }
     hipLaunchKernelGGL(fn, dim3(y.n_wg), dim3(64 * (bf3 ? e->nw_bf3 : e->nw)), 0, st, a);
+    if (hp && !(p->flags & NCDE_FLAG_DEBUG_PROFILE)) {  // re-execution of range-faulted tiles (normally none: every workgroup exits at once)
+        a.only_faulted = 1;
+        hipLaunchKernelGGL(e->fwd_bf3(p->interp, p->method, p->n_layers, 0), dim3(y.n_wg), dim3(64 * e->nw_bf3), 0, st, a);
+    }
     return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
 }
 
@@ -2509,8 +2756,9 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     const bool v1 = !discrete && ((p->flags & NCDE_FLAG_ADJOINT_V1) != 0 || (e->adj2 == nullptr && e->adj3 == nullptr));
     const bool v3 = discrete || (!v1 && e->adj3 != nullptr && !(p->flags & NCDE_FLAG_ADJOINT_V2));
     const bool v2 = !v1 && !v3;
-    FwdFn fn = discrete ? e->adj3_disc(p->interp, p->method)
-                        : (v1 ? e->adj(p->interp, p->method) : (v3 ? e->adj3(p->interp, p->method) : e->adj2(p->interp, p->method)));
+    const int hp = (v3 && (p->flags & NCDE_FLAG_SPLIT_FP16) && !(p->flags & 0x200u)) ? 1 : 0;
+    FwdFn fn = discrete ? e->adj3_disc(p->interp, p->method, hp)
+                        : (v1 ? e->adj(p->interp, p->method) : (v3 ? e->adj3(p->interp, p->method, hp) : e->adj2(p->interp, p->method)));
     if (!fn) return NCDE_ERR_UNSUPPORTED;
     if (discrete && (p->flags & (NCDE_FLAG_DEBUG_PROFILE | 0x200u))) return NCDE_ERR_UNSUPPORTED;
     const Layout y = make_layout(p);
@@ -2538,14 +2786,27 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     }
     if (p->flags & NCDE_FLAG_DEBUG_PROFILE) {  // phase-cycle counters -> tail of the workspace [n_wg][NW][6] u64
         if (!(e->shape.H == 32 && e->shape.C == 20 && p->interp == NCDE_INTERP_LINEAR && p->method == NCDE_RK4_38)) return NCDE_ERR_UNSUPPORTED;
-        fn = v3 ? ncde_adj_fast3<3, 20, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>
+        fn = v3 ? (hp ? ncde_adj_fast3<3, 20, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1, 0, 1> : ncde_adj_fast3<3, 20, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>)
                 : (v2 ? ncde_adj_fast2<32, 32, 20, 3, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1> : ncde_adj_fast<32, 32, 20, 3, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>);
         a.out = (float*)ws + (size_t)y.n_wg * y.theta_size + 64;
     }
-    const size_t lds = v1 ? e->adj_lds(p->interp) : (v3 ? e->adj3_lds(p->interp) : e->adj2_lds(p->interp));
+    const size_t lds = v1 ? e->adj_lds(p->interp) : (v3 ? e->adj3_lds(p->interp, hp) : e->adj2_lds(p->interp));
     if (ncde_lds_optin((const void*)fn, lds) != hipSuccess) return NCDE_ERR_HIP;
+    a.fault = hp ? reinterpret_cast<int*>(static_cast<char*>(ws) + ncde_fast_workspace_bytes(p, discrete ? 2 : 1) - fault_bytes(y)) : nullptr;
     hipLaunchKernelGGL(fn, dim3(y.n_wg), dim3(v1 ? 64 * e->nw : 512), lds, st, a);
     if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
+#ifdef NCDE_H2_NOFIXUP
+    if (false) {
+#else
+    if (hp && !(p->flags & NCDE_FLAG_DEBUG_PROFILE)) {  // re-execution of range-faulted tiles in split-bf16
+#endif (normally none: every workgroup exits at once)
+        FwdFn fx = discrete ? e->adj3_disc(p->interp, p->method, 0) : e->adj3(p->interp, p->method, 0);
+        const size_t ldx = e->adj3_lds(p->interp, 0);
+        if (ncde_lds_optin((const void*)fx, ldx) != hipSuccess) return NCDE_ERR_HIP;
+        a.only_faulted = 1;
+        hipLaunchKernelGGL(fx, dim3(y.n_wg), dim3(512), ldx, st, a);
+        if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
+    }
     if (main_kernel_only) return NCDE_OK;
     return launch_reduce_partials(p, y, g, (const float*)ws, y.n_wg, st);
 }

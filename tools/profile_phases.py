@@ -15,14 +15,15 @@ spec = model.func.fused_spec()
 with torch.no_grad():
     z0 = model.initial_linear(coeffs[:, 0]).contiguous()
 lib = _lib.lib()
-for flags, label in ((4, "fp32-mfma plain"), (0x104, "fp32-mfma instrumented"), (0, "split-bf16 plain"), (0x100, "split-bf16 instrumented")):
+for flags, label in ((4, "fp32-mfma plain"), (0x104, "fp32-mfma instrumented"), (0, "split-bf16 plain"), (0x100, "split-bf16 instrumented"),
+                     (64, "split-fp16 plain"), (0x140, "split-fp16 instrumented")):
     p = solver.build_problem(coeffs, "linear", z0, spec, "rk4", _lib.OUT_INTERVAL, flags)
     ws = torch.zeros(int(lib.ncde_workspace_bytes(ctypes.byref(p), 0)), dtype=torch.uint8, device="cuda")
     out = torch.empty(B, 2, 32, device="cuda")
     ms = ctypes.c_float()
     _lib.check(lib.ncde_time_kernel(ctypes.byref(p), 0, out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), None, 3, ctypes.byref(ms)), "time")
     print(label, "ms/launch", ms.value)
-    if flags:
+    if flags & 0x100:
         nwv = 4
         cyc = ws[: (B // 16) * nwv * 4 * 8].view(torch.int64).view(-1, nwv, 4).cpu().numpy().astype(np.float64)
         stages = 398 * 4
@@ -34,7 +35,7 @@ for flags, label in ((4, "fp32-mfma plain"), (0x104, "fp32-mfma instrumented"), 
 
 # ---- adjoint ----
 theta = 32*32+32+32*32+32+640*32+640
-for flags, label in ((0, "adj v3 plain"), (0x100, "adj v3 instrumented"), (32, "adj v4 plain"), (0x120, "adj v4 instrumented")):
+for flags, label in ((0, "adj v3 plain"), (0x100, "adj v3 instrumented"), (64, "adj v3 split-fp16 plain"), (0x140, "adj v3 split-fp16 instrumented")):
     p = solver.build_problem(coeffs, "linear", z0, spec, "rk4", _lib.OUT_INTERVAL, flags)
     ws = torch.zeros(int(lib.ncde_workspace_bytes(ctypes.byref(p), 1)), dtype=torch.uint8, device="cuda")
     out = torch.randn(B, 2, 32, device="cuda"); gout = torch.randn(B, 2, 32, device="cuda")

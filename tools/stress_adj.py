@@ -6,7 +6,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
 import gpu_util
 import test_gpu_parity as tg
 from ncde_amd import _lib
-FLAGS = _lib.FLAG_ADJOINT_V4 if "v4" in sys.argv else 0
+FLAGS = _lib.FLAG_ADJOINT_V4 if "v4" in sys.argv else (64 if "h2" in sys.argv else 0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8
 bad = 0
 for interp in ("linear", "cubic"):

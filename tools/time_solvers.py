@@ -9,10 +9,12 @@ B = int(os.environ.get("B", 4096))
 coeffs = bench.make_inputs(c, B, 0, torch.device("cuda", 0))
 y = (torch.rand(B, 1, device="cuda") > 0.5).float()
 for label, kw, opts in (("rk4 default grid", dict(solver="rk4"), None), ("rk4 step_size 0.5", dict(solver="rk4"), {"step_size": 0.5}),
-                        ("dopri5 (min_step 0.5)", dict(solver="dopri5"), None)):
+                        ("dopri5 (min_step 0.5)", dict(solver="dopri5"), None),
+                        ("dopri5, adjoint=False", dict(solver="dopri5", adjoint=False), None)):
     torch.manual_seed(0)
     try:
-        m = ncde_amd.NeuralCDE(c["C"], c["H"], 1, hidden_hidden_dim=c["HH"], num_layers=c["nl"], interpolation="rectilinear", adjoint=True, **kw).cuda()
+        m = ncde_amd.NeuralCDE(c["C"], c["H"], 1, hidden_hidden_dim=c["HH"], num_layers=c["nl"], interpolation="rectilinear",
+                               **dict(dict(adjoint=True), **kw)).cuda()
     except TypeError as e:
         print(label, "not constructible:", e); continue
     if opts is not None:

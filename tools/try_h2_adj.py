@@ -1,0 +1,76 @@
+"""Split-fp16 (flag 64) vs split-bf16 specialised kernels: errors against the oracle on the small seeded cases of the parity test, then
+timing of forward + adjoint at cfg2 size."""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ncde_amd
+from ncde_amd import _lib, solver
+import gpu_util, golden_util as gu
+import test_gpu_parity as T
+import bench
+
+FL = 64
+worst = {}
+for interp in ("linear", "cubic"):
+    for method in ("rk4", "midpoint", "euler"):
+        for seq in (False, True):
+            case = T._seeded_case(interp, method, seq, B=21, L=9, C=20, H=32, HH=32, nl=3, seed=120)
+            ex = case["expect"]
+            line = "%-6s %-8s seq=%d " % (interp, method, seq)
+            for fl in (0, FL):
+                res = gpu_util.run_case(case, flags=fl)
+                ez = gu.relerr(res["z_out"], ex["z_out"])
+                iso = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=fl)
+                eg = max(T._grad_errors(case, iso).values())
+                isod = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=fl, stages=case["stage_record"])
+                ed = max(T._grad_errors(case, isod, "bp_").values())
+                e2e = max(T._grad_errors(case, res).values())
+                line += " | fl=%-2d z %.1e adj %.1e disc %.1e e2e %.1e %s" % (fl, ez, eg, ed, e2e, res["kernels"][1][:26] if fl else "")
+                for k, v in (("z", ez), ("adj", eg), ("disc", ed)):
+                    worst[(fl, k)] = max(worst.get((fl, k), 0), v)
+            print(line, flush=True)
+print("worst", worst)
+
+# scale sweep of the cotangent: gradients must scale exactly like grad_out (power-of-two factors are exact)
+case = T._seeded_case("linear", "rk4", False, B=21, L=9, C=20, H=32, HH=32, nl=3, seed=120)
+ex = case["expect"]
+base = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=FL)
+for sc in (2.0 ** -40, 2.0 ** 30):
+    c2 = dict(case); c2["expect"] = dict(ex); c2["expect"]["grad_out"] = (ex["grad_out"] * sc).astype(np.float32)
+    r = gpu_util.run_adjoint_direct(c2, ex["z_out"], flags=FL)
+    print("cotangent x 2^%d: dz0 identical up to the factor: %s" % (int(np.log2(sc)), np.array_equal(r["dz0"], (base["dz0"] * sc).astype(np.float32))),
+          " grads:", all(np.array_equal(r["grads"][k], (base["grads"][k] * sc).astype(np.float32)) for k in base["grads"]))
+
+# timing at cfg2
+c = dict(bench.CONFIGS["cfg2"]); B = 4096
+coeffs = bench.make_inputs(c, B, 0, torch.device("cuda", 0))
+model, fw, rw = bench.make_model(c, "cuda")
+spec = model.func.fused_spec()
+with torch.no_grad():
+    z0 = model.initial_linear(coeffs[:, 0]).contiguous()
+lib = _lib.lib()
+outs = {}
+for flags in (4 | 8, 0, FL):
+    p = solver.build_problem(coeffs, "linear", z0, spec, "rk4", _lib.OUT_INTERVAL, flags)
+    ws = torch.zeros(int(lib.ncde_workspace_bytes(ctypes.byref(p), 0)), dtype=torch.uint8, device="cuda")
+    out = torch.empty(B, 2, 32, device="cuda")
+    ms = ctypes.c_float()
+    _lib.check(lib.ncde_time_kernel(ctypes.byref(p), 0, out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), None, 5, ctypes.byref(ms)), "time")
+    tf = ms.value
+    ws = torch.zeros(int(lib.ncde_workspace_bytes(ctypes.byref(p), 1)), dtype=torch.uint8, device="cuda")
+    torch.manual_seed(0)
+    gout = torch.randn(B, 2, 32, device="cuda") / B
+    uniq = spec.unique_params(); gbuf = {id(q): torch.empty_like(q) for q in uniq}
+    g = _lib.NcdeGrads(); gz0 = torch.empty_like(z0); g.grad_z0 = gz0.data_ptr()
+    for i, (w, b) in enumerate(spec.layers):
+        g.grad_layer_W[i], g.grad_layer_b[i] = gbuf[id(w)].data_ptr(), gbuf[id(b)].data_ptr()
+    g.grad_Wo, g.grad_bo = gbuf[id(spec.Wo)].data_ptr(), gbuf[id(spec.bo)].data_ptr()
+    _lib.check(lib.ncde_time_kernel(ctypes.byref(p), 1, out.data_ptr(), gout.data_ptr(), ctypes.byref(g), ws.data_ptr(), ws.numel(), None, 5, ctypes.byref(ms)), "time")
+    print("flags %d: forward %.3f ms, adjoint %.3f ms" % (flags, tf, ms.value))
+    _lib.check(lib.ncde_adjoint(ctypes.byref(p), out.data_ptr(), gout.data_ptr(), ctypes.byref(g), ws.data_ptr(), ws.numel(), None), "adj")
+    torch.cuda.synchronize()
+    outs[flags] = [gz0.clone()] + [gbuf[id(q)].clone() for q in uniq]
+for x, y, w in zip(outs[0], outs[FL], outs[12]):
+    print("cfg2 gradient max|diff|/max: fl64 vs fl0 %.2e   fl0 vs fp32 single-role %.2e   fl64 vs fp32 %.2e" % (
+        float((x - y).abs().max() / x.abs().max()), float((x - w).abs().max() / x.abs().max()), float((y - w).abs().max() / x.abs().max())))
