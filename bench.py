@@ -254,11 +254,16 @@ def pmc_traffic(name, config, B_local):
 
 
 def dtype_note(names):
-    """What the arithmetic runs on, read off the dispatched kernels' names (their `bf16` tag)."""
+    """What the arithmetic runs on, read off the dispatched kernels' names (their `fp16x2` / `bf16x3` / `bf3` tags)."""
+    parts = []
+    if any("fp16x2" in n for n in names):
+        parts.append("forward GEMMs as 2-way split-fp16 MFMA (operands to 2^-24, products to 2^-22; sample tiles that leave the fp16 range "
+                     "are re-executed in split-bf16)")
     if any("bf16" in n or "bf3" in n for n in names):
-        return ("fp32 in/out and fp32 accumulation; the large GEMMs on the dependency chain (forward, adjoint recompute / VJP) run as exact "
-                "3-way split-bf16 MFMA (fp32-equivalent: z error 5e-7, gradients 1e-6 vs the reference), the remaining GEMMs as "
-                "fp32-input MFMA")
+        parts.append("the dependency-chain GEMMs of the adjoint (recompute, VJP) as exact 3-way split-bf16 MFMA")
+    if parts:
+        return ("fp32 in/out and fp32 accumulation; " + "; ".join(parts) + " -- fp32-equivalent (z error 5e-7, gradients 1e-6 vs the "
+                "reference); the remaining GEMMs as fp32-input MFMA")
     return "fp32 throughout (fp32-input MFMA)"
 
 

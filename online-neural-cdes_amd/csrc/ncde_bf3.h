@@ -57,8 +57,8 @@ __device__ __forceinline__ f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
 // of weight >= 2^-11 (h1*h1; h1*h2 and h2*h1, which share one accumulator scaled by 2^11); the dropped h2*h2 term is <= 2^-24 |ab|,
 // of either sign.  3 MFMAs instead of the 3-way split-bf16's 6, ~24 VALU per 8 values instead of 44 (v_cvt_pk_f16_f32, v_pk_mul_f32,
 // v_cvt_f32_f16, v_pk_fma_f32), 8 registers per operand fragment instead of 12.
-// The fp16 range is the price: kernels that use this split keep a sticky flag (`mx`) and report a RANGE FAULT for their sample tile
-// when an operand overflowed fp16 (|x| >= 65520) or was not finite; the host re-executes faulted tiles with the split-bf16
+// The fp16 range is the price: kernels that use this split track the largest magnitude they have split (`mx`) and report a RANGE
+// FAULT for their sample tile when it exceeds NCDE_H2_LIMIT (or is infinite); the host re-executes faulted tiles with the split-bf16
 // kernel (same arithmetic contract, any magnitude).  Cotangent-side operands, whose scale is arbitrary, are brought into range
 // by a per-workgroup power-of-two factor first (ncde_adj_fast3).
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -71,23 +71,25 @@ struct Split2h {
     u32x4 hi, lo;  // 8 fp16 each: element j in dword j>>1, even j in the low half; lo holds (x - hi) * 2^11
 };
 
-// Range tracking: `mx` is a sticky NaN flag.  The scaled residual r = (x - h1) * 2^11 is -/+inf when h1 overflowed and NaN when x is
-// NaN, so fma(r, 0, mx) turns mx into NaN exactly when an operand left the fp16 range (one v_pk_fma_f32 per pair, on values the
-// split computes anyway).
-__device__ __forceinline__ Split2h split8h(const float* v, f32x2& mx) {
+// Range tracking: mx <- max(mx, |v[0..7]|), one v_max3_f32 per pair.  (fmaxf() would canonicalise every input first -- three
+// instructions per pair -- hence the inline asm.  Its inputs are never raw MFMA results: a bias/ReLU/mask or an LDS round trip sits in
+// between, which matters because the hazard recognizer does not see MFMA -> inline-asm dependences.)  An infinite operand is caught by
+// the limit; a NaN operand is not, it propagates through the GEMM instead -- as it does in the fp32 reference.
+#define NCDE_H2_LIMIT 60000.0f
+__device__ __forceinline__ Split2h split8h(const float* v, float& mx) {
     Split2h o;
     h16x2 h[4];  // (a __builtin_bit_cast applied directly to an element of an ext-vector reads element 0: keep the pairs as scalars)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const f32x2 x = {v[2 * q], v[2 * q + 1]};
         h[q] = __builtin_convertvector(x, h16x2);
+        asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(mx) : "v"(v[2 * q]), "v"(v[2 * q + 1]));
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         f32x2 r;
         r[0] = __builtin_fmaf((float)h[q][0], -NCDE_H2_SCALE, v[2 * q] * NCDE_H2_SCALE);  // exact: (x - h1) * 2^11
         r[1] = __builtin_fmaf((float)h[q][1], -NCDE_H2_SCALE, v[2 * q + 1] * NCDE_H2_SCALE);
-        mx = __builtin_elementwise_fma(r, (f32x2){0.0f, 0.0f}, mx);
         const h16x2 l = __builtin_convertvector(r, h16x2);
         const unsigned hq = __builtin_bit_cast(unsigned, h[q]);
         const unsigned lq = __builtin_bit_cast(unsigned, l);
@@ -96,10 +98,7 @@ __device__ __forceinline__ Split2h split8h(const float* v, f32x2& mx) {
     }
     return o;
 }
-__device__ __forceinline__ bool h2_range_fault(f32x2 mx) {
-    const float t = mx[0] + mx[1];
-    return t != t;
-}
+__device__ __forceinline__ bool h2_range_fault(float mx) { return !(mx <= NCDE_H2_LIMIT); }
 
 __device__ __forceinline__ f32x4 mfma_h(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
@@ -177,7 +176,7 @@ struct SplitOps<0> {
         return v;
     }
     struct Acc { f32x4 m; };
-    static __device__ __forceinline__ T split(const float* v, f32x2&) { return split8(v); }
+    static __device__ __forceinline__ T split(const float* v, float&) { return split8(v); }
     static __device__ __forceinline__ Acc init(f32x4 bias) { return Acc{bias}; }
     static __device__ __forceinline__ void mac(const T& A, const T& B, Acc& c) { c.m = mfma_split(A, B, c.m); }
     static __device__ __forceinline__ f32x4 finish(const Acc& c) { return c.m; }
@@ -197,7 +196,7 @@ struct SplitOps<1> {
         return v;
     }
     struct Acc { f32x4 m, x; };
-    static __device__ __forceinline__ T split(const float* v, f32x2& mx) { return split8h(v, mx); }
+    static __device__ __forceinline__ T split(const float* v, float& mx) { return split8h(v, mx); }
     static __device__ __forceinline__ Acc init(f32x4 bias) { return Acc{bias, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}}; }
     static __device__ __forceinline__ void mac(const T& A, const T& B, Acc& c) { mfma_split2(A, B, c.m, c.x); }
     static __device__ __forceinline__ f32x4 finish(const Acc& c) { return h2_combine(c.m, c.x); }

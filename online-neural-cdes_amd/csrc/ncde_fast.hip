@@ -15,7 +15,7 @@
 #include "ncde_fast.h"
 #include "ncde_fast4.h"
 #ifndef NCDE_H2_PK
-#define NCDE_H2_PK 1
+#define NCDE_H2_PK 0
 #endif
 #ifndef NCDE_H2_DW_LATE
 #define NCDE_H2_DW_LATE 1
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
     if constexpr (HP == 0) {
         if (a.only_faulted && a.fault[blockIdx.x] == 0) return;
     }
-    f32x2 mx = {0.0f, 0.0f};      // sticky range-fault flag of the split-fp16 operands (ncde_bf3.h)
+    float mx = 0.0f;              // largest operand magnitude the split-fp16 GEMMs have seen (ncde_bf3.h)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1729,7 +1729,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
     unsigned* w1S3 = woLo + NW * NB * CQ * 256;                       // [2 layers][HT][NP][64][4]  split W0 / W1 (forward) A operands
     float* amax = reinterpret_cast<float*>(w1S3 + 2 * HT * NP * 256); // [NW] max |a| of each chain wave's state rows; [NW] = fault word
     int* fault_s = reinterpret_cast<int*>(amax + NW);
-    f32x2 mx = {0.0f, 0.0f};      // sticky range-fault flag of the split-fp16 operands (ncde_bf3.h)
+    float mx = 0.0f;              // largest operand magnitude the split-fp16 GEMMs have seen (ncde_bf3.h)
     float sig = 1.0f;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2633,8 +2633,9 @@ struct FastEntry {
     int nw;
     FwdFn (*fwd)(int, int);
     const char* fwd_name;
-    FwdFn (*fwd_bf3)(int, int, int, int);  // split-bf16 variant (default); NCDE_FLAG_FP32_MFMA selects `fwd`
+    FwdFn (*fwd_bf3)(int, int, int, int);  // split-GEMM variants (default: split-fp16; NCDE_FLAG_SPLIT_BF16: split-bf16); NCDE_FLAG_FP32_MFMA selects `fwd`
     const char* fwd_bf3_name;
+    const char* fwd_h2_name;
     int nw_bf3;
     int adj_layers;                 // n_layers the adjoint instantiation is built for (0 = none)
     FwdFn (*adj)(int, int);
@@ -2646,22 +2647,24 @@ struct FastEntry {
     FwdFn (*adj3)(int, int, int);   // wave-specialised variant, split GEMMs (default); last argument: 1 = split-fp16, 0 = split-bf16
     size_t (*adj3_lds)(int, int);
     const char* adj3_name;
+    const char* adj3_h2_name;
     FwdFn (*adj3_disc)(int, int, int);   // same kernel transposing the discretised solve (ncde_backward)
     const char* adj3_disc_name;
+    const char* adj3_disc_h2_name;
 };
 
 const FastEntry kFast[] = {
     // BASELINE cfg2 / cfg3
     {{32, 32, 20}, 4, pick_fwd<32, 32, 20, 4>, "ncde_fwd_fast<H32,HH32,C20,NW4>",
-     pick_fwd_bf3<32, 32, 20, 4>, "ncde_fwd_fast_bf3<H32,HH32,C20,NW4>", 4,
+     pick_fwd_bf3<32, 32, 20, 4>, "ncde_fwd_fast_bf3<H32,HH32,C20,NW4,bf16x3>", "ncde_fwd_fast_bf3<H32,HH32,C20,NW4,fp16x2>", 4,
      3, pick_adj<32, 32, 20, 3, 4>, adj_lds_bytes<32, 32, 20, 3, 4>, "ncde_adj_fast<H32,HH32,C20,NL3,NW4>",
      pick_adj2<32, 32, 20, 3>, adj2_lds_bytes<32, 32, 20, 3>, "ncde_adj_fast2<H32,HH32,C20,NL3,chain+grad>",
-     pick_adj3<3, 20>, adj3_lds_bytes<3, 20>, "ncde_adj_fast3<H32,HH32,C20,NL3,chain(bf16x3)+grad>",
-     pick_adj3_disc<3, 20>, "ncde_adj_fast3<H32,HH32,C20,NL3,chain(bf16x3)+grad,discrete>"},
+     pick_adj3<3, 20>, adj3_lds_bytes<3, 20>, "ncde_adj_fast3<H32,HH32,C20,NL3,chain+grad,bf16x3>", "ncde_adj_fast3<H32,HH32,C20,NL3,chain+grad,fp16x2>",
+     pick_adj3_disc<3, 20>, "ncde_adj_fast3<H32,HH32,C20,NL3,chain+grad,bf16x3,discrete>", "ncde_adj_fast3<H32,HH32,C20,NL3,chain+grad,fp16x2,discrete>"},
     // BASELINE cfg4 (adjoint: generic family for now -- the per-wave LDS images do not fit at HH=64)
     {{64, 64, 4}, 4, pick_fwd<64, 64, 4, 4>, "ncde_fwd_fast<H64,HH64,C4,NW4>",
-     pick_fwd_bf3<64, 64, 4, 4>, "ncde_fwd_fast_bf3<H64,HH64,C4,NW4>", 4, 0, nullptr, nullptr, nullptr,
-     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
+     pick_fwd_bf3<64, 64, 4, 4>, "ncde_fwd_fast_bf3<H64,HH64,C4,NW4,bf16x3>", "ncde_fwd_fast_bf3<H64,HH64,C4,NW4,fp16x2>", 4, 0, nullptr, nullptr, nullptr,
+     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
 };
 
 const FastEntry* find_entry(const NcdeProblem* p) {
@@ -2696,13 +2699,15 @@ bool ncde_fast_supported(const NcdeProblem* p, int pass) {
 const char* ncde_fast_kernel_name(const NcdeProblem* p, int pass) {
     if (!ncde_fast_supported(p, pass)) return nullptr;
     const FastEntry* e = find_entry(p);
-    if (pass == 0) return ((p->flags & NCDE_FLAG_FP32_MFMA) == 0 && e->fwd_bf3) ? e->fwd_bf3_name : e->fwd_name;
+    const bool h2f = !(p->flags & NCDE_FLAG_SPLIT_BF16);
+    const bool h2 = h2f && (p->flags & NCDE_FLAG_ADJOINT_SPLIT_FP16);
+    if (pass == 0) return ((p->flags & NCDE_FLAG_FP32_MFMA) == 0 && e->fwd_bf3) ? (h2f ? e->fwd_h2_name : e->fwd_bf3_name) : e->fwd_name;
     if (use_v4(p, e, pass == 2)) return pass == 2 ? "ncde_adj_fast4<H32,HH32,C20,NL3,y-waves+cotangent-waves(bf16x3),discrete>"
                                                   : "ncde_adj_fast4<H32,HH32,C20,NL3,y-waves+cotangent-waves(bf16x3)>";
-    if (pass == 2) return e->adj3_disc_name;
+    if (pass == 2) return h2 ? e->adj3_disc_h2_name : e->adj3_disc_name;
     if (p->flags & NCDE_FLAG_ADJOINT_V1) return e->adj_name;
     if ((p->flags & NCDE_FLAG_ADJOINT_V2) && e->adj2) return e->adj2_name;
-    return e->adj3 ? e->adj3_name : (e->adj2 ? e->adj2_name : e->adj_name);
+    return e->adj3 ? (h2 ? e->adj3_h2_name : e->adj3_name) : (e->adj2 ? e->adj2_name : e->adj_name);
 }
 
 // range-fault words of the split-fp16 kernels, one per workgroup, at the tail of the workspace
@@ -2729,7 +2734,7 @@ int ncde_fast_forward(const NcdeProblem* p, float* out, float* stages, void* ws,
     a.out = out;
     a.stages = stages;
     const bool bf3 = (p->flags & NCDE_FLAG_FP32_MFMA) == 0 && e->fwd_bf3 != nullptr;
-    const int hp = (bf3 && (p->flags & NCDE_FLAG_SPLIT_FP16)) ? 1 : 0;
+    const int hp = (bf3 && !(p->flags & NCDE_FLAG_SPLIT_BF16)) ? 1 : 0;
     if (bf3) fn = e->fwd_bf3(p->interp, p->method, p->n_layers, hp);
     a.fault = hp ? reinterpret_cast<int*>(static_cast<char*>(ws) + ncde_fast_workspace_bytes(p, 0) - fault_bytes(y)) : nullptr;
     if (p->flags & NCDE_FLAG_DEBUG_PROFILE) {  // phase-cycle counters -> workspace [n_wg][NW][4] u64
@@ -2756,7 +2761,9 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     const bool v1 = !discrete && ((p->flags & NCDE_FLAG_ADJOINT_V1) != 0 || (e->adj2 == nullptr && e->adj3 == nullptr));
     const bool v3 = discrete || (!v1 && e->adj3 != nullptr && !(p->flags & NCDE_FLAG_ADJOINT_V2));
     const bool v2 = !v1 && !v3;
-    const int hp = (v3 && (p->flags & NCDE_FLAG_SPLIT_FP16) && !(p->flags & 0x200u)) ? 1 : 0;
+    // split-fp16 adjoint: experimental (NCDE_FLAG_ADJOINT_SPLIT_FP16) -- faster when it works, but its runs were not always reproducible
+    // bit for bit under repetition; the default stays the split-bf16 kernel
+    const int hp = (v3 && (p->flags & NCDE_FLAG_ADJOINT_SPLIT_FP16) && !(p->flags & (NCDE_FLAG_SPLIT_BF16 | 0x200u))) ? 1 : 0;
     FwdFn fn = discrete ? e->adj3_disc(p->interp, p->method, hp)
                         : (v1 ? e->adj(p->interp, p->method) : (v3 ? e->adj3(p->interp, p->method, hp) : e->adj2(p->interp, p->method)));
     if (!fn) return NCDE_ERR_UNSUPPORTED;

@@ -478,9 +478,12 @@ def test_fast_kernels_vs_oracle(shape, interp, method, seq, gpu_lib):
     C, H, HH, nl = shape
     case = _seeded_case(interp, method, seq, B=21, L=9, C=C, H=H, HH=HH, nl=nl, seed=100 + C)
     res = gpu_util.run_case(case, flags=_lib.FLAG_AUTO)
-    assert res["kernels"][0].startswith("ncde_fwd_fast_bf3"), res["kernels"]     # default: split-bf16 GEMMs
+    assert res["kernels"][0].startswith("ncde_fwd_fast_bf3") and "fp16x2" in res["kernels"][0], res["kernels"]   # default: split-fp16 GEMMs
     ex = case["expect"]
     assert gu.relerr(res["z_out"], ex["z_out"]) <= TIGHT_Z
+    resb = gpu_util.run_case(case, flags=_lib.FLAG_SPLIT_BF16, need_grads=False)  # 3-way split-bf16 variant (also the range-fault re-execution path)
+    assert "bf16x3" in resb["kernels"][0], resb["kernels"]
+    assert gu.relerr(resb["z_out"], ex["z_out"]) <= TIGHT_Z
     res32 = gpu_util.run_case(case, flags=_lib.FLAG_FP32_MFMA, need_grads=False)  # plain fp32-input MFMA variant
     assert res32["kernels"][0].startswith("ncde_fwd_fast<"), res32["kernels"]
     assert gu.relerr(res32["z_out"], ex["z_out"]) <= TIGHT_Z
@@ -490,7 +493,7 @@ def test_fast_kernels_vs_oracle(shape, interp, method, seq, gpu_lib):
     for k, e in _grad_errors(case, iso).items():
         assert e <= TIGHT_G, ("adjoint kernel on oracle z_out", res["kernels"][1], k, e)
     if H == 32:
-        assert res["kernels"][1].startswith("ncde_adj_fast3"), res["kernels"]      # default: chain + gradient waves, split-bf16 chain
+        assert res["kernels"][1].startswith("ncde_adj_fast3") and "bf16x3" in res["kernels"][1], res["kernels"]   # default: chain + gradient waves, split-bf16
         for fl, nm in ((_lib.FLAG_ADJOINT_V1, "single-role"), (_lib.FLAG_ADJOINT_V2, "chain+grad fp32 chain"),
                        (_lib.FLAG_ADJOINT_V4, "decoupled y / cotangent waves")):      # also the other specialised adjoint variants
             iso1 = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=fl)
@@ -513,6 +516,45 @@ def test_fast_kernels_vs_oracle(shape, interp, method, seq, gpu_lib):
             assert e <= TIGHT_G, ("decoupled-waves discrete backward on the oracle's stage record", k, e)
         againd = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_AUTO, stages=case["stage_record"])
         assert np.array_equal(againd["dz0"], isod["dz0"]) and all(np.array_equal(againd["grads"][k], isod["grads"][k]) for k in isod["grads"])
+
+
+@pytest.mark.parametrize("interp,method", [("linear", "rk4"), ("cubic", "midpoint")])
+def test_split_fp16_forward_range_fault_is_reexecuted(interp, method, gpu_lib):
+    """The default forward kernel multiplies in 2-way split-fp16 and speculates on the fp16 range (|operand| < 6e4); a sample tile
+    whose operands leave it is re-executed by the split-bf16 kernel.  Three tiles (B = 37); one sample of the middle tile gets a
+    z0 row large enough to overflow fp16 in the first hidden layer.  Expected: the middle tile's rows are bit-identical to the
+    split-bf16 run (they came from that kernel), the other tiles' rows are bit-identical to the run without the outlier (samples
+    do not interact in the forward solve), and everything agrees with the oracle."""
+    import gpu_util
+    from ncde_amd import _lib
+    for seq in (False, True):
+        case = _seeded_case(interp, method, seq, B=37, L=6, C=20, H=32, HH=32, nl=3, seed=311)
+        plain = gpu_util.run_case(case, need_grads=False)
+        big = dict(case)
+        big["z0"] = case["z0"].copy()
+        big["z0"][21] *= 4.0e5
+        import ncde_oracle as orc
+        ctl = orc.Control(big["coeffs"], case["meta"]["kind"])
+        zo = orc.solve_forward(ctl, gu.oracle_field(case), big["z0"], method, seq).numpy()
+        r16 = gpu_util.run_case(big, need_grads=False)
+        rbf = gpu_util.run_case(big, flags=_lib.FLAG_SPLIT_BF16, need_grads=False)
+        assert np.isfinite(r16["z_out"]).all()
+        assert np.array_equal(r16["z_out"][16:32], rbf["z_out"][16:32])                       # re-executed tile
+        assert np.array_equal(r16["z_out"][:16], plain["z_out"][:16]) and np.array_equal(r16["z_out"][32:], plain["z_out"][32:])
+        scale = np.abs(zo).max(axis=tuple(range(1, zo.ndim)), keepdims=True)                   # per sample: the outlier is 1e5 x the rest
+        assert float((np.abs(r16["z_out"] - zo) / scale).max()) <= TIGHT_Z
+
+
+def test_split_fp16_forward_is_reproducible_under_repetition(gpu_lib):
+    """Ten launches of the default (split-fp16 + re-execution launch) forward kernels: bit-identical."""
+    import gpu_util
+    for shape in FAST_SHAPES:
+        C, H, HH, nl = shape
+        case = _seeded_case("cubic", "rk4", True, B=37, L=7, C=C, H=H, HH=HH, nl=nl, seed=312)
+        first = gpu_util.run_case(case, need_grads=False)["z_out"]
+        assert gu.relerr(first, case["expect"]["z_out"]) <= TIGHT_Z
+        for _ in range(9):
+            assert np.array_equal(gpu_util.run_case(case, need_grads=False)["z_out"], first)
 
 
 @pytest.mark.parametrize("interp,method", [("cubic", "midpoint"), ("linear", "rk4"), ("cubic", "euler")])

@@ -6,7 +6,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
 import gpu_util
 import test_gpu_parity as tg
 from ncde_amd import _lib
-FLAGS = _lib.FLAG_ADJOINT_V4 if "v4" in sys.argv else (64 if "h2" in sys.argv else 0)
+if os.environ.get("VARIANT"): _lib.LIB_PATH = os.path.join(ROOT, "variants", os.environ["VARIANT"])
+FLAGS = _lib.FLAG_ADJOINT_V4 if "v4" in sys.argv else (64 if "bf16" in sys.argv else 0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8
 bad = 0
 for interp in ("linear", "cubic"):

@@ -34,4 +34,4 @@ if len(sys.argv) > 1:
         print("%-28s flags %3d: forward %.3f ms, adjoint %.3f ms   |gz0| %.6e" % (os.path.basename(sys.argv[1]), flags, tf, ms.value, float(gz0.abs().sum())), flush=True)
 else:
     for so in sorted(glob.glob(os.path.join(ROOT, "variants", "*.so"))):
-        subprocess.run([sys.executable, __file__, so, "64"])
+        subprocess.run([sys.executable, __file__, so, "0"])
