@@ -1703,9 +1703,15 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
     // HP = 1: 2-way split-fp16 GEMMs (ncde_bf3.h) -- the forward-side operands as they are, the cotangent-side ones in units of a
     // per-workgroup power of two `sig` that follows max |a| over the tile from step to step; the workgroup reports a range fault
     // (a.fault) when any operand left the fp16 range, and the HP = 0 instance re-executes exactly those workgroups (only_faulted).
-    typedef SplitOps<HP> SO;
+    // HP = 2 (default): only the FORWARD-side GEMMs of the chain waves (stage recompute, output tiles: operands z, x_l, W -- O(1)
+    // magnitudes) are split-fp16; everything that carries the cotangent, and the whole gradient wave, stays as in HP = 0.
+    // Nothing changes in what the two roles exchange.  HP = 1 (experimental, NCDE_FLAG_ADJOINT_SPLIT_FP16): everything split-fp16.
+    constexpr int HPF = HP != 0 ? 1 : 0, HPC = HP == 1 ? 1 : 0;
+    typedef SplitOps<HPF> SF;       // forward-side operands
+    typedef SplitOps<HPC> SO;       // cotangent-side operands, gradient waves
+    typedef typename SF::T SpF;
     typedef typename SO::T SpT;
-    constexpr int NP = SO::NP;
+    constexpr int NPF = SF::NP, NP = SO::NP;
     if constexpr (HP == 0) {
         if (a.only_faulted && a.fault[blockIdx.x] == 0) return;
     }
@@ -1719,15 +1725,15 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
     float* ximg = tiles + NW * NTILE * 256;            // [2][XROWS][16]          by stage parity (chain wave 0)
     float* dpimg = ximg + 2 * XROWS * 16;              // [NDP][NL][HH][16]       (chain wave 0); NDP = 2 (by stage parity) when the
                                                        // gradient waves consume it behind barrier A of the NEXT stage (HP = 1)
-    constexpr int NDP = (HP != 0 && NCDE_H2_DW_LATE != 0) ? 2 : 1;
+    constexpr int NDP = (HPC != 0 && NCDE_H2_DW_LATE != 0) ? 2 : 1;
     int* flags = reinterpret_cast<int*>(dpimg + NDP * NL * HH * 16);  // [NW][NFLAG]
     float* biasL = reinterpret_cast<float*>(flags + NW * NFLAG);      // [2][HT][4 g][4 r]: b[8g + 4t + r]
     unsigned* w1T3 = reinterpret_cast<unsigned*>(biasL + 2 * HT * 16);  // [HT][NP][64][4]  split W1^T A operands
     unsigned* w0T3 = w1T3 + HT * NP * 256;                            // [NW][NP][64][4]   split W0^T (own state rows)
     unsigned* woLo = w0T3 + NW * NP * 256;                            // [NW][NB][CQ][64][4] lo pieces: of the chain waves' Wo A operands
                                                                       // (HP = 0) / of the gradient waves' Wo^T A operands (HP = 1)
-    unsigned* w1S3 = woLo + NW * NB * CQ * 256;                       // [2 layers][HT][NP][64][4]  split W0 / W1 (forward) A operands
-    float* amax = reinterpret_cast<float*>(w1S3 + 2 * HT * NP * 256); // [NW] max |a| of each chain wave's state rows; [NW] = fault word
+    unsigned* w1S3 = woLo + NW * NB * CQ * 256;                       // [2 layers][HT][NPF][64][4]  split W0 / W1 (forward) A operands
+    float* amax = reinterpret_cast<float*>(w1S3 + 2 * HT * NPF * 256); // [NW] max |a| of each chain wave's state rows; [NW] = fault word
     int* fault_s = reinterpret_cast<int*>(amax + NW);
     float mx = 0.0f;              // largest operand magnitude the split-fp16 GEMMs have seen (ncde_bf3.h)
     float sig = 1.0f;
@@ -1774,7 +1780,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
             float tmp[8];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) tmp[jj] = a.W[layer][unitA * HH + 8 * (l >> 4) + jj];   // H == HH
-            SO::store(w1S3 + (layer * HT + t) * NP * 256, l, SO::split(tmp, mx));
+            SF::store(w1S3 + (layer * HT + t) * NPF * 256, l, SF::split(tmp, mx));
         }
     } else if (tid < 64 * HT + 64 * NW) {  // split W0^T rows of the state entries pair wv owns
         const int l = tid & 63, wv = (tid >> 6) - HT;
@@ -1792,11 +1798,11 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         // =================================================================================================
         u32x4 woHi[NB][CQ], woMid[NB][CQ];      // HP = 1: (hi, lo), both in registers
         unsigned* my_woLo = woLo + pw * NB * CQ * 256;
-        auto fwd_weights = [&](int layer, int tt) { return SO::load(w1S3 + (layer * HT + tt) * NP * 256, lane); };
+        auto fwd_weights = [&](int layer, int tt) { return SF::load(w1S3 + (layer * HT + tt) * NPF * 256, lane); };
         auto wo_operand = [&](int nb, int cq) {
-            SpT As;
+            SpF As;
             As.hi = woHi[nb][cq];
-            if constexpr (HP != 0) {
+            if constexpr (HPF != 0) {
                 As.lo = woMid[nb][cq];
             } else {
                 As.mid = woMid[nb][cq];
@@ -1812,9 +1818,9 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                 float tmp[8];
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) tmp[jj] = cA < C ? NCDE_TANH_PRESCALE * a.Wo[(hA * C + cA) * HH + 8 * g + jj] : 0.0f;
-                const SpT sp = SO::split(tmp, mx);
+                const SpF sp = SF::split(tmp, mx);
                 woHi[nb][cq] = sp.hi;
-                if constexpr (HP != 0) {
+                if constexpr (HPF != 0) {
                     woMid[nb][cq] = sp.lo;
                 } else {
                     woMid[nb][cq] = sp.mid;
@@ -1889,7 +1895,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         // max |a| over this wave's state rows -> amax[pw] (read by every wave behind the next barrier)
         auto publish_amax = [&](const float* av) {
-            if constexpr (HP != 0) {
+            if constexpr (HPC != 0) {
                 float m = __builtin_fmaxf(__builtin_fabsf(av[0]), __builtin_fabsf(av[1]));
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off, 64));
@@ -1899,7 +1905,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         static_assert(NB == 2, "publish_amax reads two entries");
         publish_amax(a0);
         __syncthreads();
-        if constexpr (HP != 0) sig = h2_pick_scale(__builtin_fmaxf(__builtin_fmaxf(amax[0], amax[1]), __builtin_fmaxf(amax[2], amax[3])), 1.0f);
+        if constexpr (HPC != 0) sig = h2_pick_scale(__builtin_fmaxf(__builtin_fmaxf(amax[0], amax[1]), __builtin_fmaxf(amax[2], amax[3])), 1.0f);
         float isig = h2_inv_scale(sig);
 
         int zpar = 0, sc = 0;
@@ -1921,37 +1927,37 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                 const float* dxp = dxs + (idx % 3) * 16 * DXW + s * DXW;
                 // ---- forward recompute (split-bf16); x[l][4t+r] <-> unit 8g + 4t + r -----------------------------------
                 float x[NL][8];
-                SpT xb;
+                SpF xb;
                 {
-                    typename SO::Acc acc[HT];
-                    xb = SO::split(zreg, mx);
+                    typename SF::Acc acc[HT];
+                    xb = SF::split(zreg, mx);
 #pragma unroll
                     for (int tt = 0; tt < HT; ++tt) {
-                        acc[tt] = SO::init(*reinterpret_cast<const f32x4*>(biasL + (tt * 4 + g) * 4));
-                        SO::mac(fwd_weights(0, tt), xb, acc[tt]);
+                        acc[tt] = SF::init(*reinterpret_cast<const f32x4*>(biasL + (tt * 4 + g) * 4));
+                        SF::mac(fwd_weights(0, tt), xb, acc[tt]);
                     }
 #pragma unroll
                     for (int tt = 0; tt < HT; ++tt) {
-                        const f32x4 pre = SO::finish(acc[tt]);
+                        const f32x4 pre = SF::finish(acc[tt]);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) x[0][4 * tt + r] = relu_bits(pre[r]);
                     }
 #pragma unroll
                     for (int l = 1; l < NL; ++l) {
-                        xb = SO::split(x[l - 1], mx);
+                        xb = SF::split(x[l - 1], mx);
 #pragma unroll
                         for (int tt = 0; tt < HT; ++tt) {
-                            acc[tt] = SO::init(*reinterpret_cast<const f32x4*>(biasL + ((HT + tt) * 4 + g) * 4));
-                            SO::mac(fwd_weights(1, tt), xb, acc[tt]);
+                            acc[tt] = SF::init(*reinterpret_cast<const f32x4*>(biasL + ((HT + tt) * 4 + g) * 4));
+                            SF::mac(fwd_weights(1, tt), xb, acc[tt]);
                         }
 #pragma unroll
                         for (int tt = 0; tt < HT; ++tt) {
-                            const f32x4 pre = SO::finish(acc[tt]);
+                            const f32x4 pre = SF::finish(acc[tt]);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) x[l][4 * tt + r] = relu_bits(pre[r]);
                         }
                     }
-                    xb = SO::split(x[NL - 1], mx);
+                    xb = SF::split(x[NL - 1], mx);
                 }
                 NCDE_TICK(0)
                 if (wq != 0.0f) {  // [unit][sample] images for the gradient waves: the chain waves hold identical copies, wave pw
@@ -1986,9 +1992,9 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                     f32x4 o[NB];
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
-                        typename SO::Acc oa = SO::init(*reinterpret_cast<const f32x4*>(boLw + ((nb * CQ + cq) * 4 + g) * 4));
-                        SO::mac(wo_operand(nb, cq), xb, oa);
-                        o[nb] = SO::finish(oa);
+                        typename SF::Acc oa = SF::init(*reinterpret_cast<const f32x4*>(boLw + ((nb * CQ + cq) * 4 + g) * 4));
+                        SF::mac(wo_operand(nb, cq), xb, oa);
+                        o[nb] = SF::finish(oa);
                     }
                     f32x4 dx;
                     if constexpr (INTERP == NCDE_INTERP_LINEAR) {
@@ -2010,7 +2016,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                         const int tau = cq * NB + nb;
                         float* tl = my_tiles + tau * 256;
                         const float a4 = (4.0f * sig) * as_[nb];     // dP, and everything downstream of it, in units of sig
-                        if constexpr (HP != 0 && NCDE_H2_PK != 0) {   // on pairs (v_pk_add / v_pk_fma / v_pk_mul): even and odd channels accumulate apart
+                        if constexpr (HPF != 0 && NCDE_H2_PK != 0) {   // on pairs (v_pk_add / v_pk_fma / v_pk_mul): even and odd channels accumulate apart
 #pragma unroll
                             for (int q = 0; q < 2; ++q) {
                                 const f32x2 e = {__builtin_amdgcn_exp2f(o[nb][2 * q]), __builtin_amdgcn_exp2f(o[nb][2 * q + 1])};
@@ -2036,7 +2042,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                         }
                     }
                 }
-                if constexpr (HP != 0 && NCDE_H2_PK != 0) {
+                if constexpr (HPF != 0 && NCDE_H2_PK != 0) {
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) kout[nb] = kout2[nb][0] + kout2[nb][1];
                 }
@@ -2084,7 +2090,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                     typename SO::Acc va = SO::init(zero4);
                     SO::mac(SO::load(w0T3 + pw * NP * 256, lane), gb, va);
                     vy = SO::finish(va);
-                    if constexpr (HP != 0) {
+                    if constexpr (HPC != 0) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) vy[r] *= isig;
                     }
@@ -2124,7 +2130,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                         publish_amax(a0);
                     }
                     __syncthreads();  // barrier B
-                    if constexpr (HP != 0) {
+                    if constexpr (HPC != 0) {
                         if (j == S - 1) {
                             sig = h2_pick_scale(__builtin_fmaxf(__builtin_fmaxf(amax[0], amax[1]), __builtin_fmaxf(amax[2], amax[3])), sig);
                             isig = h2_inv_scale(sig);
@@ -2173,7 +2179,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                     for (int jj = 0; jj < 8; ++jj) zreg[jj] = zw[(8 * g + jj) * 16 + s];
                     zpar ^= 1;
                 }
-                if constexpr (HP != 0) {
+                if constexpr (HPC != 0) {
                     if (j == S - 1) {
                         sig = h2_pick_scale(__builtin_fmaxf(__builtin_fmaxf(amax[0], amax[1]), __builtin_fmaxf(amax[2], amax[3])), sig);
                         isig = h2_inv_scale(sig);
@@ -2199,8 +2205,8 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         // A operands of the dL/dx_L GEMM, output row i <-> unit 8(i>>2)+4t'+(i&3).  HP = 0: fp32 (v_mfma_f32_16x16x4_f32), one
         // value per (tile, t', r).  HP = 1: split-fp16, K = the 32 rows of a block (= one cq): k = 8 kg + jj <-> tile nb = k >> 4,
         // row 4 g' + r = k & 15 of that tile; hi pieces in 40 registers, lo pieces in this pair's LDS image.
-        float woT[HP ? 1 : NTILE][HT][4];
-        u32x4 woT2h[HP ? NBLK : 1][HT];
+        float woT[HPC ? 1 : NTILE][HT][4];
+        u32x4 woT2h[HPC ? NBLK : 1][HT];
         unsigned* my_woTlo = woLo + pw * NBLK * HT * 256;
         static_assert(NBLK * HT == NB * CQ, "the lo-piece image reuses the chain waves' region");
 #pragma unroll
@@ -2210,7 +2216,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
 #pragma unroll
             for (int tp = 0; tp < HT; ++tp) {
                 const int jrow = 8 * (s >> 2) + 4 * tp + (s & 3);
-                if constexpr (HP == 0) {
+                if constexpr (HPC == 0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int c = 4 * cq + r;
@@ -2243,7 +2249,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
             for (int q = 0; q < 16; ++q) gWo[i][q] = 0.0f;
         }
         __syncthreads();
-        if constexpr (HP != 0) sig = h2_pick_scale(__builtin_fmaxf(__builtin_fmaxf(amax[0], amax[1]), __builtin_fmaxf(amax[2], amax[3])), 1.0f);
+        if constexpr (HPC != 0) sig = h2_pick_scale(__builtin_fmaxf(__builtin_fmaxf(amax[0], amax[1]), __builtin_fmaxf(amax[2], amax[3])), 1.0f);
         float acc_sig = sig;        // the units the gradient accumulators are in
 
         const int tr = pw >> 1, tc = pw & 1;
@@ -2263,7 +2269,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
             gbo[blk] += w * (((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7])));
             const SpT As = SO::split(av, mx);
             f32x16 c = gWo[blk];
-            if constexpr (HP == 0) {
+            if constexpr (HPC == 0) {
                 c = mfma_bf32(As.lo, Bs.hi, c);
                 c = mfma_bf32(As.hi, Bs.lo, c);
                 c = mfma_bf32(As.mid, Bs.mid, c);
@@ -2320,7 +2326,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         f32x4 accJ[HT], accJx[HT];
         auto dxl_tiles = [&](auto t_lo_c, auto t_hi_c) {
             constexpr int t_lo = decltype(t_lo_c)::value, t_hi = decltype(t_hi_c)::value;
-            if constexpr (HP != 0) {        // one block: B = dP of the 32 rows of this block for sample s, k = 8g + jj
+            if constexpr (HPC != 0) {        // one block: B = dP of the 32 rows of this block for sample s, k = 8g + jj
                 static_assert(t_hi - t_lo == 2, "a block is two tiles");
                 float bv[8];
                 const float* tl = my_tiles + (t_lo + (g >> 1)) * 256 + (8 * (g & 1)) * 16 + s;
@@ -2351,7 +2357,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         // the cotangent scale moved at the last step boundary: bring the accumulators along (after the last contribution in the
         // old units -- dw_hidden of the previous stage -- and before the first in the new ones)
         auto rescale_acc = [&]() {
-            if constexpr (HP != 0) {
+            if constexpr (HPC != 0) {
                 if (sig != acc_sig) {
                     const float ratio = sig * h2_inv_scale(acc_sig);
 #pragma unroll
@@ -2399,7 +2405,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                     else if (blk == 3) { if constexpr (NBLK > 3) dxl_tiles(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{}); }
                     else if (blk == 4) { if constexpr (NBLK > 4) dxl_tiles(std::integral_constant<int, 8>{}, std::integral_constant<int, 10>{}); }
                     static_assert(NBLK <= 5, "extend the block dispatch");
-                    if (wq != 0.0f && blk == 1 && (HP == 0 || NCDE_H2_DWO_EARLY != 0)) {
+                    if (wq != 0.0f && blk == 1 && (HPC == 0 || NCDE_H2_DWO_EARLY != 0)) {
                         if (!have_bs) {
                             while (__builtin_amdgcn_readfirstlane(*xflag) != sc) __builtin_amdgcn_s_sleep(1);
                             wave_lds_order();
@@ -2412,7 +2418,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                 NCDE_TICK(3)
 #pragma unroll
                 for (int tt = 0; tt < HT; ++tt) {
-                    if constexpr (HP != 0) accJ[tt] = h2_combine(accJ[tt], accJx[tt]);
+                    if constexpr (HPC != 0) accJ[tt] = h2_combine(accJ[tt], accJx[tt]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) red[pw * HH * 16 + (8 * g + 4 * tt + r) * 16 + s] = accJ[tt][r];
                 }
@@ -2430,11 +2436,11 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                     }
 #pragma unroll
                     for (int blk = 0; blk < NBLK; ++blk)
-                        if (blk >= 1 || (HP != 0 && NCDE_H2_DWO_EARLY == 0)) dwo_block(Bs, wq, blk);
+                        if (blk >= 1 || (HPC != 0 && NCDE_H2_DWO_EARLY == 0)) dwo_block(Bs, wq, blk);
 
                 }
                 __syncthreads();  // barrier B
-                if constexpr (HP != 0) {
+                if constexpr (HPC != 0) {
                     if (j == S - 1) sig = h2_pick_scale(__builtin_fmaxf(__builtin_fmaxf(amax[0], amax[1]), __builtin_fmaxf(amax[2], amax[3])), sig);
                 }
                 NCDE_TICK(5)
@@ -2450,7 +2456,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         }
         // ---- write-out of this workgroup's parameter-gradient partial ------------------------------------------
         float* gp = a.gpart + (long long)blockIdx.x * a.theta_size;
-        if constexpr (HP != 0) {
+        if constexpr (HPC != 0) {
             const float un = h2_inv_scale(acc_sig);
 #pragma unroll
             for (int i = 0; i < NBLK; ++i) {
@@ -2585,7 +2591,7 @@ size_t adj2_lds_bytes(int interp) {
 template <int NL, int C>
 FwdFn pick_adj3(int interp, int method, int hp) {
 #define NCDE_PICK(I, M) \
-    if (interp == I && method == M) return hp ? ncde_adj_fast3<NL, C, I, M, 0, 0, 1> : ncde_adj_fast3<NL, C, I, M>;
+    if (interp == I && method == M) return hp == 2 ? ncde_adj_fast3<NL, C, I, M, 0, 0, 2> : (hp == 1 ? ncde_adj_fast3<NL, C, I, M, 0, 0, 1> : ncde_adj_fast3<NL, C, I, M>);
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_RK4_38)
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_MIDPOINT)
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_EULER)
@@ -2599,7 +2605,7 @@ FwdFn pick_adj3(int interp, int method, int hp) {
 template <int NL, int C>
 FwdFn pick_adj3_disc(int interp, int method, int hp) {
 #define NCDE_PICK(I, M) \
-    if (interp == I && method == M) return hp ? ncde_adj_fast3<NL, C, I, M, 0, 1, 1> : ncde_adj_fast3<NL, C, I, M, 0, 1>;
+    if (interp == I && method == M) return hp == 2 ? ncde_adj_fast3<NL, C, I, M, 0, 1, 2> : (hp == 1 ? ncde_adj_fast3<NL, C, I, M, 0, 1, 1> : ncde_adj_fast3<NL, C, I, M, 0, 1>);
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_RK4_38)
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_MIDPOINT)
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_EULER)
@@ -2611,13 +2617,13 @@ FwdFn pick_adj3_disc(int interp, int method, int hp) {
 }
 
 template <int NL, int C>
-size_t adj3_lds_bytes(int interp, int hp) {
+size_t adj3_lds_bytes(int interp, int hp) {   // hp: the kernel's HP template argument (0, 1, 2)
     constexpr int H = 32, HH = 32, NW = 4, HT = 2, CP = (C + 3) & ~3, CQ = CP / 4, NB = 2, NTILE = NB * CQ;
     const int DXW = interp == NCDE_INTERP_LINEAR ? CP : 3 * CP;
-    const int NP = hp ? 2 : 3;
+    const int NPF = hp ? 2 : 3, NP = hp == 1 ? 2 : 3, NDP = (hp == 1 && NCDE_H2_DW_LATE) ? 2 : 1;
     return sizeof(float) * (size_t)(2 * H * 16 + 3 * 16 * DXW + NW * HH * 16 + NW * NTILE * 16 + NW * NTILE * 256 +
-                                    2 * (H + NL * HH) * 16 + ((hp && NCDE_H2_DW_LATE) ? 2 : 1) * NL * HH * 16 + NW * (NTILE + 2) + 2 * HT * 16 +
-                                    HT * NP * 256 + NW * NP * 256 + NW * NB * CQ * 256 + 2 * HT * NP * 256 + NW + 4);
+                                    2 * (H + NL * HH) * 16 + NDP * NL * HH * 16 + NW * (NTILE + 2) + 2 * HT * 16 +
+                                    HT * NP * 256 + NW * NP * 256 + NW * NB * CQ * 256 + 2 * HT * NPF * 256 + NW + 4);
 }
 
 template <int H, int HH, int C, int NL, int NW>
@@ -2647,10 +2653,12 @@ struct FastEntry {
     FwdFn (*adj3)(int, int, int);   // wave-specialised variant, split GEMMs (default); last argument: 1 = split-fp16, 0 = split-bf16
     size_t (*adj3_lds)(int, int);
     const char* adj3_name;
-    const char* adj3_h2_name;
+    const char* adj3_h2_name;       // HP = 1
+    const char* adj3_f2_name;       // HP = 2
     FwdFn (*adj3_disc)(int, int, int);   // same kernel transposing the discretised solve (ncde_backward)
     const char* adj3_disc_name;
     const char* adj3_disc_h2_name;
+    const char* adj3_disc_f2_name;
 };
 
 const FastEntry kFast[] = {
@@ -2660,11 +2668,13 @@ const FastEntry kFast[] = {
      3, pick_adj<32, 32, 20, 3, 4>, adj_lds_bytes<32, 32, 20, 3, 4>, "ncde_adj_fast<H32,HH32,C20,NL3,NW4>",
      pick_adj2<32, 32, 20, 3>, adj2_lds_bytes<32, 32, 20, 3>, "ncde_adj_fast2<H32,HH32,C20,NL3,chain+grad>",
      pick_adj3<3, 20>, adj3_lds_bytes<3, 20>, "ncde_adj_fast3<H32,HH32,C20,NL3,chain+grad,bf16x3>", "ncde_adj_fast3<H32,HH32,C20,NL3,chain+grad,fp16x2>",
-     pick_adj3_disc<3, 20>, "ncde_adj_fast3<H32,HH32,C20,NL3,chain+grad,bf16x3,discrete>", "ncde_adj_fast3<H32,HH32,C20,NL3,chain+grad,fp16x2,discrete>"},
+     "ncde_adj_fast3<H32,HH32,C20,NL3,chain+grad,fwd-side fp16x2 + bf16x3>",
+     pick_adj3_disc<3, 20>, "ncde_adj_fast3<H32,HH32,C20,NL3,chain+grad,bf16x3,discrete>", "ncde_adj_fast3<H32,HH32,C20,NL3,chain+grad,fp16x2,discrete>",
+     "ncde_adj_fast3<H32,HH32,C20,NL3,chain+grad,fwd-side fp16x2 + bf16x3,discrete>"},
     // BASELINE cfg4 (adjoint: generic family for now -- the per-wave LDS images do not fit at HH=64)
     {{64, 64, 4}, 4, pick_fwd<64, 64, 4, 4>, "ncde_fwd_fast<H64,HH64,C4,NW4>",
      pick_fwd_bf3<64, 64, 4, 4>, "ncde_fwd_fast_bf3<H64,HH64,C4,NW4,bf16x3>", "ncde_fwd_fast_bf3<H64,HH64,C4,NW4,fp16x2>", 4, 0, nullptr, nullptr, nullptr,
-     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
+     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
 };
 
 const FastEntry* find_entry(const NcdeProblem* p) {
@@ -2701,13 +2711,14 @@ const char* ncde_fast_kernel_name(const NcdeProblem* p, int pass) {
     const FastEntry* e = find_entry(p);
     const bool h2f = !(p->flags & NCDE_FLAG_SPLIT_BF16);
     const bool h2 = h2f && (p->flags & NCDE_FLAG_ADJOINT_SPLIT_FP16);
+    const bool f2 = h2f && !h2 && !(p->flags & 0x200u);
     if (pass == 0) return ((p->flags & NCDE_FLAG_FP32_MFMA) == 0 && e->fwd_bf3) ? (h2f ? e->fwd_h2_name : e->fwd_bf3_name) : e->fwd_name;
     if (use_v4(p, e, pass == 2)) return pass == 2 ? "ncde_adj_fast4<H32,HH32,C20,NL3,y-waves+cotangent-waves(bf16x3),discrete>"
                                                   : "ncde_adj_fast4<H32,HH32,C20,NL3,y-waves+cotangent-waves(bf16x3)>";
-    if (pass == 2) return h2 ? e->adj3_disc_h2_name : e->adj3_disc_name;
+    if (pass == 2) return h2 ? e->adj3_disc_h2_name : (f2 ? e->adj3_disc_f2_name : e->adj3_disc_name);
     if (p->flags & NCDE_FLAG_ADJOINT_V1) return e->adj_name;
     if ((p->flags & NCDE_FLAG_ADJOINT_V2) && e->adj2) return e->adj2_name;
-    return e->adj3 ? (h2 ? e->adj3_h2_name : e->adj3_name) : (e->adj2 ? e->adj2_name : e->adj_name);
+    return e->adj3 ? (h2 ? e->adj3_h2_name : (f2 ? e->adj3_f2_name : e->adj3_name)) : (e->adj2 ? e->adj2_name : e->adj_name);
 }
 
 // range-fault words of the split-fp16 kernels, one per workgroup, at the tail of the workspace
@@ -2761,9 +2772,9 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     const bool v1 = !discrete && ((p->flags & NCDE_FLAG_ADJOINT_V1) != 0 || (e->adj2 == nullptr && e->adj3 == nullptr));
     const bool v3 = discrete || (!v1 && e->adj3 != nullptr && !(p->flags & NCDE_FLAG_ADJOINT_V2));
     const bool v2 = !v1 && !v3;
-    // split-fp16 adjoint: experimental (NCDE_FLAG_ADJOINT_SPLIT_FP16) -- faster when it works, but its runs were not always reproducible
-    // bit for bit under repetition; the default stays the split-bf16 kernel
-    const int hp = (v3 && (p->flags & NCDE_FLAG_ADJOINT_SPLIT_FP16) && !(p->flags & (NCDE_FLAG_SPLIT_BF16 | 0x200u))) ? 1 : 0;
+    // hp = the kernel's HP: 2 (default) forward-side GEMMs of the chain waves split-fp16, 0 (NCDE_FLAG_SPLIT_BF16) all split-bf16,
+    // 1 (NCDE_FLAG_ADJOINT_SPLIT_FP16, experimental: DESIGN.md section 5.4c) everything split-fp16
+    const int hp = (!v3 || (p->flags & (NCDE_FLAG_SPLIT_BF16 | 0x200u))) ? 0 : ((p->flags & NCDE_FLAG_ADJOINT_SPLIT_FP16) ? 1 : 2);
     FwdFn fn = discrete ? e->adj3_disc(p->interp, p->method, hp)
                         : (v1 ? e->adj(p->interp, p->method) : (v3 ? e->adj3(p->interp, p->method, hp) : e->adj2(p->interp, p->method)));
     if (!fn) return NCDE_ERR_UNSUPPORTED;
@@ -2793,7 +2804,8 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     }
     if (p->flags & NCDE_FLAG_DEBUG_PROFILE) {  // phase-cycle counters -> tail of the workspace [n_wg][NW][6] u64
         if (!(e->shape.H == 32 && e->shape.C == 20 && p->interp == NCDE_INTERP_LINEAR && p->method == NCDE_RK4_38)) return NCDE_ERR_UNSUPPORTED;
-        fn = v3 ? (hp ? ncde_adj_fast3<3, 20, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1, 0, 1> : ncde_adj_fast3<3, 20, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>)
+        fn = v3 ? (hp == 2 ? ncde_adj_fast3<3, 20, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1, 0, 2>
+                           : (hp == 1 ? ncde_adj_fast3<3, 20, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1, 0, 1> : ncde_adj_fast3<3, 20, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>))
                 : (v2 ? ncde_adj_fast2<32, 32, 20, 3, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1> : ncde_adj_fast<32, 32, 20, 3, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>);
         a.out = (float*)ws + (size_t)y.n_wg * y.theta_size + 64;
     }

@@ -493,7 +493,11 @@ def test_fast_kernels_vs_oracle(shape, interp, method, seq, gpu_lib):
     for k, e in _grad_errors(case, iso).items():
         assert e <= TIGHT_G, ("adjoint kernel on oracle z_out", res["kernels"][1], k, e)
     if H == 32:
-        assert res["kernels"][1].startswith("ncde_adj_fast3") and "bf16x3" in res["kernels"][1], res["kernels"]   # default: chain + gradient waves, split-bf16
+        # default: chain + gradient waves; forward-side GEMMs of the chain waves split-fp16, the cotangent side split-bf16
+        assert res["kernels"][1].startswith("ncde_adj_fast3") and "fp16x2 + bf16x3" in res["kernels"][1], res["kernels"]
+        isob = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_SPLIT_BF16)             # all split-bf16
+        for k, e in _grad_errors(case, isob).items():
+            assert e <= TIGHT_G, ("split-bf16 adjoint kernel on oracle z_out", k, e)
         for fl, nm in ((_lib.FLAG_ADJOINT_V1, "single-role"), (_lib.FLAG_ADJOINT_V2, "chain+grad fp32 chain"),
                        (_lib.FLAG_ADJOINT_V4, "decoupled y / cotangent waves")):      # also the other specialised adjoint variants
             iso1 = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=fl)
@@ -543,6 +547,32 @@ def test_split_fp16_forward_range_fault_is_reexecuted(interp, method, gpu_lib):
         assert np.array_equal(r16["z_out"][:16], plain["z_out"][:16]) and np.array_equal(r16["z_out"][32:], plain["z_out"][32:])
         scale = np.abs(zo).max(axis=tuple(range(1, zo.ndim)), keepdims=True)                   # per sample: the outlier is 1e5 x the rest
         assert float((np.abs(r16["z_out"] - zo) / scale).max()) <= TIGHT_Z
+
+
+@pytest.mark.parametrize("disc", [False, True])
+def test_split_fp16_adjoint_range_fault_is_reexecuted(disc, gpu_lib):
+    """The default adjoint / discrete-backward kernel recomputes the forward side of each stage in split-fp16 and speculates on the
+    fp16 range like the forward kernel does.  One sample of the middle tile gets a state large enough to overflow: that tile's dz0
+    rows must be bit-identical to the all-split-bf16 run (the tile was re-executed by that kernel), the other tiles' rows
+    bit-identical to the run without the outlier, and the parameter gradients must agree with the all-split-bf16 run to fp32 round-off."""
+    import gpu_util
+    from ncde_amd import _lib
+    case = _seeded_case("linear", "rk4", False, B=37, L=6, C=20, H=32, HH=32, nl=3, seed=313)
+    z = case["expect"]["z_out"].copy()
+    rec = case["stage_record"].copy()
+    kw = {}
+    plain = gpu_util.run_adjoint_direct(case, z, stages=rec if disc else None)
+    z[21] *= 4.0e5
+    rec[:, 21] *= 4.0e5
+    if disc:
+        kw["stages"] = rec
+    r16 = gpu_util.run_adjoint_direct(case, z, **kw)
+    rbf = gpu_util.run_adjoint_direct(case, z, flags=_lib.FLAG_SPLIT_BF16, **kw)
+    assert np.isfinite(r16["dz0"]).all()
+    assert np.array_equal(r16["dz0"][16:32], rbf["dz0"][16:32])
+    assert np.array_equal(r16["dz0"][:16], plain["dz0"][:16]) and np.array_equal(r16["dz0"][32:], plain["dz0"][32:])
+    for k in rbf["grads"]:
+        assert gu.relerr(r16["grads"][k], rbf["grads"][k]) <= TIGHT_G, k
 
 
 def test_split_fp16_forward_is_reproducible_under_repetition(gpu_lib):
