@@ -11,14 +11,28 @@ ap = argparse.ArgumentParser()
 ap.add_argument("root"); ap.add_argument("out")
 ap.add_argument("--config", default="cfg2"); ap.add_argument("--batch", type=int, default=4096); ap.add_argument("--note", default="")
 a = ap.parse_args()
-acc = defaultdict(lambda: defaultdict(list))
+# Counters are collected per full kernel name (template arguments included): the split-fp16 kernels are followed by a launch of
+# the split-bf16 instantiation of the SAME kernel template that re-executes range-faulted tiles (normally none -- every workgroup
+# exits at once).  Per base name the instantiation that does the work (largest average counter values) is reported under the base
+# name, any other one under "<base name>|<template arguments>".
+full = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(a.root, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
         if "ncde_" not in name:
             continue
-        short = name.split("ncde_")[1].split("(")[0].split("<")[0]
-        acc["ncde_" + short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        body = name.split("ncde_")[1].split("(")[0]
+        full["ncde_" + body][r["Counter_Name"]].append(float(r["Counter_Value"]))
+by_base = defaultdict(list)
+for k in full:
+    by_base[k.split("<")[0]].append(k)
+acc = {}
+for base, ks in by_base.items():
+    weight = lambda k: sum(sum(v) / len(v) for v in full[k].values())      # noqa: E731
+    ks.sort(key=weight, reverse=True)
+    acc[base] = full[ks[0]]
+    for k in ks[1:]:
+        acc[base + "|" + k[len(base):]] = full[k]
 res = {}
 for k, cs in acc.items():
     d = {c: sum(v) / len(v) for c, v in cs.items()}
