@@ -17,6 +17,19 @@
 #ifndef NCDE_H2_PK
 #define NCDE_H2_PK 0
 #endif
+// HP = 2 (the default adjoint): hidden-layer dW/db of the previous stage behind barrier A (dL/dpre images double-buffered) / all five
+// dWo blocks behind barrier A -- both shorten what the gradient waves do before barrier A, where the chain waves wait for them
+#ifndef NCDE_F2_DW_LATE
+#define NCDE_F2_DW_LATE 0
+#endif
+// HP = 2: dL/dx_L = Wo^T dP as split-bf16 (60 x 16-cycle MFMAs per stage instead of 80 x 32-cycle fp32 ones); the hi and mid pieces of
+// Wo^T take the 80 registers the fp32 operand took, the lo pieces live in the LDS region the chain waves' Wo lo pieces used to occupy
+#ifndef NCDE_F2_DXL_BF3
+#define NCDE_F2_DXL_BF3 1
+#endif
+#ifndef NCDE_F2_DWO_EARLY
+#define NCDE_F2_DWO_EARLY 0
+#endif
 #ifndef NCDE_H2_DW_LATE
 #define NCDE_H2_DW_LATE 1
 #endif
@@ -1725,14 +1738,17 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
     float* ximg = tiles + NW * NTILE * 256;            // [2][XROWS][16]          by stage parity (chain wave 0)
     float* dpimg = ximg + 2 * XROWS * 16;              // [NDP][NL][HH][16]       (chain wave 0); NDP = 2 (by stage parity) when the
                                                        // gradient waves consume it behind barrier A of the NEXT stage (HP = 1)
-    constexpr int NDP = (HPC != 0 && NCDE_H2_DW_LATE != 0) ? 2 : 1;
+    constexpr int NDP = ((HP == 1 && NCDE_H2_DW_LATE != 0) || (HP == 2 && NCDE_F2_DW_LATE != 0)) ? 2 : 1;
+    constexpr bool DXL3 = HP == 2 && NCDE_F2_DXL_BF3 != 0;
+    constexpr bool DWO0_LATE = (HP == 1 && NCDE_H2_DWO_EARLY == 0) || (HP == 2 && NCDE_F2_DWO_EARLY == 0);   // block 0 behind barrier A too
     int* flags = reinterpret_cast<int*>(dpimg + NDP * NL * HH * 16);  // [NW][NFLAG]
     float* biasL = reinterpret_cast<float*>(flags + NW * NFLAG);      // [2][HT][4 g][4 r]: b[8g + 4t + r]
     unsigned* w1T3 = reinterpret_cast<unsigned*>(biasL + 2 * HT * 16);  // [HT][NP][64][4]  split W1^T A operands
     unsigned* w0T3 = w1T3 + HT * NP * 256;                            // [NW][NP][64][4]   split W0^T (own state rows)
     unsigned* woLo = w0T3 + NW * NP * 256;                            // [NW][NB][CQ][64][4] lo pieces: of the chain waves' Wo A operands
                                                                       // (HP = 0) / of the gradient waves' Wo^T A operands (HP = 1)
-    unsigned* w1S3 = woLo + NW * NB * CQ * 256;                       // [2 layers][HT][NPF][64][4]  split W0 / W1 (forward) A operands
+    unsigned* w1S3 = woLo + ((HP == 2 && !DXL3) ? 0 : NW * NB * CQ * 256);       // [2 layers][HT][NPF][64][4]  split W0 / W1 (forward) A operands
+                                                                      // (HP = 2 has no lo-piece image: nobody reads one)
     float* amax = reinterpret_cast<float*>(w1S3 + 2 * HT * NPF * 256); // [NW] max |a| of each chain wave's state rows; [NW] = fault word
     int* fault_s = reinterpret_cast<int*>(amax + NW);
     float mx = 0.0f;              // largest operand magnitude the split-fp16 GEMMs have seen (ncde_bf3.h)
@@ -2205,8 +2221,9 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         // A operands of the dL/dx_L GEMM, output row i <-> unit 8(i>>2)+4t'+(i&3).  HP = 0: fp32 (v_mfma_f32_16x16x4_f32), one
         // value per (tile, t', r).  HP = 1: split-fp16, K = the 32 rows of a block (= one cq): k = 8 kg + jj <-> tile nb = k >> 4,
         // row 4 g' + r = k & 15 of that tile; hi pieces in 40 registers, lo pieces in this pair's LDS image.
-        float woT[HPC ? 1 : NTILE][HT][4];
-        u32x4 woT2h[HPC ? NBLK : 1][HT];
+        float woT[(HPC || DXL3) ? 1 : NTILE][HT][4];
+        u32x4 woT2h[(HPC || DXL3) ? NBLK : 1][HT];
+        u32x4 woT3m[DXL3 ? NBLK : 1][HT];      // DXL3: (hi, mid) of the 3-way bf16 split in registers, lo in LDS
         unsigned* my_woTlo = woLo + pw * NBLK * HT * 256;
         static_assert(NBLK * HT == NB * CQ, "the lo-piece image reuses the chain waves' region");
 #pragma unroll
@@ -2216,7 +2233,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
 #pragma unroll
             for (int tp = 0; tp < HT; ++tp) {
                 const int jrow = 8 * (s >> 2) + 4 * tp + (s & 3);
-                if constexpr (HPC == 0) {
+                if constexpr (HPC == 0 && !DXL3) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int c = 4 * cq + r;
@@ -2230,9 +2247,16 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                         const int hh = 4 * (pw * NB + (kk >> 4)) + ((kk & 15) >> 2), c = 4 * cq + (kk & 3);
                         tmp[jj] = c < C ? a.Wo[(hh * C + c) * HH + jrow] : 0.0f;
                     }
-                    const Split2h sp = split8h(tmp, mx);
-                    woT2h[cq][tp] = sp.hi;
-                    *reinterpret_cast<u32x4*>(my_woTlo + ((cq * HT + tp) * 64 + lane) * 4) = sp.lo;
+                    if constexpr (DXL3) {
+                        const Split3 sp = split8(tmp);
+                        woT2h[cq][tp] = sp.hi;
+                        woT3m[cq][tp] = sp.mid;
+                        *reinterpret_cast<u32x4*>(my_woTlo + ((cq * HT + tp) * 64 + lane) * 4) = sp.lo;
+                    } else {
+                        const Split2h sp = split8h(tmp, mx);
+                        woT2h[cq][tp] = sp.hi;
+                        *reinterpret_cast<u32x4*>(my_woTlo + ((cq * HT + tp) * 64 + lane) * 4) = sp.lo;
+                    }
                 }
             }
         }
@@ -2326,19 +2350,31 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         f32x4 accJ[HT], accJx[HT];
         auto dxl_tiles = [&](auto t_lo_c, auto t_hi_c) {
             constexpr int t_lo = decltype(t_lo_c)::value, t_hi = decltype(t_hi_c)::value;
-            if constexpr (HPC != 0) {        // one block: B = dP of the 32 rows of this block for sample s, k = 8g + jj
+            if constexpr (HPC != 0 || DXL3) {        // one block: B = dP of the 32 rows of this block for sample s, k = 8g + jj
                 static_assert(t_hi - t_lo == 2, "a block is two tiles");
                 float bv[8];
                 const float* tl = my_tiles + (t_lo + (g >> 1)) * 256 + (8 * (g & 1)) * 16 + s;
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) bv[jj] = tl[jj * 16];
-                const Split2h Bq = split8h(bv, mx);
+                if constexpr (DXL3) {
+                    const Split3 Bq = split8(bv);
 #pragma unroll
-                for (int tt = 0; tt < HT; ++tt) {
-                    Split2h Aw;
-                    Aw.hi = woT2h[t_lo / 2][tt];
-                    Aw.lo = *reinterpret_cast<const u32x4*>(my_woTlo + (((t_lo / 2) * HT + tt) * 64 + lane) * 4);
-                    mfma_split2(Aw, Bq, accJ[tt], accJx[tt]);
+                    for (int tt = 0; tt < HT; ++tt) {
+                        Split3 Aw;
+                        Aw.hi = woT2h[t_lo / 2][tt];
+                        Aw.mid = woT3m[t_lo / 2][tt];
+                        Aw.lo = *reinterpret_cast<const u32x4*>(my_woTlo + (((t_lo / 2) * HT + tt) * 64 + lane) * 4);
+                        accJ[tt] = mfma_split(Aw, Bq, accJ[tt]);
+                    }
+                } else {
+                    const Split2h Bq = split8h(bv, mx);
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt) {
+                        Split2h Aw;
+                        Aw.hi = woT2h[t_lo / 2][tt];
+                        Aw.lo = *reinterpret_cast<const u32x4*>(my_woTlo + (((t_lo / 2) * HT + tt) * 64 + lane) * 4);
+                        mfma_split2(Aw, Bq, accJ[tt], accJx[tt]);
+                    }
                 }
             } else {
                 float bq[t_hi - t_lo][4];
@@ -2405,7 +2441,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                     else if (blk == 3) { if constexpr (NBLK > 3) dxl_tiles(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{}); }
                     else if (blk == 4) { if constexpr (NBLK > 4) dxl_tiles(std::integral_constant<int, 8>{}, std::integral_constant<int, 10>{}); }
                     static_assert(NBLK <= 5, "extend the block dispatch");
-                    if (wq != 0.0f && blk == 1 && (HPC == 0 || NCDE_H2_DWO_EARLY != 0)) {
+                    if (wq != 0.0f && blk == 1 && !DWO0_LATE) {
                         if (!have_bs) {
                             while (__builtin_amdgcn_readfirstlane(*xflag) != sc) __builtin_amdgcn_s_sleep(1);
                             wave_lds_order();
@@ -2436,7 +2472,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                     }
 #pragma unroll
                     for (int blk = 0; blk < NBLK; ++blk)
-                        if (blk >= 1 || (HPC != 0 && NCDE_H2_DWO_EARLY == 0)) dwo_block(Bs, wq, blk);
+                        if (blk >= 1 || DWO0_LATE) dwo_block(Bs, wq, blk);
 
                 }
                 __syncthreads();  // barrier B
@@ -2620,10 +2656,10 @@ template <int NL, int C>
 size_t adj3_lds_bytes(int interp, int hp) {   // hp: the kernel's HP template argument (0, 1, 2)
     constexpr int H = 32, HH = 32, NW = 4, HT = 2, CP = (C + 3) & ~3, CQ = CP / 4, NB = 2, NTILE = NB * CQ;
     const int DXW = interp == NCDE_INTERP_LINEAR ? CP : 3 * CP;
-    const int NPF = hp ? 2 : 3, NP = hp == 1 ? 2 : 3, NDP = (hp == 1 && NCDE_H2_DW_LATE) ? 2 : 1;
+    const int NPF = hp ? 2 : 3, NP = hp == 1 ? 2 : 3, NDP = ((hp == 1 && NCDE_H2_DW_LATE) || (hp == 2 && NCDE_F2_DW_LATE)) ? 2 : 1;
     return sizeof(float) * (size_t)(2 * H * 16 + 3 * 16 * DXW + NW * HH * 16 + NW * NTILE * 16 + NW * NTILE * 256 +
                                     2 * (H + NL * HH) * 16 + NDP * NL * HH * 16 + NW * (NTILE + 2) + 2 * HT * 16 +
-                                    HT * NP * 256 + NW * NP * 256 + NW * NB * CQ * 256 + 2 * HT * NPF * 256 + NW + 4);
+                                    HT * NP * 256 + NW * NP * 256 + ((hp == 2 && !NCDE_F2_DXL_BF3) ? 0 : NW * NB * CQ * 256) + 2 * HT * NPF * 256 + NW + 4);
 }
 
 template <int H, int HH, int C, int NL, int NW>
