@@ -1738,7 +1738,8 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
     float* ximg = tiles + NW * NTILE * 256;            // [2][XROWS][16]          by stage parity (chain wave 0)
     float* dpimg = ximg + 2 * XROWS * 16;              // [NDP][NL][HH][16]       (chain wave 0); NDP = 2 (by stage parity) when the
                                                        // gradient waves consume it behind barrier A of the NEXT stage (HP = 1)
-    constexpr int NDP = ((HP == 1 && NCDE_H2_DW_LATE != 0) || (HP == 2 && NCDE_F2_DW_LATE != 0)) ? 2 : 1;
+    // (HP = 2: only where the second image fits -- the cubic control path stages three coefficient rows per piece and is at the LDS limit)
+    constexpr int NDP = ((HP == 1 && NCDE_H2_DW_LATE != 0) || (HP == 2 && NCDE_F2_DW_LATE != 0 && INTERP == NCDE_INTERP_LINEAR)) ? 2 : 1;
     constexpr bool DXL3 = HP == 2 && NCDE_F2_DXL_BF3 != 0;
     constexpr bool DWO0_LATE = (HP == 1 && NCDE_H2_DWO_EARLY == 0) || (HP == 2 && NCDE_F2_DWO_EARLY == 0);   // block 0 behind barrier A too
     int* flags = reinterpret_cast<int*>(dpimg + NDP * NL * HH * 16);  // [NW][NFLAG]
@@ -2656,7 +2657,7 @@ template <int NL, int C>
 size_t adj3_lds_bytes(int interp, int hp) {   // hp: the kernel's HP template argument (0, 1, 2)
     constexpr int H = 32, HH = 32, NW = 4, HT = 2, CP = (C + 3) & ~3, CQ = CP / 4, NB = 2, NTILE = NB * CQ;
     const int DXW = interp == NCDE_INTERP_LINEAR ? CP : 3 * CP;
-    const int NPF = hp ? 2 : 3, NP = hp == 1 ? 2 : 3, NDP = ((hp == 1 && NCDE_H2_DW_LATE) || (hp == 2 && NCDE_F2_DW_LATE)) ? 2 : 1;
+    const int NPF = hp ? 2 : 3, NP = hp == 1 ? 2 : 3, NDP = ((hp == 1 && NCDE_H2_DW_LATE) || (hp == 2 && NCDE_F2_DW_LATE && interp == NCDE_INTERP_LINEAR)) ? 2 : 1;
     return sizeof(float) * (size_t)(2 * H * 16 + 3 * 16 * DXW + NW * HH * 16 + NW * NTILE * 16 + NW * NTILE * 256 +
                                     2 * (H + NL * HH) * 16 + NDP * NL * HH * 16 + NW * (NTILE + 2) + 2 * HT * 16 +
                                     HT * NP * 256 + NW * NP * 256 + ((hp == 2 && !NCDE_F2_DXL_BF3) ? 0 : NW * NB * CQ * 256) + 2 * HT * NPF * 256 + NW + 4);

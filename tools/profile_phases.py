@@ -15,8 +15,8 @@ spec = model.func.fused_spec()
 with torch.no_grad():
     z0 = model.initial_linear(coeffs[:, 0]).contiguous()
 lib = _lib.lib()
-for flags, label in ((4, "fp32-mfma plain"), (0x104, "fp32-mfma instrumented"), (0, "split-bf16 plain"), (0x100, "split-bf16 instrumented"),
-                     (64, "split-fp16 plain"), (0x140, "split-fp16 instrumented")):
+for flags, label in ((4, "fp32-mfma plain"), (0x104, "fp32-mfma instrumented"), (64, "split-bf16 plain"), (0x140, "split-bf16 instrumented"),
+                     (0, "split-fp16 plain (default)"), (0x100, "split-fp16 instrumented")):
     p = solver.build_problem(coeffs, "linear", z0, spec, "rk4", _lib.OUT_INTERVAL, flags)
     ws = torch.zeros(int(lib.ncde_workspace_bytes(ctypes.byref(p), 0)), dtype=torch.uint8, device="cuda")
     out = torch.empty(B, 2, 32, device="cuda")
@@ -35,7 +35,7 @@ for flags, label in ((4, "fp32-mfma plain"), (0x104, "fp32-mfma instrumented"), 
 
 # ---- adjoint ----
 theta = 32*32+32+32*32+32+640*32+640
-for flags, label in ((0, "adj v3 plain"), (0x100, "adj v3 instrumented"), (64, "adj v3 split-fp16 plain"), (0x140, "adj v3 split-fp16 instrumented")):
+for flags, label in ((64, "adj v3 all split-bf16 plain"), (0x140, "adj v3 all split-bf16 instrumented"), (0, "adj v3 default plain"), (0x100, "adj v3 default instrumented")):
     p = solver.build_problem(coeffs, "linear", z0, spec, "rk4", _lib.OUT_INTERVAL, flags)
     ws = torch.zeros(int(lib.ncde_workspace_bytes(ctypes.byref(p), 1)), dtype=torch.uint8, device="cuda")
     out = torch.randn(B, 2, 32, device="cuda"); gout = torch.randn(B, 2, 32, device="cuda")
