@@ -575,6 +575,46 @@ def test_split_fp16_adjoint_range_fault_is_reexecuted(disc, gpu_lib):
         assert gu.relerr(r16["grads"][k], rbf["grads"][k]) <= TIGHT_G, k
 
 
+@pytest.mark.parametrize("interp,method,seq", [("linear", "rk4", False), ("cubic", "midpoint", True), ("cubic", "euler", False)])
+def test_default_adjoint_is_reproducible_under_repetition(interp, method, seq, gpu_lib):
+    """The default adjoint / discrete-backward kernel (chain waves + gradient waves handing dP tiles, x images and dL/dx_L partials
+    to each other through LDS flags and two barriers per stage): ten launches on the oracle's z, ragged three-workgroup batch, must be
+    bit-identical and within the tight tolerance.  (An experimental all-split-fp16 variant of this kernel failed exactly this kind
+    of test -- DESIGN.md section 5.4c; `tools/stress_adj.py` runs the full matrix.)"""
+    import gpu_util
+    case = _seeded_case(interp, method, seq, B=37, L=7, C=20, H=32, HH=32, nl=3, seed=77)
+    ex = case["expect"]
+    for kw, pre in (({}, ""), ({"stages": case["stage_record"]}, "bp_")):
+        first = None
+        for _ in range(10):
+            iso = gpu_util.run_adjoint_direct(case, ex["z_out"], **kw)
+            for k, e in _grad_errors(case, iso, pre).items():
+                assert e <= TIGHT_G, (interp, method, pre, k, e)
+            if first is None:
+                first = iso
+            else:
+                assert np.array_equal(first["dz0"], iso["dz0"]) and all(np.array_equal(first["grads"][k], iso["grads"][k]) for k in iso["grads"])
+
+
+@pytest.mark.parametrize("nl", [1, 2, 4])
+def test_fast_forward_with_other_layer_counts(nl, gpu_lib):
+    """The specialised forward kernels have a runtime layer count besides the unrolled nl = 3 instantiation (and the specialised
+    adjoint exists for nl = 3 only: other counts take the batch-tiled / generic backward).  nl = 1, 2, 4 at both specialised
+    shapes, split-fp16 (default) and split-bf16, against the oracle -- forward and end-to-end gradients."""
+    import gpu_util
+    from ncde_amd import _lib
+    for (C, H, HH, _) in FAST_SHAPES:
+        case = _seeded_case("linear", "rk4", True, B=21, L=6, C=C, H=H, HH=HH, nl=nl, seed=400 + nl)
+        ex = case["expect"]
+        res = gpu_util.run_case(case)
+        assert res["kernels"][0].startswith("ncde_fwd_fast_bf3") and "fp16x2" in res["kernels"][0], res["kernels"]
+        assert gu.relerr(res["z_out"], ex["z_out"]) <= TIGHT_Z
+        resb = gpu_util.run_case(case, flags=_lib.FLAG_SPLIT_BF16, need_grads=False)
+        assert gu.relerr(resb["z_out"], ex["z_out"]) <= TIGHT_Z
+        for k, e in _grad_errors(case, res).items():
+            assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), (nl, C, k, e)
+
+
 def test_split_fp16_forward_is_reproducible_under_repetition(gpu_lib):
     """Ten launches of the default (split-fp16 + re-execution launch) forward kernels: bit-identical."""
     import gpu_util
