@@ -2851,11 +2851,7 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     a.fault = hp ? reinterpret_cast<int*>(static_cast<char*>(ws) + ncde_fast_workspace_bytes(p, discrete ? 2 : 1) - fault_bytes(y)) : nullptr;
     hipLaunchKernelGGL(fn, dim3(y.n_wg), dim3(v1 ? 64 * e->nw : 512), lds, st, a);
     if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
-#ifdef NCDE_H2_NOFIXUP
-    if (false) {
-#else
-    if (hp && !(p->flags & NCDE_FLAG_DEBUG_PROFILE)) {  // re-execution of range-faulted tiles in split-bf16
-#endif (normally none: every workgroup exits at once)
+    if (hp && !(p->flags & NCDE_FLAG_DEBUG_PROFILE)) {  // re-execution of range-faulted tiles in split-bf16 (normally none: every workgroup exits at once)
         FwdFn fx = discrete ? e->adj3_disc(p->interp, p->method, 0) : e->adj3(p->interp, p->method, 0);
         const size_t ldx = e->adj3_lds(p->interp, 0);
         if (ncde_lds_optin((const void*)fx, ldx) != hipSuccess) return NCDE_ERR_HIP;
