@@ -14,9 +14,6 @@
 // Reference semantics: see ncde_generic.hip (same stage tables, same knot-index rule).
 #include "ncde_fast.h"
 #include "ncde_fast4.h"
-#ifndef NCDE_H2_PK
-#define NCDE_H2_PK 0
-#endif
 // HP = 2 (the default adjoint): hidden-layer dW/db of the previous stage behind barrier A (dL/dpre images double-buffered) / all five
 // dWo blocks behind barrier A -- both shorten what the gradient waves do before barrier A, where the chain waves wait for them
 #ifndef NCDE_F2_DW_LATE
@@ -498,12 +495,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
             NCDE_TICK(0)
             // ---- output layer tiles owned by this wave: tanh + channel contraction -----------------------
             float kout[NB];
-            f32x2 kout2[NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                kout[nb] = 0.0f;
-                kout2[nb] = (f32x2){0.0f, 0.0f};
-            }
+            for (int nb = 0; nb < NB; ++nb) kout[nb] = 0.0f;
 #pragma unroll
             for (int cq = 0; cq < CQ; ++cq) {
                 typename SO::Acc oa[NB];
@@ -529,27 +522,10 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
                         dx[r] = cb[r] + inner * frac;
                     }
                 }
-                if constexpr (HP != 0 && NCDE_H2_PK != 0) {   // the same arithmetic on pairs (v_pk_add / v_pk_fma): even and odd channels accumulate apart
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
+                for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const f32x2 e = {__builtin_amdgcn_exp2f(o[nb][2 * q]), __builtin_amdgcn_exp2f(o[nb][2 * q + 1])};
-                            const f32x2 d = e + 1.0f;
-                            const f32x2 rr = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-                            const f32x2 th = __builtin_elementwise_fma((f32x2){-2.0f, -2.0f}, rr, (f32x2){1.0f, 1.0f});
-                            kout2[nb] = __builtin_elementwise_fma(th, (f32x2){dx[2 * q], dx[2 * q + 1]}, kout2[nb]);
-                        }
-                } else {
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) kout[nb] = fmaf(tanh_prescaled(o[nb][r]), dx[r], kout[nb]);
-                }
-            }
-            if constexpr (HP != 0 && NCDE_H2_PK != 0) {
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) kout[nb] = kout2[nb][0] + kout2[nb][1];
+                    for (int r = 0; r < 4; ++r) kout[nb] = fmaf(tanh_prescaled(o[nb][r]), dx[r], kout[nb]);
             }
             NCDE_TICK(1)
             float ys[NB];
@@ -1695,6 +1671,12 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
 //     partial per tile group right behind the chain wave and this stage's dWo blocks in its shadow; only the
 //     hidden-layer dW/db lag one stage (x images double-buffered by stage parity);
 //   * the lo pieces of the output-layer weights and the split W1^T / W0^T A-operands live in LDS images.
+// HP selects the split arithmetic (DESIGN.md sections 5.2b, 5.4a, 5.4c):
+//   0  everything 3-way split-bf16; dL/dx_L as fp32 MFMA (round-2 kernel; also the instantiation that re-executes range-faulted
+//      tiles of the other two: `only_faulted`)
+//   2  the DEFAULT: forward-side GEMMs of the chain waves (recompute, output tiles) 2-way split-fp16; dL/dx_L = Wo^T dP as split-bf16
+//      with the lo pieces of Wo^T in the LDS region the chain waves' Wo lo pieces no longer need; all dWo blocks behind barrier A
+//   1  experimental (NCDE_FLAG_ADJOINT_SPLIT_FP16): everything split-fp16, cotangents normalised by a per-workgroup power of two
 template <int NL, int C, int INTERP, int METHOD, int PROF = 0, int DISC = 0, int HP = 0>
 __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
     unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
@@ -1997,13 +1979,9 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                 }
                 // ---- output tiles: P, r = 1/(exp(2P)+1), f, dP -> LDS tile + flag -----------------------------------
                 float kout[NB];
-                f32x2 kout2[NB];
                 float sdx = 0.0f;
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    kout[nb] = 0.0f;
-                    kout2[nb] = (f32x2){0.0f, 0.0f};
-                }
+                for (int nb = 0; nb < NB; ++nb) kout[nb] = 0.0f;
 #pragma unroll
                 for (int cq = 0; cq < CQ; ++cq) {
                     f32x4 o[NB];
@@ -2033,35 +2011,17 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                         const int tau = cq * NB + nb;
                         float* tl = my_tiles + tau * 256;
                         const float a4 = (4.0f * sig) * as_[nb];     // dP, and everything downstream of it, in units of sig
-                        if constexpr (HPF != 0 && NCDE_H2_PK != 0) {   // on pairs (v_pk_add / v_pk_fma / v_pk_mul): even and odd channels accumulate apart
 #pragma unroll
-                            for (int q = 0; q < 2; ++q) {
-                                const f32x2 e = {__builtin_amdgcn_exp2f(o[nb][2 * q]), __builtin_amdgcn_exp2f(o[nb][2 * q + 1])};
-                                const f32x2 d = e + 1.0f;
-                                const f32x2 rr = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-                                const f32x2 dx2 = {dx[2 * q], dx[2 * q + 1]};
-                                if constexpr (DISC == 0) kout2[nb] = __builtin_elementwise_fma(rr, dx2, kout2[nb]);
-                                const f32x2 t2 = (dx2 * a4) * __builtin_elementwise_fma(-rr, rr, rr);
-                                tl[(4 * g + 2 * q) * 16 + s] = t2[0];
-                                tl[(4 * g + 2 * q + 1) * 16 + s] = t2[1];
-                            }
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float rr = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[nb][r]) + 1.0f);
-                                if constexpr (DISC == 0) kout[nb] = fmaf(rr, dx[r], kout[nb]);
-                                tl[(4 * g + r) * 16 + s] = (a4 * dx[r]) * fmaf(-rr, rr, rr);
-                            }
+                        for (int r = 0; r < 4; ++r) {
+                            const float rr = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[nb][r]) + 1.0f);
+                            if constexpr (DISC == 0) kout[nb] = fmaf(rr, dx[r], kout[nb]);
+                            tl[(4 * g + r) * 16 + s] = (a4 * dx[r]) * fmaf(-rr, rr, rr);
                         }
                         if (nb == NB - 1) {      // one publication per block (= cq, both tiles): the gradient wave polls odd tiles only
                             wave_lds_order();
                             my_flags[tau] = sc;
                         }
                     }
-                }
-                if constexpr (HPF != 0 && NCDE_H2_PK != 0) {
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) kout[nb] = kout2[nb][0] + kout2[nb][1];
                 }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) kout[nb] = fmaf(-2.0f, kout[nb], sdx);
