@@ -14,7 +14,9 @@
  *   - every pointer inside NcdeProblem is a DEVICE pointer to fp32 data owned by the caller;
  *   - the library is stateless and re-entrant; work is enqueued on `stream` (a hipStream_t, NULL =
  *     default stream) and the calls never synchronise and never allocate;
- *   - scratch memory is passed in: ask ncde_workspace_bytes(), hand over `workspace`;
+ *   - scratch memory is passed in: ask ncde_workspace_bytes(), hand over `workspace` (per-workgroup gradient partials; for the
+ *     specialised kernels also one range-fault word per 16-sample tile -- they multiply in 2-way split-fp16 and re-execute a tile
+ *     in 3-way split-bf16, with a second launch on the same stream, when its operands leave the fp16 range: NCDE_FLAG_SPLIT_BF16);
  *   - return value 0 = success, negative = NcdeStatus; ncde_last_error_string() describes the last
  *     failure of the calling thread.  Nothing throws across the boundary.
  */

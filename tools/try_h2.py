@@ -48,7 +48,7 @@ def ref64():
 with torch.no_grad():
     zr = ref64()
 print("max |z_T| %.3f" % float(zr.abs().max()))
-for flags, label in ((4, "fp32-mfma"), (0, "split-bf16"), (64, "split-fp16")):
+for flags, label in ((4, "fp32-mfma"), (64, "split-bf16"), (0, "split-fp16")):      # 0 = default, 64 = NCDE_FLAG_SPLIT_BF16
     p = solver.build_problem(coeffs, "linear", z0, spec, "rk4", _lib.OUT_INTERVAL, flags)
     ws = torch.zeros(int(lib.ncde_workspace_bytes(ctypes.byref(p), 0)), dtype=torch.uint8, device="cuda")
     out = torch.empty(B, 2, 32, device="cuda")

@@ -1,4 +1,4 @@
-"""Split-fp16 (flag 64) vs split-bf16 specialised kernels: errors against the oracle on the small seeded cases of the parity test, then
+"""Default (split-fp16 forward side, flags 0) vs all-split-bf16 (NCDE_FLAG_SPLIT_BF16 = 64) specialised kernels: errors against the oracle on the small seeded cases of the parity test, then
 timing of forward + adjoint at cfg2 size."""
 import ctypes, os, sys
 import numpy as np, torch
