@@ -69,8 +69,8 @@ typedef enum NcdeOutput { NCDE_OUT_INTERVAL = 0, NCDE_OUT_KNOTS = 1, NCDE_OUT_TI
 #define NCDE_FLAG_SPLIT_BF16 64u    /* specialised forward kernels: 3-way split-bf16 GEMMs (6 MFMAs per product, any operand magnitude) instead of
                                        the default 2-way split-fp16 ones (3 MFMAs per product; sample tiles whose operands leave the fp16 range
                                        are re-executed by the split-bf16 kernel, so results do not depend on this flag beyond fp32 round-off) */
-#define NCDE_FLAG_ADJOINT_SPLIT_FP16 128u /* experimental: split-fp16 GEMMs in the specialised adjoint / discrete-backward kernel too (default:
-                                       split-bf16).  Not for production use: see DESIGN.md section 5.4c */
+#define NCDE_FLAG_ADJOINT_SPLIT_FP16 128u /* development builds (-DNCDE_DEV_KNOBS) only, ignored otherwise: split-fp16 GEMMs on the cotangent
+                                       side of the specialised adjoint too (not reproducible run to run) */
 #define NCDE_FLAG_DEBUG_PROFILE 0x100u /* development: instrumented kernel variant, cycle counters land in the workspace */
 #define NCDE_FLAG_TILED_NS1 0x1000u    /* batch-tiled forward: force 1 / 2 / 4 sixteen-sample tiles per workgroup     */
 #define NCDE_FLAG_TILED_NS2 0x2000u    /*   (default: the largest that still gives >= 256 workgroups)                 */

@@ -2585,10 +2585,20 @@ size_t adj2_lds_bytes(int interp) {
                                     (HH / 16) * (HH / 16) * 256 + NW * (HH / 16) * 256);
 }
 
+// The all-split-fp16 instantiations (HP = 1) exist in development builds only (-DNCDE_DEV_KNOBS): the shipped
+// library neither contains them nor honours NCDE_FLAG_ADJOINT_SPLIT_FP16.
+#ifdef NCDE_DEV_KNOBS
+#define NCDE_ADJ3_HP1(NL_, C_, I_, M_, P_, D_) ncde_adj_fast3<NL_, C_, I_, M_, P_, D_, 1>
+#define NCDE_ADJ3_HP1_AVAILABLE 1
+#else
+#define NCDE_ADJ3_HP1(NL_, C_, I_, M_, P_, D_) static_cast<FwdFn>(nullptr)
+#define NCDE_ADJ3_HP1_AVAILABLE 0
+#endif
+
 template <int NL, int C>
 FwdFn pick_adj3(int interp, int method, int hp) {
 #define NCDE_PICK(I, M) \
-    if (interp == I && method == M) return hp == 2 ? ncde_adj_fast3<NL, C, I, M, 0, 0, 2> : (hp == 1 ? ncde_adj_fast3<NL, C, I, M, 0, 0, 1> : ncde_adj_fast3<NL, C, I, M>);
+    if (interp == I && method == M) return hp == 2 ? ncde_adj_fast3<NL, C, I, M, 0, 0, 2> : (hp == 1 ? NCDE_ADJ3_HP1(NL, C, I, M, 0, 0) : ncde_adj_fast3<NL, C, I, M>);
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_RK4_38)
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_MIDPOINT)
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_EULER)
@@ -2602,7 +2612,7 @@ FwdFn pick_adj3(int interp, int method, int hp) {
 template <int NL, int C>
 FwdFn pick_adj3_disc(int interp, int method, int hp) {
 #define NCDE_PICK(I, M) \
-    if (interp == I && method == M) return hp == 2 ? ncde_adj_fast3<NL, C, I, M, 0, 1, 2> : (hp == 1 ? ncde_adj_fast3<NL, C, I, M, 0, 1, 1> : ncde_adj_fast3<NL, C, I, M, 0, 1>);
+    if (interp == I && method == M) return hp == 2 ? ncde_adj_fast3<NL, C, I, M, 0, 1, 2> : (hp == 1 ? NCDE_ADJ3_HP1(NL, C, I, M, 0, 1) : ncde_adj_fast3<NL, C, I, M, 0, 1>);
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_RK4_38)
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_MIDPOINT)
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_EULER)
@@ -2707,7 +2717,7 @@ const char* ncde_fast_kernel_name(const NcdeProblem* p, int pass) {
     if (!ncde_fast_supported(p, pass)) return nullptr;
     const FastEntry* e = find_entry(p);
     const bool h2f = !(p->flags & NCDE_FLAG_SPLIT_BF16);
-    const bool h2 = h2f && (p->flags & NCDE_FLAG_ADJOINT_SPLIT_FP16);
+    const bool h2 = h2f && NCDE_ADJ3_HP1_AVAILABLE != 0 && (p->flags & NCDE_FLAG_ADJOINT_SPLIT_FP16);
     const bool f2 = h2f && !h2 && !(p->flags & 0x200u);
     if (pass == 0) return ((p->flags & NCDE_FLAG_FP32_MFMA) == 0 && e->fwd_bf3) ? (h2f ? e->fwd_h2_name : e->fwd_bf3_name) : e->fwd_name;
     if (use_v4(p, e, pass == 2)) return pass == 2 ? "ncde_adj_fast4<H32,HH32,C20,NL3,y-waves+cotangent-waves(bf16x3),discrete>"
@@ -2771,7 +2781,8 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     const bool v2 = !v1 && !v3;
     // hp = the kernel's HP: 2 (default) forward-side GEMMs of the chain waves split-fp16, 0 (NCDE_FLAG_SPLIT_BF16) all split-bf16,
     // 1 (NCDE_FLAG_ADJOINT_SPLIT_FP16, experimental: DESIGN.md section 5.4c) everything split-fp16
-    const int hp = (!v3 || (p->flags & (NCDE_FLAG_SPLIT_BF16 | 0x200u))) ? 0 : ((p->flags & NCDE_FLAG_ADJOINT_SPLIT_FP16) ? 1 : 2);
+    const int hp = (!v3 || (p->flags & (NCDE_FLAG_SPLIT_BF16 | 0x200u))) ? 0
+                   : ((NCDE_ADJ3_HP1_AVAILABLE != 0 && (p->flags & NCDE_FLAG_ADJOINT_SPLIT_FP16)) ? 1 : 2);
     FwdFn fn = discrete ? e->adj3_disc(p->interp, p->method, hp)
                         : (v1 ? e->adj(p->interp, p->method) : (v3 ? e->adj3(p->interp, p->method, hp) : e->adj2(p->interp, p->method)));
     if (!fn) return NCDE_ERR_UNSUPPORTED;
@@ -2802,7 +2813,7 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     if (p->flags & NCDE_FLAG_DEBUG_PROFILE) {  // phase-cycle counters -> tail of the workspace [n_wg][NW][6] u64
         if (!(e->shape.H == 32 && e->shape.C == 20 && p->interp == NCDE_INTERP_LINEAR && p->method == NCDE_RK4_38)) return NCDE_ERR_UNSUPPORTED;
         fn = v3 ? (hp == 2 ? ncde_adj_fast3<3, 20, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1, 0, 2>
-                           : (hp == 1 ? ncde_adj_fast3<3, 20, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1, 0, 1> : ncde_adj_fast3<3, 20, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>))
+                           : (hp == 1 ? NCDE_ADJ3_HP1(3, 20, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1, 0) : ncde_adj_fast3<3, 20, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>))
                 : (v2 ? ncde_adj_fast2<32, 32, 20, 3, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1> : ncde_adj_fast<32, 32, 20, 3, 4, NCDE_INTERP_LINEAR, NCDE_RK4_38, 1>);
         a.out = (float*)ws + (size_t)y.n_wg * y.theta_size + 64;
     }
