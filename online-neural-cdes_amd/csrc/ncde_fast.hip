@@ -14,6 +14,7 @@
 // Reference semantics: see ncde_generic.hip (same stage tables, same knot-index rule).
 #include "ncde_fast.h"
 #include "ncde_fast4.h"
+#include "ncde_fast64.h"
 // HP = 2 (the default adjoint): hidden-layer dW/db of the previous stage behind barrier A (dL/dpre images double-buffered) / all five
 // dWo blocks behind barrier A -- both shorten what the gradient waves do before barrier A, where the chain waves wait for them
 #ifndef NCDE_F2_DW_LATE
@@ -2705,7 +2706,11 @@ bool use_v4(const NcdeProblem* p, const FastEntry* e, bool discrete) {
 
 }  // namespace
 
+// H = HH = 64, C <= 4: the in-sweep adjoint of ncde_fast64.hip (the entry's own adjoint slots are empty; C < 4 has no entry at all)
+static bool use_h64(const NcdeProblem* p, int pass) { return pass >= 1 && ncde_fast64_supported(p, pass); }
+
 bool ncde_fast_supported(const NcdeProblem* p, int pass) {
+    if (use_h64(p, pass)) return true;
     const FastEntry* e = find_entry(p);
     if (!e) return false;
     if (pass == 0) return true;
@@ -2714,6 +2719,7 @@ bool ncde_fast_supported(const NcdeProblem* p, int pass) {
 }
 
 const char* ncde_fast_kernel_name(const NcdeProblem* p, int pass) {
+    if (use_h64(p, pass)) return ncde_fast64_kernel_name(p, pass);
     if (!ncde_fast_supported(p, pass)) return nullptr;
     const FastEntry* e = find_entry(p);
     const bool h2f = !(p->flags & NCDE_FLAG_SPLIT_BF16);
@@ -2732,6 +2738,7 @@ const char* ncde_fast_kernel_name(const NcdeProblem* p, int pass) {
 static int64_t fault_bytes(const Layout& y) { return ((int64_t)y.n_wg * 4 + 255) & ~(int64_t)255; }
 
 int64_t ncde_fast_workspace_bytes(const NcdeProblem* p, int pass) {
+    if (use_h64(p, pass)) return ncde_fast64_workspace_bytes(p, pass);
     if (!ncde_fast_supported(p, pass)) return NCDE_ERR_UNSUPPORTED;
     const Layout y = make_layout(p);
     if (pass == 0) return ((p->flags & NCDE_FLAG_DEBUG_PROFILE) ? 256 + (int64_t)y.n_wg * 8 * 4 * 8 : 256) + fault_bytes(y);
@@ -2773,7 +2780,7 @@ int ncde_fast_forward(const NcdeProblem* p, float* out, float* stages, void* ws,
 
 int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* grad_out, const NcdeGrads* g, void* ws,
                       size_t ws_bytes, hipStream_t st, bool main_kernel_only, bool discrete) {
-    (void)ws_bytes;
+    if (use_h64(p, discrete ? 2 : 1)) return ncde_fast64_adjoint(p, z_out, grad_out, g, ws, ws_bytes, st, main_kernel_only, discrete);
     if (!ncde_fast_supported(p, discrete ? 2 : 1)) return NCDE_ERR_UNSUPPORTED;
     const FastEntry* e = find_entry(p);
     const bool v1 = !discrete && ((p->flags & NCDE_FLAG_ADJOINT_V1) != 0 || (e->adj2 == nullptr && e->adj3 == nullptr));

@@ -505,6 +505,20 @@ def test_fast_kernels_vs_oracle(shape, interp, method, seq, gpu_lib):
                 assert e <= TIGHT_G, (nm + " adjoint kernel on oracle z_out", k, e)
         again = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_AUTO)     # hand-off protocol: bit-reproducible
         assert np.array_equal(again["dz0"], iso["dz0"]) and all(np.array_equal(again["grads"][k], iso["grads"][k]) for k in iso["grads"])
+    if H == 64:
+        # the in-sweep adjoint of ncde_fast64.hip: one / two sample tiles per workgroup, split-fp16 forward side / all fp32-input MFMA
+        assert res["kernels"][1].startswith("ncde_adj_h64") and "fp16x2" in res["kernels"][1], res["kernels"]
+        assert res["kernels"][2].startswith("ncde_adj_h64") and "discrete" in res["kernels"][2], res["kernels"]
+        for fl in (_lib.FLAG_TILED_NS1, _lib.FLAG_TILED_NS2, _lib.FLAG_TILED_NS2 | _lib.FLAG_FP32_MFMA, _lib.FLAG_TILED_NS1 | _lib.FLAG_SPLIT_BF16):
+            isn = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=fl)
+            for k, e in _grad_errors(case, isn).items():
+                assert e <= TIGHT_G, ("ncde_adj_h64 flags %#x on oracle z_out" % fl, k, e)
+            isnd = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=fl, stages=case["stage_record"])
+            for k, e in _grad_errors(case, isnd, "bp_").items():
+                assert e <= TIGHT_G, ("ncde_adj_h64 discrete flags %#x on the oracle's stage record" % fl, k, e)
+        again = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_TILED_NS2)
+        first = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_TILED_NS2)
+        assert np.array_equal(again["dz0"], first["dz0"]) and all(np.array_equal(again["grads"][k], first["grads"][k]) for k in first["grads"])
     # adjoint=False: recording forward + exact discrete backward
     resd = gpu_util.run_case(case, flags=_lib.FLAG_AUTO, adjoint=False)
     assert np.array_equal(resd["z_out"], res["z_out"])                      # recording does not change the solution
