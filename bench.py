@@ -113,6 +113,28 @@ def time_kernels(model, c, coeffs, iters=3):
     return ms_fwd, ms.value, names
 
 
+def golden_z_err(model, c, coeffs):
+    """max |z_T - z_T(reference)| / max |z_T(reference)| of the DEFAULT forward kernel (the one the step times) on the full cfg2
+    workload, against the reference's own z_T (tests/golden/g5_cfg2_full.npz, written by oracle/gen_golden.py from the imported
+    reference on the same deterministic inputs and weights).  Outside the timed region, before any optimizer step."""
+    path = os.path.join(ROOT, "tests", "golden", "g5_cfg2_full.npz")
+    if not os.path.exists(path):
+        return None
+    ref = np.load(path)["zT"]
+    if ref.shape != (coeffs.shape[0], c["H"]):
+        return None
+    spec = model.func.fused_spec()
+    with torch.no_grad():
+        z0 = model.initial_linear(coeffs[:, 0, :c["C"]]).contiguous()
+    p = solver.build_problem(coeffs, "linear", z0, spec, c["solver"], _lib.OUT_INTERVAL, 0)
+    out = torch.empty(z0.shape[0], 2, c["H"], device=coeffs.device)
+    ws = solver._workspace(p, 0, coeffs.device)
+    _lib.check(_lib.lib().ncde_forward(ctypes.byref(p), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ncde_forward")
+    zT = out[:, -1].cpu().numpy()
+    return float(np.abs(zT - ref).max() / np.abs(ref).max())
+
+
 def host_cores():
     """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box
     shows 256 logical CPUs but grants 16; spinning 256 OpenMP threads on 16 CPUs takes minutes per solve)."""
@@ -228,29 +250,64 @@ class Workload:
         return float(tmax.item()), float(loss)
 
 
-def pmc_traffic(name, config, B_local):
-    """HBM bytes per launch of kernel `name` from the committed rocprofv3 PMC summary (bench.py cannot run the profiler on
-    itself) -- only if that summary was taken on exactly the kernel sources this library is built from (fingerprint) and
-    on this workload; otherwise None."""
-    pmc = None
-    for rnd in ("r03", "r02"):
+def _pmc_summary(config, B_local):
+    """The committed rocprofv3 PMC summary of this config (bench.py cannot run the profiler on itself) -- only if it was taken on
+    exactly the kernel sources this library is built from (fingerprint) and on this workload; otherwise None."""
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_%s_summary.json" % (rnd, config))
         try:
             with open(path) as fh:
                 pmc = json.load(fh)
-            break
         except (OSError, ValueError):
             continue
-    if pmc is None:
+        meta = pmc.get("_meta", {})
+        if meta.get("source_fingerprint") == _lib.source_fingerprint() and meta.get("batch") == B_local:
+            return pmc, os.path.relpath(path, ROOT)
         return None, None
-    meta = pmc.get("_meta", {})
-    if meta.get("source_fingerprint") != _lib.source_fingerprint() or meta.get("batch") != B_local:
-        return None, None
-    for key, rec_ in pmc.items():
-        if key.startswith("ncde_") and name.startswith(key) and "hbm_read_MB_per_launch_corrected_x2" in rec_:
-            return round((rec_["hbm_read_MB_per_launch_corrected_x2"] + rec_.get("hbm_write_MB_per_launch", 0.0)) * 1e6), os.path.relpath(path, ROOT)
     return None, None
 
+
+def pmc_pass(name, config, B_local):
+    """Counters of ONE forward / backward pass: `name` is the C-ABI's kernel name of the pass, "a<...>+b<...>" when the pass is
+    several kernels (the windowed batch-tiled backward launches its sweep and its output-layer gradient kernel once per time
+    window).  HBM bytes are SUMMED over every launch of every one of them in a pass (`*_per_pass` of tools/pmc_summary.py);
+    MFMA-busy / VALU-active are those of the kernel with the most wave cycles.  None where no valid summary is committed."""
+    pmc, src = _pmc_summary(config, B_local)
+    if pmc is None:
+        return None
+    bases = [part.split("<")[0] for part in name.split("+")]
+    recs = [pmc[b] for b in bases if b in pmc]
+    if len(recs) != len(bases) or not all("hbm_read_MB_per_pass_corrected_x2" in r for r in recs):
+        return None
+    dom = max(recs, key=lambda r: r.get("SQ_WAVE_CYCLES", 0.0) * r.get("launches_per_pass", 1.0))
+    return {"traffic": round(sum(r["hbm_read_MB_per_pass_corrected_x2"] + r.get("hbm_write_MB_per_pass", 0.0) for r in recs) * 1e6),
+            "launches_per_pass": {b: r.get("launches_per_pass") for b, r in zip(bases, recs)},
+            "mfma_busy": round(dom["MfmaUtil_pct"] / 100.0, 4) if "MfmaUtil_pct" in dom else None,
+            "valu_active": round(dom["VALU_active_frac_of_wave_cycles"], 4) if "VALU_active_frac_of_wave_cycles" in dom else None,
+            "wait": round(dom["wait_frac_of_wave_cycles"], 4) if "wait_frac_of_wave_cycles" in dom else None,
+            "source": src}
+
+
+PEAK_F16_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA peak (MI355X_MICROARCH.md)
+TRANS_PER_S = 256 * 4 * 8 * 2.4e9   # quarter-rate transcendentals: 8 lanes per clock and SIMD, 1024 SIMDs, 2.4 GHz
+
+
+def issued_pipe_peak(name, backward):
+    """fp32-equivalent peak (TFLOP/s) of the matrix pipe the kernel actually issues on, read off its name tags: a 2-way split-fp16
+    product is 3 f16 MFMAs (2500 / 3), a 3-way split-bf16 product 6 bf16 MFMAs (2500 / 6), fp32-input MFMA runs at 157.3.  A backward
+    pass is 1/3 forward-side flops (stage recompute) and 2/3 cotangent-side (VJP wrt z and wrt theta): harmonic mix of the two."""
+    f16, bf16, f32 = PEAK_F16_TFLOPS / 3, PEAK_F16_TFLOPS / 6, PEAK_FP32_TFLOPS
+    if "fwd-side fp16x2 + bf16x3" in name:
+        return 1.0 / ((1 / 3) / f16 + (2 / 3) / bf16), "1/3 split-fp16 (3 f16 MFMAs per product) + 2/3 split-bf16 (6 per product)"
+    if "fwd-side fp16x2 + fp32" in name:
+        return 1.0 / ((1 / 3) / f16 + (2 / 3) / f32), "1/3 split-fp16 (3 f16 MFMAs per product) + 2/3 fp32-input MFMA"
+    if "fp16x2" in name:
+        return f16, "split-fp16: 3 f16 MFMAs per fp32 product"
+    if "bf16" in name or "bf3" in name:
+        if backward:      # batch-tiled backward: P on split-bf16, the transposed products and hidden layers on fp32-input MFMA
+            return 1.0 / ((1 / 2) / bf16 + (1 / 2) / f32), "about half split-bf16 (6 bf16 MFMAs per product), half fp32-input MFMA"
+        return bf16, "split-bf16: 6 bf16 MFMAs per fp32 product"
+    return f32, "fp32-input MFMA"
 
 
 def dtype_note(names):
@@ -275,19 +332,40 @@ def rooflines(model, c, coeffs, config, B_local, T):
     f_adj = 3 * f_fwd     # stage recompute + VJP wrt z + VJP wrt theta
     by_fwd = bytes_forward_per_sample_step(c)
 
-    def roof(ms, flops, nbytes, name):
+    tanh_per_step = stages_of(c["solver"]) * c["H"] * c["C"] * 2      # exp + rcp per tanh; the backward recomputes every tanh once
+
+    def roof(ms, flops, nbytes, name, backward):
         tf_s = flops * steps_per_launch / (ms * 1e-3) / 1e12
-        traffic, src = pmc_traffic(name, config, B_local)
-        r = {"bound": "mfma", "kernel": name, "achieved": round(tf_s, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-             "frac": round(tf_s / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-             "algorithmic_bytes_per_launch": nbytes * steps_per_launch, "ms_per_launch": round(ms, 4),
-             "hbm_algorithmic_GBs": round(nbytes * steps_per_launch / (ms * 1e-3) / 1e9, 2),
-             "hbm_frac": round(nbytes * steps_per_launch / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6)}
-        if traffic is not None:
-            r["traffic_unit"] = "bytes/launch (rocprofv3 PMC passes on these kernel sources, %s)" % src
+        pm = pmc_pass(name, config, B_local)
+        pipe_peak, pipe_note = issued_pipe_peak(name, backward)
+        alg = nbytes * steps_per_launch
+        # which unit the counters say the kernel is waiting on: the fp32 peak below is the contract's convention for `frac`
+        # (algorithmic fp32 flops / fp32 MFMA-vector peak), not a statement that the matrix pipe is the limiter
+        bound = "unmeasured"
+        if pm is not None and pm["mfma_busy"] is not None and pm["valu_active"] is not None:
+            if pm["traffic"] / (ms * 1e-3) / 1e9 > 0.5 * PEAK_HBM_GBS:
+                bound = "hbm"
+            else:
+                bound = "mfma" if pm["mfma_busy"] >= pm["valu_active"] else "valu"
+        r = {"bound": bound, "kernel": name, "achieved": round(tf_s, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+             "frac": round(tf_s / PEAK_FP32_TFLOPS, 4), "traffic": pm["traffic"] if pm else None,
+             "traffic_ratio": round(pm["traffic"] / alg, 3) if pm else None,
+             "algorithmic_bytes_per_launch": alg, "ms_per_launch": round(ms, 4),
+             "hbm_algorithmic_GBs": round(alg / (ms * 1e-3) / 1e9, 2),
+             "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6),
+             "mfma_busy": pm["mfma_busy"] if pm else None, "valu_active": pm["valu_active"] if pm else None,
+             "wait": pm["wait"] if pm else None,
+             "tanh_ceiling_ms": round(tanh_per_step * steps_per_launch / TRANS_PER_S * 1e3, 4),
+             "issued_pipe": pipe_note, "issued_pipe_peak": round(pipe_peak, 1), "frac_of_issued_pipe": round(tf_s / pipe_peak, 4),
+             "bound_note": "`frac` prices algorithmic fp32 flops against the fp32 MFMA/vector peak (SURVEY.md section 8d); `bound` is the "
+                           "unit the SQ counters show busiest (valu = VALU + transcendental issue), `frac_of_issued_pipe` the same flops "
+                           "against the matrix pipe the kernel really issues on"}
+        if pm is not None:
+            r["traffic_unit"] = "HBM bytes per pass, summed over all launches of all kernels of the pass (rocprofv3 PMC passes on these kernel sources, %s)" % pm["source"]
+            r["launches_per_pass"] = pm["launches_per_pass"]
         return r
 
-    return (roof(ms_fwd, f_fwd, by_fwd, names[0]), roof(ms_adj, f_adj, by_fwd, names[1])), names
+    return (roof(ms_fwd, f_fwd, by_fwd, names[0], False), roof(ms_adj, f_adj, by_fwd, names[1], True)), names
 
 
 def other_config(name, dev, steps=3, warmup=1):
@@ -340,9 +418,10 @@ def main():
     B_local, B_total, lo = shard(args.scaling)
     w = Workload(c, B_local, B_total, lo, dev)
     model, coeffs, T = w.model, w.coeffs, w.T
+    z_err = golden_z_err(model, c, coeffs) if (rank == 0 and args.config == "cfg2" and lo == 0) else None
     dt, loss = w.timed(args.steps, args.warmup, world, dev)
 
-    tf = td = None
+    tf = td = t32 = None
     other = None
     if not args.no_extras:
         # forward-only throughput (inference), same inputs
@@ -364,6 +443,17 @@ def main():
         torch.cuda.synchronize()
         td = (time.perf_counter() - td0) / args.steps
         model.adjoint = True
+        # the same training step with every GEMM as plain fp32-input MFMA (NCDE_FLAG_FP32_MFMA): the headline beside it does not rest
+        # on the split-fp16 / split-bf16 argument
+        model.kernel_flags = _lib.FLAG_FP32_MFMA
+        w.step()
+        torch.cuda.synchronize()
+        t320 = time.perf_counter()
+        for _ in range(args.steps):
+            w.step()
+        torch.cuda.synchronize()
+        t32 = (time.perf_counter() - t320) / args.steps
+        model.kernel_flags = 0
         if world > 1:      # the other scaling mode, same contract (barrier + synchronize, max over ranks)
             oname = "strong" if args.scaling == "weak" else "weak"
             oB_local, oB_total, olo = shard(oname)
@@ -393,6 +483,14 @@ def main():
             "roofline_forward": roofs[0],
             "loss": loss,
         }
+        if z_err is not None:
+            rec["z_err_vs_golden"] = z_err
+            rec["z_err_note"] = ("max-abs error of z_T from the timed default forward kernel (%s) on this full workload, relative to max |z_T|, "
+                                 "against the reference's own z_T (tests/golden/g5_cfg2_full.npz); north-star tolerance 1e-4" % names[0])
+        if t32 is not None:
+            rec["fp32_mfma_ms_per_step"] = t32 * 1e3
+            rec["fp32_mfma_value"] = B_local * (T - 1) / t32
+            rec["fp32_mfma_note"] = "same step with NCDE_FLAG_FP32_MFMA: every GEMM as plain fp32-input MFMA (per rank, no barrier)"
         if tf is not None:
             rec.update({"forward_only_value": B_local * (T - 1) / tf, "forward_only_ms": tf * 1e3,
                         "adjoint_false_value": B_local * (T - 1) / td, "adjoint_false_ms_per_step": td * 1e3,

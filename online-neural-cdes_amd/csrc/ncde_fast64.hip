@@ -113,6 +113,38 @@ __device__ __forceinline__ f32x4 tile_mac(const OpA<P>& A, const OpB<P>& B, f32x
         return acc;
     }
 }
+// the same for N sample tiles at once, tile index innermost: consecutive MFMAs belong to independent accumulator chains
+template <int P, int N>
+__device__ __forceinline__ void tile_mac_n(const OpA<P>& A, const OpB<P> (&B)[N], f32x4 bias, f32x4 (&out)[N]) {
+    if constexpr (P == 1) {
+        f32x4 m[N], x[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) { m[i] = bias; x[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) m[i] = mfma_h(A.c[cc].hi, B[i].c[cc].hi, m[i]);
+#pragma unroll
+            for (int i = 0; i < N; ++i) x[i] = mfma_h(A.c[cc].lo, B[i].c[cc].hi, x[i]);
+#pragma unroll
+            for (int i = 0; i < N; ++i) x[i] = mfma_h(A.c[cc].hi, B[i].c[cc].lo, x[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) out[i] = h2_combine(m[i], x[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) out[i] = bias;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+            for (int i = 0; i < N; ++i) out[i] = mfma16(A.k[ks], B[i].k[ks], out[i]);
+    }
+}
+template <int P>
+__device__ __forceinline__ u32x4 make_piece(const float* v, float& mx) {
+    if constexpr (P == 1) return split4h(v, mx);
+    else return (u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+}
 template <int P>
 __device__ __forceinline__ void write_piece(float* ex, int q, int lane, const float* v, float& mx) {
     u32x4 o;
@@ -122,6 +154,17 @@ __device__ __forceinline__ void write_piece(float* ex, int q, int lane, const fl
 }
 
 constexpr int kF64MaxLayers = 4;
+
+// development: s_memtime phase counters (cycles per phase, summed over the sweep) -> the first floats of the workgroup's gradient
+// partial, which is garbage in such a build.  Slots: 0 hidden forward, 1 output tiles + dL/dx_L, 2 reduce + dWo, 3 hidden backward,
+// 4 a^T df/dy + bookkeeping, 7 time spent waiting at the workgroup barriers.
+#ifdef NCDE_F64_PROF
+#define F64_TICK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); prof[k] += now_ - tlast; tlast = now_; }
+#define F64_SYNC(k) { F64_TICK(k) __syncthreads(); F64_TICK(7) }
+#else
+#define F64_TICK(k)
+#define F64_SYNC(k) __syncthreads();
+#endif
 
 __host__ __device__ constexpr int f64_lds_floats(int nl, int ns, bool cubic) {
     const int SP = 16 * ns, RS = SP + 4;
@@ -289,28 +332,35 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
     }
     __syncthreads();
 
-    // hidden-layer weight gradient of layer l: dW_l += (w gpre_l) x_l^T over all SP samples (gimg rows are this wave's own)
-    auto dw_hidden = [&](int l) {
+    // hidden-layer weight gradient of layer l: dW_l += (w gpre_l) x_l^T over all SP samples (gimg rows are this wave's own, written
+    // one phase earlier): operands first (load), MFMAs later (mac), so that the reads do not queue behind the phase's own writes
+    auto dw_hidden_load = [&](int l, float (&av)[KS], float (&bv)[4][KS]) {
         const float* gi = gimg + ((l & 1) * 64 + 16 * q + s) * RS + KS * g;
         const float* xi = (l == 0 ? zimg + zp * 64 * RS : ximg + (l - 1) * 64 * RS) + s * RS + KS * g;
-        float av[KS];
 #pragma unroll
         for (int v = 0; v < NS; ++v) *reinterpret_cast<f32x4*>(av + 4 * v) = *reinterpret_cast<const f32x4*>(gi + 4 * v);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            float bv[KS];
+        for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-            for (int v = 0; v < NS; ++v) *reinterpret_cast<f32x4*>(bv + 4 * v) = *reinterpret_cast<const f32x4*>(xi + 16 * ct * RS + 4 * v);
-            if (l == 0) {
+            for (int v = 0; v < NS; ++v) *reinterpret_cast<f32x4*>(bv[ct] + 4 * v) = *reinterpret_cast<const f32x4*>(xi + 16 * ct * RS + 4 * v);
+    };
+    auto dw_hidden_mac = [&](int l, const float (&av)[KS], const float (&bv)[4][KS]) {
+        if (l == 0) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) gW[0][ct] = mfma16(av[ks], bv[ks], gW[0][ct]);
-            } else {
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) gW[1][ct] = mfma16(av[ks], bv[ks], gW[1][ct]);
-            }
+                for (int ct = 0; ct < 4; ++ct) gW[0][ct] = mfma16(av[ks], bv[ct][ks], gW[0][ct]);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) gW[1][ct] = mfma16(av[ks], bv[ct][ks], gW[1][ct]);
         }
     };
 
+#ifdef NCDE_F64_PROF
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
     for (int n = a.T - 1; n >= 1; --n) {
         if (n - 3 >= 0) stage_load(n - 3);
 #pragma unroll 1
@@ -325,38 +375,49 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
                 if (lin >= 1) rec_fetch(lin - 1);
             }
             const bool at_knot = j == S - 1 && (a.output == NCDE_OUT_KNOTS || n == 1);
+            // Every phase below is written "read everything -> compute -> write everything" with the sample tile innermost: the two
+            // tiles are independent, but their LDS reads and writes may alias as far as the compiler can tell, and a tile-by-tile body
+            // was scheduled exactly so -- tile 1's reads behind tile 0's writes, every phase twice as long (measured with F64_TICK).
             // ---- forward recompute: phase l = layer l (reads exchange buffer (l+1)&1, writes l&1) ---------------------------
-            unsigned xmask = 0;        // ReLU masks of this wave's tile of x_1 .. x_NL (units 16q + 4g + r): bit (l NS + hf) 4 + r
 #pragma unroll
             for (int l = 0; l < NLM; ++l) {
                 if (l < NL) {
+                    OpB<HPF> B[NS];
+#pragma unroll
+                    for (int hf = 0; hf < NS; ++hf) B[hf] = read_opB<HPF>(exch + (((l + 1) & 1) * NS + hf) * 1024, lane);
+                    const f32x4 bias = *reinterpret_cast<const f32x4*>(b_l + (l == 0 ? 0 : 64));
+                    f32x4 pre[NS];
+                    if (l == 0) tile_mac_n<HPF, NS>(w_f[0], B, bias, pre);
+                    else tile_mac_n<HPF, NS>(w_f[1], B, bias, pre);
+                    float xv[NS][4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int hf = 0; hf < NS; ++hf) xv[hf][r] = relu_bits(pre[hf][r]);
+                    u32x4 piece[NS];
+#pragma unroll
+                    for (int hf = 0; hf < NS; ++hf) piece[hf] = make_piece<HPF>(xv[hf], mx);
 #pragma unroll
                     for (int hf = 0; hf < NS; ++hf) {
-                        const OpB<HPF> B = read_opB<HPF>(exch + (((l + 1) & 1) * NS + hf) * 1024, lane);
-                        const f32x4 pre = l == 0 ? tile_mac<HPF>(w_f[0], B, *reinterpret_cast<const f32x4*>(b_l))
-                                                 : tile_mac<HPF>(w_f[1], B, *reinterpret_cast<const f32x4*>(b_l + 64));
-                        float xv[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            xv[r] = relu_bits(pre[r]);
-                            xmask |= xv[r] > 0.0f ? 1u << ((l * NS + hf) * 4 + r) : 0u;
-                            ximg[(l * 64 + 16 * q + 4 * g + r) * RS + 16 * hf + s] = xv[r];
-                        }
-                        write_piece<HPF>(exch + ((l & 1) * NS + hf) * 1024, q, lane, xv, mx);
+                        for (int r = 0; r < 4; ++r) ximg[(l * 64 + 16 * q + 4 * g + r) * RS + 16 * hf + s] = xv[hf][r];
+                        *reinterpret_cast<u32x4*>(exch + ((l & 1) * NS + hf) * 1024 + q * 256 + lane * 4) = piece[hf];
                     }
-                    __syncthreads();
+                    F64_SYNC(0)
                 }
             }
             // ---- phase NL: output tiles of this wave (P, tanh, f, dP) and its partial of dL/dx_L = Wo^T dP ------------------
             float kout[NS][4];
+            {
+                OpB<HPF> B[NS];
+                f32x4 dx[NS];
+                float sdx[NS];
 #pragma unroll
-            for (int hf = 0; hf < NS; ++hf) {
-                const OpB<HPF> B = read_opB<HPF>(exch + (((NL + 1) & 1) * NS + hf) * 1024, lane);
-                f32x4 dx;
-                {
+                for (int hf = 0; hf < NS; ++hf) {
+                    B[hf] = read_opB<HPF>(exch + (((NL + 1) & 1) * NS + hf) * 1024, lane);
                     const float* dp = dxp + (16 * hf + s) * DXW;
                     if (!cubic) {
-                        dx = *reinterpret_cast<const f32x4*>(dp);
+                        dx[hf] = *reinterpret_cast<const f32x4*>(dp);
                     } else {      // b + (2c + 3d fr) fr  (interpolation_cubic.py:331-336)
                         const f32x4 cb = *reinterpret_cast<const f32x4*>(dp);
                         const f32x4 cc = *reinterpret_cast<const f32x4*>(dp + 4);
@@ -364,69 +425,95 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float inner = cc[r] + cd[r] * frac;
-                            dx[r] = cb[r] + inner * frac;
+                            dx[hf][r] = cb[r] + inner * frac;
                         }
                     }
+                    sdx[hf] = (dx[hf][0] + dx[hf][1]) + (dx[hf][2] + dx[hf][3]);
                 }
-                const float sdx = (dx[0] + dx[1]) + (dx[2] + dx[3]);
-                float dP[4][4];
+                float dP[NS][4][4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const f32x4 o = tile_mac<HPF>(wo_f[t], B, *reinterpret_cast<const f32x4*>(bo_l + 64 * t));
-                    const float a4 = 4.0f * as_[hf][t];
-                    float ko = 0.0f;
+                    f32x4 o[NS];
+                    tile_mac_n<HPF, NS>(wo_f[t], B, *reinterpret_cast<const f32x4*>(bo_l + 16 * t), o);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float rr = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[r]) + 1.0f);      // tanh = 1 - 2 rr
-                        ko = fmaf(rr, dx[r], ko);
-                        dP[t][r] = (a4 * dx[r]) * fmaf(-rr, rr, rr);                                         // a dX (1 - tanh^2)
-                    }
-                    kout[hf][t] = fmaf(-2.0f, ko, sdx);
-                    if (w != 0.0f) {
+                    for (int hf = 0; hf < NS; ++hf) {
+                        const float a4 = 4.0f * as_[hf][t];
+                        float ko = 0.0f;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float wd = w * dP[t][r];
-                            gbo[t][r] += wd;
-                            dpT[(64 * q + 16 * t + 4 * g + r) * RS + 16 * hf + s] = wd;
+                            const float rr = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[hf][r]) + 1.0f);      // tanh = 1 - 2 rr
+                            ko = fmaf(rr, dx[hf][r], ko);
+                            dP[hf][t][r] = (a4 * dx[hf][r]) * fmaf(-rr, rr, rr);                                     // a dX (1 - tanh^2)
                         }
+                        kout[hf][t] = fmaf(-2.0f, ko, sdx[hf]);
                     }
                 }
-#pragma unroll
-                for (int tp = 0; tp < 4; ++tp) {
-                    f32x4 acc = zero4;
+                if (w != 0.0f) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc = mfma16(woT[t][tp][r], dP[t][r], acc);
-                    *reinterpret_cast<f32x4*>(red + ((hf * 4 + q) * 4 + tp) * 256 + lane * 4) = acc;
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int hf = 0; hf < NS; ++hf) {
+                                const float wd = w * dP[hf][t][r];
+                                gbo[t][r] += wd;
+                                dpT[(64 * q + 16 * t + 4 * g + r) * RS + 16 * hf + s] = wd;
+                            }
                 }
+                f32x4 acc[NS][4];
+#pragma unroll
+                for (int hf = 0; hf < NS; ++hf)
+#pragma unroll
+                    for (int tp = 0; tp < 4; ++tp) acc[hf][tp] = zero4;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+                            for (int hf = 0; hf < NS; ++hf) acc[hf][tp] = mfma16(woT[t][tp][r], dP[hf][t][r], acc[hf][tp]);
+#pragma unroll
+                for (int hf = 0; hf < NS; ++hf)
+#pragma unroll
+                    for (int tp = 0; tp < 4; ++tp) *reinterpret_cast<f32x4*>(red + ((hf * 4 + q) * 4 + tp) * 256 + lane * 4) = acc[hf][tp];
             }
-            __syncthreads();
+            F64_SYNC(1)
             // ---- phase NL+1: dL/dpre of the last hidden layer (tile q) = sum of the four partials, masked; dWo of this stage --------
             float gpre[NS][4];
+            {
+                f32x4 part[NS][4];
+                float xl[NS][4];
 #pragma unroll
-            for (int hf = 0; hf < NS; ++hf) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(red + ((hf * 4 + 0) * 4 + q) * 256 + lane * 4);
+                for (int hf = 0; hf < NS; ++hf) {
 #pragma unroll
-                for (int qp = 1; qp < 4; ++qp) {
-                    const f32x4 u = *reinterpret_cast<const f32x4*>(red + ((hf * 4 + qp) * 4 + q) * 256 + lane * 4);
+                    for (int qp = 0; qp < 4; ++qp) part[hf][qp] = *reinterpret_cast<const f32x4*>(red + ((hf * 4 + qp) * 4 + q) * 256 + lane * 4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += u[r];
+                    for (int r = 0; r < 4; ++r) xl[hf][r] = ximg[((NL - 1) * 64 + 16 * q + 4 * g + r) * RS + 16 * hf + s];      // own tile of x_L: the ReLU mask
                 }
-                const unsigned mk = xmask >> (((NL - 1) * NS + hf) * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gpre[hf][r] = (mk >> r) & 1u ? v[r] : 0.0f;
-                float dummy = 0.0f;
-                write_piece<2>(exch + (((NL + 1) & 1) * NS + hf) * 1024, q, lane, gpre[hf], dummy);
-                if (w != 0.0f) {
-                    const int sl = NL - 1 == 0 ? 0 : 1;
+                for (int hf = 0; hf < NS; ++hf)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float wg = w * gpre[hf][r];
-                        gb[1][r] += sl == 1 ? wg : 0.0f;
-                        gb[0][r] += sl == 0 ? wg : 0.0f;
-                        gimg[((((NL - 1) & 1) * 64) + 16 * q + 4 * g + r) * RS + 16 * hf + s] = wg;
+                        const float v = ((part[hf][0][r] + part[hf][1][r]) + part[hf][2][r]) + part[hf][3][r];
+                        gpre[hf][r] = xl[hf][r] > 0.0f ? v : 0.0f;
                     }
+#pragma unroll
+                for (int hf = 0; hf < NS; ++hf) {
+                    float dummy = 0.0f;
+                    write_piece<2>(exch + (((NL + 1) & 1) * NS + hf) * 1024, q, lane, gpre[hf], dummy);
+                }
+                if (w != 0.0f) {
+                    const bool sl1 = NL - 1 >= 1;
+#pragma unroll
+                    for (int hf = 0; hf < NS; ++hf)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float wg = w * gpre[hf][r];
+                            gb[1][r] += sl1 ? wg : 0.0f;
+                            gb[0][r] += sl1 ? 0.0f : wg;
+                            gimg[((((NL - 1) & 1) * 64) + 16 * q + 4 * g + r) * RS + 16 * hf + s] = wg;
+                        }
                 }
             }
             if (w != 0.0f) {      // dWo: rows of this wave x all 64 units of x_L, K = the SP samples (k-step ks, k-sub g <-> sample KS g + ks)
@@ -443,59 +530,69 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
 #pragma unroll
                     for (int v = 0; v < NS; ++v) *reinterpret_cast<f32x4*>(av + 4 * v) = *reinterpret_cast<const f32x4*>(di + 4 * v);
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
+                    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                        for (int ks = 0; ks < KS; ++ks) gWo[t][ct] = mfma16(av[ks], bv[ct][ks], gWo[t][ct]);
+                        for (int ct = 0; ct < 4; ++ct) gWo[t][ct] = mfma16(av[ks], bv[ct][ks], gWo[t][ct]);
                 }
             }
-            __syncthreads();
+            F64_SYNC(2)
             // ---- phases NL+2 .. 2NL: hidden layers l = NL-1 .. 1 backwards (tile q of W_l^T gpre_l, masked by x_l) ------------
 #pragma unroll
             for (int lr = 0; lr < NLM - 1; ++lr) {
                 const int l = NL - 1 - lr;      // layer whose transpose runs in this phase (phase index p = NL + 2 + lr)
                 if (l >= 1) {
                     const int p = NL + 2 + lr;
+                    OpB<2> B[NS];
+                    float xl[NS][4];
 #pragma unroll
                     for (int hf = 0; hf < NS; ++hf) {
-                        const OpB<2> B = read_opB<2>(exch + (((p + 1) & 1) * NS + hf) * 1024, lane);
-                        f32x4 gx = zero4;
+                        B[hf] = read_opB<2>(exch + (((p + 1) & 1) * NS + hf) * 1024, lane);
 #pragma unroll
-                        for (int ks = 0; ks < 16; ++ks) gx = mfma16(w_b[1][ks], B.k[ks], gx);
-                        const unsigned mk = xmask >> (((l - 1) * NS + hf) * 4);
+                        for (int r = 0; r < 4; ++r) xl[hf][r] = ximg[((l - 1) * 64 + 16 * q + 4 * g + r) * RS + 16 * hf + s];      // own tile of x_l
+                    }
+                    float av[KS], bv[4][KS];      // operands of dW_l (gimg written in the previous phase by this wave), requested before the chain
+                    if (w != 0.0f) dw_hidden_load(l, av, bv);
+                    f32x4 gx[NS];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) gpre[hf][r] = (mk >> r) & 1u ? gx[r] : 0.0f;
+                    for (int hf = 0; hf < NS; ++hf) gx[hf] = zero4;
+#pragma unroll
+                    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+                        for (int hf = 0; hf < NS; ++hf) gx[hf] = mfma16(w_b[1][ks], B[hf].k[ks], gx[hf]);
+#pragma unroll
+                    for (int hf = 0; hf < NS; ++hf)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) gpre[hf][r] = xl[hf][r] > 0.0f ? gx[hf][r] : 0.0f;
+#pragma unroll
+                    for (int hf = 0; hf < NS; ++hf) {
                         float dummy = 0.0f;
                         write_piece<2>(exch + ((p & 1) * NS + hf) * 1024, q, lane, gpre[hf], dummy);
                     }
                     if (w != 0.0f) {
-                        dw_hidden(l);      // reads gimg[l & 1] (written in the previous phase by this wave) before ...
-                        wave_lds_order();
+                        dw_hidden_mac(l, av, bv);
+                        const bool sl1 = l - 1 >= 1;
 #pragma unroll
                         for (int hf = 0; hf < NS; ++hf)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const float wg = w * gpre[hf][r];
-                                gb[1][r] += l - 1 >= 1 ? wg : 0.0f;
-                                gb[0][r] += l - 1 == 0 ? wg : 0.0f;
-                                gimg[((((l - 1) & 1) * 64) + 16 * q + 4 * g + r) * RS + 16 * hf + s] = wg;      // ... gpre_{l-1} goes to the other buffer
+                                gb[1][r] += sl1 ? wg : 0.0f;
+                                gb[0][r] += sl1 ? 0.0f : wg;
+                                gimg[((((l - 1) & 1) * 64) + 16 * q + 4 * g + r) * RS + 16 * hf + s] = wg;      // gpre_{l-1}: the other buffer
                             }
                     }
-                    __syncthreads();
+                    F64_SYNC(3)
                 }
             }
             // ---- phase 2NL+1: a^T df/dy for the state entries of this wave, Butcher bookkeeping, next stage input -----------------
             {
                 const int p = 2 * NL + 1;
-                f32x4 vy[NS];
+                OpB<2> B[NS];
 #pragma unroll
-                for (int hf = 0; hf < NS; ++hf) {
-                    const OpB<2> B = read_opB<2>(exch + (((p + 1) & 1) * NS + hf) * 1024, lane);
-                    f32x4 acc = zero4;
-#pragma unroll
-                    for (int ks = 0; ks < 16; ++ks) acc = mfma16(w_b[0][ks], B.k[ks], acc);
-                    vy[hf] = acc;
-                }
-                // sequence outputs: the stored state / cotangent of knot n-1 (requested before the weight-gradient MFMAs below)
+                for (int hf = 0; hf < NS; ++hf) B[hf] = read_opB<2>(exch + (((p + 1) & 1) * NS + hf) * 1024, lane);
+                float av[KS], bv[4][KS];
+                if (w != 0.0f) dw_hidden_load(0, av, bv);
+                // sequence outputs: the stored state / cotangent of knot n-1 (requested before the MFMAs below)
                 float zk[NS][4], gk[NS][4];
                 if (at_knot) {
                     const int row = a.output == NCDE_OUT_KNOTS ? n - 1 : 0;
@@ -508,13 +605,17 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
                             zk[hf][t] = (DISC == 0 && a.output == NCDE_OUT_KNOTS && valid[hf]) ? a.z_out[o] : 0.0f;
                         }
                 }
-                if (w != 0.0f) {
-                    wave_lds_order();
-                    dw_hidden(0);
-                }
+                f32x4 vy[NS];
+#pragma unroll
+                for (int hf = 0; hf < NS; ++hf) vy[hf] = zero4;
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+                    for (int hf = 0; hf < NS; ++hf) vy[hf] = mfma16(w_b[0][ks], B[hf].k[ks], vy[hf]);
+                if (w != 0.0f) dw_hidden_mac(0, av, bv);
+                float ys[NS][4];
 #pragma unroll
                 for (int hf = 0; hf < NS; ++hf) {
-                    float ys[4];
                     if constexpr (DISC != 0) {
                         // transpose of the Butcher step (RK4 3/8: c4 = a/8; c3 = 3c4 + d4; c2 = 3c4 - d4 + d3; c1 = c4 + d4 - d3/3 + d2/3;
                         // a += d4 + d3 + d2 + d1), d = vy = dL/dY of this stage
@@ -537,30 +638,36 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
                                 if (at_knot) a0[hf][t] += gk[hf][t];
                                 as_[hf][t] = METHOD == NCDE_RK4_38 ? a0[hf][t] * 0.125f : a0[hf][t];
                             }
-                            ys[t] = znext[hf][t];
+                            ys[hf][t] = znext[hf][t];
                         }
                     } else {
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
-                            ys[t] = Combine<METHOD>::apply(j, -kout[hf][t], y0[hf][t], ky1[hf][t], ky2[hf][t]);
+                            ys[hf][t] = Combine<METHOD>::apply(j, -kout[hf][t], y0[hf][t], ky1[hf][t], ky2[hf][t]);
                             as_[hf][t] = Combine<METHOD>::apply(j, vy[hf][t], a0[hf][t], ka1[hf][t], ka2[hf][t]);
                             if (at_knot) {
                                 if (a.output == NCDE_OUT_KNOTS) {      // reset y to the stored knot value, add dL/dz of that knot
                                     y0[hf][t] = zk[hf][t];
-                                    ys[t] = y0[hf][t];
+                                    ys[hf][t] = y0[hf][t];
                                 }
                                 a0[hf][t] += gk[hf][t];
                                 as_[hf][t] = a0[hf][t];
                             }
                         }
                     }
+                }
+                u32x4 piece[NS];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) zimg[((zp ^ 1) * 64 + 16 * q + 4 * t + g) * RS + 16 * hf + s] = ys[t];
-                    write_piece<HPF>(exch + ((p & 1) * NS + hf) * 1024, q, lane, ys, mx);
+                for (int hf = 0; hf < NS; ++hf) piece[hf] = make_piece<HPF>(ys[hf], mx);
+#pragma unroll
+                for (int hf = 0; hf < NS; ++hf) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) zimg[((zp ^ 1) * 64 + 16 * q + 4 * t + g) * RS + 16 * hf + s] = ys[hf][t];
+                    *reinterpret_cast<u32x4*>(exch + ((p & 1) * NS + hf) * 1024 + q * 256 + lane * 4) = piece[hf];
                 }
                 if (j == S - 1 && n - 3 >= 0) stage_store(n - 3);
                 zp ^= 1;
-                __syncthreads();
+                F64_SYNC(4)
             }
         }
     }
@@ -597,6 +704,10 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
             if (s == 0) gp[a.gb_off[sl] + 16 * q + 4 * g + r] = v;
         }
     }
+#ifdef NCDE_F64_PROF
+    if (lane == 0)
+        for (int k = 0; k < 8; ++k) gp[q * 8 + k] = (float)prof[k] / (float)((a.T - 1) * S);
+#endif
     if constexpr (HPF == 1) {
         if (a.fault != nullptr) {
             if (__builtin_amdgcn_ballot_w64(h2_range_fault(mx)) != 0 && lane == 0) *fault_s = 1;
@@ -625,12 +736,11 @@ F64Fn pick_kernel(int method, int ns, int hpf, bool disc) {
 
 size_t f64_lds_bytes(const NcdeProblem* p, int ns) { return sizeof(float) * (size_t)f64_lds_floats(p->n_layers, ns, p->interp != NCDE_INTERP_LINEAR); }
 
-// sample tiles per workgroup: two once that still leaves a workgroup for every CU (the in-wave second tile is what hides the chain's
-// latency: measured in DESIGN.md section 5.4d); NCDE_FLAG_TILED_NS1 / _NS2 force it (tests)
+// sample tiles per workgroup.  Measured at cfg4 (B = 8192, MI355X): NS = 1 (512 workgroups, two rounds) 3.56 ms, NS = 2 (one workgroup
+// per CU, the two tiles interleaved in every wave) 3.7 - 4.8 ms: with both tiles' operands live the 512-register file spills and
+// the scheduler serialises the tiles again.  NS = 2 stays selectable (NCDE_FLAG_TILED_NS2; tested).
 int f64_ns(const NcdeProblem* p) {
-    const int tiles = (p->batch + 15) / 16;
-    int ns = tiles > 256 ? 2 : 1;
-    if (p->flags & NCDE_FLAG_TILED_NS1) ns = 1;
+    int ns = 1;
     if (p->flags & NCDE_FLAG_TILED_NS2) ns = 2;
     if (ns == 2 && f64_lds_bytes(p, 2) > (size_t)kLdsLimit) ns = 1;
     return ns;

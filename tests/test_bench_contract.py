@@ -24,7 +24,17 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu_lib):
     assert rec["higher_is_better"] is True and rec["vs_baseline"] is None and rec["data"] == "synthetic"
     assert "workload" in rec["config"] and "model" not in rec["config"]
     r = rec["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    # `bound` is what the committed SQ counters of exactly these kernel sources show busiest ("valu" = VALU + transcendental issue),
+    # "unmeasured" while no counter summary of the current sources is committed
+    assert r["bound"] in ("hbm", "mfma", "valu", "unmeasured") and r["unit"] in ("GB/s", "TFLOP/s")
+    for k in ("traffic_ratio", "mfma_busy", "valu_active", "tanh_ceiling_ms", "frac_of_issued_pipe", "issued_pipe_peak"):
+        assert k in r, k
+    assert 0 < r["tanh_ceiling_ms"] < r["ms_per_launch"] and 0 < r["frac_of_issued_pipe"] < 1
+    if r["traffic"] is not None:
+        assert abs(r["traffic_ratio"] - r["traffic"] / r["algorithmic_bytes_per_launch"]) < 1e-2 and r["bound"] != "unmeasured"
+    # the timed default forward kernel against the reference's own z_T on this very workload (golden g5), and the all-fp32-MFMA step
+    assert 0 <= rec["z_err_vs_golden"] <= 1e-4, rec["z_err_vs_golden"]
+    assert rec["fp32_mfma_ms_per_step"] >= 0.9 * rec["ms_per_step"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1.5
     assert "traffic" in r
     c = rec["cpu_baseline"]

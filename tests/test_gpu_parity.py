@@ -563,15 +563,17 @@ def test_split_fp16_forward_range_fault_is_reexecuted(interp, method, gpu_lib):
         assert float((np.abs(r16["z_out"] - zo) / scale).max()) <= TIGHT_Z
 
 
+@pytest.mark.parametrize("shape", [(20, 32, "linear", "rk4"), (4, 64, "cubic", "midpoint")])
 @pytest.mark.parametrize("disc", [False, True])
-def test_split_fp16_adjoint_range_fault_is_reexecuted(disc, gpu_lib):
+def test_split_fp16_adjoint_range_fault_is_reexecuted(disc, shape, gpu_lib):
     """The default adjoint / discrete-backward kernel recomputes the forward side of each stage in split-fp16 and speculates on the
     fp16 range like the forward kernel does.  One sample of the middle tile gets a state large enough to overflow: that tile's dz0
     rows must be bit-identical to the all-split-bf16 run (the tile was re-executed by that kernel), the other tiles' rows
     bit-identical to the run without the outlier, and the parameter gradients must agree with the all-split-bf16 run to fp32 round-off."""
     import gpu_util
     from ncde_amd import _lib
-    case = _seeded_case("linear", "rk4", False, B=37, L=6, C=20, H=32, HH=32, nl=3, seed=313)
+    C, H, interp, method = shape      # (4, 64, ...): ncde_adj_h64, whose re-execution instance multiplies in fp32-input MFMA (same flag)
+    case = _seeded_case(interp, method, False, B=37, L=6, C=C, H=H, HH=H, nl=3, seed=313)
     z = case["expect"]["z_out"].copy()
     rec = case["stage_record"].copy()
     kw = {}
@@ -608,6 +610,25 @@ def test_default_adjoint_is_reproducible_under_repetition(interp, method, seq, g
                 first = iso
             else:
                 assert np.array_equal(first["dz0"], iso["dz0"]) and all(np.array_equal(first["grads"][k], iso["grads"][k]) for k in iso["grads"])
+
+
+@pytest.mark.parametrize("C,nl", [(4, 1), (4, 2), (4, 4), (3, 3), (2, 2)])
+@pytest.mark.parametrize("interp,method,seq", [("linear", "rk4", True), ("cubic", "midpoint", False)])
+def test_h64_in_sweep_adjoint_other_layer_counts_and_channels(C, nl, interp, method, seq, gpu_lib):
+    """ncde_adj_h64 has a runtime layer count (1..4) and takes any C <= 4 (rows of missing channels are zero weights): continuous
+    adjoint and exact discrete backward on the oracle's z / stage record, one and two sample tiles per workgroup, ragged batch."""
+    import gpu_util
+    from ncde_amd import _lib
+    case = _seeded_case(interp, method, seq, B=37, L=7, C=C, H=64, HH=64, nl=nl, seed=640 + 10 * C + nl)
+    ex = case["expect"]
+    for fl in (_lib.FLAG_AUTO, _lib.FLAG_TILED_NS2):
+        iso = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=fl)
+        assert gpu_util.kernel_names(case, fl)[1].startswith("ncde_adj_h64")
+        for k, e in _grad_errors(case, iso).items():
+            assert e <= TIGHT_G, ("continuous", fl, k, e)
+        isod = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=fl, stages=case["stage_record"])
+        for k, e in _grad_errors(case, isod, "bp_").items():
+            assert e <= TIGHT_G, ("discrete", fl, k, e)
 
 
 @pytest.mark.parametrize("nl", [1, 2, 4])
