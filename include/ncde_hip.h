@@ -238,10 +238,14 @@ int ncde_dopri5_adjoint(const NcdeProblem* p, const NcdeTimeSpec* ts, const Ncde
  * step, (t0, dt, the state at its start, the outputs interpolated in it) in a caller-owned device record; ncde_dopri5_backward is the
  * exact reverse-mode sweep over that record -- six stage VJPs per step with FSAL, the transpose of the 4th-order dense output
  * (interp.py:4-61), and the gradient of the FIRST step size through _select_initial_step (misc.py:33-74; every later step size is a
- * constant because _optimal_step_size is @torch.no_grad(), misc.py:84-97).  The backward is stream-ordered (one persistent launch
- * + two small ones + the partial reduction); the forward synchronises like ncde_dopri5_forward.
- * Record size: ncde_dopri5_record_bytes() is enough for every solve with options.min_step > 0; without a minimum step it is a
- * default that a solve with very many steps can exceed (NCDE_ERR_WORKSPACE: pass a larger record).  Workspace of the backward:
+ * constant because _optimal_step_size is @torch.no_grad(), misc.py:84-97).  The backward first reads the record's 64-byte header back
+ * (step count, overflow flag: one small copy + stream synchronisation; a second one uploads a user knot grid), then enqueues one
+ * persistent launch + two small ones + the partial reduction; the forward synchronises like ncde_dopri5_forward.
+ * Limits of the taped path (checked by ncde_dopri5_record_bytes / _forward_record, NCDE_ERR_UNSUPPORTED): hidden <= 128, last
+ * hidden width <= 128, the reverse sweep's 7 [H][16] LDS arrays within 160 KB.
+ * Record size: ncde_dopri5_record_bytes() is enough for every solve with options.min_step > 0 (never more than max_num_steps per
+ * output interval); without a minimum step it is an estimate (about two steps per knot) that a solve can exceed: it then returns
+ * NCDE_ERR_WORKSPACE ("pass a larger record") and may simply be repeated with a larger one (the Python host doubles it).  Workspace of the backward:
  * ncde_dopri5_workspace_bytes(p, ts, 2). */
 int64_t ncde_dopri5_record_bytes(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt);
 int ncde_dopri5_forward_record(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt, float* out, void* record,

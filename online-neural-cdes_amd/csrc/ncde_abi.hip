@@ -95,8 +95,138 @@ int generic_supported(const NcdeProblem* p, const Layout& y, int pass) {
     return NCDE_OK;
 }
 
-// pick the kernel family: 1 = fast (shape-specialised), 2 = tiled (batch-tiled, large hidden), 0 = generic, <0 = error
+
+// ---- zero-padding into the batch-tiled family ----------------------------------------------------------------------------------
+// The batch-tiled kernels want H and the layer widths as multiples of 16 (the last one 16 / 32 / 64 / 128 for the backward) and C as a
+// multiple of 4.  Any other shape -- the reference's default hidden_hidden_dim = 15 (src/ncde/ncde.py:47), odd channel counts,
+// its hyper-parameter ranges (experiments/configurations/configurations.json5:34-36) -- is padded HERE: the parameters are copied
+// once per call into zero-padded buffers at the head of the workspace (a few hundred KB), the kernels run on the padded problem, and
+// the parameter gradients are sliced back.  The caller's activations are NOT copied: the kernels take the real row width of
+// z0 / out / z_out / grad_out / grad_z0 / the stage record and the real channel count of the coefficient tensor (KArgs.Hr, Cc).
+// Exactness: a padded hidden unit has zero weights and bias, so relu(0) = 0 feeds zeros forward and relu'(0) = 0 masks its
+// cotangent; a padded state row has zero rows in Wo / bo, so tanh(0) * dX = 0 leaves it at 0; a padded channel has dX = 0.
+struct PadSegs {
+    int n;
+    const float* src[12];
+    float* dst[12];
+    int d[12][6];      // real extents n0, n1, n2 and padded extents p0, p1, p2 (row-major, last index fastest)
+};
+// dir = 0: dst (padded) <- src (real), zeros elsewhere;  dir = 1: dst (real) <- src (padded)
+__global__ __launch_bounds__(256) void ncde_pad_params(PadSegs sg, int dir) {
+    const int k = blockIdx.y;
+    const int n0 = sg.d[k][0], n1 = sg.d[k][1], n2 = sg.d[k][2], p1 = sg.d[k][4], p2 = sg.d[k][5];
+    const long long total = dir == 0 ? (long long)sg.d[k][3] * p1 * p2 : (long long)n0 * n1 * n2;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        if (dir == 0) {
+            const int i2 = (int)(e % p2), i1 = (int)((e / p2) % p1), i0 = (int)(e / ((long long)p1 * p2));
+            sg.dst[k][e] = (i0 < n0 && i1 < n1 && i2 < n2) ? sg.src[k][((long long)i0 * n1 + i1) * n2 + i2] : 0.0f;
+        } else {
+            const int i2 = (int)(e % n2), i1 = (int)((e / n2) % n1), i0 = (int)(e / ((long long)n1 * n2));
+            sg.dst[k][e] = sg.src[k][((long long)i0 * p1 + i1) * p2 + i2];
+        }
+    }
+}
+
+inline int pad_width(int w) { return w <= 16 ? 16 : (w <= 32 ? 32 : (w <= 64 ? 64 : (w <= 128 ? 128 : hru16(w)))); }
+
+struct PadPlan {
+    bool ok;
+    NcdeProblem q;                       // the padded problem; its parameter pointers are OFFSETS (floats, +1) until bound to a workspace
+    int n_seg;
+    int dims[12][6];
+    const float* real[12];               // the caller's parameter of segment k
+    long long off[12];                   // float offset of its padded copy
+    int slot_W[NCDE_MAX_LAYERS], slot_b[NCDE_MAX_LAYERS], slot_Wo, slot_bo, slot_Wg, slot_bg;
+    long long param_floats;              // padded parameters (and, for the backward, the same again for their gradients)
+};
+
+// Would padding bring `p` into the batch-tiled family?  (original / minimal-gated field, matmul input)
+PadPlan make_pad_plan(const NcdeProblem* p, int pass) {
+    PadPlan P{};
+    P.ok = false;
+    if (p->n_layers < 1 || p->field_input != NCDE_INPUT_MATMUL || p->field_kind == NCDE_FIELD_GRU) return P;
+    if (p->hidden > 2048 || p->channels > 4095) return P;
+    NcdeProblem& q = P.q;
+    q = *p;
+    q.hidden = hru16(p->hidden);
+    q.channels = hru4(p->channels);
+    q.reserved_ = (p->hidden << 12) | p->channels;
+    int n = 0;
+    long long off = 0;
+    auto add = [&](const float* src, int n0, int n1, int n2, int p0, int p1, int p2) {
+        for (int k = 0; k < n; ++k)
+            if (P.real[k] == src) return k;      // a shared layer: one padded copy
+        const int k = n++;
+        P.real[k] = src;
+        P.dims[k][0] = n0; P.dims[k][1] = n1; P.dims[k][2] = n2; P.dims[k][3] = p0; P.dims[k][4] = p1; P.dims[k][5] = p2;
+        P.off[k] = off;
+        off += ((long long)p0 * p1 * p2 + 3) & ~3LL;
+        return k;
+    };
+    int din = q.hidden;
+    for (int l = 0; l < p->n_layers; ++l) {
+        const int dout = pad_width(p->layer_out[l]);
+        q.layer_in[l] = din; q.layer_out[l] = dout;
+        P.slot_W[l] = add(p->layer_W[l], 1, p->layer_out[l], p->layer_in[l], 1, dout, din);
+        P.slot_b[l] = add(p->layer_b[l], 1, 1, p->layer_out[l], 1, 1, dout);
+        // the same real matrix must get the same padded shape in every slot it is used in
+        if (P.dims[P.slot_W[l]][4] != dout || P.dims[P.slot_W[l]][5] != din || P.dims[P.slot_b[l]][5] != dout) return P;
+        din = dout;
+    }
+    const int dl = p->layer_out[p->n_layers - 1];
+    P.slot_Wo = add(p->Wo, p->hidden, p->channels, dl, q.hidden, q.channels, din);
+    P.slot_bo = add(p->bo, 1, p->hidden, p->channels, 1, q.hidden, q.channels);
+    if (p->field_kind == NCDE_FIELD_MINIMAL) {
+        P.slot_Wg = add(p->Wg, p->hidden, p->channels, dl, q.hidden, q.channels, din);
+        P.slot_bg = add(p->bg, 1, p->hidden, p->channels, 1, q.hidden, q.channels);
+    }
+    if (n > 12) return P;
+    P.n_seg = n;
+    P.param_floats = (off + 63) & ~63LL;
+    // bind to a fake base so that the support checks see aligned, distinct pointers (offset + 64 floats: never NULL)
+    auto fake = [&](int k) { return reinterpret_cast<const float*>((uintptr_t)(P.off[k] + 64) * sizeof(float)); };
+    for (int l = 0; l < p->n_layers; ++l) { q.layer_W[l] = fake(P.slot_W[l]); q.layer_b[l] = fake(P.slot_b[l]); }
+    q.Wo = fake(P.slot_Wo); q.bo = fake(P.slot_bo);
+    if (p->field_kind == NCDE_FIELD_MINIMAL) { q.Wg = fake(P.slot_Wg); q.bg = fake(P.slot_bg); }
+    P.ok = ncde_tiled_supported(&q, pass);
+    return P;
+}
+// head of the workspace of a padded call: [padded parameters | (backward) padded parameter gradients | the tiled family's own workspace]
+long long pad_head_floats(const PadPlan& P, int pass) { return (pass == 0 ? 1 : 2) * P.param_floats + 64; }
+
+void pad_bind(PadPlan& P, const NcdeProblem* p, float* base) {
+    NcdeProblem& q = P.q;
+    for (int l = 0; l < p->n_layers; ++l) { q.layer_W[l] = base + P.off[P.slot_W[l]]; q.layer_b[l] = base + P.off[P.slot_b[l]]; }
+    q.Wo = base + P.off[P.slot_Wo]; q.bo = base + P.off[P.slot_bo];
+    if (p->field_kind == NCDE_FIELD_MINIMAL) { q.Wg = base + P.off[P.slot_Wg]; q.bg = base + P.off[P.slot_bg]; }
+}
+int pad_launch(const PadPlan& P, float* base, int dir, float* const* real_dst, hipStream_t st) {
+    PadSegs sg{};
+    sg.n = P.n_seg;
+    long long biggest = 1;
+    for (int k = 0; k < P.n_seg; ++k) {
+        for (int i = 0; i < 6; ++i) sg.d[k][i] = P.dims[k][i];
+        if (dir == 0) { sg.src[k] = P.real[k]; sg.dst[k] = base + P.off[k]; }
+        else { sg.src[k] = base + P.off[k]; sg.dst[k] = real_dst[k]; if (!real_dst[k]) return NCDE_ERR_INVALID; }
+        biggest = std::max(biggest, (long long)P.dims[k][3] * P.dims[k][4] * P.dims[k][5]);
+    }
+    const int gx = (int)std::min<long long>((biggest + 255) / 256, 512);
+    hipLaunchKernelGGL(ncde_pad_params, dim3(gx, P.n_seg), dim3(256), 0, st, sg, dir);
+    return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
+}
+
+// pick the kernel family: 1 = fast (shape-specialised), 2 = tiled (batch-tiled, large hidden), 4 = tiled on the zero-padded problem,
+// 3 = variant, 0 = generic, <0 = error
+int select_family_unpadded(const NcdeProblem* p, const Layout& y, int pass);
 int select_family(const NcdeProblem* p, const Layout& y, int pass) {
+    const int fam = select_family_unpadded(p, y, pass);
+    // generic / variant fallback (or nothing at all): try the batch-tiled family on the zero-padded problem first
+    if ((fam == 0 || fam == 3 || fam == NCDE_ERR_UNSUPPORTED) && !(p->flags & (NCDE_FLAG_FORCE_GENERIC | NCDE_FLAG_FORCE_FAST)) &&
+        !ncde_tiled_supported(p, pass) && make_pad_plan(p, pass).ok)
+        return 4;
+    return fam;
+}
+int select_family_unpadded(const NcdeProblem* p, const Layout& y, int pass) {
     if (p->output == NCDE_OUT_TIMES) {   // general time axis: the plan-driven kernels -- batch-tiled where the shape allows
                                          // (multiples of 16 / 4; 2.8x the generic family at cfg2 widths, 10x at cfg5's), else generic / variant
         if (p->flags & NCDE_FLAG_FORCE_FAST) return fail(NCDE_ERR_UNSUPPORTED, "the shape-specialised kernels run the default time axis only");
@@ -141,6 +271,17 @@ int launch_reduce(const NcdeProblem* p, const Layout& y, const NcdeGrads* g, con
 
 int launch_forward(const NcdeProblem* p, const Layout& y, int family, float* out, float* stages, void* ws, size_t ws_bytes,
                    hipStream_t st) {
+    if (family == 4) {
+        PadPlan P = make_pad_plan(p, 0);
+        if (!P.ok) return fail(NCDE_ERR_UNSUPPORTED, "padded problem outside the batch-tiled family");
+        float* base = (float*)ws;
+        const long long head = pad_head_floats(P, 0);
+        pad_bind(P, p, base);
+        if (pad_launch(P, base, 0, nullptr, st) != NCDE_OK) return fail(NCDE_ERR_HIP, "parameter padding launch failed");
+        const int rc = ncde_tiled_forward(&P.q, out, stages, base + head, ws_bytes - sizeof(float) * (size_t)head, st);
+        if (rc != NCDE_OK) return fail(rc, "tiled forward (zero-padded problem) launch failed");
+        return NCDE_OK;
+    }
     if (family == 1) {
         const int rc = ncde_fast_forward(p, out, stages, ws, ws_bytes, st);
         if (rc != NCDE_OK) return fail(rc, "fast forward launch failed");
@@ -169,6 +310,35 @@ int launch_forward(const NcdeProblem* p, const Layout& y, int family, float* out
 // discrete = false: continuous adjoint, `src` = z_out; discrete = true: exact backward, `src` = the stage record
 int launch_adjoint(const NcdeProblem* p, const Layout& y, int family, const float* src, const float* grad_out,
                    const NcdeGrads* g, void* ws, size_t ws_bytes, hipStream_t st, bool main_kernel_only, bool discrete) {
+    if (family == 4) {
+        PadPlan P = make_pad_plan(p, discrete ? 2 : 1);
+        if (!P.ok) return fail(NCDE_ERR_UNSUPPORTED, "padded problem outside the batch-tiled family");
+        float* base = (float*)ws;
+        const long long head = pad_head_floats(P, 1);
+        pad_bind(P, p, base);
+        if (pad_launch(P, base, 0, nullptr, st) != NCDE_OK) return fail(NCDE_ERR_HIP, "parameter padding launch failed");
+        float* gbase = base + P.param_floats;      // padded gradients, same layout as the padded parameters
+        NcdeGrads gq{};
+        gq.grad_z0 = g->grad_z0;                   // real row width: written in place
+        float* real_dst[12] = {nullptr};
+        for (int l = 0; l < p->n_layers; ++l) {
+            gq.grad_layer_W[l] = gbase + P.off[P.slot_W[l]]; gq.grad_layer_b[l] = gbase + P.off[P.slot_b[l]];
+            real_dst[P.slot_W[l]] = g->grad_layer_W[l]; real_dst[P.slot_b[l]] = g->grad_layer_b[l];
+        }
+        gq.grad_Wo = gbase + P.off[P.slot_Wo]; gq.grad_bo = gbase + P.off[P.slot_bo];
+        real_dst[P.slot_Wo] = g->grad_Wo; real_dst[P.slot_bo] = g->grad_bo;
+        if (p->field_kind == NCDE_FIELD_MINIMAL) {
+            gq.grad_Wg = gbase + P.off[P.slot_Wg]; gq.grad_bg = gbase + P.off[P.slot_bg];
+            real_dst[P.slot_Wg] = g->grad_Wg; real_dst[P.slot_bg] = g->grad_bg;
+        }
+        const int rc = ncde_tiled_adjoint(&P.q, src, grad_out, &gq, base + head, ws_bytes - sizeof(float) * (size_t)head, st, main_kernel_only, discrete);
+        if (rc != NCDE_OK) return fail(rc, "tiled adjoint (zero-padded problem) launch failed");
+        if (main_kernel_only) return NCDE_OK;
+        const int rc2 = pad_launch(P, gbase, 1, real_dst, st);
+        if (rc2 == NCDE_ERR_INVALID) return fail(rc2, "NcdeGrads: NULL destination for a parameter gradient");
+        if (rc2 != NCDE_OK) return fail(rc2, "gradient un-padding launch failed");
+        return NCDE_OK;
+    }
     if (family == 1) {
         const int rc = ncde_fast_adjoint(p, src, grad_out, g, ws, ws_bytes, st, main_kernel_only, discrete);
         if (rc != NCDE_OK) return fail(rc, "fast adjoint launch failed");
@@ -229,7 +399,8 @@ int dopri5_prepare(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdapt
     if (!ts || !ts->t || ts->n_t < 2) return fail(NCDE_ERR_INVALID, "time spec: need >= 2 output times");
     if (opt && (!(opt->rtol > 0.0) || !(opt->atol >= 0.0))) return fail(NCDE_ERR_INVALID, "rtol must be > 0 and atol >= 0");
     char why[200] = "";
-    if (!ncde_dp_supported(q, adj, why, sizeof(why))) return fail(NCDE_ERR_UNSUPPORTED, "%s", why);
+    if (!ncde_dp_supported(q, adj == 2 ? 0 : adj, why, sizeof(why))) return fail(NCDE_ERR_UNSUPPORTED, "%s", why);
+    if (adj == 2 && (!ncde_dp_supported(q, 1, why, sizeof(why)) || !ncde_dp_tape_supported(q, why, sizeof(why)))) return fail(NCDE_ERR_UNSUPPORTED, "%s", why);
     return NCDE_OK;
 }
 }  // namespace
@@ -238,7 +409,7 @@ int64_t ncde_dopri5_workspace_bytes(const NcdeProblem* p, const NcdeTimeSpec* ts
     NcdeProblem q_;
     NcdeAdaptiveOptions o{};
     o.rtol = 1e-4;
-    const int rc = dopri5_prepare(p, ts, &o, pass != 0, &q_);
+    const int rc = dopri5_prepare(p, ts, &o, pass == 2 ? 2 : (pass != 0), &q_);
     if (rc != NCDE_OK) return rc;
     return ncde_dp_workspace_bytes(&q_, ts->n_t, pass);
 }
@@ -246,7 +417,7 @@ int64_t ncde_dopri5_workspace_bytes(const NcdeProblem* p, const NcdeTimeSpec* ts
 int64_t ncde_dopri5_record_bytes(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt) {
     NcdeProblem q_;
     if (!opt) return fail(NCDE_ERR_INVALID, "options are NULL");
-    const int rc = dopri5_prepare(p, ts, opt, 0, &q_);
+    const int rc = dopri5_prepare(p, ts, opt, 2, &q_);      // 2: a taped solve -- also the limits of its reverse sweep
     if (rc != NCDE_OK) return rc;
     return ncde_dp_record_bytes(&q_, ts, opt);
 }
@@ -255,7 +426,7 @@ int ncde_dopri5_forward_record(const NcdeProblem* p, const NcdeTimeSpec* ts, con
                                size_t record_bytes, void* workspace, size_t workspace_bytes, void* stream, NcdeAdaptiveStats* stats) {
     NcdeProblem q_;
     if (!opt) return fail(NCDE_ERR_INVALID, "options are NULL");
-    int rc = dopri5_prepare(p, ts, opt, 0, &q_);
+    int rc = dopri5_prepare(p, ts, opt, 2, &q_);
     if (rc != NCDE_OK) return rc;
     if (!out || !workspace || !record) return fail(NCDE_ERR_INVALID, "out / workspace / record is NULL");
     char msg[256] = "";
@@ -271,7 +442,7 @@ int ncde_dopri5_backward(const NcdeProblem* p, const NcdeTimeSpec* ts, const Ncd
                          void* stream) {
     NcdeProblem q_;
     if (!opt) return fail(NCDE_ERR_INVALID, "options are NULL");
-    int rc = dopri5_prepare(p, ts, opt, 1, &q_);
+    int rc = dopri5_prepare(p, ts, opt, 2, &q_);
     if (rc != NCDE_OK) return rc;
     if (!record || !grad_out || !grads || !grads->grad_z0 || !workspace) return fail(NCDE_ERR_INVALID, "NULL record/grad_out/grads/workspace");
     char msg[256] = "";
@@ -334,6 +505,11 @@ int64_t ncde_workspace_bytes(const NcdeProblem* p, int pass) {
     const int fam = select_family(p, y, pass);
     if (fam < 0) return fam;
     if (fam == 1) return ncde_fast_workspace_bytes(p, pass);
+    if (fam == 4) {
+        const PadPlan P = make_pad_plan(p, pass);
+        const int64_t inner = ncde_tiled_workspace_bytes(&P.q, pass);
+        return inner < 0 ? inner : inner + (int64_t)sizeof(float) * pad_head_floats(P, pass);
+    }
     if (fam == 2) return ncde_tiled_workspace_bytes(p, pass);
     if (fam == 3) return ncde_variant_workspace_bytes(p, pass);
     if (pass == 0) return 256;
@@ -360,6 +536,7 @@ const char* ncde_kernel_name(const NcdeProblem* p, int pass) {
     const Layout y = make_layout(p);
     const int fam = select_family(p, y, pass);
     if (fam < 0) return nullptr;
+    if (fam == 4) { const PadPlan P = make_pad_plan(p, pass); return ncde_tiled_kernel_name(&P.q, pass); }   // (on the zero-padded problem)
     if (fam == 2) return ncde_tiled_kernel_name(p, pass);
     if (fam == 3) return pass == 0 ? "ncde_fwd_variant" : (pass == 1 ? "ncde_adj_variant" : "ncde_adj_variant<discrete>");
     return fam == 1 ? ncde_fast_kernel_name(p, pass) : (pass == 0 ? "ncde_fwd_generic" : (pass == 1 ? "ncde_adj_generic" : "ncde_adj_generic<discrete>"));

@@ -1173,8 +1173,12 @@ TapeLayout tape_layout(const NcdeProblem* p, int n_t, int cap) {
 // accepted steps a solve can take: every step but the first is >= min_step long and starts before t[-1]
 int tape_default_cap(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* op) {
     const double span = ts->t[ts->n_t - 1] - ts->t[0];
-    if (op->min_step > 0.0) return (int)std::min(1.0e6, std::ceil(span / op->min_step)) + 4;
-    return 4 * p->n_knots + 4 * ts->n_t + 1024;       // no lower bound on the step: a generous default; a larger record may be passed
+    // torchdiffeq counts max_num_steps per output interval (rk_common.py:232): no solve that finishes takes more steps than this
+    const double by_max = op->max_num_steps > 0 ? (double)op->max_num_steps * (ts->n_t - 1) + 4.0 : 1.0e6;
+    if (op->min_step > 0.0) return (int)std::min(std::min(1.0e6, by_max), std::ceil(span / op->min_step) + 4.0);
+    // no lower bound on the step: a default of about two steps per knot; a solve that needs more returns NCDE_ERR_WORKSPACE ("pass a
+    // larger record") and the caller repeats it with a larger one -- the forward is deterministic (ncde_amd/solver.py doubles it)
+    return (int)std::min(by_max, 2.0 * p->n_knots + 2.0 * ts->n_t + 256.0);
 }
 // the largest capacity a record of `bytes` holds
 int tape_cap_of(const NcdeProblem* p, int n_t, size_t bytes) {
@@ -1227,6 +1231,19 @@ bool ncde_dp_supported(const NcdeProblem* p, int adj, char* why, size_t n) {
         if (base > (size_t)kLdsLimit) { snprintf(why, n, "dopri5 adjoint needs %zu B of LDS", base); return false; }
         if (y.dlast > 128) { snprintf(why, n, "dopri5 adjoint supports a last hidden width <= 128 (got %d)", y.dlast); return false; }
     }
+    return true;
+}
+
+// The reverse sweep of a taped solve (ncde_dp_tape_backward) keeps its cotangents in per-thread arrays of DP_NE elements
+// (element e = tid + 256 q < 16 H, i.e. H <= 128) and needs 7 [H][16] arrays of LDS where the stage kernels need 4.  Checked when
+// the record is SIZED and when the recording forward is launched, so that a model outside these bounds fails before any work is
+// done instead of producing silently wrong gradients (rows h >= 128 never initialised) or failing only in backward().
+bool ncde_dp_tape_supported(const NcdeProblem* p, char* why, size_t n) {
+    const Layout y = make_layout(p);
+    if (y.Hp > 16 * DP_NE) { snprintf(why, n, "dopri5 with adjoint=False supports hidden <= %d (got %d)", 16 * DP_NE, p->hidden); return false; }
+    if (y.dlast > 128) { snprintf(why, n, "dopri5 with adjoint=False supports a last hidden width <= 128 (got %d)", y.dlast); return false; }
+    const size_t lds = sizeof(float) * (size_t)(7 * y.HS + ((y.L > 0 ? y.L : 1) + 4) * y.DS + 2 * y.Cp * 16 + 4 * 16 * 17) + 4 * 256 * sizeof(double);
+    if (lds > (size_t)kLdsLimit) { snprintf(why, n, "dopri5 with adjoint=False needs %zu B of LDS for its reverse sweep (> %d)", lds, kLdsLimit); return false; }
     return true;
 }
 
@@ -1393,8 +1410,9 @@ int ncde_dp_solve(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdapti
 #undef DP_TRY
 }
 
-// Reverse sweep of a taped solve: dL/dz0 and dL/dtheta from the record of ncde_dp_solve(..., record).  Stream-ordered, no
-// synchronisation except for the (tiny) knot upload when the control has a user knot grid.
+// Reverse sweep of a taped solve: dL/dz0 and dL/dtheta from the record of ncde_dp_solve(..., record).  Synchronises the stream
+// once to read the record header back (step count / overflow: a record of an unfinished solve must be refused before any launch), and
+// once more for the (tiny) knot upload when the control has a user knot grid; everything after that is stream-ordered.
 int ncde_dp_tape_backward_run(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* op, const void* record, size_t record_bytes,
                               const float* grad_out, const NcdeGrads* g, void* ws, size_t ws_bytes, hipStream_t st, char* err, size_t errn) {
     const Layout y = make_layout(p);

@@ -67,6 +67,11 @@ struct KArgs {
     // batch-tiled direct modes: LDS-resident row-major copies of the small matrices, [N][K] with row stride K + 4, the bias behind
     // (float offset into the dynamic LDS, 0 = streamed from L2)
     int tres[NCDE_MAX_LAYERS], tres_o, tres_g;
+    // zero-padded problems (ncde_abi.hip pads H / layer widths to multiples of 16 and C to a multiple of 4 so that the batch-tiled
+    // family covers any shape): the caller's tensors keep their REAL extents -- Hr = row width of z0 / out / z_out / grad_out /
+    // grad_z0 / the stage record (units >= Hr are not read or written; they stay exactly 0), Cc = channels of the coefficient
+    // tensor (channels >= Cc have dX/dt = X = 0).  Unpadded: Hr = H, Cc = C.
+    int Hr, Cc;
 };
 
 // ---- time plan (built on the host by ncde_time_plan_build, csrc/ncde_timeplan.hip; layout in 4-byte words) -------------
@@ -207,7 +212,7 @@ __device__ __forceinline__ float plan_out_cotangent(const KArgs& a, const int* p
     for (int q = q0; q < q1; ++q) {
         const int kind = pout[2 * q];
         const float slope = __int_as_float(pout[2 * q + 1]);
-        const float g = a.grad_out[(brow + q) * a.H + h];
+        const float g = a.grad_out[(brow + q) * a.Hr + h];
         if (part == 1) acc += kind == 1 ? g : (kind == 2 ? slope * g : 0.0f);
         else acc += kind == 0 ? g : (kind == 2 ? g - slope * g : 0.0f);
     }

@@ -133,6 +133,9 @@ inline void fill_kargs(const NcdeProblem* p, const Layout& y, KArgs* a) {
     a->Wg = p->Wg; a->bg = p->bg; a->Wr = p->Wr; a->br = p->br;
     a->gWg_off = y.gWg_off; a->gbg_off = y.gbg_off; a->gWr_off = y.gWr_off; a->gbr_off = y.gbr_off;
     a->gacc_in_lds = y.gacc_in_lds;
+    // internal (zero-padded problems, see KArgs): reserved_ = (real hidden size << 12) | real channel count, 0 = not padded
+    a->Hr = p->reserved_ ? (p->reserved_ >> 12) : p->hidden;
+    a->Cc = p->reserved_ ? (p->reserved_ & 0xFFF) : p->channels;
 }
 
 // K4: sum the per-workgroup partials and scatter into the caller's buffers. 0 = ok, else NcdeStatus.

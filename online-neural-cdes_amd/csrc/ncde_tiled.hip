@@ -28,18 +28,18 @@ namespace {
 template <int NS, int NT>
 __device__ __forceinline__ void tl_load_dx(const KArgs& a, int b0, int idx, float frac, float kdt, float* DX, int tid) {
     constexpr int NSP = NS * 16;
-    const int C = a.C;
+    const int C = a.C, Cc = a.Cc;      // Cc: channels of the coefficient tensor (< C when the problem was zero-padded)
     for (int e = tid; e < NSP * C; e += NT) {
         const int s = e / C, c = e - s * C;
         const int b = b0 + s;
         float v = 0.0f;
-        if (b < a.B) {
+        if (b < a.B && c < Cc) {
             const float* p = a.coeffs + (long long)b * a.cs_b + (long long)idx * a.cs_t;
             if (a.interp == NCDE_INTERP_LINEAR) {
                 v = p[a.cs_t + c] - p[c];
                 if (kdt != 1.0f) v = v / kdt;      // user knot grid (interpolation_linear.py:231-234); 1 on the default grid
             } else {
-                const float bb = p[C + c], cc = p[2 * C + c], dd = p[3 * C + c];
+                const float bb = p[Cc + c], cc = p[2 * Cc + c], dd = p[3 * Cc + c];
                 const float inner = cc + dd * frac;
                 v = bb + inner * frac;
             }
@@ -201,18 +201,18 @@ __device__ __forceinline__ void tl_fill_resident(const KArgs& a, float* lds, int
 template <int NS, int NT>
 __device__ __forceinline__ void tl_load_cin(const KArgs& a, int b0, const StageDesc& sd, bool value, float* U, int row0, int tid) {
     constexpr int NSP = NS * 16;
-    const int C = a.C;
+    const int C = a.C, Cc = a.Cc;
     for (int e = tid; e < NSP * C; e += NT) {
         const int s = e / C, c = e - s * C;
         const int b = b0 + s;
         float v = 0.0f;
-        if (b < a.B) {
+        if (b < a.B && c < Cc) {
             const float* p = a.coeffs + (long long)b * a.cs_b + (long long)sd.idx * a.cs_t;
             if (a.interp == NCDE_INTERP_LINEAR) {
                 const float d = p[a.cs_t + c] - p[c];
                 v = value ? p[c] + (sd.frac * d) / sd.kdt : (sd.kdt != 1.0f ? d / sd.kdt : d);
             } else {
-                const float aa = p[c], bb = p[C + c], cc = p[2 * C + c], dd = p[3 * C + c];
+                const float aa = p[c], bb = p[Cc + c], cc = p[2 * Cc + c], dd = p[3 * Cc + c];
                 if (value) {
                     float inner = 0.5f * cc + (dd * sd.frac) / 3.0f;
                     inner = bb + inner * sd.frac;
@@ -573,10 +573,11 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
         y0[q] = k1[q] = k2[q] = 0.0f;
         if (e < HS) {
             const int u = ((e >> 2) / NSP) * 4 + (e & 3), s = (e >> 2) % NSP, b = b0 + s;
-            const float v = b < a.B ? a.z0[(long long)b * H + u] : 0.0f;
+            const bool live = b < a.B && u < a.Hr;      // (zero-padded problems: units >= Hr are not the caller's)
+            const float v = live ? a.z0[(long long)b * a.Hr + u] : 0.0f;
             y0[q] = v;
             YS[e] = v;
-            if (b < a.B) a.out[((long long)b * a.n_out) * H + u] = v;
+            if (live) a.out[((long long)b * a.n_out) * a.Hr + u] = v;
         }
     }
     const int S = n_stages(a.method);
@@ -618,9 +619,10 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
             }
             __syncthreads();
             if (a.stages) {  // record the stage input for the exact discrete backward
-                float* rec = a.stages + ((long long)(n * S + j) * a.B + b0) * H;
-                for (int e = tid; e < NSP * H; e += NT) {
-                    const int s = e / H, u = e - s * H;
+                const int Hr = a.Hr;
+                float* rec = a.stages + ((long long)(n * S + j) * a.B + b0) * Hr;
+                for (int e = tid; e < NSP * Hr; e += NT) {
+                    const int s = e / Hr, u = e - s * Hr;
                     if (b0 + s < a.B) rec[e] = YS[((u >> 2) * NSP + s) * 4 + (u & 3)];
                 }
             }
@@ -699,7 +701,8 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                     YS[e] = ys;
                     if (last) {
                         const int u = ((e >> 2) / NSP) * 4 + (e & 3), s = (e >> 2) % NSP, b = b0 + s;
-                        if (b < a.B) {
+                        if (b < a.B && u < a.Hr) {
+                            const int H = a.Hr;      // row width of the caller's solution tensor
                             if (planned) {      // output pick / interpolation between the step's end points (solvers.py:103-117)
                                 const int q0 = pstep[1], q1 = q0 + pstep[2];
                                 for (int r = q0; r < q1; ++r) {
@@ -992,15 +995,16 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
         y0[q] = ky1[q] = ky2[q] = a0[q] = ka1[q] = ka2[q] = 0.0f;
         if (e < HS) {
             const int u = ((e >> 2) / NSP) * 4 + (e & 3), s = (e >> 2) % NSP, b = b0 + s;
-            const long long o = ((long long)b * a.n_out + last_row) * H + u;
+            const bool live = b < a.B && u < a.Hr;      // (zero-padded problems: units >= Hr are not the caller's; they stay 0)
+            const long long o = ((long long)b * a.n_out + last_row) * a.Hr + u;
             float g, y;
             if (a.resume) {      // a later time window: (y, a) at knot win_hi as the previous launch left them
                 y = a.carry[(long long)blockIdx.x * HS + e];
                 g = a.carry[((long long)gridDim.x + blockIdx.x) * HS + e];
             } else {
-                g = b < a.B ? a.grad_out[o] : 0.0f;
-                if (planned && disc && b < a.B) g = plan_out_cotangent(a, pfwd + (a.n_steps_fwd - 1) * pw_, pout, 1, (long long)b * a.n_out, u);
-                y = (!disc && b < a.B) ? a.z_out[o] : 0.0f;
+                g = live ? a.grad_out[o] : 0.0f;
+                if (planned && disc && live) g = plan_out_cotangent(a, pfwd + (a.n_steps_fwd - 1) * pw_, pout, 1, (long long)b * a.n_out, u);
+                y = (!disc && live) ? a.z_out[o] : 0.0f;
             }
             a0[q] = g;
             if (disc) {
@@ -1113,7 +1117,8 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
             float v = 0.0f;
             if (e < NSP * C) {
                 const int s = e / C, c = e - s * C, b = b0 + s;
-                if (b < a.B) {
+                const int Cc = a.Cc;      // channels of the coefficient tensor (zero-padded problems: < C)
+                if (b < a.B && c < Cc) {
                     const float* cp = a.coeffs + (long long)b * a.cs_b + (long long)idx * a.cs_t;
                     const bool value = DIRECT != 0 && a.field_input == NCDE_INPUT_EVALUATE;      // X(t) instead of dX/dt(t)
                     if (a.interp == NCDE_INTERP_LINEAR) {
@@ -1121,7 +1126,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                         if (value) v = cp[c] + (frac * v) / kdt;
                         else if (kdt != 1.0f) v = v / kdt;
                     } else {
-                        const float bb = cp[C + c], cc = cp[2 * C + c], dd = cp[3 * C + c];
+                        const float bb = cp[Cc + c], cc = cp[2 * Cc + c], dd = cp[3 * Cc + c];
                         if (value) {
                             float inner = 0.5f * cc + (dd * frac) / 3.0f;
                             inner = bb + inner * frac;
@@ -1136,13 +1141,14 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
             dxn[q] = v;
         }
         if (disc) {
-            const float* rec = a.stages + ((long long)((n - 1) * S + (S - 1 - j)) * a.B + b0) * H;
+            const int Hr = a.Hr;
+            const float* rec = a.stages + ((long long)((n - 1) * S + (S - 1 - j)) * a.B + b0) * Hr;
 #pragma unroll
             for (int q = 0; q < YSE; ++q) {
                 const int e = tid + q * NT;
                 float v = 0.0f;
-                if (e < NSP * H) {
-                    const int s = e / H;
+                if (e < NSP * Hr) {
+                    const int s = e / Hr;
                     if (b0 + s < a.B) v = rec[e];
                 }
                 ysn[q] = v;
@@ -1163,8 +1169,8 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
 #pragma unroll
             for (int q = 0; q < YSE; ++q) {
                 const int e = tid + q * NT;
-                if (e < NSP * H) {
-                    const int s = e / H, u = e - s * H;
+                if (e < NSP * a.Hr) {
+                    const int s = e / a.Hr, u = e - s * a.Hr;
                     YS[((u >> 2) * NSP + s) * 4 + (u & 3)] = ysn[q];
                 }
             }
@@ -1368,7 +1374,8 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                 const int e = tid + q * NT;
                 if (e < HS) {
                     const int u = ((e >> 2) / NSP) * 4 + (e & 3), s = (e >> 2) % NSP, b = b0 + s;
-                    const bool valid = b < a.B;
+                    const bool valid = b < a.B && u < a.Hr;      // (zero-padded problems: units >= Hr are not the caller's)
+                    const int H = a.Hr;                          // row width of the caller's z_out / grad_out / grad_z0
                     const float d = KOA[e];
                     if (disc) {
                         // transpose of the Butcher step: d = dL/dY of this stage (see ncde_generic.hip / ncde_variant.hip)

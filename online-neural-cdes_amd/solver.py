@@ -160,20 +160,37 @@ def _stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-_ARENA = {}      # (device index, stream) -> one byte tensor, grown on demand and reused by every solve on that stream
+_ARENA = {}      # (device index, stream, host thread) -> one byte tensor, grown on demand and reused by every solve issued there
+_ARENA_MAX = 32
 
 
-def _workspace(p, pass_, device):
-    """Scratch for one C-ABI call: a per-(device, stream) arena instead of an allocation per call.  The kernels are stream-ordered
-    and a workspace is dead when its call's kernels are, so consecutive calls on ONE stream may share it; another stream gets its own."""
-    need = max(int(_lib.check(_lib.lib().ncde_workspace_bytes(ctypes.byref(p), pass_), "ncde_workspace_bytes")), 256)
+def clear_workspace_arena():
+    """Drop every cached workspace (they are ordinary torch allocations: torch.cuda.empty_cache() can then return the memory)."""
+    _ARENA.clear()
+
+
+def _workspace_bytes(need, device):
+    """Scratch for one C-ABI call: an arena per (device, stream, host thread) instead of an allocation per call.  The kernels are
+    stream-ordered and a workspace is dead when its call's kernels are, so consecutive calls issued by ONE thread on ONE stream may
+    share it.  Two host threads on the same stream could interleave their launches (ctypes drops the GIL) -- A's main kernel, B's
+    main kernel, A's reduction reading B's partials -- so the thread is part of the key; entries of dead streams / threads are
+    pruned once the table grows."""
+    import threading
+    need = max(int(need), 256)
     dev = torch.device(device)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream,
+           threading.get_ident())
     buf = _ARENA.get(key)
     if buf is None or buf.numel() < need:
+        if len(_ARENA) >= _ARENA_MAX:
+            _ARENA.clear()
         buf = torch.empty(need + need // 8, dtype=torch.uint8, device=dev)
         _ARENA[key] = buf
     return buf[:need]
+
+
+def _workspace(p, pass_, device):
+    return _workspace_bytes(_lib.check(_lib.lib().ncde_workspace_bytes(ctypes.byref(p), pass_), "ncde_workspace_bytes"), device)
 
 
 def _check_tensor(x, name):
@@ -311,7 +328,7 @@ class _FusedDopri5(torch.autograd.Function):
         stats = _lib.NcdeAdaptiveStats()
         with torch.cuda.device(z0.device):
             need = _lib.check(lib.ncde_dopri5_workspace_bytes(ctypes.byref(p), ctypes.byref(ad.ts), 0), "ncde_dopri5_workspace_bytes")
-            ws = torch.empty(int(need), dtype=torch.uint8, device=z0.device)
+            ws = _workspace_bytes(int(need), z0.device)
             rc = lib.ncde_dopri5_forward(ctypes.byref(p), ctypes.byref(ad.ts), ctypes.byref(ad.opt), out.data_ptr(), ws.data_ptr(),
                                          ws.numel(), _stream_ptr(), ctypes.byref(stats))
         if rc == -1:
@@ -352,7 +369,7 @@ class _FusedDopri5(torch.autograd.Function):
         stats = _lib.NcdeAdaptiveStats()
         with torch.cuda.device(dev):
             need = _lib.check(lib.ncde_dopri5_workspace_bytes(ctypes.byref(p), ctypes.byref(ad.ts), 1), "ncde_dopri5_workspace_bytes")
-            ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+            ws = _workspace_bytes(int(need), dev)
             rc = lib.ncde_dopri5_adjoint(ctypes.byref(p), ctypes.byref(ad.ts), ctypes.byref(ad.opt), out.data_ptr(), grad_out.data_ptr(),
                                          ctypes.byref(g), ws.data_ptr(), ws.numel(), _stream_ptr(), ctypes.byref(stats))
         if rc == -1:
@@ -379,23 +396,40 @@ class _FusedDopri5Taped(torch.autograd.Function):
         out = torch.empty(z0.shape[0], len(ad.tv), z0.shape[1], dtype=torch.float32, device=z0.device)
         lib = _lib.lib()
         stats = _lib.NcdeAdaptiveStats()
+        # nothing to differentiate (torch.no_grad(), frozen inputs): the plain solve, no step record at all
+        taped = any(ctx.needs_input_grad)
+        rec = None
         with torch.cuda.device(z0.device):
             need = _lib.check(lib.ncde_dopri5_workspace_bytes(ctypes.byref(p), ctypes.byref(ad.ts), 0), "ncde_dopri5_workspace_bytes")
-            ws = torch.empty(int(need), dtype=torch.uint8, device=z0.device)
-            rbytes = _lib.check(lib.ncde_dopri5_record_bytes(ctypes.byref(p), ctypes.byref(ad.ts), ctypes.byref(ad.opt)), "ncde_dopri5_record_bytes")
-            rec = torch.empty(int(rbytes), dtype=torch.uint8, device=z0.device)
-            rc = lib.ncde_dopri5_forward_record(ctypes.byref(p), ctypes.byref(ad.ts), ctypes.byref(ad.opt), out.data_ptr(), rec.data_ptr(),
-                                                rec.numel(), ws.data_ptr(), ws.numel(), _stream_ptr(), ctypes.byref(stats))
+            ws = _workspace_bytes(int(need), z0.device)
+            if not taped:
+                rc = lib.ncde_dopri5_forward(ctypes.byref(p), ctypes.byref(ad.ts), ctypes.byref(ad.opt), out.data_ptr(), ws.data_ptr(),
+                                             ws.numel(), _stream_ptr(), ctypes.byref(stats))
+            else:
+                # The record holds one start state per ACCEPTED step; its default size is a guess when the options give no min_step
+                # (ncde_dopri5_record_bytes).  A solve that outgrows it reports NCDE_ERR_WORKSPACE: repeat it with twice the record
+                # -- the forward is deterministic -- where the reference's autograd tape would simply have grown.
+                rbytes = int(_lib.check(lib.ncde_dopri5_record_bytes(ctypes.byref(p), ctypes.byref(ad.ts), ctypes.byref(ad.opt)), "ncde_dopri5_record_bytes"))
+                rbytes = int(cfg.get("record_bytes") or rbytes)
+                for _ in range(8):
+                    rec = torch.empty(rbytes, dtype=torch.uint8, device=z0.device)
+                    rc = lib.ncde_dopri5_forward_record(ctypes.byref(p), ctypes.byref(ad.ts), ctypes.byref(ad.opt), out.data_ptr(), rec.data_ptr(),
+                                                        rec.numel(), ws.data_ptr(), ws.numel(), _stream_ptr(), ctypes.byref(stats))
+                    if rc != -3 or b"record" not in (lib.ncde_last_error_string() or b""):
+                        break
+                    rec = None
+                    rbytes *= 2
         if rc == -1:
             raise AssertionError(lib.ncde_last_error_string().decode())      # the reference asserts (rk_common.py:232-233, 195)
-        _lib.check(rc, "ncde_dopri5_forward_record")
+        _lib.check(rc, "ncde_dopri5_forward_record" if taped else "ncde_dopri5_forward")
         cfg["stats_forward"] = (stats.nfe, stats.n_accepted, stats.n_rejected)
         if ad.trace is not None and cfg["func"] is not None:
             cfg["func"].dopri5_trace = ad.trace[:stats.n_accepted + stats.n_rejected].copy()
         if cfg["func"] is not None and hasattr(cfg["func"], "nfe"):
             cfg["func"].nfe += stats.nfe
         ctx.cfg, ctx.coeffs, ctx.z0_shape = cfg, coeffs, z0.shape
-        ctx.save_for_backward(z0c, rec, *params)
+        if taped:
+            ctx.save_for_backward(z0c, rec, *params)
         return out
 
     @staticmethod
@@ -418,7 +452,7 @@ class _FusedDopri5Taped(torch.autograd.Function):
         lib = _lib.lib()
         with torch.cuda.device(dev):
             need = _lib.check(lib.ncde_dopri5_workspace_bytes(ctypes.byref(p), ctypes.byref(ad.ts), 2), "ncde_dopri5_workspace_bytes")
-            ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+            ws = _workspace_bytes(int(need), dev)
             rc = lib.ncde_dopri5_backward(ctypes.byref(p), ctypes.byref(ad.ts), ctypes.byref(ad.opt), rec.data_ptr(), rec.numel(),
                                           grad_out.data_ptr(), ctypes.byref(g), ws.data_ptr(), ws.numel(), _stream_ptr())
         _lib.check(rc, "ncde_dopri5_backward")
@@ -426,7 +460,8 @@ class _FusedDopri5Taped(torch.autograd.Function):
         return (grad_z0 if ctx.needs_input_grad[0] else None, None, None, *grads)
 
 
-_DOPRI5_OPTIONS = ("min_step", "max_step", "first_step", "safety", "ifactor", "dfactor", "max_num_steps", "_trace", "_replay")
+_DOPRI5_OPTIONS = ("min_step", "max_step", "first_step", "safety", "ifactor", "dfactor", "max_num_steps", "_trace", "_replay",
+                   "_record_bytes")      # _record_bytes: initial size of the step record of adjoint=False (default: the library's estimate)
 
 
 def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
@@ -531,7 +566,7 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
             raise NotImplementedError("method='dopri5' runs the original vector field with the matmul input only")
         bopt = dict(ad_options) if adjoint_options is None else {k: v for k, v in adjoint_options.items() if k in _DOPRI5_OPTIONS}
         cfg = {"spec": spec, "interp": X.interp_name, "flags": flags, "func": func, "adjoint_param_ids": ap,
-               "adaptive": _AdaptiveSpec(X, t, rtol, atol, ad_options),
+               "adaptive": _AdaptiveSpec(X, t, rtol, atol, ad_options), "record_bytes": ad_options.get("_record_bytes"),
                "adaptive_backward": _AdaptiveSpec(X, t, rtol if adjoint_rtol is None else adjoint_rtol,
                                                   atol if adjoint_atol is None else adjoint_atol, bopt)}
         out = (_FusedDopri5 if adjoint else _FusedDopri5Taped).apply(z0, coeffs.detach(), cfg, *uniq)

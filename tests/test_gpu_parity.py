@@ -804,8 +804,12 @@ def test_tiled_minimal_gated_vs_oracle(shape, interp, method, seq, gpu_lib):
 
 
 _SWEEP = [  # (B, L, C, H, HH, nl, interp, method, seq)  -- whatever family the dispatcher picks for each
-    (5, 4, 3, 7, 15, 1, "linear", "rk4", False),         # reference defaults: hidden_hidden_dim = 15 (odd widths: generic)
-    (33, 6, 6, 10, 15, 3, "cubic", "midpoint", True),
+    (5, 4, 3, 7, 15, 1, "linear", "rk4", False),         # reference defaults: hidden_hidden_dim = 15 (odd widths: zero-padded
+    (33, 6, 6, 10, 15, 3, "cubic", "midpoint", True),    #   into the batch-tiled family by the library)
+    (37, 5, 5, 47, 93, 3, "linear", "rk4", True),        # odd everything inside the reference's hyper-parameter ranges
+    (21, 6, 21, 96, 15, 2, "cubic", "midpoint", False),  # C = 21 -> 24, H = 96, HH = 15 -> 16
+    (18, 4, 10, 32, 47, 4, "linear", "euler", False),    # HH = 47 -> 64, four layers
+    (9, 7, 7, 128, 100, 3, "cubic", "rk4", True),        # HH = 100 -> 128
     (19, 9, 8, 32, 32, 2, "linear", "euler", True),      # multiples of 16/4 without a specialised kernel: tiled
     (40, 5, 12, 48, 16, 3, "cubic", "rk4", False),
     (17, 7, 20, 32, 32, 4, "linear", "rk4", True),       # cfg2 dims but nl = 4: no fast adjoint instantiation
@@ -826,7 +830,10 @@ def test_shape_sweep_every_family_vs_oracle(cfg, gpu_lib):
     ex = case["expect"]
     res = gpu_util.run_case(case)
     assert gu.relerr(res["z_out"], ex["z_out"]) <= TIGHT_Z, res["kernels"]
+    # no shape with dims <= 128 runs on the generic family unless asked to: odd shapes are zero-padded
+    assert not any("generic" in k for k in res["kernels"]), res["kernels"]
     gen = gpu_util.run_case(case, flags=1, need_grads=False)
+    assert "generic" in gen["kernels"][0]
     assert gu.relerr(res["z_out"], gen["z_out"]) <= TIGHT_Z
     iso = gpu_util.run_adjoint_direct(case, ex["z_out"])
     for k, e in _grad_errors(case, iso).items():

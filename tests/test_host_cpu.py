@@ -109,7 +109,12 @@ def test_kernel_family_selection():
     p = _problem()                                    # BASELINE cfg2 shape -> specialised kernels
     assert name(p, 0).startswith("ncde_fwd_fast") and name(p, 1).startswith("ncde_adj_fast")
     assert name(_problem(flags=_lib.FLAG_FORCE_GENERIC), 0) == "ncde_fwd_generic"
-    q = _problem(C=5, H=16, HH=24)                    # arbitrary shape -> generic family
+    q = _problem(C=5, H=16, HH=24)                    # arbitrary shape -> zero-padded (C 8, HH 32) into the batch-tiled family
+    assert name(q, 0).startswith("ncde_fwd_tiled") and name(q, 1).startswith("ncde_adj_tiled") and name(q, 2).startswith("ncde_adj_tiled")
+    wq = lib.ncde_workspace_bytes(ctypes.byref(q), 1)
+    q8 = _problem(C=8, H=16, HH=32)                   # the aligned shape it is padded to: same kernels, workspace without the padded copies
+    assert name(q8, 1) == name(q, 1) and 0 < lib.ncde_workspace_bytes(ctypes.byref(q8), 1) < wq
+    q.flags = _lib.FLAG_FORCE_GENERIC                 # ... unless the generic family is asked for
     assert name(q, 0) == "ncde_fwd_generic" and name(q, 1) == "ncde_adj_generic"
     q.flags = _lib.FLAG_FORCE_FAST
     assert lib.ncde_workspace_bytes(ctypes.byref(q), 0) == -2

@@ -3,6 +3,9 @@ import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ncde_amd
+if len(sys.argv) > 1:
+    print("note: NCDE_CUBIC_LDS_KB / NCDE_CUBIC_DBG are read only by a library built with -DNCDE_DEV_KNOBS (make EXTRA=-DNCDE_DEV_KNOBS); "
+          "the shipped library ignores them and every iteration below then times the same configuration", file=sys.stderr)
 xc = torch.from_numpy(ncde_amd.data.synthetic_series(8192, 182, 3, missing=0.0, seed=1234)).cuda()
 for kb in sys.argv[1:] or ["52"]:
     if ":" in kb:
