@@ -56,6 +56,27 @@ def _field_spec(func):
         "arbitrary Python vector fields are outside the fused MI355X path")
 
 
+def _unfused_reason(X, func, z0, t, adjoint, adjoint_params):
+    """Why this call cannot run on the fused kernels (None = it can).  Such calls run on the unfused torch-op solver
+    (unfused.py) -- on the GPU: CPU tensors stay refused, there is no CPU fallback."""
+    if not torch.is_tensor(z0):
+        return None      # tuple-valued z0: refused further down, on either path
+    if not hasattr(func, "fused_spec"):
+        return "func does not expose fused_spec()"
+    tt = torch.as_tensor(t)
+    if tt.dim() == 1 and tt.numel() >= 2 and bool(tt[0] > tt[1]):
+        return "decreasing output times"
+    if torch.is_tensor(t) and t.requires_grad:
+        return "the output times require gradients"
+    ap = set(id(q) for q in adjoint_params) if adjoint_params is not None else set()
+    for buffer in X.buffers():
+        if buffer.requires_grad and (not adjoint or id(buffer) in ap):
+            return "the control path requires gradients"
+    if z0.is_cuda and (z0.dtype != torch.float32 or X.fused_coeffs.dtype != torch.float32):
+        return "tensors are not fp32"
+    return None
+
+
 def _time_mode(X, t):
     """-> _lib.OUT_INTERVAL / OUT_KNOTS.  Tagged tensors from X.interval / X.grid_points avoid a device sync."""
     kind = getattr(t, "_ncde_kind", None)
@@ -497,6 +518,30 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
         raise NotImplementedError("adjoint_method != method is outside the fused path")
     if not isinstance(X, (LinearInterpolation, NaturalCubicSpline)):
         raise NotImplementedError("X must be ncde_amd.LinearInterpolation or ncde_amd.NaturalCubicSpline")
+    reason = _unfused_reason(X, func, z0, t, adjoint, adjoint_params)
+    if reason is not None:
+        # outside the fused kernels: the own unfused torch-op solver, same algorithms (unfused.py), on the tensors' device
+        from . import unfused
+        if not z0.is_cuda:
+            raise NotImplementedError("cdeint needs tensors on the GPU (there is no CPU fallback); z0 is on %s" % z0.device)
+        if method not in _FIXED_METHODS:
+            raise NotImplementedError("method '%s' outside the fused path (%s): the unfused solver runs %s" % (method, reason, _FIXED_METHODS))
+        step = options.pop("step_size", None)
+        if "grid_constructor" in options:
+            raise NotImplementedError("options['grid_constructor'] is not supported; give options={'step_size': h}")
+        options.pop("perturb", None)
+        for k in options:
+            warnings.warn("cdeint: Unexpected arguments {}".format({k: options[k]}))
+        if adjoint:
+            ids = set(id(q) for q in adjoint_params) if adjoint_params is not None else set()
+            for buffer in X.buffers():
+                if buffer.requires_grad and id(buffer) not in ids:      # the reference's warning (solver.py:207-221)
+                    warnings.warn("One of the inputs to the control path X requires gradients but is not listed in "
+                                  "`options['adjoint_params']`. It will not receive a gradient when using the adjoint method.")
+        unfused.warn_once(reason)
+        if torch.is_tensor(step):
+            step = step.item()
+        return unfused.cdeint_unfused(X, func, z0, t, adjoint, vector_field_type, method, step, adjoint_params)
     adaptive = method == "dopri5"
     if adaptive:
         for k in list(options):

@@ -78,8 +78,19 @@ def test_field_variants_match_reference_golden(name, gpu_lib):
     import ncde_oracle as orc
     case = gu.load_case(name)
     m, ex = case["meta"], case["expect"]
+    vnames = ("ncde_fwd_variant", "ncde_adj_variant", "ncde_adj_variant<discrete>")
     res = gpu_util.run_case(case)
-    assert res["kernels"] == ("ncde_fwd_variant", "ncde_adj_variant", "ncde_adj_variant<discrete>"), res["kernels"]
+    if m.get("field_kind") == "minimal" and m.get("field_mode", "matmul") == "matmul":
+        # the library zero-pads the golden's odd widths into the batch-tiled family (its gated kernels); the variant kernels are
+        # what NCDE_FLAG_FORCE_GENERIC selects, and they are held to the same golden below
+        assert all(k.startswith(("ncde_fwd_tiled<", "ncde_adj_tiled<")) and "gated" in k for k in res["kernels"]), res["kernels"]
+        resv = gpu_util.run_case(case, flags=1)
+        assert resv["kernels"] == vnames, resv["kernels"]
+        assert gu.relerr(resv["z_out"], ex["z_out"]) <= TIGHT_Z
+        for k, e in _grad_errors(case, resv).items():
+            assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), ("variant kernels end-to-end", k, e)
+    else:
+        assert res["kernels"] == vnames, res["kernels"]
     assert gu.relerr(res["z_out"], ex["z_out"]) <= TIGHT_Z
     for k, e in _grad_errors(case, res).items():
         assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), ("end-to-end", k, e)

@@ -235,18 +235,24 @@ def test_no_cpu_fallback_product_path_fails_loudly_on_cpu_tensors():
 
 
 def test_control_path_gradients_are_refused_not_dropped():
-    """adjoint=False tapes the solve in the reference, so coefficients that require grad would receive one; the fused
-    backward has no dL/dcoeffs: refuse.  adjoint=True: the reference's warning (torchcde/solver.py:207-221), and an
-    explicit request through adjoint_params is refused as well.  perturb=True is not silently swallowed."""
+    """adjoint=False tapes the solve in the reference, so coefficients that require grad would receive one; the fused backward
+    has no dL/dcoeffs, so such a call (and an explicit request through adjoint_params) is routed to the unfused torch-op solver --
+    which runs on the GPU only: on CPU tensors it is refused (no CPU fallback), never silently dropped.  adjoint=True without
+    listing the coefficients: the reference's warning (torchcde/solver.py:207-221).  perturb=True is not silently swallowed."""
     import warnings
     c = torch.zeros(2, 5, 3, requires_grad=True)
     X = ncde_amd.LinearInterpolation(c)
     f = ncde_amd.OriginalVectorField(3, 4, 8, 2)
     z0 = torch.zeros(2, 4)
     kw = dict(method="rk4", options={"step_size": 1})
-    with pytest.raises(NotImplementedError, match="coefficients"):
+    assert solver._unfused_reason(X, f, z0, X.interval, False, None) == "the control path requires gradients"
+    assert solver._unfused_reason(X, f, z0, X.interval, True, tuple(f.parameters()) + (c,)) == "the control path requires gradients"
+    assert solver._unfused_reason(X, f, z0, X.interval, True, None) is None          # the fused path, with the reference's warning
+    assert solver._unfused_reason(X, torch.nn.Linear(4, 12), z0, X.interval, True, None) == "func does not expose fused_spec()"
+    assert solver._unfused_reason(X, f, z0, torch.tensor([4.0, 0.0]), True, None) == "decreasing output times"
+    with pytest.raises(NotImplementedError, match="no CPU fallback"):
         ncde_amd.cdeint(X, f, z0, X.interval, adjoint=False, **kw)
-    with pytest.raises(NotImplementedError, match="coefficients"):
+    with pytest.raises(NotImplementedError, match="no CPU fallback"):
         ncde_amd.cdeint(X, f, z0, X.interval, adjoint=True, adjoint_params=tuple(f.parameters()) + (c,), **kw)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
