@@ -400,9 +400,14 @@ def main():
     rank, local_rank, world = D.env_world()
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU fallback for the product path"
+    # (NCDE_BENCH_BACKEND=gloo: the test-suite's way to run the world > 1 branches on a ONE-GPU box, both ranks on cuda:0 -- RCCL
+    # refuses two ranks on one device; the driver's runs use the default, nccl = RCCL, one rank per GPU)
+    backend = os.environ.get("NCDE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    D.init_process_group("nccl")
+    D.init_process_group(backend)
     c = dict(CONFIGS[args.config])
 
     def shard(scaling):
@@ -415,11 +420,35 @@ def main():
         assert B_total % world == 0, "strong scaling needs a global batch divisible by the number of ranks"
         return hi - lo, B_total, lo
 
+    # the collective the training step uses, exercised once on a tiny tensor before anything is timed: `rccl_ranks` in the record is
+    # what the backend itself reports after a real all-reduce (N ranks each contributing 1)
+    rccl_ranks, ms_allreduce = 1, 0.0
+    if world > 1:
+        probe = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(probe)
+        rccl_ranks = int(round(float(probe.item())))
+        assert rccl_ranks == torch.distributed.get_world_size() == world
+
     B_local, B_total, lo = shard(args.scaling)
     w = Workload(c, B_local, B_total, lo, dev)
     model, coeffs, T = w.model, w.coeffs, w.T
     z_err = golden_z_err(model, c, coeffs) if (rank == 0 and args.config == "cfg2" and lo == 0) else None
     dt, loss = w.timed(args.steps, args.warmup, world, dev)
+
+    if world > 1:      # the step's one exchange in isolation: all-reduce of the flat fp32 gradient bucket, per rank, HIP events
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            torch.distributed.all_reduce(w.bucket.flat)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20):
+            torch.distributed.all_reduce(w.bucket.flat)
+        e1.record()
+        torch.cuda.synchronize()
+        tar = torch.tensor([e0.elapsed_time(e1) / 20], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tar, op=torch.distributed.ReduceOp.MAX)
+        ms_allreduce = float(tar.item())
+        w.bucket.flat.zero_()
 
     tf = td = t32 = None
     other = None
@@ -482,6 +511,9 @@ def main():
             "roofline": roofs[1],
             "roofline_forward": roofs[0],
             "loss": loss,
+            "rccl_ranks": rccl_ranks, "collective_backend": backend if world > 1 else None,
+            "ms_allreduce": ms_allreduce,
+            "allreduce_floats": int(w.bucket.flat.numel()),
         }
         if z_err is not None:
             rec["z_err_vs_golden"] = z_err

@@ -121,3 +121,46 @@ def test_two_rank_data_parallel_at_the_benchmarked_shape(tmp_path, gpu_lib):
         SHAPE.update({"B": B, "L": L})
     eg = float((grad - r0["grad"]).abs().max()) / float(grad.abs().max())
     assert eg <= 2e-5, eg
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs on one node: RCCL with more than one rank (the pool's boxes have one)")
+def test_bench_two_gpus_over_rccl(gpu_lib):
+    """bench.py --gpus 2 under torch.distributed.run (started before anything touches a GPU in this process tree's child), `nccl`
+    (= RCCL) backend, one rank per GPU: the world>1 branches of the benchmark -- barrier, all-reduce of the flat gradient bucket,
+    max-over-ranks timing, weak AND strong legs -- run for real, and the record says how many ranks RCCL saw."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["scaling"] == "weak" and rec["ms_allreduce"] > 0
+    assert rec["config"]["global_batch"] == 2 * 4096 and "strong" in rec and rec["strong"]["global_batch"] == 4096
+    assert abs(rec["value"] - 2 * 4096 * 398 / (rec["ms_per_step"] * 1e-3)) / rec["value"] < 1e-6
+
+
+def test_bench_world_size_two_branches_on_one_gpu(gpu_lib):
+    """The same launch on a ONE-GPU box: two ranks, both on cuda:0, gloo instead of RCCL (NCDE_BENCH_BACKEND) -- the world > 1
+    code of bench.py (probe all-reduce, barrier + max-over-ranks timing, all-reduce timing, the strong-scaling leg, rank-0-only
+    output) executes on hardware; only the transport differs from the driver's 2/4/8-GPU runs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    env = dict(os.environ, NCDE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["collective_backend"] == "gloo" and rec["ms_allreduce"] > 0
+    assert rec["strong"]["global_batch"] == 4096 and rec["strong"]["batch_per_gpu"] == 2048
+    assert "cpu_baseline" not in rec      # rank 0 at N = 1 only
