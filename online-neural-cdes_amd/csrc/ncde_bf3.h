@@ -99,6 +99,18 @@ __device__ __forceinline__ Split2h split8h(const float* v, float& mx) {
     return o;
 }
 __device__ __forceinline__ bool h2_range_fault(float mx) { return !(mx <= NCDE_H2_LIMIT); }
+// two values -> one dword of each piece (even value in the low half), as split8h does for eight
+__device__ __forceinline__ void split_pair_h(float x0, float x1, unsigned& hi, unsigned& lo, float& mx) {
+    const f32x2 x = {x0, x1};
+    const h16x2 h = __builtin_convertvector(x, h16x2);
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(mx) : "v"(x0), "v"(x1));
+    f32x2 r;
+    r[0] = __builtin_fmaf((float)h[0], -NCDE_H2_SCALE, x0 * NCDE_H2_SCALE);  // exact: (x - h1) * 2^11
+    r[1] = __builtin_fmaf((float)h[1], -NCDE_H2_SCALE, x1 * NCDE_H2_SCALE);
+    const h16x2 l = __builtin_convertvector(r, h16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
 
 __device__ __forceinline__ f32x4 mfma_h(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);

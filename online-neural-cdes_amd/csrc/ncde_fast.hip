@@ -15,6 +15,7 @@
 #include "ncde_fast.h"
 #include "ncde_fast4.h"
 #include "ncde_fast64.h"
+#include "ncde_fast_nl.h"
 // HP = 2 (the default adjoint): hidden-layer dW/db of the previous stage behind barrier A (dL/dpre images double-buffered) / all five
 // dWo blocks behind barrier A -- both shorten what the gradient waves do before barrier A, where the chain waves wait for them
 #ifndef NCDE_F2_DW_LATE
@@ -1763,14 +1764,14 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
     }
     for (int e = tid; e < 2 * HT * 16; e += 512) {
         const int r = e & 3, gg = (e >> 2) & 3, t = (e >> 4) % HT, layer = e / (16 * HT);
-        biasL[e] = a.b[layer][8 * gg + 4 * t + r];
+        biasL[e] = (layer == 0 || NL > 1) ? a.b[layer][8 * gg + 4 * t + r] : 0.0f;      // NL = 1: no inner layer, no second (W, b)
     }
     if (tid < 64 * HT) {  // split W1^T: A row i <-> output unit 8(i>>2)+4t+(i&3), k = 8kg + jj
         const int l = tid & 63, t = tid >> 6;
         const int unit_out = 8 * ((l & 15) >> 2) + 4 * t + (l & 3);
         float tmp[8];
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) tmp[jj] = a.W[1][(8 * (l >> 4) + jj) * HH + unit_out];
+        for (int jj = 0; jj < 8; ++jj) tmp[jj] = NL > 1 ? a.W[1][(8 * (l >> 4) + jj) * HH + unit_out] : 0.0f;
         SO::store(w1T3 + t * NP * 256, l, SO::split(tmp, mx));
     } else if (tid >= 64 * HT + 64 * NW && tid < 64 * HT + 64 * NW + 64 * HT) {  // split W0 and W1 (forward), shared by all chain waves
         const int l = tid & 63, t = (tid >> 6) - HT - NW;
@@ -1779,7 +1780,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         for (int layer = 0; layer < 2; ++layer) {
             float tmp[8];
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) tmp[jj] = a.W[layer][unitA * HH + 8 * (l >> 4) + jj];   // H == HH
+            for (int jj = 0; jj < 8; ++jj) tmp[jj] = (layer == 0 || NL > 1) ? a.W[layer][unitA * HH + 8 * (l >> 4) + jj] : 0.0f;   // H == HH
             SF::store(w1S3 + (layer * HT + t) * NPF * 256, l, SF::split(tmp, mx));
         }
     } else if (tid < 64 * HT + 64 * NW) {  // split W0^T rows of the state entries pair wv owns
@@ -2485,7 +2486,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            gp[a.gW_off[1] + (16 * tr + 4 * g + r) * HH + 16 * tc + s] = gW1[r];
+            if constexpr (NL > 1) gp[a.gW_off[1] + (16 * tr + 4 * g + r) * HH + 16 * tc + s] = gW1[r];
             gp[a.gW_off[0] + (16 * tr + 4 * g + r) * H + 16 * tc + s] = gW0[r];
         }
         {
@@ -2493,7 +2494,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
             v1 += __shfl_xor(v1, 16, 64); v1 += __shfl_xor(v1, 32, 64);
             v0 += __shfl_xor(v0, 16, 64); v0 += __shfl_xor(v0, 32, 64);
             if (tc == 0 && g == 0) {
-                gp[a.gb_off[1] + 16 * tr + s] = v1;
+                if constexpr (NL > 1) gp[a.gb_off[1] + 16 * tr + s] = v1;
                 gp[a.gb_off[0] + 16 * tr + s] = v0;
             }
         }
@@ -2508,6 +2509,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
 #undef NCDE_TICK
 }
 
+#ifndef NCDE_FAST_KERNELS_ONLY      // (ncde_fast_nl.hip includes this file for the kernel templates alone)
 // ------------------------------------------------------------------------------------------------
 // dispatch tables
 // ------------------------------------------------------------------------------------------------
@@ -2624,6 +2626,7 @@ FwdFn pick_adj3_disc(int interp, int method, int hp) {
     return nullptr;
 }
 
+#endif  // NCDE_FAST_KERNELS_ONLY
 template <int NL, int C>
 size_t adj3_lds_bytes(int interp, int hp) {   // hp: the kernel's HP template argument (0, 1, 2)
     constexpr int H = 32, HH = 32, NW = 4, HT = 2, CP = (C + 3) & ~3, CQ = CP / 4, NB = 2, NTILE = NB * CQ;
@@ -2634,6 +2637,7 @@ size_t adj3_lds_bytes(int interp, int hp) {   // hp: the kernel's HP template ar
                                     HT * NP * 256 + NW * NP * 256 + ((hp == 2 && !NCDE_F2_DXL_BF3) ? 0 : NW * NB * CQ * 256) + 2 * HT * NPF * 256 + NW + 4);
 }
 
+#ifndef NCDE_FAST_KERNELS_ONLY
 template <int H, int HH, int C, int NL, int NW>
 size_t adj_lds_bytes(int interp) {
     constexpr int CP = (C + 3) & ~3, CQ = CP / 4, HT = HH / 16, NB = H / 4 / NW, NTILE = NB * CQ;
@@ -2706,6 +2710,13 @@ bool use_v4(const NcdeProblem* p, const FastEntry* e, bool discrete) {
 
 }  // namespace
 
+// (32, 32, 20) with a layer count besides the entry's own: the further instantiations of ncde_adj_fast3 in ncde_fast_nl.hip
+static int nl_hp(const NcdeProblem* p) { return (p->flags & (NCDE_FLAG_SPLIT_BF16 | NCDE_FLAG_FP32_MFMA)) ? 0 : 2; }
+static bool use_nl(const NcdeProblem* p, const FastEntry* e, int pass) {
+    if (pass < 1 || !e || e->adj3 == nullptr || e->adj_layers == p->n_layers) return false;
+    if (p->flags & (NCDE_FLAG_ADJOINT_V1 | NCDE_FLAG_ADJOINT_V2 | NCDE_FLAG_ADJOINT_V4 | NCDE_FLAG_DEBUG_PROFILE | 0x200u)) return false;
+    return ncde_fast_adj3_nl(p->n_layers, p->interp, p->method, nl_hp(p), pass == 2) != nullptr;
+}
 // H = HH = 64, C <= 4: the in-sweep adjoint of ncde_fast64.hip (the entry's own adjoint slots are empty; C < 4 has no entry at all)
 static bool use_h64(const NcdeProblem* p, int pass) { return pass >= 1 && ncde_fast64_supported(p, pass); }
 
@@ -2714,6 +2725,7 @@ bool ncde_fast_supported(const NcdeProblem* p, int pass) {
     const FastEntry* e = find_entry(p);
     if (!e) return false;
     if (pass == 0) return true;
+    if (use_nl(p, e, pass)) return true;
     if (pass == 2) return e->adj3_disc != nullptr && e->adj_layers == p->n_layers;
     return e->adj != nullptr && e->adj_layers == p->n_layers;
 }
@@ -2722,6 +2734,7 @@ const char* ncde_fast_kernel_name(const NcdeProblem* p, int pass) {
     if (use_h64(p, pass)) return ncde_fast64_kernel_name(p, pass);
     if (!ncde_fast_supported(p, pass)) return nullptr;
     const FastEntry* e = find_entry(p);
+    if (use_nl(p, e, pass)) return ncde_fast_adj3_nl_name(p->n_layers, nl_hp(p), pass == 2);
     const bool h2f = !(p->flags & NCDE_FLAG_SPLIT_BF16);
     const bool h2 = h2f && NCDE_ADJ3_HP1_AVAILABLE != 0 && (p->flags & NCDE_FLAG_ADJOINT_SPLIT_FP16);
     const bool f2 = h2f && !h2 && !(p->flags & 0x200u);
@@ -2783,6 +2796,28 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     if (use_h64(p, discrete ? 2 : 1)) return ncde_fast64_adjoint(p, z_out, grad_out, g, ws, ws_bytes, st, main_kernel_only, discrete);
     if (!ncde_fast_supported(p, discrete ? 2 : 1)) return NCDE_ERR_UNSUPPORTED;
     const FastEntry* e = find_entry(p);
+    if (use_nl(p, e, discrete ? 2 : 1)) {      // another layer count of the same kernel template: same launch protocol as below
+        const int hp = nl_hp(p);
+        const Layout y = make_layout(p);
+        KArgs a;
+        fill_kargs(p, y, &a);
+        a.grad_out = grad_out; a.grad_z0 = g->grad_z0;
+        if (discrete) { a.stages = const_cast<float*>(z_out); a.discrete = 1; }
+        else a.z_out = z_out;
+        a.gpart = (float*)ws;
+        a.fault = hp ? reinterpret_cast<int*>(static_cast<char*>(ws) + ncde_fast_workspace_bytes(p, discrete ? 2 : 1) - fault_bytes(y)) : nullptr;
+        for (int pass_hp : {hp, 0}) {      // main launch, then (hp = 2) the split-bf16 instance on range-faulted tiles only
+            NcdeFastNlKernel fn = ncde_fast_adj3_nl(p->n_layers, p->interp, p->method, pass_hp, discrete);
+            const size_t lds = ncde_fast_adj3_nl_lds(p->n_layers, p->interp, pass_hp);
+            if (!fn || ncde_lds_optin((const void*)fn, lds) != hipSuccess) return NCDE_ERR_HIP;
+            hipLaunchKernelGGL(fn, dim3(y.n_wg), dim3(512), lds, st, a);
+            if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
+            if (hp == 0) break;
+            a.only_faulted = 1;
+        }
+        if (main_kernel_only) return NCDE_OK;
+        return launch_reduce_partials(p, y, g, (const float*)ws, y.n_wg, st);
+    }
     const bool v1 = !discrete && ((p->flags & NCDE_FLAG_ADJOINT_V1) != 0 || (e->adj2 == nullptr && e->adj3 == nullptr));
     const bool v3 = discrete || (!v1 && e->adj3 != nullptr && !(p->flags & NCDE_FLAG_ADJOINT_V2));
     const bool v2 = !v1 && !v3;
@@ -2840,3 +2875,5 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     if (main_kernel_only) return NCDE_OK;
     return launch_reduce_partials(p, y, g, (const float*)ws, y.n_wg, st);
 }
+
+#endif  // NCDE_FAST_KERNELS_ONLY

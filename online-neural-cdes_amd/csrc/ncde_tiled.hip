@@ -100,11 +100,14 @@ __host__ __device__ __forceinline__ int tl_panel_k(int nkb) { return (nkb % 8 ==
 // (NS = 1 only): word (((c * 3 + piece) * 4 + kg) * 16 + sample) * 4 + dw holds units 32 c + 8 kg + 2 dw, + 1.
 // ACT: 0 relu (hidden layers), 1 tanh, 2 sigmoid (the heads of the evaluate / derivative input modes, which are plain
 // H-row dense layers)
-template <int NS, int PK, int NWV, int ACT = 0>
+// XH = 1: the split image of the result is the 2-way split-fp16 one (two pieces per chunk instead of three: word
+// (((c * 2 + piece) * 4 + kg) * 16 + sample) * 4 + dw) and *mxp tracks the largest magnitude split (range fault, ncde_bf3.h)
+template <int NS, int PK, int NWV, int ACT = 0, int XH = 0>
 // ld = row stride of W in floats (0: K; a resident LDS copy is stored with K + 4 so that the 16 rows of a fragment load spread
 // over the banks)
 __device__ __forceinline__ void tl_dense_relu_pk(const float* __restrict__ W, const float* __restrict__ bias, int N, int K,
-                                                 const float* in, float* out, int wave, int lane, unsigned* xb = nullptr, int ld = 0) {
+                                                 const float* in, float* out, int wave, int lane, unsigned* xb = nullptr, int ld = 0,
+                                                 float* mxp = nullptr) {
     constexpr int NSP = NS * 16;
     const int li = lane & 15, lk = lane >> 4;
     const int npan = (K >> 4) / PK;
@@ -137,28 +140,38 @@ __device__ __forceinline__ void tl_dense_relu_pk(const float* __restrict__ W, co
                 *reinterpret_cast<f32x4*>(out + ((4 * t + lk) * NSP + st * 16 + li) * 4) = o;
                 if constexpr (NS == 1 && ACT == 0) {
                     if (xb) {      // units 16 t + 4 lk + r: chunk t >> 1, k-group 2 (t & 1) + (lk >> 1), dwords 2 (lk & 1), + 1
-                        unsigned h0, m0, l0, h1, m1, l1;
-                        split_pair(o[0], o[1], h0, m0, l0);
-                        split_pair(o[2], o[3], h1, m1, l1);
-                        unsigned* dst = xb + ((((t >> 1) * 3) * 4 + 2 * (t & 1) + (lk >> 1)) * 16 + li) * 4 + 2 * (lk & 1);
                         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                        *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
-                        *reinterpret_cast<u32x2*>(dst + 256) = (u32x2){m0, m1};
-                        *reinterpret_cast<u32x2*>(dst + 512) = (u32x2){l0, l1};
+                        if constexpr (XH != 0) {
+                            unsigned h0, l0, h1, l1;
+                            split_pair_h(o[0], o[1], h0, l0, *mxp);
+                            split_pair_h(o[2], o[3], h1, l1, *mxp);
+                            unsigned* dst = xb + ((((t >> 1) * 2) * 4 + 2 * (t & 1) + (lk >> 1)) * 16 + li) * 4 + 2 * (lk & 1);
+                            *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
+                            *reinterpret_cast<u32x2*>(dst + 256) = (u32x2){l0, l1};
+                        } else {
+                            unsigned h0, m0, l0, h1, m1, l1;
+                            split_pair(o[0], o[1], h0, m0, l0);
+                            split_pair(o[2], o[3], h1, m1, l1);
+                            unsigned* dst = xb + ((((t >> 1) * 3) * 4 + 2 * (t & 1) + (lk >> 1)) * 16 + li) * 4 + 2 * (lk & 1);
+                            *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
+                            *reinterpret_cast<u32x2*>(dst + 256) = (u32x2){m0, m1};
+                            *reinterpret_cast<u32x2*>(dst + 512) = (u32x2){l0, l1};
+                        }
                     }
                 }
             }
         }
     }
 }
-template <int NS, int NWV, int ACT = 0>
+template <int NS, int NWV, int ACT = 0, int XH = 0>
 __device__ __forceinline__ void tl_dense_relu(const float* __restrict__ W, const float* __restrict__ bias, int N, int K,
-                                              const float* in, float* out, int wave, int lane, unsigned* xb = nullptr, int ld = 0) {
+                                              const float* in, float* out, int wave, int lane, unsigned* xb = nullptr, int ld = 0,
+                                              float* mxp = nullptr) {
     switch (tl_panel_k(K >> 4)) {
-        case 8: tl_dense_relu_pk<NS, 8, NWV, ACT>(W, bias, N, K, in, out, wave, lane, xb, ld); break;
-        case 4: tl_dense_relu_pk<NS, 4, NWV, ACT>(W, bias, N, K, in, out, wave, lane, xb, ld); break;
-        case 2: tl_dense_relu_pk<NS, 2, NWV, ACT>(W, bias, N, K, in, out, wave, lane, xb, ld); break;
-        default: tl_dense_relu_pk<NS, 1, NWV, ACT>(W, bias, N, K, in, out, wave, lane, xb, ld); break;
+        case 8: tl_dense_relu_pk<NS, 8, NWV, ACT, XH>(W, bias, N, K, in, out, wave, lane, xb, ld, mxp); break;
+        case 4: tl_dense_relu_pk<NS, 4, NWV, ACT, XH>(W, bias, N, K, in, out, wave, lane, xb, ld, mxp); break;
+        case 2: tl_dense_relu_pk<NS, 2, NWV, ACT, XH>(W, bias, N, K, in, out, wave, lane, xb, ld, mxp); break;
+        default: tl_dense_relu_pk<NS, 1, NWV, ACT, XH>(W, bias, N, K, in, out, wave, lane, xb, ld, mxp); break;
     }
 }
 
@@ -478,6 +491,116 @@ __device__ __forceinline__ void tl_output_bf(const KArgs& a, const unsigned* xb,
     if (nq & 1) step(TA);
 }
 
+
+// ---- split-fp16 output tiles (round 4; NS = 1, last hidden width a multiple of 32) ------------------------------------------------
+// The forward-side operands -- weights and x_L, O(1) magnitudes -- as TWO fp16 pieces (ncde_bf3.h): 3 f16 MFMAs per K-chunk of 32
+// instead of 6 bf16 ones, and a weight stream of 1.0 x the fp32 bytes instead of 1.5 x -- the stream is what bounds the output
+// phase at cfg5.  The fp16 range is speculated on exactly as in the register-resident family: the
+// workgroup reports a range fault for its sample tile and the split-bf16 instantiation, launched behind it, re-executes that tile.
+template <int NCH, int GATED>
+struct H2Tile {
+    u32x4 w[NCH][2];
+    f32x4 bias;
+    u32x4 g[GATED ? NCH : 1][2];
+    f32x4 biasg;
+};
+template <int NCH>
+__device__ __forceinline__ void tl_load_h2(const unsigned* tile, int lane, u32x4 (&w)[NCH][2]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) w[c][p] = *reinterpret_cast<const u32x4*>(tile + ((c * 2 + p) * 64 + lane) * 4);
+}
+// bias + W(tile) x: main accumulator (hi hi) and cross accumulator (hi lo + lo hi, carries 2^11), one pair per chunk parity
+template <int NCH>
+__device__ __forceinline__ f32x4 tl_mma_h2(const u32x4 (&w)[NCH][2], const unsigned* xb, int lane, f32x4 bias) {
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 m0 = bias, x0 = z4, m1 = z4, x1 = z4;
+#pragma unroll
+    for (int c = 0; c < NCH; c += 2) {
+        u32x4 B0[2], B1[2];
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            B0[pc] = *reinterpret_cast<const u32x4*>(xb + ((c * 2 + pc) * 64 + lane) * 4);
+            if constexpr (NCH > 1) B1[pc] = *reinterpret_cast<const u32x4*>(xb + (((c + 1) * 2 + pc) * 64 + lane) * 4);
+        }
+        m0 = mfma_h(w[c][0], B0[0], m0);
+        if constexpr (NCH > 1) m1 = mfma_h(w[c + 1][0], B1[0], m1);
+        x0 = mfma_h(w[c][1], B0[0], x0);
+        if constexpr (NCH > 1) x1 = mfma_h(w[c + 1][1], B1[0], x1);
+        x0 = mfma_h(w[c][0], B0[1], x0);
+        if constexpr (NCH > 1) x1 = mfma_h(w[c + 1][0], B1[1], x1);
+    }
+    if constexpr (NCH > 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { m0[r] += m1[r]; x0[r] += x1[r]; }
+    }
+    return h2_combine(m0, x0);
+}
+
+template <int NCH, int NWV, int GATED>
+__device__ __forceinline__ void tl_output_h2(const KArgs& a, const unsigned* xb, const float* DX, float* KO, int wave, int lane) {
+    constexpr int NSP = 16;
+    const int li = lane & 15, lk = lane >> 4;
+    const int C = a.C, nhb = a.H >> 2, ncq = C >> 2;
+    const int nhb_w = (nhb - wave + NWV - 1) / NWV;
+    if (nhb_w <= 0) return;
+    const int nq = nhb_w * ncq;
+    using TileIn = H2Tile<NCH, GATED>;
+    const unsigned* wo = reinterpret_cast<const unsigned*>(a.Wo_pk);
+    const unsigned* wg = reinterpret_cast<const unsigned*>(a.Wg_pk);
+    int fhi = 0, fcq = 0, fq = 0;
+    auto fetch = [&]() {
+        const int hb = wave + NWV * fhi;
+        TileIn t;
+        const long long woff = (long long)(hb * ncq + fcq) * (NCH * 2 * 256);
+        tl_load_h2<NCH>(wo + woff, lane, t.w);
+        t.bias = *reinterpret_cast<const f32x4*>(a.bo + (4 * hb + lk) * C + 4 * fcq);
+        if constexpr (GATED != 0) {
+            tl_load_h2<NCH>(wg + woff, lane, t.g);
+            t.biasg = *reinterpret_cast<const f32x4*>(a.bg + (4 * hb + lk) * C + 4 * fcq);
+        }
+        const bool more = fq + 1 < nq, wrap = fcq + 1 == ncq;
+        fq += more ? 1 : 0;
+        fhi += (more && wrap) ? 1 : 0;
+        fcq = more ? (wrap ? 0 : fcq + 1) : fcq;
+        return t;
+    };
+    int chi = 0, ccq = 0;
+    float kacc = 0.0f;
+    auto step = [&](const TileIn& t) {
+        const int hb = wave + NWV * chi;
+        const f32x4 acc = tl_mma_h2<NCH>(t.w, xb, lane, t.bias);
+        f32x4 accg;
+        if constexpr (GATED != 0) accg = tl_mma_h2<NCH>(t.g, xb, lane, t.biasg);
+        const f32x4 dx = *reinterpret_cast<const f32x4*>(DX + (ccq * NSP + li) * 4);
+        float kk = ccq == 0 ? 0.0f : kacc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float m = tanh_dev(acc[r]);
+            if constexpr (GATED != 0) m = tl_sigmoid(accg[r]) * m;
+            kk = fmaf(m, dx[r], kk);
+        }
+        kacc = kk;
+        KO[(hb * NSP + li) * 4 + lk] = kk;     // running sum; the last channel quad leaves the total
+        const bool wrap = ccq + 1 == ncq;
+        chi += wrap ? 1 : 0;
+        ccq = wrap ? 0 : ccq + 1;
+    };
+    TileIn TA = fetch(), TB;
+    for (int i = 0; i < (nq >> 1); ++i) {
+        TB = fetch();          // fences: see tl_output_whole
+        __builtin_amdgcn_sched_barrier(0);
+        step(TA);
+        __builtin_amdgcn_sched_barrier(0);
+        TA = fetch();
+        __builtin_amdgcn_sched_barrier(0);
+        step(TB);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nq & 1) step(TA);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -529,6 +652,30 @@ __global__ __launch_bounds__(256) void ncde_pack_panels_bf(const float* __restri
     }
 }
 
+// The split-fp16 copy: word (((tile * NCH + c) * 2 + piece) * 64 + lane) * 4 + dw -- the A operand of v_mfma_f32_16x16x32_f16.
+// A weight outside the fp16 range faults EVERY sample tile: *wfault is set and the forward kernel ORs it into its tile's word.
+__global__ __launch_bounds__(256) void ncde_pack_panels_h2(const float* __restrict__ W, unsigned* __restrict__ dst, int H, int C, int nch, int* wfault) {
+    const long long n = (long long)H * C / 16 * nch * 64;          // (tile, chunk, lane) triples
+    const int ncq = C >> 2;
+    float mx = 0.0f;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < n; v += (long long)gridDim.x * 256) {
+        const int lane = (int)(v & 63);
+        const long long tc = v >> 6;
+        const int c = (int)(tc % nch);
+        const int tile = (int)(tc / nch);
+        const int hb = tile / ncq, cq = tile - hb * ncq, li = lane & 15, kg = lane >> 4;
+        const long long row = (long long)(4 * hb + (li >> 2)) * C + 4 * cq + (li & 3);
+        const float* src = W + row * (32 * nch) + 32 * c + 8 * kg;
+        float vals[8];
+        *reinterpret_cast<f32x4*>(vals) = *reinterpret_cast<const f32x4*>(src);
+        *reinterpret_cast<f32x4*>(vals + 4) = *reinterpret_cast<const f32x4*>(src + 4);
+        const Split2h sp = split8h(vals, mx);
+        u32x4* o = reinterpret_cast<u32x4*>(dst) + (tc * 2) * 64 + lane;
+        o[0] = sp.hi; o[64] = sp.lo;
+    }
+    if (h2_range_fault(mx)) *wfault = 1;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -541,10 +688,17 @@ __global__ __launch_bounds__(256) void ncde_pack_panels_bf(const float* __restri
 template <int NS, int NWV, int EM, int GATED = 0, int BF = 0, int RESH = 0, int DIRECT = 0>
 __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
     static_assert(DIRECT == 0 || (BF == 0 && RESH == 0), "direct heads: plain fp32 dense layers");
-    static_assert(BF == 0 || NS == 1, "the split-bf16 output tiles are built for one sample tile per workgroup");
+    static_assert(BF == 0 || NS == 1, "the split-bf16 / split-fp16 output tiles are built for one sample tile per workgroup");
     static_assert(RESH == 0 || (NS == 1 && RESH <= NWV), "resident hidden fragments: one sample tile, one row tile per wave");
+    // BF = 1: 3-way split-bf16 output tiles; BF = 2 (default since round 4): 2-way split-fp16 ones, range faults per sample tile
+    // -> a.fault[blockIdx.x]; the BF = 1 instantiation launched behind it with only_faulted set re-executes exactly those tiles
     constexpr int NSP = NS * 16, NT = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int fault_s;
+    if constexpr (BF == 1) {
+        if (a.only_faulted && a.fault[blockIdx.x] == 0) return;
+    }
+    float mx = 0.0f;      // largest magnitude split into fp16 pieces by this thread
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b0 = blockIdx.x * NSP;
@@ -643,21 +797,34 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                         *reinterpret_cast<f32x4*>(outb + ((4 * wave + lk) * NSP + li) * 4) = o;
                         if constexpr (BF != 0) {
                             if (l == a.n_layers - 1) {      // split image of x_L, as tl_dense_relu_pk writes it (row tile t = wave)
-                                unsigned h0, m0, l0, h1, m1, l1;
-                                split_pair(o[0], o[1], h0, m0, l0);
-                                split_pair(o[2], o[3], h1, m1, l1);
-                                unsigned* dst = XB + ((((wave >> 1) * 3) * 4 + 2 * (wave & 1) + (lk >> 1)) * 16 + li) * 4 + 2 * (lk & 1);
                                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                                *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
-                                *reinterpret_cast<u32x2*>(dst + 256) = (u32x2){m0, m1};
-                                *reinterpret_cast<u32x2*>(dst + 512) = (u32x2){l0, l1};
+                                if constexpr (BF == 2) {
+                                    unsigned h0, l0, h1, l1;
+                                    split_pair_h(o[0], o[1], h0, l0, mx);
+                                    split_pair_h(o[2], o[3], h1, l1, mx);
+                                    unsigned* dst = XB + ((((wave >> 1) * 2) * 4 + 2 * (wave & 1) + (lk >> 1)) * 16 + li) * 4 + 2 * (lk & 1);
+                                    *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
+                                    *reinterpret_cast<u32x2*>(dst + 256) = (u32x2){l0, l1};
+                                } else {
+                                    unsigned h0, m0, l0, h1, m1, l1;
+                                    split_pair(o[0], o[1], h0, m0, l0);
+                                    split_pair(o[2], o[3], h1, m1, l1);
+                                    unsigned* dst = XB + ((((wave >> 1) * 3) * 4 + 2 * (wave & 1) + (lk >> 1)) * 16 + li) * 4 + 2 * (lk & 1);
+                                    *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
+                                    *reinterpret_cast<u32x2*>(dst + 256) = (u32x2){m0, m1};
+                                    *reinterpret_cast<u32x2*>(dst + 512) = (u32x2){l0, l1};
+                                }
                             }
                         }
                     }
                 } else {
                     const TlW wr_ = tl_wref(lds, DIRECT != 0 ? a.tres[l] : 0, a.W[l], a.b[l], a.dout[l], a.din[l]);
-                    tl_dense_relu<NS, NWV>(wr_.W, wr_.b, a.dout[l], a.din[l], in, outb, wave, lane,
-                                           (BF != 0 && l == a.n_layers - 1) ? XB : nullptr, wr_.ld);
+                    if constexpr (BF == 2)
+                        tl_dense_relu<NS, NWV, 0, 1>(wr_.W, wr_.b, a.dout[l], a.din[l], in, outb, wave, lane,
+                                                     l == a.n_layers - 1 ? XB : nullptr, wr_.ld, &mx);
+                    else
+                        tl_dense_relu<NS, NWV>(wr_.W, wr_.b, a.dout[l], a.din[l], in, outb, wave, lane,
+                                               (BF != 0 && l == a.n_layers - 1) ? XB : nullptr, wr_.ld);
                 }
                 __syncthreads();
                 in = outb;
@@ -671,7 +838,13 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                     tl_dense_relu<NS, NWV, 2>(wg_.W, wg_.b, H, dlast, in, KG, wave, lane, nullptr, wg_.ld);
                 }
             } else
-            if constexpr (BF != 0) {
+            if constexpr (BF == 2) {
+                switch (nkb_o) {
+                    case 8: tl_output_h2<4, NWV, GATED>(a, XB, DX, KO, wave, lane); break;
+                    case 4: tl_output_h2<2, NWV, GATED>(a, XB, DX, KO, wave, lane); break;
+                    default: tl_output_h2<1, NWV, GATED>(a, XB, DX, KO, wave, lane); break;
+                }
+            } else if constexpr (BF != 0) {
                 switch (nkb_o) {
                     case 8: tl_output_bf<4, NWV, GATED>(a, XB, DX, KO, wave, lane); break;
                     case 4: tl_output_bf<2, NWV, GATED>(a, XB, DX, KO, wave, lane); break;
@@ -716,6 +889,15 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                     }
                 }
             }
+        }
+    }
+    if constexpr (BF == 2) {      // range fault of this sample tile (or of the weights: the pack kernel's word behind the tiles')
+        if (a.fault != nullptr) {
+            if (tid == 0) fault_s = a.fault[gridDim.x];
+            __syncthreads();
+            if (__builtin_amdgcn_ballot_w64(h2_range_fault(mx)) != 0 && lane == 0) fault_s = 1;
+            __syncthreads();
+            if (tid == 0) a.fault[blockIdx.x] = fault_s;
         }
     }
 }
@@ -1925,6 +2107,10 @@ bool tiled_fwd_bf(const NcdeProblem* p) {
     const int dl = p->layer_out[p->n_layers - 1];
     return !(p->flags & NCDE_FLAG_FP32_MFMA) && (dl == 32 || dl == 64 || dl == 128) && tiled_fwd_ns(p) == 1;
 }
+// which split the forward's output tiles multiply in: 0 none (fp32-input MFMA), 2 = 2-way split-fp16 (default), 1 = 3-way
+// split-bf16 (NCDE_FLAG_SPLIT_BF16; also what re-executes range-faulted sample tiles of mode 2)
+int tiled_fwd_split(const NcdeProblem* p) { return !tiled_fwd_bf(p) ? 0 : ((p->flags & NCDE_FLAG_SPLIT_BF16) ? 1 : 2); }
+int64_t tiled_fault_floats(const NcdeProblem* p) { return (((int64_t)(p->batch + 15) / 16 + 1) + 63) & ~(int64_t)63; }   // one word per tile + the weights' word
 // Floats of the fragment-ordered copy of the output layer (and of the gate head): 0 when the last hidden width is not one
 // of the whole-panel cases the kernels read packed.  The split-bf16 copy (forward, pass 0) takes 1.5 x.
 int64_t tiled_pack_floats(const NcdeProblem* p, bool bf) {
@@ -1963,13 +2149,17 @@ size_t tiled_direct_residency(const NcdeProblem* p, KArgs* a, size_t base) {
 }
 
 // Packs Wo (and Wg) into `dst` and hands the copies to the kernels.
-void tiled_pack_launch(const NcdeProblem* p, KArgs* a, float* dst, bool bf, hipStream_t st) {
+// mode: 0 = fp32 fragments, 1 = split-bf16 (bf = true), 2 = split-fp16 (same size as the fp32 copy; wfault = the weights' range-fault word)
+void tiled_pack_launch(const NcdeProblem* p, KArgs* a, float* dst, bool bf, hipStream_t st, int mode = -1, int* wfault = nullptr) {
     const int dl = p->layer_out[p->n_layers - 1];
     const long long n4 = (long long)p->hidden * p->channels * dl / 4;
     const long long per = bf ? n4 * 6 : n4 * 4;       // floats per packed matrix
     const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
     const bool gated = p->field_kind == NCDE_FIELD_MINIMAL;
-    if (bf) {
+    if (mode == 2) {
+        hipLaunchKernelGGL(ncde_pack_panels_h2, dim3(grid), dim3(256), 0, st, a->Wo, (unsigned*)dst, p->hidden, p->channels, dl / 32, wfault);
+        if (gated) hipLaunchKernelGGL(ncde_pack_panels_h2, dim3(grid), dim3(256), 0, st, a->Wg, (unsigned*)(dst + per), p->hidden, p->channels, dl / 32, wfault);
+    } else if (bf) {
         hipLaunchKernelGGL(ncde_pack_panels_bf, dim3(grid), dim3(256), 0, st, a->Wo, (unsigned*)dst, p->hidden, p->channels, dl / 32);
         if (gated) hipLaunchKernelGGL(ncde_pack_panels_bf, dim3(grid), dim3(256), 0, st, a->Wg, (unsigned*)(dst + per), p->hidden, p->channels, dl / 32);
     } else {
@@ -2182,6 +2372,7 @@ const char* ncde_tiled_kernel_name(const NcdeProblem* p, int pass) {
     if (pass == 2) return gated ? "ncde_adj_tiled<gated,discrete>+ncde_dwo_tiled" : "ncde_adj_tiled<discrete>+ncde_dwo_tiled";
     if (p->field_input != NCDE_INPUT_MATMUL) return gated ? "ncde_fwd_tiled<NS1,gated,direct>" : "ncde_fwd_tiled<NS1,direct>";
     const int ns = tiled_fwd_ns(p);
+    if (tiled_fwd_split(p) == 2) return gated ? "ncde_fwd_tiled<NS1,gated,fp16x2>" : "ncde_fwd_tiled<NS1,fp16x2>";
     if (tiled_fwd_bf(p)) return gated ? "ncde_fwd_tiled<NS1,gated,bf16>" : "ncde_fwd_tiled<NS1,bf16>";
     if (gated) return ns == 4 ? "ncde_fwd_tiled<NS4,gated>" : (ns == 2 ? "ncde_fwd_tiled<NS2,gated>" : "ncde_fwd_tiled<NS1,gated>");
     return ns == 4 ? "ncde_fwd_tiled<NS4>" : (ns == 2 ? "ncde_fwd_tiled<NS2>" : "ncde_fwd_tiled<NS1>");
@@ -2190,9 +2381,22 @@ const char* ncde_tiled_kernel_name(const NcdeProblem* p, int pass) {
 int64_t ncde_tiled_workspace_bytes(const NcdeProblem* p, int pass) {
     if (!ncde_tiled_supported(p, pass)) return NCDE_ERR_UNSUPPORTED;
     if (pass == 0 && p->field_input != NCDE_INPUT_MATMUL) return 256 + (int64_t)sizeof(float) * p->layer_out[0] * ((p->layer_in[0] + 15) & ~15);
-    if (pass == 0) return 256 + tiled_pack_floats(p, tiled_fwd_bf(p)) * (int64_t)sizeof(float);
+    if (pass == 0) {
+        const int split = tiled_fwd_split(p);      // split-fp16: its own copy + the split-bf16 copy of the re-execution launch + fault words
+        if (split == 2) return 256 + (tiled_pack_floats(p, false) + tiled_pack_floats(p, true) + tiled_fault_floats(p)) * (int64_t)sizeof(float);
+        return 256 + tiled_pack_floats(p, split == 1) * (int64_t)sizeof(float);
+    }
     const Layout y = make_layout(p);
     return (int64_t)sizeof(float) * tiled_adj_plan(p, y).total;
+}
+
+// forward instantiation with split output tiles: BF = 1 split-bf16, 2 split-fp16; resh = resident hidden fragments (0 / 2 / 4)
+template <int BF>
+static void (*tiled_fwd_split_fn(bool g, bool small, int resh))(KArgs) {
+    if (resh == 2) return g ? ncde_fwd_tiled<1, TL_NW, 4, 1, BF, 2> : ncde_fwd_tiled<1, TL_NW, 4, 0, BF, 2>;
+    if (resh == 4) return g ? ncde_fwd_tiled<1, TL_NW, 4, 1, BF, 4> : ncde_fwd_tiled<1, TL_NW, 4, 0, BF, 4>;
+    if (g) return small ? ncde_fwd_tiled<1, TL_NW, 4, 1, BF> : ncde_fwd_tiled<1, TL_NW, 16, 1, BF>;
+    return small ? ncde_fwd_tiled<1, TL_NW, 4, 0, BF> : ncde_fwd_tiled<1, TL_NW, 16, 0, BF>;
 }
 
 int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -2205,13 +2409,22 @@ int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws
     a.stages = stages;
     const bool direct = p->field_input != NCDE_INPUT_MATMUL;
     const bool bf = !direct && tiled_fwd_bf(p);
+    const int split = direct ? 0 : tiled_fwd_split(p);
+    float* wsf = (float*)ws + 64;
+    float* pack_bf = wsf + (split == 2 ? tiled_pack_floats(p, false) : 0);      // split-fp16: [h2 copy | bf16 copy | fault words]
+    int* fault = split == 2 ? reinterpret_cast<int*>(pack_bf + tiled_pack_floats(p, true)) : nullptr;
     if (direct) {      // layer 0 with its H + C columns zero-padded to a multiple of 16
         const int d0p = (p->layer_in[0] + 15) & ~15, n0 = p->layer_out[0];
         float* w0 = (float*)ws + 64;
         hipLaunchKernelGGL(ncde_pad_columns, dim3((n0 * d0p + 255) / 256), dim3(256), 0, st, a.W[0], w0, n0, p->layer_in[0], d0p);
         a.W[0] = w0;
         a.din[0] = d0p;
-    } else if (tiled_pack_floats(p, bf) > 0) tiled_pack_launch(p, &a, (float*)ws + 64, bf, st);
+    } else if (split == 2) {
+        const int n_tiles = (p->batch + 15) / 16;
+        if (hipMemsetAsync(fault + n_tiles, 0, sizeof(int), st) != hipSuccess) return NCDE_ERR_HIP;
+        tiled_pack_launch(p, &a, wsf, false, st, 2, fault + n_tiles);
+        a.fault = fault;
+    } else if (tiled_pack_floats(p, bf) > 0) tiled_pack_launch(p, &a, wsf, bf, st);
     const int ns = direct ? 1 : tiled_fwd_ns(p);
     const size_t lds = direct ? tiled_direct_residency(p, &a, tiled_fwd_lds(p, ns)) : tiled_fwd_lds(p, ns);
     const bool small = p->hidden * ns * 16 <= 4 * TL_THREADS;   // state slice of <= 4 elements per thread: fewer live registers
@@ -2220,17 +2433,15 @@ int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws
                                            : (small ? ncde_fwd_tiled<1, TL_NW, 4> : ncde_fwd_tiled<1, TL_NW, 16>));
     if (p->field_kind == NCDE_FIELD_MINIMAL)
         fn = ns == 4 ? ncde_fwd_tiled<4, TL_NW, 16, 1> : (ns == 2 ? ncde_fwd_tiled<2, TL_NW, 16, 1> : ncde_fwd_tiled<1, TL_NW, 16, 1>);
+    void (*fx)(KArgs) = nullptr;      // split-fp16: the split-bf16 instantiation of the same configuration re-executes range-faulted tiles
     if (bf) {
-        if (p->field_kind == NCDE_FIELD_MINIMAL) fn = small ? ncde_fwd_tiled<1, TL_NW, 4, 1, 1> : ncde_fwd_tiled<1, TL_NW, 16, 1, 1>;
-        else fn = small ? ncde_fwd_tiled<1, TL_NW, 4, 0, 1> : ncde_fwd_tiled<1, TL_NW, 16, 0, 1>;
         // small square hidden stack (H = every width = 32 or 64): hidden fragments resident
         bool sq = (p->hidden == 32 || p->hidden == 64) && ncde_dev_env("NCDE_TILED_NO_RES2") == nullptr;
         for (int l = 0; l < p->n_layers; ++l) sq = sq && p->layer_out[l] == p->hidden && p->layer_in[l] == p->hidden;
-        if (sq) {
-            const bool g = p->field_kind == NCDE_FIELD_MINIMAL;
-            if (p->hidden == 32) fn = g ? ncde_fwd_tiled<1, TL_NW, 4, 1, 1, 2> : ncde_fwd_tiled<1, TL_NW, 4, 0, 1, 2>;
-            else fn = g ? ncde_fwd_tiled<1, TL_NW, 4, 1, 1, 4> : ncde_fwd_tiled<1, TL_NW, 4, 0, 1, 4>;
-        }
+        const bool g = p->field_kind == NCDE_FIELD_MINIMAL;
+        const int resh = !sq ? 0 : (p->hidden == 32 ? 2 : 4);
+        fx = tiled_fwd_split_fn<1>(g, small, resh);
+        fn = split == 2 ? tiled_fwd_split_fn<2>(g, small, resh) : fx;
     }
     if (direct) {
         if (p->field_kind == NCDE_FIELD_MINIMAL) fn = small ? ncde_fwd_tiled<1, TL_NW, 4, 1, 0, 0, 1> : ncde_fwd_tiled<1, TL_NW, 16, 1, 0, 0, 1>;
@@ -2239,6 +2450,12 @@ int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws
     if (ncde_lds_optin((const void*)fn, lds) != hipSuccess) return NCDE_ERR_HIP;
     const int nwg = (p->batch + ns * 16 - 1) / (ns * 16);
     hipLaunchKernelGGL(fn, dim3(nwg), dim3(TL_THREADS), lds, st, a);
+    if (split == 2) {      // re-execution of range-faulted sample tiles in split-bf16 (normally none: every workgroup exits at once)
+        tiled_pack_launch(p, &a, pack_bf, true, st);
+        a.only_faulted = 1;
+        if (ncde_lds_optin((const void*)fx, lds) != hipSuccess) return NCDE_ERR_HIP;
+        hipLaunchKernelGGL(fx, dim3(nwg), dim3(TL_THREADS), lds, st, a);
+    }
     return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
 }
 

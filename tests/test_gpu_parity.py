@@ -644,8 +644,7 @@ def test_h64_in_sweep_adjoint_other_layer_counts_and_channels(C, nl, interp, met
 
 @pytest.mark.parametrize("nl", [1, 2, 4])
 def test_fast_forward_with_other_layer_counts(nl, gpu_lib):
-    """The specialised forward kernels have a runtime layer count besides the unrolled nl = 3 instantiation (and the specialised
-    adjoint exists for nl = 3 only: other counts take the batch-tiled / generic backward).  nl = 1, 2, 4 at both specialised
+    """The specialised forward kernels have a runtime layer count besides the unrolled nl = 3 instantiation.  nl = 1, 2, 4 at both specialised
     shapes, split-fp16 (default) and split-bf16, against the oracle -- forward and end-to-end gradients."""
     import gpu_util
     from ncde_amd import _lib
@@ -659,6 +658,39 @@ def test_fast_forward_with_other_layer_counts(nl, gpu_lib):
         assert gu.relerr(resb["z_out"], ex["z_out"]) <= TIGHT_Z
         for k, e in _grad_errors(case, res).items():
             assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), (nl, C, k, e)
+
+
+@pytest.mark.parametrize("nl", [1, 2, 4])
+@pytest.mark.parametrize("interp,method,seq", [("linear", "rk4", False), ("cubic", "midpoint", True), ("linear", "euler", True)])
+def test_h32_chain_grad_adjoint_other_layer_counts(nl, interp, method, seq, gpu_lib):
+    """ncde_adj_fast3 instantiated for nl = 1, 2 (both control paths) and nl = 4 (linear path; the cubic one's LDS plan does not fit and
+    stays on the batch-tiled family): continuous adjoint and exact discrete backward on the oracle's z / stage record, default
+    (forward side split-fp16) and all-split-bf16, bit-reproducible; range-fault re-execution as for nl = 3."""
+    import gpu_util
+    from ncde_amd import _lib
+    case = _seeded_case(interp, method, seq, B=37, L=7, C=20, H=32, HH=32, nl=nl, seed=900 + nl)
+    ex = case["expect"]
+    names = gpu_util.kernel_names(case)
+    if nl == 4 and interp == "cubic":
+        assert names[1].startswith("ncde_adj_tiled"), names
+        return
+    assert names[1].startswith("ncde_adj_fast3<H32,HH32,C20,NL%d" % nl) and "discrete" in names[2] and ("NL%d" % nl) in names[2], names
+    for fl in (_lib.FLAG_AUTO, _lib.FLAG_SPLIT_BF16):
+        iso = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=fl)
+        for k, e in _grad_errors(case, iso).items():
+            assert e <= TIGHT_G, ("continuous", nl, fl, k, e)
+        isod = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=fl, stages=case["stage_record"])
+        for k, e in _grad_errors(case, isod, "bp_").items():
+            assert e <= TIGHT_G, ("discrete", nl, fl, k, e)
+    again = gpu_util.run_adjoint_direct(case, ex["z_out"])
+    first = gpu_util.run_adjoint_direct(case, ex["z_out"])
+    assert np.array_equal(again["dz0"], first["dz0"]) and all(np.array_equal(again["grads"][k], first["grads"][k]) for k in first["grads"])
+    z = ex["z_out"].copy()
+    z[21] *= 4.0e5      # one sample of the middle tile leaves the fp16 range: that tile comes from the split-bf16 instance
+    r16 = gpu_util.run_adjoint_direct(case, z)
+    rbf = gpu_util.run_adjoint_direct(case, z, flags=_lib.FLAG_SPLIT_BF16)
+    assert np.isfinite(r16["dz0"]).all() and np.array_equal(r16["dz0"][16:32], rbf["dz0"][16:32])
+    assert np.array_equal(r16["dz0"][:16], first["dz0"][:16]) and np.array_equal(r16["dz0"][32:], first["dz0"][32:])
 
 
 def test_split_fp16_forward_is_reproducible_under_repetition(gpu_lib):
@@ -711,9 +743,11 @@ def test_tiled_family_vs_oracle(shape, interp, method, seq, gpu_lib):
         res = gpu_util.run_case(case, flags=flag, need_grads=False)
         assert res["kernels"][0].startswith("ncde_fwd_tiled"), res["kernels"]
         if ns:
-            assert res["kernels"][0] in ("ncde_fwd_tiled<NS%d>" % ns, "ncde_fwd_tiled<NS1,bf16>"), res["kernels"]
-            if ns == 1 and HH % 32 == 0:      # one sample tile, last hidden width a multiple of 32: the split-bf16 output tiles ...
-                assert res["kernels"][0] == "ncde_fwd_tiled<NS1,bf16>"
+            assert res["kernels"][0] in ("ncde_fwd_tiled<NS%d>" % ns, "ncde_fwd_tiled<NS1,fp16x2>"), res["kernels"]
+            if ns == 1 and HH % 32 == 0:      # one sample tile, last hidden width a multiple of 32: the split-fp16 output tiles (default) ...
+                assert res["kernels"][0] == "ncde_fwd_tiled<NS1,fp16x2>"
+                rbf = gpu_util.run_case(case, flags=flag | _lib.FLAG_SPLIT_BF16, need_grads=False)     # ... the split-bf16 ones ...
+                assert rbf["kernels"][0] == "ncde_fwd_tiled<NS1,bf16>" and gu.relerr(rbf["z_out"], ex["z_out"]) <= TIGHT_Z
                 r32 = gpu_util.run_case(case, flags=flag | _lib.FLAG_FP32_MFMA, need_grads=False)      # ... and the fp32-input MFMA ones
                 assert r32["kernels"][0] == "ncde_fwd_tiled<NS1>" and gu.relerr(r32["z_out"], ex["z_out"]) <= TIGHT_Z
         assert gu.relerr(res["z_out"], ex["z_out"]) <= TIGHT_Z, (flag, gu.relerr(res["z_out"], ex["z_out"]))
@@ -741,6 +775,34 @@ def test_tiled_family_vs_oracle(shape, interp, method, seq, gpu_lib):
     isod32 = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=FT | _lib.FLAG_FP32_MFMA, stages=case["stage_record"])
     for k, e in _grad_errors(case, isod32, "bp_").items():
         assert e <= TIGHT_G, ("tiled discrete backward (fp32 MFMA) on the oracle's stage record", k, e)
+
+
+@pytest.mark.parametrize("shape,kind", [((80, 128, 128, 3), "original"), ((8, 48, 64, 2), "original"), ((12, 32, 32, 3), "minimal"), ((5, 47, 93, 2), "original")])
+def test_tiled_split_fp16_forward_range_fault_is_reexecuted(shape, kind, gpu_lib):
+    """The batch-tiled forward multiplies its output tiles in 2-way split-fp16 and speculates on the fp16 range of x_L (and of the
+    weights); a sample tile whose x_L leaves it is re-executed by the split-bf16 instantiation.  Three tiles (B = 37), one sample
+    of the middle tile with a state large enough to overflow: its tile's rows are bit-identical to the split-bf16 run, the other
+    tiles' rows to the run without the outlier, everything agrees with the oracle.  The last shape reaches the kernels through the
+    library's zero-padding (C 5 -> 8, H 47 -> 48, HH 93 -> 128)."""
+    import gpu_util
+    import ncde_oracle as orc
+    from ncde_amd import _lib
+    C, H, HH, nl = shape
+    for seq in (False, True):
+        case = _seeded_case("linear", "rk4", seq, B=37, L=6, C=C, H=H, HH=HH, nl=nl, seed=411, kind=kind)
+        plain = gpu_util.run_case(case, need_grads=False)
+        assert "fp16x2" in plain["kernels"][0] and plain["kernels"][0].startswith("ncde_fwd_tiled"), plain["kernels"]
+        big = dict(case)
+        big["z0"] = case["z0"].copy()
+        big["z0"][21] *= 1.0e8      # (only x_L is split here -- the hidden layers run on fp32-input MFMA --, and it must leave the fp16 range)
+        zo = orc.solve_forward(orc.Control(big["coeffs"], "linear"), gu.oracle_field(case), big["z0"], "rk4", seq).numpy()
+        r16 = gpu_util.run_case(big, need_grads=False)
+        rbf = gpu_util.run_case(big, flags=_lib.FLAG_SPLIT_BF16, need_grads=False)
+        assert np.isfinite(r16["z_out"]).all()
+        assert np.array_equal(r16["z_out"][16:32], rbf["z_out"][16:32])                       # re-executed tile
+        assert np.array_equal(r16["z_out"][:16], plain["z_out"][:16]) and np.array_equal(r16["z_out"][32:], plain["z_out"][32:])
+        scale = np.abs(zo).max(axis=tuple(range(1, zo.ndim)), keepdims=True)
+        assert float((np.abs(r16["z_out"] - zo) / scale).max()) <= TIGHT_Z
 
 
 @pytest.mark.parametrize("shape,gated", [((80, 128, 128, 3), False), ((8, 48, 64, 2), False), ((20, 32, 32, 3), True),
