@@ -913,6 +913,16 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
 //   backwards (their dW/db accumulate in MFMA accumulator registers for the whole solve) -> Butcher bookkeeping.
 // Wo^T fragments come from the SAME 16-byte panel loads as the forward fragments, transposed through a per-wave LDS
 // scratch (row stride K + 4), so the weight stream is read once per stage.
+// development: s_memtime phase counters of the sweep (-DNCDE_TL_PROF): cycles per stage by phase -> the head of the workgroup's
+// hidden-layer partial (garbage gradients in such a build).  Slots: 0 forward recompute, 1 output tiles + VJP, 2 records,
+// 3 partial sum, 4 hidden backward, 5 bookkeeping + publish, 7 waiting at barriers
+#ifdef NCDE_TL_PROF
+#define TL_TICK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tprof[k] += now_ - tlast; tlast = now_; }
+#define TL_SYNC(k) { TL_TICK(k) __syncthreads(); TL_TICK(7) }
+#else
+#define TL_TICK(k)
+#define TL_SYNC(k) __syncthreads();
+#endif
 #define TL_ADJ_NW 8  // waves per workgroup of the sweep.  Measured at cfg5: 8 waves (two per SIMD, 256 registers each, the
                      // cold hidden-dW accumulators spilled) 736 ms; 4 waves (one per SIMD, 494 registers, no spill) 929 ms
 
@@ -1363,6 +1373,9 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     __syncthreads();
 
     int sc = 0;      // stage counter within this time window = record index
+#ifdef NCDE_TL_PROF
+    unsigned long long tprof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
     for (int n = a.win_hi; n > a.win_lo; --n) {
         const int* pstep = step_of(n);
         const float dt = planned ? __int_as_float(pstep[0]) : 1.0f;
@@ -1405,7 +1418,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                     const TlW wr_ = tl_wref(lds, DIRECT != 0 ? a.tres[l] : 0, a.W[l], a.b[l], a.dout[l], a.din[l]);
                     tl_dense_relu<1, NWV>(wr_.W, wr_.b, a.dout[l], a.din[l], in, outb, wave, lane, (BF != 0 && l == L - 1) ? XBA : nullptr, wr_.ld);
                 }
-                __syncthreads();
+                TL_SYNC(0)
                 in = outb;
             }
             if constexpr (DIRECT != 0) {
@@ -1449,6 +1462,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
             } else {
                 // ---- output layer: f, dP, per-wave partial of dL/dx_L -----------------------------------------------------
                 tl_output_vjp<PK, NWV, RES, GATED, (BF != 0 && GATED == 0) ? 1 : 0>(a, in, AS, DX, KOY, scr, wave, lane, wo, XBA);
+                TL_TICK(1)
                 // ---- records for pass B (x_L twice, weighted cotangent, dX/dt) --------------------------------------------
                 {
                     const long long tile = (long long)sc * n_st + blockIdx.x;
@@ -1496,7 +1510,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                     }
                     for (int e = tid; e < C * NSP; e += NT) rd[e] = DX[e];
                 }
-                __syncthreads();
+                TL_SYNC(2)
                 // ---- dL/dpre_L = (sum of the 8 partials) * relu'(x_L) ---------------------------------------------------------
                 for (int e = tid; e < dlast * NSP; e += NT) {
                     float g = 0.0f;
@@ -1504,7 +1518,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                     for (int wv = 0; wv < NWV; ++wv) g += SC[wv * SCW + e];
                     G1[e] = in[e] > 0.0f ? g : 0.0f;
                 }
-                __syncthreads();
+                TL_SYNC(3)
             }
             // ---- hidden layers backwards ----------------------------------------------------------------------------------
             float* gpre = G1;
@@ -1547,7 +1561,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                     const TlW wr_ = tl_wref(lds, DIRECT != 0 ? a.tres[l] : 0, a.W[l], a.b[l], N, K);
                     tl_hidden_bwd<NWV>(wr_.W, N, K, gpre, xin, l > 0, l == 0 ? KOA : gx, wave, lane, nullptr, nullptr, wr_.ld);
                 }
-                __syncthreads();
+                TL_SYNC(4)
                 float* tmp = gpre; gpre = gx; gx = tmp;
             }
             // ---- Butcher bookkeeping (registers) ---------------------------------------------------------------------------
@@ -1624,7 +1638,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                 }
             }
             publish();
-            __syncthreads();
+            TL_SYNC(5)
         }
     }
     if (a.win_lo > 0) {      // hand (y, a) at knot win_lo to the next time window
@@ -1639,6 +1653,10 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     }
     // ---- this workgroup's partial of the hidden-layer parameter gradients ------------------------------------------
     float* gp = a.gpart + (long long)blockIdx.x * a.gstride;
+#ifdef NCDE_TL_PROF
+    if (lane == 0 && sc > 0)
+        for (int k = 0; k < 8; ++k) a.grad_z0[(long long)b0 * a.Hr + wave * 8 + k] = (float)tprof[k] / (float)sc;      // (over the tile's dz0 rows)
+#endif
     {
         const int li = lane & 15, lk = lane >> 4;
         int l1 = -1;

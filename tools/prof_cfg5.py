@@ -1,0 +1,36 @@
+"""development: phase-cycle breakdown of the batch-tiled sweep (ncde_adj_tiled) from the instrumented build (tools/build_tlprof.sh).
+usage: python tools/prof_cfg5.py [variants/tlprof.so] [cfg] [B] [L]   (run on the GPU box; the gradients of such a build are garbage)"""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT]
+from ncde_amd import _lib
+_lib.LIB_PATH = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "variants/tlprof.so")
+import ncde_amd, bench
+from ncde_amd import solver
+c = dict(bench.CONFIGS[sys.argv[2] if len(sys.argv) > 2 else "cfg5"])
+B = int(sys.argv[3]) if len(sys.argv) > 3 else c["B"]
+c["L"] = int(sys.argv[4]) if len(sys.argv) > 4 else 60
+dev = torch.device("cuda", 0)
+coeffs = bench.make_inputs(c, B, 0, dev)
+model, fw, rw = bench.make_model(c, "cuda")
+spec = model.func.fused_spec()
+interp = "cubic" if c["interpolation"] == "cubic" else "linear"
+with torch.no_grad():
+    z0 = model.initial_linear(coeffs[:, 0, :c["C"]]).contiguous()
+lib = _lib.lib()
+H = c["H"]
+gout = torch.randn(B, 2, H, device=dev) / B
+for flags, label in ((_lib.FLAG_FORCE_TILED, "default"), (_lib.FLAG_FORCE_TILED | _lib.FLAG_FP32_MFMA, "fp32 records")):
+    p = solver.build_problem(coeffs, interp, z0, spec, c["solver"], _lib.OUT_INTERVAL, flags)
+    out = torch.randn(B, 2, H, device=dev)
+    ws = solver._workspace(p, 1, dev)
+    g = _lib.NcdeGrads(); gz0 = torch.zeros_like(z0); g.grad_z0 = gz0.data_ptr()
+    ms = ctypes.c_float()
+    _lib.check(lib.ncde_time_kernel(ctypes.byref(p), 1, out.data_ptr(), gout.data_ptr(), ctypes.byref(g), ws.data_ptr(), ws.numel(), None, 1, ctypes.byref(ms)), "time")
+    name = (lib.ncde_kernel_name(ctypes.byref(p), 1) or b"?").decode()
+    per = gz0.view(B // 16, 16 * H)[:, :64].view(-1, 8, 8).cpu().numpy().mean(axis=0)
+    T = coeffs.shape[1] + (1 if interp == "cubic" else 0)
+    print("%s  %s: backward %.2f ms (%.1f us per stage incl. pass B); sweep cycles per stage by wave x [fwd recompute | output tiles + VJP | records | "
+          "partial sum | hidden bwd | bookkeeping | - | barrier wait]" % (label, name, ms.value, ms.value * 1e3 / ((T - 1) * bench.stages_of(c["solver"]))))
+    print(np.array2string(per, precision=0, suppress_small=True), " total", per.sum(axis=1).round())
