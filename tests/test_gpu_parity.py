@@ -272,6 +272,49 @@ def test_full_size_cfg2_adjoint_and_discrete_backward_vs_oracle(gpu_lib):
         assert e <= CFG2_FULL_BATCH_G, (pname, e)
 
 
+def test_full_size_cfg4_all_samples_vs_oracle(gpu_lib):
+    """BASELINE config 4 at the benchmarked size (B = 8192, cubic path of 182 observations, midpoint, H = HH = 64) -- every one of the
+    512 workgroups of `ncde_adj_h64`, continuous adjoint AND exact discrete backward, against the oracle on ALL samples: z_T, the
+    per-sample dL/dz0 rows (on the oracle's z, so that forward round-off does not enter) and the batch-summed parameter gradients."""
+    import gpu_util
+    import ncde_oracle as orc
+    B, L, C, H, HH, nl, interp, method = 8192, 182, 4, 64, 64, 3, "cubic", "midpoint"
+    coeffs = gu.data.make_cubic_coeffs(B, L, C - 1, seed=1234)
+    p = gu.data.make_field_weights(H, HH, C, seed=0)
+    rw = gu.data.make_readin_weights(H, C, 1, seed=0)
+    z0 = (coeffs[:, 0, :C] @ rw["Wi"].T + rw["bi"]).astype(np.float32)
+    names = ["W0", "b0", "W1", "b1", "Wo", "bo"]
+    meta = {"kind": interp, "method": method, "sequence": False, "param_names": names, "field": "original",
+            "dims": {"C": C, "H": H, "HH": HH, "nl": nl}}
+    gout = (gu.data.normal(3, B * 2 * H, stream=1).reshape(B, 2, H) / np.sqrt(2.0)).astype(np.float32)
+    big = {"meta": meta, "coeffs": coeffs, "z0": z0, "params": p, "layers": [("W0", "b0")] + [("W1", "b1")] * (nl - 1),
+           "H": H, "C": C, "expect": {"grad_out": gout}}
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    rb = gpu_util.run_case(big, need_grads=False)
+    assert rb["kernels"][1].startswith("ncde_adj_h64") and rb["kernels"][2].startswith("ncde_adj_h64"), rb["kernels"]
+    field, ctl = gu.oracle_field(big), orc.Control(coeffs, interp)
+    z = orc.solve_forward(ctl, field, z0, method, False)
+    assert gu.relerr(rb["z_out"], z) <= TIGHT_Z
+    dz0, gp = orc.solve_adjoint(ctl, field, z, gout, method, False)
+    iso = gpu_util.run_adjoint_direct(big, z.numpy())
+    per = np.abs(iso["dz0"] - dz0.numpy()).max(1) / np.abs(dz0.numpy()).max()
+    full = {pname: gu.relerr(iso["grads"][pname], g) for pname, g in zip(names, gp)}
+    print("cfg4 full batch, continuous adjoint: dz0 per-sample rel err median %.2e, p99 %.2e, max %.2e;" % (np.median(per), np.quantile(per, 0.99), per.max()),
+          {k: "%.2e" % v for k, v in full.items()})
+    assert np.quantile(per, 0.99) <= 5e-5 and per.max() <= 2e-2, (np.quantile(per, 0.99), per.max())      # (a ReLU mask may flip on single samples)
+    for pname, e in full.items():
+        assert e <= E2E_G, (pname, e)
+    bdz0, bgp = orc.solve_discrete_backward(ctl, field, z0, gout, method, False)
+    rec = orc.stage_record(ctl, field, z0, method).numpy()
+    isod = gpu_util.run_adjoint_direct(big, z.numpy(), stages=rec)
+    perd = np.abs(isod["dz0"] - bdz0.numpy()).max(1) / np.abs(bdz0.numpy()).max()
+    fulld = {pname: gu.relerr(isod["grads"][pname], g) for pname, g in zip(names, bgp)}
+    print("cfg4 full batch, discrete backward: dz0 per-sample p99 %.2e, max %.2e;" % (np.quantile(perd, 0.99), perd.max()), {k: "%.2e" % v for k, v in fulld.items()})
+    assert np.quantile(perd, 0.99) <= 5e-5 and perd.max() <= 2e-2
+    for pname, e in fulld.items():
+        assert e <= E2E_G, (pname, e)
+
+
 @pytest.mark.parametrize("cfg", ["cfg4", "cfg5"])
 def test_full_batch_cfg4_cfg5_sample_independence(cfg, gpu_lib):
     """cfg4 at B = 8192 and cfg5 at B = 4096 (their full batch AND length, through forward and backward, i.e. the full
