@@ -275,9 +275,15 @@ def test_full_size_cfg2_adjoint_and_discrete_backward_vs_oracle(gpu_lib):
 def test_full_size_cfg4_all_samples_vs_oracle(gpu_lib):
     """BASELINE config 4 at the benchmarked size (B = 8192, cubic path of 182 observations, midpoint, H = HH = 64) -- every one of the
     512 workgroups of `ncde_adj_h64`, continuous adjoint AND exact discrete backward, against the oracle on ALL samples: z_T, the
-    per-sample dL/dz0 rows (on the oracle's z, so that forward round-off does not enter) and the batch-summed parameter gradients."""
+    per-sample dL/dz0 rows (on the oracle's z, so that forward round-off does not enter) and the batch-summed parameter gradients.
+    A sum over 8192 samples carries the handful of samples whose ReLU masks flip under ANY fp32 rounding (24 rows here, for every
+    kernel family alike -- generic, batch-tiled, this one with fp32-input MFMA throughout: 4e-4 .. 9e-4, tools/cfg4_errors.py): the bar
+    for the sums is therefore relative to the fp64 run of the same discrete scheme -- as close to it as the bit-pinned fp32 oracle is,
+    within 2 x, with the documented gradient tolerance TOL_DTHETA = 1e-3 as the floor -- for the default (forward side split-fp16) and
+    the all-fp32-MFMA instance; the per-sample rows are held to 5e-5 at the 99th percentile."""
     import gpu_util
     import ncde_oracle as orc
+    from ncde_amd import _lib
     B, L, C, H, HH, nl, interp, method = 8192, 182, 4, 64, 64, 3, "cubic", "midpoint"
     coeffs = gu.data.make_cubic_coeffs(B, L, C - 1, seed=1234)
     p = gu.data.make_field_weights(H, HH, C, seed=0)
@@ -295,24 +301,27 @@ def test_full_size_cfg4_all_samples_vs_oracle(gpu_lib):
     field, ctl = gu.oracle_field(big), orc.Control(coeffs, interp)
     z = orc.solve_forward(ctl, field, z0, method, False)
     assert gu.relerr(rb["z_out"], z) <= TIGHT_Z
-    dz0, gp = orc.solve_adjoint(ctl, field, z, gout, method, False)
-    iso = gpu_util.run_adjoint_direct(big, z.numpy())
-    per = np.abs(iso["dz0"] - dz0.numpy()).max(1) / np.abs(dz0.numpy()).max()
-    full = {pname: gu.relerr(iso["grads"][pname], g) for pname, g in zip(names, gp)}
-    print("cfg4 full batch, continuous adjoint: dz0 per-sample rel err median %.2e, p99 %.2e, max %.2e;" % (np.median(per), np.quantile(per, 0.99), per.max()),
-          {k: "%.2e" % v for k, v in full.items()})
-    assert np.quantile(per, 0.99) <= 5e-5 and per.max() <= 2e-2, (np.quantile(per, 0.99), per.max())      # (a ReLU mask may flip on single samples)
-    for pname, e in full.items():
-        assert e <= E2E_G, (pname, e)
-    bdz0, bgp = orc.solve_discrete_backward(ctl, field, z0, gout, method, False)
+    c64 = dict(big, params={k: v.astype(np.float64) for k, v in p.items()})
+    f64, ctl64 = gu.oracle_field(c64), orc.Control(coeffs.astype(np.float64), interp)
+    z64 = orc.solve_forward(ctl64, f64, z0.astype(np.float64), method, False)
     rec = orc.stage_record(ctl, field, z0, method).numpy()
-    isod = gpu_util.run_adjoint_direct(big, z.numpy(), stages=rec)
-    perd = np.abs(isod["dz0"] - bdz0.numpy()).max(1) / np.abs(bdz0.numpy()).max()
-    fulld = {pname: gu.relerr(isod["grads"][pname], g) for pname, g in zip(names, bgp)}
-    print("cfg4 full batch, discrete backward: dz0 per-sample p99 %.2e, max %.2e;" % (np.quantile(perd, 0.99), perd.max()), {k: "%.2e" % v for k, v in fulld.items()})
-    assert np.quantile(perd, 0.99) <= 5e-5 and perd.max() <= 2e-2
-    for pname, e in fulld.items():
-        assert e <= E2E_G, (pname, e)
+    for disc in (False, True):
+        if disc:
+            d32, g32 = orc.solve_discrete_backward(ctl, field, z0, gout, method, False)
+            d64, g64 = orc.solve_discrete_backward(ctl64, f64, z0.astype(np.float64), gout.astype(np.float64), method, False)
+        else:
+            d32, g32 = orc.solve_adjoint(ctl, field, z, gout, method, False)
+            d64, g64 = orc.solve_adjoint(ctl64, f64, z64, gout.astype(np.float64), method, False)
+        ref = {n: gu.relerr(a.numpy(), b.numpy()) for n, a, b in zip(names, g32, g64)}
+        for flags in (_lib.FLAG_AUTO, _lib.FLAG_FP32_MFMA):
+            iso = gpu_util.run_adjoint_direct(big, z.numpy(), flags=flags, stages=rec if disc else None)
+            per = np.abs(iso["dz0"] - d32.numpy()).max(1) / np.abs(d32.numpy()).max()
+            err = {n: gu.relerr(iso["grads"][n], g.numpy()) for n, g in zip(names, g64)}
+            print("cfg4 full batch, %s, flags %d: dz0 rows p99 %.2e max %.2e (%d rows > 1e-5);" % ("discrete backward" if disc else "continuous adjoint", flags,
+                  np.quantile(per, 0.99), per.max(), int((per > 1e-5).sum())), {k: "%.1e (fp32 oracle %.1e)" % (err[k], ref[k]) for k in err})
+            assert np.quantile(per, 0.99) <= 5e-5 and per.max() <= 2e-2, (np.quantile(per, 0.99), per.max())
+            for k in err:
+                assert err[k] <= max(2.0 * ref[k], TOL_DTHETA), (disc, flags, k, err[k], ref[k])
 
 
 @pytest.mark.parametrize("cfg", ["cfg4", "cfg5"])
