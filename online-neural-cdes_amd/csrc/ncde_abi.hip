@@ -131,6 +131,7 @@ inline int pad_width(int w) { return w <= 16 ? 16 : (w <= 32 ? 32 : (w <= 64 ? 6
 
 struct PadPlan {
     bool ok;
+    int inner;                           // family the padded problem runs on: 2 = batch-tiled, 1 = shape-specialised (register-resident)
     NcdeProblem q;                       // the padded problem; its parameter pointers are OFFSETS (floats, +1) until bound to a workspace
     int n_seg;
     int dims[12][6];
@@ -140,16 +141,33 @@ struct PadPlan {
     long long param_floats;              // padded parameters (and, for the backward, the same again for their gradients)
 };
 
-// Would padding bring `p` into the batch-tiled family?  (original / minimal-gated field, matmul input)
-PadPlan make_pad_plan(const NcdeProblem* p, int pass) {
+// Would padding bring `p` into the batch-tiled family (target 0: original / minimal-gated field, matmul input), or onto one of the
+// shape-specialised kernel sets (target 1: (H, HH, C) = (32, 32, 20), target 2: (64, 64, 4); original field, default time axis, ONE
+// shared inner layer as the reference's fields have)?  Measured at B = 4096, T = 99 (profiles/r04_shape_sweep_perf.txt): the
+// specialised kernels at their full padded size take no longer than the SMALLEST batch-tiled shapes (forward 0.6 - 0.9 ms vs 0.7 ms,
+// adjoint 1.8 - 2.0 ms vs 2.1 ms at (4, 32, 16)), so a shape they can hold is always sent there.
+PadPlan make_pad_plan(const NcdeProblem* p, int pass, int target = 0) {
     PadPlan P{};
     P.ok = false;
+    P.inner = target == 0 ? 2 : 1;
     if (p->n_layers < 1 || p->field_input != NCDE_INPUT_MATMUL || p->field_kind == NCDE_FIELD_GRU) return P;
     if (p->hidden > 2048 || p->channels > 4095) return P;
+    const int tH = target == 1 ? 32 : 64, tHH = tH, tC = target == 1 ? 20 : 4;
+    if (target != 0) {
+        if (p->field_kind != NCDE_FIELD_ORIGINAL || p->output == NCDE_OUT_TIMES || p->hidden > tH || p->channels > tC) return P;
+        // (any batch-tiled knob is a request for that family; the non-default adjoint variants exist for the exact shapes only)
+        if (p->flags & (NCDE_FLAG_ADJOINT_V1 | NCDE_FLAG_ADJOINT_V2 | NCDE_FLAG_ADJOINT_V4 | NCDE_FLAG_DEBUG_PROFILE | NCDE_FLAG_FORCE_TILED |
+                        NCDE_FLAG_TILED_NS1 | NCDE_FLAG_TILED_NS2 | NCDE_FLAG_TILED_NS4 | 0x00FF0000u | 0x200u)) return P;
+        for (int l = 0; l < p->n_layers; ++l) {
+            if (p->layer_out[l] > tHH) return P;
+            if (l >= 1 && (p->layer_W[l] != p->layer_W[1] || p->layer_b[l] != p->layer_b[1])) return P;
+        }
+        if (p->n_layers > 1 && (p->layer_W[1] == p->layer_W[0] || p->layer_b[1] == p->layer_b[0])) return P;
+    }
     NcdeProblem& q = P.q;
     q = *p;
-    q.hidden = hru16(p->hidden);
-    q.channels = hru4(p->channels);
+    q.hidden = target == 0 ? hru16(p->hidden) : tH;
+    q.channels = target == 0 ? hru4(p->channels) : tC;
     q.reserved_ = (p->hidden << 12) | p->channels;
     int n = 0;
     long long off = 0;
@@ -165,7 +183,7 @@ PadPlan make_pad_plan(const NcdeProblem* p, int pass) {
     };
     int din = q.hidden;
     for (int l = 0; l < p->n_layers; ++l) {
-        const int dout = pad_width(p->layer_out[l]);
+        const int dout = target == 0 ? pad_width(p->layer_out[l]) : tHH;
         q.layer_in[l] = din; q.layer_out[l] = dout;
         P.slot_W[l] = add(p->layer_W[l], 1, p->layer_out[l], p->layer_in[l], 1, dout, din);
         P.slot_b[l] = add(p->layer_b[l], 1, 1, p->layer_out[l], 1, 1, dout);
@@ -188,8 +206,18 @@ PadPlan make_pad_plan(const NcdeProblem* p, int pass) {
     for (int l = 0; l < p->n_layers; ++l) { q.layer_W[l] = fake(P.slot_W[l]); q.layer_b[l] = fake(P.slot_b[l]); }
     q.Wo = fake(P.slot_Wo); q.bo = fake(P.slot_bo);
     if (p->field_kind == NCDE_FIELD_MINIMAL) { q.Wg = fake(P.slot_Wg); q.bg = fake(P.slot_bg); }
-    P.ok = ncde_tiled_supported(&q, pass);
+    P.ok = target == 0 ? ncde_tiled_supported(&q, pass) : ncde_fast_supported(&q, pass);
     return P;
+}
+// the padded plan a problem takes, if any: a shape-specialised kernel set first, then the batch-tiled family
+PadPlan pick_pad_plan(const NcdeProblem* p, int pass, bool allow_tiled) {
+    for (int target = 1; target <= 2; ++target) {
+        PadPlan P = make_pad_plan(p, pass, target);
+        if (P.ok) return P;
+    }
+    if (allow_tiled && !ncde_tiled_supported(p, pass)) return make_pad_plan(p, pass, 0);
+    PadPlan none{};
+    return none;
 }
 // head of the workspace of a padded call: [padded parameters | (backward) padded parameter gradients | the tiled family's own workspace]
 long long pad_head_floats(const PadPlan& P, int pass) { return (pass == 0 ? 1 : 2) * P.param_floats + 64; }
@@ -220,10 +248,13 @@ int pad_launch(const PadPlan& P, float* base, int dir, float* const* real_dst, h
 int select_family_unpadded(const NcdeProblem* p, const Layout& y, int pass);
 int select_family(const NcdeProblem* p, const Layout& y, int pass) {
     const int fam = select_family_unpadded(p, y, pass);
-    // generic / variant fallback (or nothing at all): try the batch-tiled family on the zero-padded problem first
-    if ((fam == 0 || fam == 3 || fam == NCDE_ERR_UNSUPPORTED) && !(p->flags & (NCDE_FLAG_FORCE_GENERIC | NCDE_FLAG_FORCE_FAST)) &&
-        !ncde_tiled_supported(p, pass) && make_pad_plan(p, pass).ok)
-        return 4;
+    if (p->flags & (NCDE_FLAG_FORCE_GENERIC | NCDE_FLAG_FORCE_FAST)) return fam;
+    // no specialised kernel of its own: a zero-padded run on a specialised kernel set (also instead of the batch-tiled family, which
+    // the smallest shapes do not use well), else -- instead of the generic / variant kernels -- on the batch-tiled family
+    if (fam == 0 || fam == 2 || fam == 3 || fam == NCDE_ERR_UNSUPPORTED) {
+        const bool fallback = fam != 2;
+        if (pick_pad_plan(p, pass, fallback).ok) return 4;
+    }
     return fam;
 }
 int select_family_unpadded(const NcdeProblem* p, const Layout& y, int pass) {
@@ -272,14 +303,16 @@ int launch_reduce(const NcdeProblem* p, const Layout& y, const NcdeGrads* g, con
 int launch_forward(const NcdeProblem* p, const Layout& y, int family, float* out, float* stages, void* ws, size_t ws_bytes,
                    hipStream_t st) {
     if (family == 4) {
-        PadPlan P = make_pad_plan(p, 0);
-        if (!P.ok) return fail(NCDE_ERR_UNSUPPORTED, "padded problem outside the batch-tiled family");
+        PadPlan P = pick_pad_plan(p, 0, true);
+        if (!P.ok) return fail(NCDE_ERR_UNSUPPORTED, "padded problem outside the aligned kernel families");
         float* base = (float*)ws;
         const long long head = pad_head_floats(P, 0);
         pad_bind(P, p, base);
         if (pad_launch(P, base, 0, nullptr, st) != NCDE_OK) return fail(NCDE_ERR_HIP, "parameter padding launch failed");
-        const int rc = ncde_tiled_forward(&P.q, out, stages, base + head, ws_bytes - sizeof(float) * (size_t)head, st);
-        if (rc != NCDE_OK) return fail(rc, "tiled forward (zero-padded problem) launch failed");
+        const size_t inner_bytes = ws_bytes - sizeof(float) * (size_t)head;
+        const int rc = P.inner == 1 ? ncde_fast_forward(&P.q, out, stages, base + head, inner_bytes, st)
+                                    : ncde_tiled_forward(&P.q, out, stages, base + head, inner_bytes, st);
+        if (rc != NCDE_OK) return fail(rc, "forward (zero-padded problem) launch failed");
         return NCDE_OK;
     }
     if (family == 1) {
@@ -311,8 +344,8 @@ int launch_forward(const NcdeProblem* p, const Layout& y, int family, float* out
 int launch_adjoint(const NcdeProblem* p, const Layout& y, int family, const float* src, const float* grad_out,
                    const NcdeGrads* g, void* ws, size_t ws_bytes, hipStream_t st, bool main_kernel_only, bool discrete) {
     if (family == 4) {
-        PadPlan P = make_pad_plan(p, discrete ? 2 : 1);
-        if (!P.ok) return fail(NCDE_ERR_UNSUPPORTED, "padded problem outside the batch-tiled family");
+        PadPlan P = pick_pad_plan(p, discrete ? 2 : 1, true);
+        if (!P.ok) return fail(NCDE_ERR_UNSUPPORTED, "padded problem outside the aligned kernel families");
         float* base = (float*)ws;
         const long long head = pad_head_floats(P, 1);
         pad_bind(P, p, base);
@@ -331,8 +364,10 @@ int launch_adjoint(const NcdeProblem* p, const Layout& y, int family, const floa
             gq.grad_Wg = gbase + P.off[P.slot_Wg]; gq.grad_bg = gbase + P.off[P.slot_bg];
             real_dst[P.slot_Wg] = g->grad_Wg; real_dst[P.slot_bg] = g->grad_bg;
         }
-        const int rc = ncde_tiled_adjoint(&P.q, src, grad_out, &gq, base + head, ws_bytes - sizeof(float) * (size_t)head, st, main_kernel_only, discrete);
-        if (rc != NCDE_OK) return fail(rc, "tiled adjoint (zero-padded problem) launch failed");
+        const size_t inner_bytes = ws_bytes - sizeof(float) * (size_t)head;
+        const int rc = P.inner == 1 ? ncde_fast_adjoint(&P.q, src, grad_out, &gq, base + head, inner_bytes, st, main_kernel_only, discrete)
+                                    : ncde_tiled_adjoint(&P.q, src, grad_out, &gq, base + head, inner_bytes, st, main_kernel_only, discrete);
+        if (rc != NCDE_OK) return fail(rc, "adjoint (zero-padded problem) launch failed");
         if (main_kernel_only) return NCDE_OK;
         const int rc2 = pad_launch(P, gbase, 1, real_dst, st);
         if (rc2 == NCDE_ERR_INVALID) return fail(rc2, "NcdeGrads: NULL destination for a parameter gradient");
@@ -506,8 +541,8 @@ int64_t ncde_workspace_bytes(const NcdeProblem* p, int pass) {
     if (fam < 0) return fam;
     if (fam == 1) return ncde_fast_workspace_bytes(p, pass);
     if (fam == 4) {
-        const PadPlan P = make_pad_plan(p, pass);
-        const int64_t inner = ncde_tiled_workspace_bytes(&P.q, pass);
+        const PadPlan P = pick_pad_plan(p, pass, true);
+        const int64_t inner = P.inner == 1 ? ncde_fast_workspace_bytes(&P.q, pass) : ncde_tiled_workspace_bytes(&P.q, pass);
         return inner < 0 ? inner : inner + (int64_t)sizeof(float) * pad_head_floats(P, pass);
     }
     if (fam == 2) return ncde_tiled_workspace_bytes(p, pass);
@@ -536,7 +571,10 @@ const char* ncde_kernel_name(const NcdeProblem* p, int pass) {
     const Layout y = make_layout(p);
     const int fam = select_family(p, y, pass);
     if (fam < 0) return nullptr;
-    if (fam == 4) { const PadPlan P = make_pad_plan(p, pass); return ncde_tiled_kernel_name(&P.q, pass); }   // (on the zero-padded problem)
+    if (fam == 4) {      // (on the zero-padded problem)
+        const PadPlan P = pick_pad_plan(p, pass, true);
+        return P.inner == 1 ? ncde_fast_kernel_name(&P.q, pass) : ncde_tiled_kernel_name(&P.q, pass);
+    }
     if (fam == 2) return ncde_tiled_kernel_name(p, pass);
     if (fam == 3) return pass == 0 ? "ncde_fwd_variant" : (pass == 1 ? "ncde_adj_variant" : "ncde_adj_variant<discrete>");
     return fam == 1 ? ncde_fast_kernel_name(p, pass) : (pass == 0 ? "ncde_fwd_generic" : (pass == 1 ? "ncde_adj_generic" : "ncde_adj_generic<discrete>"));

@@ -119,9 +119,9 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_fwd_fast(KArgs a) {
         const int e = tid + q * NT;
         const int es = e / DXW, ec = e - es * DXW;
         const int part = ec / CP, c = ec - part * CP;  // cubic: part 0..2 = b, 2c, 3d
-        eok[q] = e < 16 * DXW && c < C && (b0 + es) < a.B;
+        eok[q] = e < 16 * DXW && c < a.Cc && (b0 + es) < a.B;      // a.Cc: channels of the coefficient tensor (= C unless zero-padded)
         const long long base = (long long)(eok[q] ? b0 + es : 0) * a.cs_b;
-        eptr[q] = a.coeffs + base + (INTERP == NCDE_INTERP_LINEAR ? c : (part + 1) * C + c);
+        eptr[q] = a.coeffs + base + (INTERP == NCDE_INTERP_LINEAR ? c : (part + 1) * a.Cc + c);
         eprev[q] = 0.0f;
         enext[q] = 0.0f;
     }
@@ -151,13 +151,14 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_fwd_fast(KArgs a) {
     // ---- state ----------------------------------------------------------------------------------------
     float y0[NB], k1[NB], k2[NB], zreg[HB];
 #pragma unroll
-    for (int ks = 0; ks < HB; ++ks) zreg[ks] = valid ? a.z0[(long long)bs * H + 4 * ks + g] : 0.0f;
+    for (int ks = 0; ks < HB; ++ks) zreg[ks] = (valid && 4 * ks + g < a.Hr) ? a.z0[(long long)bs * a.Hr + 4 * ks + g] : 0.0f;      // a.Hr: row width of z0 / out (= H unless zero-padded)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        y0[nb] = valid ? a.z0[(long long)bs * H + 4 * (wave * NB + nb) + g] : 0.0f;
+        const int u = 4 * (wave * NB + nb) + g;
+        y0[nb] = (valid && u < a.Hr) ? a.z0[(long long)bs * a.Hr + u] : 0.0f;
         k1[nb] = 0.0f;
         k2[nb] = 0.0f;
-        if (valid) a.out[((long long)bs * a.n_out) * H + 4 * (wave * NB + nb) + g] = y0[nb];
+        if (valid && u < a.Hr) a.out[((long long)bs * a.n_out) * a.Hr + u] = y0[nb];
     }
     __syncthreads();
 
@@ -173,9 +174,10 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_fwd_fast(KArgs a) {
             const float frac = t - (float)idx;
             const float* dxp = dxs[idx % 3] + s * DXW;
             if (a.stages != nullptr && wave == ((n * S + j) % NW) && valid) {  // record the stage input (exact backward)
-                float* rec = a.stages + ((long long)(n * S + j) * a.B + bs) * H;
+                float* rec = a.stages + ((long long)(n * S + j) * a.B + bs) * a.Hr;
 #pragma unroll
-                for (int ks = 0; ks < HB; ++ks) rec[4 * ks + g] = zreg[ks];
+                for (int ks = 0; ks < HB; ++ks)
+                    if (4 * ks + g < a.Hr) rec[4 * ks + g] = zreg[ks];
             }
             // ---- hidden layers, register to register -------------------------------------------------
             f32x4 acc[HT];
@@ -262,7 +264,8 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_fwd_fast(KArgs a) {
                 if (valid && (a.output == NCDE_OUT_KNOTS || n == a.T - 2)) {
                     const int row = a.output == NCDE_OUT_KNOTS ? n + 1 : 1;
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) a.out[((long long)bs * a.n_out + row) * H + 4 * (wave * NB + nb) + g] = ys[nb];
+                    for (int nb = 0; nb < NB; ++nb)
+                        if (4 * (wave * NB + nb) + g < a.Hr) a.out[((long long)bs * a.n_out + row) * a.Hr + 4 * (wave * NB + nb) + g] = ys[nb];
                 }
                 if (n + 1 < a.n_pieces) stage_store(n + 1);
             }
@@ -390,9 +393,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
         const int e = tid + q * NT;
         const int es = e / DXW, ec = e - es * DXW;
         const int part = ec / CP, c = ec - part * CP;
-        eok[q] = e < 16 * DXW && c < C && (b0 + es) < a.B;
+        eok[q] = e < 16 * DXW && c < a.Cc && (b0 + es) < a.B;      // a.Cc: channels of the coefficient tensor (= C unless zero-padded)
         const long long base = (long long)(eok[q] ? b0 + es : 0) * a.cs_b;
-        eptr[q] = a.coeffs + base + (INTERP == NCDE_INTERP_LINEAR ? c : (part + 1) * C + c);
+        eptr[q] = a.coeffs + base + (INTERP == NCDE_INTERP_LINEAR ? c : (part + 1) * a.Cc + c);
         eprev[q] = 0.0f;
         enext[q] = 0.0f;
     }
@@ -424,13 +427,14 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
 #pragma unroll
     for (int c = 0; c < KC0; ++c)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) zreg[c][j] = valid ? a.z0[(long long)bs * H + 32 * c + 8 * g + j] : 0.0f;
+        for (int j = 0; j < 8; ++j) zreg[c][j] = (valid && 32 * c + 8 * g + j < a.Hr) ? a.z0[(long long)bs * a.Hr + 32 * c + 8 * g + j] : 0.0f;      // a.Hr: row width of z0 / out (= H unless zero-padded)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        y0[nb] = valid ? a.z0[(long long)bs * H + 4 * (wave * NB + nb) + g] : 0.0f;
+        const int u = 4 * (wave * NB + nb) + g;
+        y0[nb] = (valid && u < a.Hr) ? a.z0[(long long)bs * a.Hr + u] : 0.0f;
         k1[nb] = 0.0f;
         k2[nb] = 0.0f;
-        if (valid) a.out[((long long)bs * a.n_out) * H + 4 * (wave * NB + nb) + g] = y0[nb];
+        if (valid && u < a.Hr) a.out[((long long)bs * a.n_out) * a.Hr + u] = y0[nb];
     }
     __syncthreads();
 
@@ -446,11 +450,19 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
             const float frac = t - (float)idx;
             const float* dxp = dxs[idx % 3] + s * DXW;
             if (a.stages != nullptr && wave == ((n * S + j) % NW) && valid) {  // record the stage input (exact backward)
-                float* rec = a.stages + ((long long)(n * S + j) * a.B + bs) * H;
+                float* rec = a.stages + ((long long)(n * S + j) * a.B + bs) * a.Hr;
+                if (a.Hr == H) {
 #pragma unroll
-                for (int c = 0; c < KC0; ++c) {
-                    *reinterpret_cast<f32x4*>(rec + 32 * c + 8 * g) = (f32x4){zreg[c][0], zreg[c][1], zreg[c][2], zreg[c][3]};
-                    *reinterpret_cast<f32x4*>(rec + 32 * c + 8 * g + 4) = (f32x4){zreg[c][4], zreg[c][5], zreg[c][6], zreg[c][7]};
+                    for (int c = 0; c < KC0; ++c) {
+                        *reinterpret_cast<f32x4*>(rec + 32 * c + 8 * g) = (f32x4){zreg[c][0], zreg[c][1], zreg[c][2], zreg[c][3]};
+                        *reinterpret_cast<f32x4*>(rec + 32 * c + 8 * g + 4) = (f32x4){zreg[c][4], zreg[c][5], zreg[c][6], zreg[c][7]};
+                    }
+                } else {      // zero-padded problem: rows of the caller's record are a.Hr wide
+#pragma unroll
+                    for (int c = 0; c < KC0; ++c)
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj)
+                            if (32 * c + 8 * g + jj < a.Hr) rec[32 * c + 8 * g + jj] = zreg[c][jj];
                 }
             }
             // ---- hidden layers ---------------------------------------------------------------------------
@@ -537,7 +549,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
                 if (valid && (a.output == NCDE_OUT_KNOTS || n == a.T - 2)) {
                     const int row = a.output == NCDE_OUT_KNOTS ? n + 1 : 1;
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) a.out[((long long)bs * a.n_out + row) * H + 4 * (wave * NB + nb) + g] = ys[nb];
+                    for (int nb = 0; nb < NB; ++nb)
+                        if (4 * (wave * NB + nb) + g < a.Hr) a.out[((long long)bs * a.n_out + row) * a.Hr + 4 * (wave * NB + nb) + g] = ys[nb];
                 }
                 if (n + 1 < a.n_pieces) stage_store(n + 1);
             }
@@ -691,9 +704,9 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_adj_fast(KArgs a) {
         const int e = tid + q * NT;
         const int es = e / DXW, ec = e - es * DXW;
         const int part = ec / CP, c = ec - part * CP;
-        eok[q] = e < 16 * DXW && c < C && (b0 + es) < a.B;
+        eok[q] = e < 16 * DXW && c < a.Cc && (b0 + es) < a.B;      // a.Cc: channels of the coefficient tensor (= C unless zero-padded)
         const long long base = (long long)(eok[q] ? b0 + es : 0) * a.cs_b;
-        eptr[q] = a.coeffs + base + (INTERP == NCDE_INTERP_LINEAR ? c : (part + 1) * C + c);
+        eptr[q] = a.coeffs + base + (INTERP == NCDE_INTERP_LINEAR ? c : (part + 1) * a.Cc + c);
         eprev[q] = 0.0f;
         enext[q] = 0.0f;
     }
@@ -1190,9 +1203,9 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
             const int e = tid + q * NT;
             const int es = e / DXW, ec = e - es * DXW;
             const int part = ec / CP, c = ec - part * CP;
-            eok[q] = e < 16 * DXW && c < C && (b0 + es) < a.B;
+            eok[q] = e < 16 * DXW && c < a.Cc && (b0 + es) < a.B;      // a.Cc: channels of the coefficient tensor (= C unless zero-padded)
             const long long base = (long long)(eok[q] ? b0 + es : 0) * a.cs_b;
-            eptr[q] = a.coeffs + base + (INTERP == NCDE_INTERP_LINEAR ? c : (part + 1) * C + c);
+            eptr[q] = a.coeffs + base + (INTERP == NCDE_INTERP_LINEAR ? c : (part + 1) * a.Cc + c);
             eprev[q] = 0.0f;
             enext[q] = 0.0f;
         }
@@ -1837,9 +1850,9 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
             const int e = tid + q * NT;
             const int es = e / DXW, ec = e - es * DXW;
             const int part = ec / CP, c = ec - part * CP;
-            eok[q] = e < 16 * DXW && c < C && (b0 + es) < a.B;
+            eok[q] = e < 16 * DXW && c < a.Cc && (b0 + es) < a.B;      // a.Cc: channels of the coefficient tensor (= C unless zero-padded)
             const long long base = (long long)(eok[q] ? b0 + es : 0) * a.cs_b;
-            eptr[q] = a.coeffs + base + (INTERP == NCDE_INTERP_LINEAR ? c : (part + 1) * C + c);
+            eptr[q] = a.coeffs + base + (INTERP == NCDE_INTERP_LINEAR ? c : (part + 1) * a.Cc + c);
             eprev[q] = 0.0f;
             enext[q] = 0.0f;
         }
@@ -1873,9 +1886,14 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         // walked backwards (linear index `lin`), fetched one stage ahead; ka1/ka2/ky1 hold dL/dY of stages 4/3/2.
         f32x4 znext[2];
         auto rec_fetch = [&](int lin) {
-            const float* rp = a.stages + ((long long)lin * a.B + (valid ? bs : 0)) * H + 8 * g;
-            znext[0] = *reinterpret_cast<const f32x4*>(rp);
-            znext[1] = *reinterpret_cast<const f32x4*>(rp + 4);
+            const float* rp = a.stages + ((long long)lin * a.B + (valid ? bs : 0)) * a.Hr + 8 * g;
+            if (a.Hr == H) {
+                znext[0] = *reinterpret_cast<const f32x4*>(rp);
+                znext[1] = *reinterpret_cast<const f32x4*>(rp + 4);
+            } else {      // zero-padded problem: rows of the caller's record are a.Hr wide (units >= a.Hr are 0)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) znext[jj >> 2][jj & 3] = 8 * g + jj < a.Hr ? rp[jj] : 0.0f;
+            }
         };
         if constexpr (DISC != 0) {
             rec_fetch((a.T - 1) * S - 1);
@@ -1883,13 +1901,14 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
             for (int jj = 0; jj < 8; ++jj) zreg[jj] = valid ? znext[jj >> 2][jj & 3] : 0.0f;
         } else {
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) zreg[jj] = valid ? a.z_out[((long long)bs * a.n_out + last_row) * H + 8 * g + jj] : 0.0f;
+            for (int jj = 0; jj < 8; ++jj) zreg[jj] = (valid && 8 * g + jj < a.Hr) ? a.z_out[((long long)bs * a.n_out + last_row) * a.Hr + 8 * g + jj] : 0.0f;
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            const long long o = ((long long)bs * a.n_out + last_row) * H + 4 * (pw * NB + nb) + g;
-            y0[nb] = (DISC == 0 && valid) ? a.z_out[o] : 0.0f;
-            a0[nb] = valid ? a.grad_out[o] : 0.0f;
+            const long long o = ((long long)bs * a.n_out + last_row) * a.Hr + 4 * (pw * NB + nb) + g;
+            const bool live = valid && 4 * (pw * NB + nb) + g < a.Hr;      // a.Hr: row width of z_out / grad_out / grad_z0 (= H unless zero-padded)
+            y0[nb] = (DISC == 0 && live) ? a.z_out[o] : 0.0f;
+            a0[nb] = live ? a.grad_out[o] : 0.0f;
             as_[nb] = (DISC != 0 && METHOD == NCDE_RK4_38) ? a0[nb] * 0.125f : a0[nb];
             ky1[nb] = ky2[nb] = ka1[nb] = ka2[nb] = 0.0f;
         }
@@ -2101,7 +2120,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                             const int row = a.output == NCDE_OUT_KNOTS ? n - 1 : 0;
 #pragma unroll
                             for (int nb = 0; nb < NB; ++nb)
-                                a0[nb] += valid ? a.grad_out[((long long)bs * a.n_out + row) * H + 4 * (pw * NB + nb) + g] : 0.0f;
+                                a0[nb] += (valid && 4 * (pw * NB + nb) + g < a.Hr) ? a.grad_out[((long long)bs * a.n_out + row) * a.Hr + 4 * (pw * NB + nb) + g] : 0.0f;
                         }
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) as_[nb] = METHOD == NCDE_RK4_38 ? a0[nb] * 0.125f : a0[nb];
@@ -2129,16 +2148,17 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                     if (a.output == NCDE_OUT_KNOTS) {  // reset y to the stored knot value, add dL/dz of that knot
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {
-                            const long long o = ((long long)bs * a.n_out + (n - 1)) * H + 4 * (pw * NB + nb) + g;
-                            y0[nb] = valid ? a.z_out[o] : 0.0f;
+                            const long long o = ((long long)bs * a.n_out + (n - 1)) * a.Hr + 4 * (pw * NB + nb) + g;
+                            const bool live = valid && 4 * (pw * NB + nb) + g < a.Hr;
+                            y0[nb] = live ? a.z_out[o] : 0.0f;
                             ys[nb] = y0[nb];
-                            a0[nb] += valid ? a.grad_out[o] : 0.0f;
+                            a0[nb] += live ? a.grad_out[o] : 0.0f;
                             as_[nb] = a0[nb];
                         }
                     } else if (n == 1) {
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {
-                            a0[nb] += valid ? a.grad_out[((long long)bs * a.n_out) * H + 4 * (pw * NB + nb) + g] : 0.0f;
+                            a0[nb] += (valid && 4 * (pw * NB + nb) + g < a.Hr) ? a.grad_out[((long long)bs * a.n_out) * a.Hr + 4 * (pw * NB + nb) + g] : 0.0f;
                             as_[nb] = a0[nb];
                         }
                     }
@@ -2147,7 +2167,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                 }
                 if (j == S - 1 && a.output == NCDE_OUT_KNOTS) {
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) zreg[jj] = valid ? a.z_out[((long long)bs * a.n_out + (n - 1)) * H + 8 * g + jj] : 0.0f;
+                    for (int jj = 0; jj < 8; ++jj) zreg[jj] = (valid && 8 * g + jj < a.Hr) ? a.z_out[((long long)bs * a.n_out + (n - 1)) * a.Hr + 8 * g + jj] : 0.0f;
                     __syncthreads();  // barrier B
                 } else {
                     float* zw = zx + zpar * H * 16;
@@ -2175,7 +2195,8 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         }
         if (valid) {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) a.grad_z0[(long long)bs * H + 4 * (pw * NB + nb) + g] = a0[nb];
+            for (int nb = 0; nb < NB; ++nb)
+                if (4 * (pw * NB + nb) + g < a.Hr) a.grad_z0[(long long)bs * a.Hr + 4 * (pw * NB + nb) + g] = a0[nb];
         }
     } else {
         // =================================================================================================

@@ -245,9 +245,9 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
         const int e = tid + k * 256;
         const int es = e / DXW, ec = e - es * DXW;
         const int part = ec >> 2, c = ec & 3;      // cubic: part 0..2 = b, 2c, 3d
-        eok[k] = e < SP * DXW && c < C && (b0 + es) < a.B;
+        eok[k] = e < SP * DXW && c < a.Cc && (b0 + es) < a.B;      // a.Cc: channels of the coefficient tensor (= C unless zero-padded)
         const long long base = (long long)(eok[k] ? b0 + es : 0) * a.cs_b;
-        eptr[k] = a.coeffs + base + (cubic ? (part + 1) * C + c : c);
+        eptr[k] = a.coeffs + base + (cubic ? (part + 1) * a.Cc + c : c);
         eprev[k] = 0.0f;
         enext[k] = 0.0f;
     }
@@ -278,6 +278,7 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
 
     // ---- state: entries h = 16q + 4t + g of sample (hf, s) ---------------------------------------------------------------
     const int last_row = a.n_out - 1;
+    const int Hr = a.Hr;      // row width of z_out / grad_out / grad_z0 / the stage record (= 64 unless the problem was zero-padded)
     bool valid[NS];
     long long brow[NS];
     float y0[NS][4], ky1[NS][4], ky2[NS][4], a0[NS][4], ka1[NS][4], ka2[NS][4], as_[NS][4];
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
         for (int hf = 0; hf < NS; ++hf)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                znext[hf][t] = valid[hf] ? a.stages[((long long)lin * a.B + (b0 + 16 * hf + s)) * 64 + 16 * q + 4 * t + g] : 0.0f;
+                znext[hf][t] = (valid[hf] && 16 * q + 4 * t + g < Hr) ? a.stages[((long long)lin * a.B + (b0 + 16 * hf + s)) * Hr + 16 * q + 4 * t + g] : 0.0f;
     };
 #pragma unroll
     for (int hf = 0; hf < NS; ++hf) {
@@ -302,9 +303,10 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
         float zs[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const long long o = (brow[hf] + last_row) * 64 + 16 * q + 4 * t + g;
-            y0[hf][t] = (DISC == 0 && valid[hf]) ? a.z_out[o] : 0.0f;
-            a0[hf][t] = valid[hf] ? a.grad_out[o] : 0.0f;
+            const long long o = (brow[hf] + last_row) * Hr + 16 * q + 4 * t + g;
+            const bool live = valid[hf] && 16 * q + 4 * t + g < Hr;
+            y0[hf][t] = (DISC == 0 && live) ? a.z_out[o] : 0.0f;
+            a0[hf][t] = live ? a.grad_out[o] : 0.0f;
             as_[hf][t] = (DISC != 0 && METHOD == NCDE_RK4_38) ? a0[hf][t] * 0.125f : a0[hf][t];
             ky1[hf][t] = ky2[hf][t] = ka1[hf][t] = ka2[hf][t] = 0.0f;
             zs[t] = DISC != 0 ? znext[hf][t] : y0[hf][t];
@@ -600,9 +602,10 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
                     for (int hf = 0; hf < NS; ++hf)
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
-                            const long long o = (brow[hf] + row) * 64 + 16 * q + 4 * t + g;
-                            gk[hf][t] = valid[hf] ? a.grad_out[o] : 0.0f;
-                            zk[hf][t] = (DISC == 0 && a.output == NCDE_OUT_KNOTS && valid[hf]) ? a.z_out[o] : 0.0f;
+                            const long long o = (brow[hf] + row) * Hr + 16 * q + 4 * t + g;
+                            const bool live = valid[hf] && 16 * q + 4 * t + g < Hr;
+                            gk[hf][t] = live ? a.grad_out[o] : 0.0f;
+                            zk[hf][t] = (DISC == 0 && a.output == NCDE_OUT_KNOTS && live) ? a.z_out[o] : 0.0f;
                         }
                 }
                 f32x4 vy[NS];
@@ -676,7 +679,8 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
     for (int hf = 0; hf < NS; ++hf)
         if (valid[hf]) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) a.grad_z0[(long long)(b0 + 16 * hf + s) * 64 + 16 * q + 4 * t + g] = a0[hf][t];
+            for (int t = 0; t < 4; ++t)
+                if (16 * q + 4 * t + g < Hr) a.grad_z0[(long long)(b0 + 16 * hf + s) * Hr + 16 * q + 4 * t + g] = a0[hf][t];
         }
     float* gp = a.gpart + (long long)blockIdx.x * a.theta_size;
 #pragma unroll

@@ -712,6 +712,42 @@ def test_fast_forward_with_other_layer_counts(nl, gpu_lib):
             assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), (nl, C, k, e)
 
 
+@pytest.mark.parametrize("shape", [(5, 16, 15, 3), (20, 32, 15, 1), (3, 7, 15, 2), (17, 30, 32, 3),      # -> (32, 32, 20)
+                                   (4, 47, 32, 3), (3, 64, 15, 2), (2, 40, 64, 1)])                           # -> (64, 64, 4)
+@pytest.mark.parametrize("interp,method,seq", [("linear", "rk4", True), ("cubic", "midpoint", False)])
+def test_small_shapes_zero_padded_onto_the_specialised_kernels(shape, interp, method, seq, gpu_lib):
+    """A model within (H, HH, C) <= (32, 32, 20) or (64, 64, 4) -- the reference's default hidden_hidden_dim = 15 with a small state --
+    is zero-padded by the library onto the specialised kernel sets (they take the real row width of z / gradients / stage record and
+    the real channel count of the coefficient tensor): forward, continuous adjoint and exact discrete backward against the oracle,
+    ragged batch, and the same results as the batch-tiled family the shape would otherwise run on."""
+    import gpu_util
+    from ncde_amd import _lib
+    C, H, HH, nl = shape
+    case = _seeded_case(interp, method, seq, B=37, L=7, C=C, H=H, HH=HH, nl=nl, seed=1200 + 7 * C + H)
+    ex = case["expect"]
+    res = gpu_util.run_case(case)
+    big = H > 32 or HH > 32
+    want = ("ncde_fwd_fast_bf3<H64,HH64,C4", "ncde_adj_h64<H64") if big else ("ncde_fwd_fast_bf3<H32,HH32,C20", "ncde_adj_fast3<H32,HH32,C20,NL%d" % nl)
+    assert res["kernels"][0].startswith(want[0]) and res["kernels"][1].startswith(want[1]) and "discrete" in res["kernels"][2], res["kernels"]
+    assert gu.relerr(res["z_out"], ex["z_out"]) <= TIGHT_Z
+    for k, e in _grad_errors(case, res).items():
+        assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), ("end-to-end", k, e)
+    iso = gpu_util.run_adjoint_direct(case, ex["z_out"])
+    for k, e in _grad_errors(case, iso).items():
+        assert e <= TIGHT_G, ("adjoint on oracle z_out", res["kernels"][1], k, e)
+    isod = gpu_util.run_adjoint_direct(case, ex["z_out"], stages=case["stage_record"])
+    for k, e in _grad_errors(case, isod, "bp_").items():
+        assert e <= TIGHT_G, ("discrete backward on the oracle's stage record", res["kernels"][2], k, e)
+    resd = gpu_util.run_case(case, adjoint=False)      # the recording forward writes the record with the REAL row width
+    assert np.array_equal(resd["z_out"], res["z_out"])
+    for k, e in _grad_errors(case, resd, "bp_").items():
+        assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), ("discrete end-to-end", k, e)
+    r32 = gpu_util.run_case(case, flags=_lib.FLAG_FP32_MFMA, need_grads=False)
+    assert gu.relerr(r32["z_out"], ex["z_out"]) <= TIGHT_Z, r32["kernels"]
+    rt = gpu_util.run_case(case, flags=_lib.FLAG_FORCE_TILED, need_grads=False)
+    assert rt["kernels"][0].startswith("ncde_fwd_tiled") and gu.relerr(rt["z_out"], res["z_out"]) <= TIGHT_Z
+
+
 @pytest.mark.parametrize("nl", [1, 2, 4])
 @pytest.mark.parametrize("interp,method,seq", [("linear", "rk4", False), ("cubic", "midpoint", True), ("linear", "euler", True)])
 def test_h32_chain_grad_adjoint_other_layer_counts(nl, interp, method, seq, gpu_lib):
@@ -793,7 +829,8 @@ def test_tiled_family_vs_oracle(shape, interp, method, seq, gpu_lib):
     ex = case["expect"]
     for flag, ns in ((0, None), (0x1000, 1), (0x2000, 2), (0x4000, 4)):
         res = gpu_util.run_case(case, flags=flag, need_grads=False)
-        assert res["kernels"][0].startswith("ncde_fwd_tiled"), res["kernels"]
+        # (without a batch-tiled knob a shape within (32, 32, 20) / (64, 64, 4) is zero-padded onto the specialised kernels instead)
+        assert res["kernels"][0].startswith("ncde_fwd_tiled" if (ns or H > 64 or C > 20 or (H > 32 and C > 4)) else "ncde_fwd_"), res["kernels"]
         if ns:
             assert res["kernels"][0] in ("ncde_fwd_tiled<NS%d>" % ns, "ncde_fwd_tiled<NS1,fp16x2>"), res["kernels"]
             if ns == 1 and HH % 32 == 0:      # one sample tile, last hidden width a multiple of 32: the split-fp16 output tiles (default) ...

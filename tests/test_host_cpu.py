@@ -109,11 +109,17 @@ def test_kernel_family_selection():
     p = _problem()                                    # BASELINE cfg2 shape -> specialised kernels
     assert name(p, 0).startswith("ncde_fwd_fast") and name(p, 1).startswith("ncde_adj_fast")
     assert name(_problem(flags=_lib.FLAG_FORCE_GENERIC), 0) == "ncde_fwd_generic"
-    q = _problem(C=5, H=16, HH=24)                    # arbitrary shape -> zero-padded (C 8, HH 32) into the batch-tiled family
-    assert name(q, 0).startswith("ncde_fwd_tiled") and name(q, 1).startswith("ncde_adj_tiled") and name(q, 2).startswith("ncde_adj_tiled")
+    q = _problem(C=5, H=16, HH=24)                    # arbitrary small shape -> zero-padded onto the (32, 32, 20) specialised kernels
+    assert name(q, 0).startswith("ncde_fwd_fast_bf3<H32,HH32,C20") and name(q, 1).startswith("ncde_adj_fast3<H32,HH32,C20") and "discrete" in name(q, 2)
     wq = lib.ncde_workspace_bytes(ctypes.byref(q), 1)
-    q8 = _problem(C=8, H=16, HH=32)                   # the aligned shape it is padded to: same kernels, workspace without the padded copies
-    assert name(q8, 1) == name(q, 1) and 0 < lib.ncde_workspace_bytes(ctypes.byref(q8), 1) < wq
+    q20 = _problem(C=20, H=32, HH=32)                 # the shape it is padded to: same kernels, workspace without the padded copies
+    assert name(q20, 1) == name(q, 1) and 0 < lib.ncde_workspace_bytes(ctypes.byref(q20), 1) < wq
+    q.flags = _lib.FLAG_FORCE_TILED                   # ... onto the batch-tiled family (C 8, HH 32) when that is asked for, or when the
+    assert name(q, 0).startswith("ncde_fwd_tiled") and name(q, 1).startswith("ncde_adj_tiled")      # shape is beyond the specialised ones
+    w = _problem(C=21, H=47, HH=93)
+    assert name(w, 0).startswith("ncde_fwd_tiled") and name(w, 1).startswith("ncde_adj_tiled") and name(w, 2).startswith("ncde_adj_tiled")
+    w24 = _problem(C=24, H=48, HH=128)
+    assert name(w24, 1) == name(w, 1) and 0 < lib.ncde_workspace_bytes(ctypes.byref(w24), 1) < lib.ncde_workspace_bytes(ctypes.byref(w), 1)
     q.flags = _lib.FLAG_FORCE_GENERIC                 # ... unless the generic family is asked for
     assert name(q, 0) == "ncde_fwd_generic" and name(q, 1) == "ncde_adj_generic"
     q.flags = _lib.FLAG_FORCE_FAST
