@@ -275,7 +275,7 @@ def pmc_pass(name, config, B_local):
     pmc, src = _pmc_summary(config, B_local)
     if pmc is None:
         return None
-    bases = [part.split("<")[0] for part in name.split("+")]
+    bases = [part.split("<")[0] for part in name.replace("+ncde_", "\x00ncde_").split("\x00")]      # ("+" also occurs inside template tags)
     recs = [pmc[b] for b in bases if b in pmc]
     if len(recs) != len(bases) or not all("hbm_read_MB_per_pass_corrected_x2" in r for r in recs):
         return None
