@@ -1,4 +1,7 @@
-"""Repetition stress of the specialised adjoint kernels: every instantiation, N runs each, all bit-identical and within tolerance."""
+"""Repetition stress of the specialised adjoint kernels: every instantiation, N runs each, all bit-identical and within tolerance.
+usage: python tools/stress_adj.py [N] [bf16|v4] [shape=C,H,HH,nl] [flags=0x...]   (default shape 20,32,32,3; e.g. shape=4,64,64,3 for
+ncde_adj_h64 -- add flags=0x2000 for its two-tile variant --, shape=20,32,32,1 for the other layer counts, shape=5,16,15,3 for a
+zero-padded problem)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,12 +12,20 @@ from ncde_amd import _lib
 if os.environ.get("VARIANT"): _lib.LIB_PATH = os.path.join(ROOT, "variants", os.environ["VARIANT"])
 FLAGS = _lib.FLAG_ADJOINT_V4 if "v4" in sys.argv else (64 if "bf16" in sys.argv else 0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8
+SHAPE = (20, 32, 32, 3)
+for arg in sys.argv[1:]:
+    if arg.startswith("shape="):
+        SHAPE = tuple(int(v) for v in arg[6:].split(","))
+    if arg.startswith("flags="):
+        FLAGS |= int(arg[6:], 0)
+C_, H_, HH_, NL_ = SHAPE
+print("shape (C, H, HH, nl) =", SHAPE, "flags %#x" % FLAGS, "runs", N)
 bad = 0
 for interp in ("linear", "cubic"):
     for method in ("rk4", "midpoint", "euler"):
         for seq in (False, True):
             for (B, L) in ((16, 4), (37, 7)):
-                case = tg._seeded_case(interp, method, seq, B=B, L=L, C=20, H=32, HH=32, nl=3, seed=77)
+                case = tg._seeded_case(interp, method, seq, B=B, L=L, C=C_, H=H_, HH=HH_, nl=NL_, seed=77)
                 ex = case["expect"]
                 for disc in (False, True):
                     kw = {"stages": case["stage_record"]} if disc else {}
