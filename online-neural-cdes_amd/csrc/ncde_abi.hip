@@ -154,7 +154,7 @@ PadPlan make_pad_plan(const NcdeProblem* p, int pass, int target = 0) {
     if (p->hidden > 2048 || p->channels > 4095) return P;
     const int tH = target == 1 ? 32 : 64, tHH = tH, tC = target == 1 ? 20 : 4;
     if (target != 0) {
-        if (p->field_kind != NCDE_FIELD_ORIGINAL || p->output == NCDE_OUT_TIMES || p->hidden > tH || p->channels > tC) return P;
+        if (p->field_kind != NCDE_FIELD_ORIGINAL || p->hidden > tH || p->channels > tC) return P;
         // (any batch-tiled knob is a request for that family; the non-default adjoint variants exist for the exact shapes only)
         if (p->flags & (NCDE_FLAG_ADJOINT_V1 | NCDE_FLAG_ADJOINT_V2 | NCDE_FLAG_ADJOINT_V4 | NCDE_FLAG_DEBUG_PROFILE | NCDE_FLAG_FORCE_TILED |
                         NCDE_FLAG_TILED_NS1 | NCDE_FLAG_TILED_NS2 | NCDE_FLAG_TILED_NS4 | 0x00FF0000u | 0x200u)) return P;
@@ -260,7 +260,14 @@ int select_family(const NcdeProblem* p, const Layout& y, int pass) {
 int select_family_unpadded(const NcdeProblem* p, const Layout& y, int pass) {
     if (p->output == NCDE_OUT_TIMES) {   // general time axis: the plan-driven kernels -- batch-tiled where the shape allows
                                          // (multiples of 16 / 4; 2.8x the generic family at cfg2 widths, 10x at cfg5's), else generic / variant
-        if (p->flags & NCDE_FLAG_FORCE_FAST) return fail(NCDE_ERR_UNSUPPORTED, "the shape-specialised kernels run the default time axis only");
+        // (round 4: the shape-specialised kernels walk the plan too -- forward of both shapes, continuous adjoint of (32, 32, 20) nl = 3
+        // and of H = 64 / C <= 4; the planned discrete backward stays on the batch-tiled family)
+        const bool fast_ok = !y.variant && !(p->flags & (NCDE_FLAG_FORCE_GENERIC | NCDE_FLAG_FORCE_TILED)) && ncde_fast_supported(p, pass);
+        if (p->flags & NCDE_FLAG_FORCE_FAST) {
+            if (!fast_ok) return fail(NCDE_ERR_UNSUPPORTED, "no shape-specialised kernel for this problem on a general time axis (pass %d)", pass);
+            return 1;
+        }
+        if (fast_ok) return 1;
         const bool tiled_ok = !(p->flags & NCDE_FLAG_FORCE_GENERIC) && ncde_tiled_supported(p, pass);
         if (p->flags & NCDE_FLAG_FORCE_TILED) {
             if (!tiled_ok) return fail(NCDE_ERR_UNSUPPORTED, "the batch-tiled family does not cover this problem (pass %d)", pass);

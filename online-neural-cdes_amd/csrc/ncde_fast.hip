@@ -16,6 +16,7 @@
 #include "ncde_fast4.h"
 #include "ncde_fast64.h"
 #include "ncde_fast_nl.h"
+#include "ncde_fast_plan.h"
 // HP = 2 (the default adjoint): hidden-layer dW/db of the previous stage behind barrier A (dL/dpre images double-buffered) / all five
 // dWo blocks behind barrier A -- both shorten what the gradient waves do before barrier A, where the chain waves wait for them
 #ifndef NCDE_F2_DW_LATE
@@ -300,7 +301,11 @@ __global__ __launch_bounds__(64 * NW, 1) void ncde_fwd_fast(KArgs a) {
 // (the split-bf16 arithmetic itself lives in ncde_bf3.h, shared with the batch-tiled family)
 // NLT = number of layers known at compile time (0 = runtime): with the layer loop unrolled the whole stage is ONE basic
 // block, so the scheduler can issue the hi-piece MFMAs of layer l+1 under the mid / lo split of layer l.
-template <int H, int HH, int C, int NW, int INTERP, int METHOD, int PROF = 0, int NLT = 0, int HP = 0>
+// PLAN = 1 (round 4): the general time axis (a.plan, ncde_timeplan.hip) -- per-step dt, per-stage (piece, t - knot, knot spacing),
+// output rows picked / interpolated between the step's end points -- instead of the default integer grid with step 1.  The control
+// path is then staged as dX/dt PER STAGE of the next step (evaluated from the plan's stage descriptors by all threads while the
+// current step computes) instead of one new coefficient row per step: a plan may revisit or skip pieces.
+template <int H, int HH, int C, int NW, int INTERP, int METHOD, int PROF = 0, int NLT = 0, int HP = 0, int PLAN = 0>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs a) {
     unsigned long long prof[4] = {0, 0, 0, 0}, tlast = 0;
 #define NCDE_TICK(k)                                                \
@@ -317,12 +322,16 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
     constexpr int EPT = (16 * DXW + NT - 1) / NT;
     static_assert(H % (4 * NW) == 0 && HH % 32 == 0 && H % 32 == 0, "shape not tileable");
     __shared__ __attribute__((aligned(16))) float zx[2][H * 16];
-    __shared__ __attribute__((aligned(16))) float dxs[3][16 * DXW];
+    __shared__ __attribute__((aligned(16))) float dxs[PLAN ? 1 : 3][PLAN ? 4 : 16 * DXW];
+    __shared__ __attribute__((aligned(16))) float dxq[PLAN ? 2 : 1][PLAN ? S * 16 * CP : 4];      // PLAN: dX/dt of every stage of a step, by step parity
     __shared__ int fault_s;
     // split-fp16 instances speculate on the fp16 range and report a fault per sample tile; the split-bf16 instance, launched behind
     // them with only_faulted set, re-executes exactly those tiles (ncde_bf3.h)
     if constexpr (HP == 0) {
         if (a.only_faulted && a.fault[blockIdx.x] == 0) return;
+    }
+    if constexpr (PLAN != 0) {
+        if (a.plan == nullptr || !plan_header_ok(a, S)) return;      // (uniform: before the first barrier)
     }
     float mx = 0.0f;              // largest operand magnitude the split-fp16 GEMMs have seen (ncde_bf3.h)
 
@@ -415,12 +424,52 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
             eprev[q] = enext[q];
         }
     };
-    if (INTERP == NCDE_INTERP_LINEAR) {
+    // PLAN: element e = (stage j, sample es, channel c) of the [S][16][CP] image of one step
+    constexpr int EPQ = PLAN ? (S * 16 * CP + NT - 1) / NT : 1;
+    float qn[EPQ];
+    auto plan_load = [&](const int* pstep) {
 #pragma unroll
-        for (int q = 0; q < EPT; ++q) eprev[q] = eok[q] ? eptr[q][0] : 0.0f;
+        for (int q = 0; q < EPQ; ++q) {
+            const int e = tid + q * NT;
+            const int j = e / (16 * CP), rem = e - j * (16 * CP), es = rem / CP, c = rem - es * CP;
+            float v = 0.0f;
+            if (e < S * 16 * CP && c < a.Cc && b0 + es < a.B) {
+                const StageDesc sd = plan_stage(pstep, j);
+                const float* p = a.coeffs + (long long)(b0 + es) * a.cs_b + (long long)sd.idx * a.cs_t;
+                if constexpr (INTERP == NCDE_INTERP_LINEAR) {
+                    v = p[a.cs_t + c] - p[c];
+                    if (sd.kdt != 1.0f) v = v / sd.kdt;      // user knot grid (interpolation_linear.py:231-234); 1 on the default grid
+                } else {
+                    const float bb = p[a.Cc + c], cc = p[2 * a.Cc + c], dd = p[3 * a.Cc + c];
+                    const float inner = cc + dd * sd.frac;
+                    v = bb + inner * sd.frac;
+                }
+            }
+            qn[q] = v;
+        }
+    };
+    auto plan_store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < EPQ; ++q) {
+            const int e = tid + q * NT;
+            if (e < S * 16 * CP) dxq[buf][e] = qn[q];
+        }
+    };
+    const int pw_ = plan_step_words(S);
+    const int* pfwd = PLAN ? a.plan + plan_off_fwd() : nullptr;
+    const int* pout = PLAN ? a.plan + plan_off_out(S, a.n_steps_fwd) : nullptr;
+    const int n_steps = PLAN ? a.n_steps_fwd : a.T - 1;
+    if constexpr (PLAN != 0) {
+        plan_load(pfwd);
+        plan_store(0);
+    } else {
+        if (INTERP == NCDE_INTERP_LINEAR) {
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) eprev[q] = eok[q] ? eptr[q][0] : 0.0f;
+        }
+        stage_load(0);
+        stage_store(0);
     }
-    stage_load(0);
-    stage_store(0);
 
     // ---- state: lane (s, g) keeps z[s][32c + 8g + j] as the layer-0 B operand ----------------------------
     float y0[NB], k1[NB], k2[NB], zreg[KC0][8];
@@ -441,14 +490,20 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
     const int n_inner = a.n_layers - 1;
     int zpar = 0;
     if constexpr (PROF != 0) tlast = __builtin_readcyclecounter();
-    for (int n = 0; n < a.T - 1; ++n) {
-        if (n + 1 < a.n_pieces) stage_load(n + 1);
+    for (int n = 0; n < n_steps; ++n) {
+        const int* pstep = PLAN ? pfwd + n * pw_ : nullptr;
+        const float dt = PLAN ? __int_as_float(pstep[0]) : 1.0f;
+        if constexpr (PLAN != 0) {
+            if (n + 1 < n_steps) plan_load(pstep + pw_);
+        } else {
+            if (n + 1 < a.n_pieces) stage_load(n + 1);
+        }
 #pragma unroll
         for (int j = 0; j < S; ++j) {
             const float t = (float)n + stage_offset(METHOD, j);
-            const int idx = piece_index(t, a.n_pieces);
+            const int idx = PLAN ? 0 : piece_index(t, a.n_pieces);
             const float frac = t - (float)idx;
-            const float* dxp = dxs[idx % 3] + s * DXW;
+            const float* dxp = PLAN ? dxq[n & 1] + (j * 16 + s) * CP : dxs[idx % 3] + s * DXW;
             if (a.stages != nullptr && wave == ((n * S + j) % NW) && valid) {  // record the stage input (exact backward)
                 float* rec = a.stages + ((long long)(n * S + j) * a.B + bs) * a.Hr;
                 if (a.Hr == H) {
@@ -524,7 +579,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) o[nb] = SO::finish(oa[nb]);
                 f32x4 dx;
-                if constexpr (INTERP == NCDE_INTERP_LINEAR) {
+                if constexpr (INTERP == NCDE_INTERP_LINEAR || PLAN != 0) {      // (PLAN: the staged values ARE dX/dt of this stage)
                     dx = *reinterpret_cast<const f32x4*>(dxp + 4 * cq);
                 } else {
                     const f32x4 cb = *reinterpret_cast<const f32x4*>(dxp + 4 * cq);
@@ -542,17 +597,41 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void ncde_fwd_fast_bf3(KArgs
                     for (int r = 0; r < 4; ++r) kout[nb] = fmaf(tanh_prescaled(o[nb][r]), dx[r], kout[nb]);
             }
             NCDE_TICK(1)
-            float ys[NB];
+            float ys[NB], yprev[NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) ys[nb] = Combine<METHOD>::apply(j, kout[nb], y0[nb], k1[nb], k2[nb]);
-            if (j == S - 1) {
-                if (valid && (a.output == NCDE_OUT_KNOTS || n == a.T - 2)) {
-                    const int row = a.output == NCDE_OUT_KNOTS ? n + 1 : 1;
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        if (4 * (wave * NB + nb) + g < a.Hr) a.out[((long long)bs * a.n_out + row) * a.Hr + 4 * (wave * NB + nb) + g] = ys[nb];
+            for (int nb = 0; nb < NB; ++nb) {
+                yprev[nb] = y0[nb];
+                if constexpr (PLAN != 0) {
+                    bool last;
+                    ys[nb] = StageCombine::apply(METHOD, j, kout[nb], dt, y0[nb], k1[nb], k2[nb], last);
+                } else {
+                    ys[nb] = Combine<METHOD>::apply(j, kout[nb], y0[nb], k1[nb], k2[nb]);
                 }
-                if (n + 1 < a.n_pieces) stage_store(n + 1);
+            }
+            if (j == S - 1) {
+                if constexpr (PLAN != 0) {      // output pick / interpolation between the step's end points (solvers.py:103-117, 166-172)
+                    if (valid) {
+                        const int q0 = pstep[1], q1 = q0 + pstep[2];
+                        for (int r = q0; r < q1; ++r) {
+                            const int kind = pout[2 * r];
+                            const float slope = __int_as_float(pout[2 * r + 1]);
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+                                if (4 * (wave * NB + nb) + g < a.Hr)
+                                    a.out[((long long)bs * a.n_out + r) * a.Hr + 4 * (wave * NB + nb) + g] =
+                                        kind == 1 ? ys[nb] : (kind == 0 ? yprev[nb] : yprev[nb] + slope * (ys[nb] - yprev[nb]));
+                        }
+                    }
+                    if (n + 1 < n_steps) plan_store((n + 1) & 1);
+                } else {
+                    if (valid && (a.output == NCDE_OUT_KNOTS || n == a.T - 2)) {
+                        const int row = a.output == NCDE_OUT_KNOTS ? n + 1 : 1;
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            if (4 * (wave * NB + nb) + g < a.Hr) a.out[((long long)bs * a.n_out + row) * a.Hr + 4 * (wave * NB + nb) + g] = ys[nb];
+                    }
+                    if (n + 1 < a.n_pieces) stage_store(n + 1);
+                }
             }
             {
                 float* zw = zx[zpar];
@@ -1692,7 +1771,10 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast2(KArgs a) {
 //   2  the DEFAULT: forward-side GEMMs of the chain waves (recompute, output tiles) 2-way split-fp16; dL/dx_L = Wo^T dP as split-bf16
 //      with the lo pieces of Wo^T in the LDS region the chain waves' Wo lo pieces no longer need; all dWo blocks behind barrier A
 //   1  experimental (NCDE_FLAG_ADJOINT_SPLIT_FP16): everything split-fp16, cotangents normalised by a per-workgroup power of two
-template <int NL, int C, int INTERP, int METHOD, int PROF = 0, int DISC = 0, int HP = 0>
+// PLAN = 1 (round 4, continuous adjoint only): the general time axis -- the reverse steps of the adjoint table of a.plan (one reverse
+// solve per output interval: y reset to the stored value and dL/dz added where the table says so), per-step dt in the Butcher
+// bookkeeping and in the quadrature weights of the gradient waves, dX/dt staged per stage of the next step as in ncde_fwd_fast_bf3.
+template <int NL, int C, int INTERP, int METHOD, int PROF = 0, int DISC = 0, int HP = 0, int PLAN = 0>
 __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
     unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
 #define NCDE_TICK(k)                                                \
@@ -1726,10 +1808,19 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         if (a.only_faulted && a.fault[blockIdx.x] == 0) return;
     }
     static_assert(NB == 2 && NTILE % 2 == 0, "one 32-row dWo block per cq");
+    static_assert(PLAN == 0 || DISC == 0, "the planned discrete backward runs on the batch-tiled family");
+    if constexpr (PLAN != 0) {
+        if (a.plan == nullptr || !plan_header_ok(a, S)) return;      // (uniform: before the first barrier)
+    }
+    // PLAN: the dxs region holds [2][S][16][CP] (dX/dt of every stage of a reverse step, by step parity) instead of the ring of pieces
+    const int pw_ = plan_step_words(S);
+    const int* padj = PLAN ? a.plan + plan_off_adj(S, a.n_steps_fwd, a.n_out) : nullptr;
+    const int n_rsteps = PLAN ? a.n_steps_adj : a.T - 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* zx = lds;                                   // [2][H*16]
-    float* dxs = zx + 2 * H * 16;                      // [3][16*DXW]
-    float* red = dxs + 3 * 16 * DXW;                   // [NW][HH*16]
+    float* dxs = zx + 2 * H * 16;                      // [3][16*DXW]  (PLAN: [2][S][16][CP])
+    constexpr int DXR = PLAN ? 2 * S * 16 * CP : 3 * 16 * DXW;
+    float* red = dxs + DXR;                            // [NW][HH*16]
     float* boL = red + NW * HH * 16;                   // [NW][NB*CQ][4 g][4 r]   (nb-major)
     float* tiles = boL + NW * NTILE * 16;              // [NW][NTILE][16][16]     raw dP of the current stage
     float* ximg = tiles + NW * NTILE * 256;            // [2][XROWS][16]          by stage parity (chain wave 0)
@@ -1869,16 +1960,51 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                 eprev[q] = enext[q];
             }
         };
-        const int p_hi = a.n_pieces - 1;
-        if (INTERP == NCDE_INTERP_LINEAR) {
+        constexpr int EPQ = PLAN ? (S * 16 * CP + NT - 1) / NT : 1;
+        float qn[EPQ];
+        auto plan_load = [&](const int* pstep) {      // element e = (stage j, sample es, channel c)
 #pragma unroll
-            for (int q = 0; q < EPT; ++q) eprev[q] = eok[q] ? eptr[q][(long long)(p_hi + 1) * a.cs_t] : 0.0f;
-        }
-        stage_load(p_hi);
-        stage_store(p_hi);
-        if (p_hi >= 1) {
-            stage_load(p_hi - 1);
-            stage_store(p_hi - 1);
+            for (int q = 0; q < EPQ; ++q) {
+                const int e = tid + q * NT;
+                const int j = e / (16 * CP), rem = e - j * (16 * CP), es = rem / CP, c = rem - es * CP;
+                float v = 0.0f;
+                if (e < S * 16 * CP && c < a.Cc && b0 + es < a.B) {
+                    const StageDesc sd = plan_stage(pstep, j);
+                    const float* p = a.coeffs + (long long)(b0 + es) * a.cs_b + (long long)sd.idx * a.cs_t;
+                    if constexpr (INTERP == NCDE_INTERP_LINEAR) {
+                        v = p[a.cs_t + c] - p[c];
+                        if (sd.kdt != 1.0f) v = v / sd.kdt;
+                    } else {
+                        const float bb = p[a.Cc + c], cc = p[2 * a.Cc + c], dd = p[3 * a.Cc + c];
+                        const float inner = cc + dd * sd.frac;
+                        v = bb + inner * sd.frac;
+                    }
+                }
+                qn[q] = v;
+            }
+        };
+        auto plan_store = [&](int buf) {
+#pragma unroll
+            for (int q = 0; q < EPQ; ++q) {
+                const int e = tid + q * NT;
+                if (e < S * 16 * CP) dxs[buf * (S * 16 * CP) + e] = qn[q];
+            }
+        };
+        const int p_hi = a.n_pieces - 1;
+        if constexpr (PLAN != 0) {
+            plan_load(padj);
+            plan_store(0);
+        } else {
+            if (INTERP == NCDE_INTERP_LINEAR) {
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) eprev[q] = eok[q] ? eptr[q][(long long)(p_hi + 1) * a.cs_t] : 0.0f;
+            }
+            stage_load(p_hi);
+            stage_store(p_hi);
+            if (p_hi >= 1) {
+                stage_load(p_hi - 1);
+                stage_store(p_hi - 1);
+            }
         }
         const int last_row = a.n_out - 1;
         float y0[NB], ky1[NB], ky2[NB], a0[NB], ka1[NB], ka2[NB], as_[NB], zreg[8];
@@ -1930,21 +2056,29 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
 
         int zpar = 0, sc = 0;
         if constexpr (PROF != 0) tlast = __builtin_readcyclecounter();
-        for (int n = a.T - 1; n >= 1; --n) {
-            if (n - 3 >= 0) stage_load(n - 3);
+        for (int n = n_rsteps; n >= 1; --n) {
+            const int rs = n_rsteps - n;      // PLAN: index of this reverse step in the adjoint table
+            const int* pstep = PLAN ? padj + rs * pw_ : nullptr;
+            const float dt = PLAN ? __int_as_float(pstep[0]) : 1.0f;
+            const int reset_row = PLAN ? pstep[1] : -1;
+            if constexpr (PLAN != 0) {
+                if (n > 1) plan_load(pstep + pw_);
+            } else {
+                if (n - 3 >= 0) stage_load(n - 3);
+            }
 #pragma unroll 1
             for (int j = 0; j < S; ++j) {
                 ++sc;
                 const int par = sc & 1;
                 const float t = DISC != 0 ? (float)(n - 1) + stage_offset(METHOD, S - 1 - j) : -(-(float)n + stage_offset(METHOD, j));
-                const int idx = piece_index(t, a.n_pieces);
+                const int idx = PLAN ? 0 : piece_index(t, a.n_pieces);
                 const float frac = t - (float)idx;
                 const float wq = DISC != 0 ? 1.0f : stage_weight(METHOD, j);
                 if constexpr (DISC != 0) {
                     const int lin = (n - 1) * S + (S - 1 - j);
                     if (lin >= 1) rec_fetch(lin - 1);
                 }
-                const float* dxp = dxs + (idx % 3) * 16 * DXW + s * DXW;
+                const float* dxp = PLAN ? dxs + (rs & 1) * (S * 16 * CP) + (j * 16 + s) * CP : dxs + (idx % 3) * 16 * DXW + s * DXW;
                 // ---- forward recompute (split-bf16); x[l][4t+r] <-> unit 8g + 4t + r -----------------------------------
                 float x[NL][8];
                 SpF xb;
@@ -2013,7 +2147,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                         o[nb] = SF::finish(oa);
                     }
                     f32x4 dx;
-                    if constexpr (INTERP == NCDE_INTERP_LINEAR) {
+                    if constexpr (INTERP == NCDE_INTERP_LINEAR || PLAN != 0) {
                         dx = *reinterpret_cast<const f32x4*>(dxp + 4 * cq);
                     } else {
                         const f32x4 cb = *reinterpret_cast<const f32x4*>(dxp + 4 * cq);
@@ -2141,10 +2275,34 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                 }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    ys[nb] = Combine<METHOD>::apply(j, -kout[nb], y0[nb], ky1[nb], ky2[nb]);
-                    as_[nb] = Combine<METHOD>::apply(j, vy[nb], a0[nb], ka1[nb], ka2[nb]);
+                    if constexpr (PLAN != 0) {
+                        bool last;
+                        ys[nb] = StageCombine::apply(METHOD, j, -kout[nb], dt, y0[nb], ky1[nb], ky2[nb], last);
+                        as_[nb] = StageCombine::apply(METHOD, j, vy[nb], dt, a0[nb], ka1[nb], ka2[nb], last);
+                    } else {
+                        ys[nb] = Combine<METHOD>::apply(j, -kout[nb], y0[nb], ky1[nb], ky2[nb]);
+                        as_[nb] = Combine<METHOD>::apply(j, vy[nb], a0[nb], ka1[nb], ka2[nb]);
+                    }
                 }
-                if (j == S - 1) {
+                const bool plan_reset = PLAN != 0 && j == S - 1 && reset_row >= 0;      // end of an output interval (adjoint.py:116-133)
+                if constexpr (PLAN != 0) {
+                    if (plan_reset) {
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const long long o = ((long long)bs * a.n_out + reset_row) * a.Hr + 4 * (pw * NB + nb) + g;
+                            const bool live = valid && 4 * (pw * NB + nb) + g < a.Hr;
+                            y0[nb] = live ? a.z_out[o] : 0.0f;
+                            ys[nb] = y0[nb];
+                            a0[nb] += live ? a.grad_out[o] : 0.0f;
+                            as_[nb] = a0[nb];
+                        }
+                    }
+                    if (j == S - 1) {
+                        if (n > 1) plan_store((rs + 1) & 1);
+                        publish_amax(as_);
+                    }
+                }
+                if (PLAN == 0 && j == S - 1) {
                     if (a.output == NCDE_OUT_KNOTS) {  // reset y to the stored knot value, add dL/dz of that knot
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {
@@ -2165,9 +2323,10 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                     if (n - 3 >= 0) stage_store(n - 3);
                     publish_amax(as_);      // as_ = a at the step's lower end (+ dL/dz of that knot)
                 }
-                if (j == S - 1 && a.output == NCDE_OUT_KNOTS) {
+                if (plan_reset || (PLAN == 0 && j == S - 1 && a.output == NCDE_OUT_KNOTS)) {
+                    const int zrow = PLAN ? reset_row : n - 1;
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) zreg[jj] = (valid && 8 * g + jj < a.Hr) ? a.z_out[((long long)bs * a.n_out + (n - 1)) * a.Hr + 8 * g + jj] : 0.0f;
+                    for (int jj = 0; jj < 8; ++jj) zreg[jj] = (valid && 8 * g + jj < a.Hr) ? a.z_out[((long long)bs * a.n_out + zrow) * a.Hr + 8 * g + jj] : 0.0f;
                     __syncthreads();  // barrier B
                 } else {
                     float* zw = zx + zpar * H * 16;
@@ -2397,12 +2556,13 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
         int sc = 0;
         float wprev = 0.0f;
         if constexpr (PROF != 0) tlast = __builtin_readcyclecounter();
-        for (int n = a.T - 1; n >= 1; --n) {
+        for (int n = n_rsteps; n >= 1; --n) {
+            const float dtw = PLAN ? __int_as_float(padj[(n_rsteps - n) * pw_]) : 1.0f;      // the step's dt scales its quadrature weights
 #pragma unroll 1
             for (int j = 0; j < S; ++j) {
                 ++sc;
                 const int par = sc & 1;
-                const float wq = DISC != 0 ? 1.0f : stage_weight(METHOD, j);
+                const float wq = DISC != 0 ? 1.0f : stage_weight(METHOD, j) * dtw;
                 // hidden-layer dW/db of the previous stage, under the chain wave's forward recompute
                 if (NDP == 1 && wprev != 0.0f) dw_hidden(par ^ 1, wprev);
                 NCDE_TICK(0)
@@ -2649,11 +2809,16 @@ FwdFn pick_adj3_disc(int interp, int method, int hp) {
 
 #endif  // NCDE_FAST_KERNELS_ONLY
 template <int NL, int C>
-size_t adj3_lds_bytes(int interp, int hp) {   // hp: the kernel's HP template argument (0, 1, 2)
+size_t adj3_lds_bytes(int interp, int hp, int plan_stages);
+template <int NL, int C>
+size_t adj3_lds_bytes(int interp, int hp) { return adj3_lds_bytes<NL, C>(interp, hp, 0); }
+template <int NL, int C>
+size_t adj3_lds_bytes(int interp, int hp, int plan_stages) {   // hp: the kernel's HP template argument (0, 1, 2); plan_stages: S of a PLAN = 1 instance
     constexpr int H = 32, HH = 32, NW = 4, HT = 2, CP = (C + 3) & ~3, CQ = CP / 4, NB = 2, NTILE = NB * CQ;
     const int DXW = interp == NCDE_INTERP_LINEAR ? CP : 3 * CP;
+    const int DXR = plan_stages ? 2 * plan_stages * 16 * CP : 3 * 16 * DXW;
     const int NPF = hp ? 2 : 3, NP = hp == 1 ? 2 : 3, NDP = ((hp == 1 && NCDE_H2_DW_LATE) || (hp == 2 && NCDE_F2_DW_LATE && interp == NCDE_INTERP_LINEAR)) ? 2 : 1;
-    return sizeof(float) * (size_t)(2 * H * 16 + 3 * 16 * DXW + NW * HH * 16 + NW * NTILE * 16 + NW * NTILE * 256 +
+    return sizeof(float) * (size_t)(2 * H * 16 + DXR + NW * HH * 16 + NW * NTILE * 16 + NW * NTILE * 256 +
                                     2 * (H + NL * HH) * 16 + NDP * NL * HH * 16 + NW * (NTILE + 2) + 2 * HT * 16 +
                                     HT * NP * 256 + NW * NP * 256 + ((hp == 2 && !NCDE_F2_DXL_BF3) ? 0 : NW * NB * CQ * 256) + 2 * HT * NPF * 256 + NW + 4);
 }
@@ -2741,9 +2906,19 @@ static bool use_nl(const NcdeProblem* p, const FastEntry* e, int pass) {
 // H = HH = 64, C <= 4: the in-sweep adjoint of ncde_fast64.hip (the entry's own adjoint slots are empty; C < 4 has no entry at all)
 static bool use_h64(const NcdeProblem* p, int pass) { return pass >= 1 && ncde_fast64_supported(p, pass); }
 
+// general time axis (NcdeProblem.time_plan): the PLAN = 1 instances of ncde_fast_plan.hip -- forward of both shapes (split GEMMs,
+// runtime layer count), continuous adjoint of (32, 32, 20) with nl = 3; (64, 64, <= 4): ncde_fast64.hip's own planned instances
+static bool planned_ok(const NcdeProblem* p, const FastEntry* e, int pass) {
+    if (p->flags & (NCDE_FLAG_FP32_MFMA | NCDE_FLAG_ADJOINT_V1 | NCDE_FLAG_ADJOINT_V2 | NCDE_FLAG_ADJOINT_V4 | NCDE_FLAG_DEBUG_PROFILE | 0x200u)) return false;
+    if (pass == 0) return e != nullptr && ncde_fast_plan_fwd(e->shape.H == 32 ? 0 : 1, p->interp, p->method, 1) != nullptr;
+    if (pass == 1) return e != nullptr && e->shape.H == 32 && ncde_fast_plan_adj3(p->n_layers, p->interp, p->method, 2) != nullptr;
+    return false;
+}
+
 bool ncde_fast_supported(const NcdeProblem* p, int pass) {
     if (use_h64(p, pass)) return true;
     const FastEntry* e = find_entry(p);
+    if (p->output == NCDE_OUT_TIMES) return planned_ok(p, e, pass);
     if (!e) return false;
     if (pass == 0) return true;
     if (use_nl(p, e, pass)) return true;
@@ -2755,6 +2930,12 @@ const char* ncde_fast_kernel_name(const NcdeProblem* p, int pass) {
     if (use_h64(p, pass)) return ncde_fast64_kernel_name(p, pass);
     if (!ncde_fast_supported(p, pass)) return nullptr;
     const FastEntry* e = find_entry(p);
+    if (p->output == NCDE_OUT_TIMES) {
+        const bool bf = (p->flags & NCDE_FLAG_SPLIT_BF16) != 0;
+        if (pass == 0) return e->shape.H == 32 ? (bf ? "ncde_fwd_fast_bf3<H32,HH32,C20,NW4,bf16x3,time plan>" : "ncde_fwd_fast_bf3<H32,HH32,C20,NW4,fp16x2,time plan>")
+                                               : (bf ? "ncde_fwd_fast_bf3<H64,HH64,C4,NW4,bf16x3,time plan>" : "ncde_fwd_fast_bf3<H64,HH64,C4,NW4,fp16x2,time plan>");
+        return bf ? "ncde_adj_fast3<H32,HH32,C20,NL3,chain+grad,bf16x3,time plan>" : "ncde_adj_fast3<H32,HH32,C20,NL3,chain+grad,fwd-side fp16x2 + bf16x3,time plan>";
+    }
     if (use_nl(p, e, pass)) return ncde_fast_adj3_nl_name(p->n_layers, nl_hp(p), pass == 2);
     const bool h2f = !(p->flags & NCDE_FLAG_SPLIT_BF16);
     const bool h2 = h2f && NCDE_ADJ3_HP1_AVAILABLE != 0 && (p->flags & NCDE_FLAG_ADJOINT_SPLIT_FP16);
@@ -2795,6 +2976,11 @@ int ncde_fast_forward(const NcdeProblem* p, float* out, float* stages, void* ws,
     const bool bf3 = (p->flags & NCDE_FLAG_FP32_MFMA) == 0 && e->fwd_bf3 != nullptr;
     const int hp = (bf3 && !(p->flags & NCDE_FLAG_SPLIT_BF16)) ? 1 : 0;
     if (bf3) fn = e->fwd_bf3(p->interp, p->method, p->n_layers, hp);
+    const bool planned = p->output == NCDE_OUT_TIMES;
+    if (planned) {
+        if (!planned_ok(p, e, 0)) return NCDE_ERR_UNSUPPORTED;
+        fn = ncde_fast_plan_fwd(e->shape.H == 32 ? 0 : 1, p->interp, p->method, hp);
+    }
     a.fault = hp ? reinterpret_cast<int*>(static_cast<char*>(ws) + ncde_fast_workspace_bytes(p, 0) - fault_bytes(y)) : nullptr;
     if (p->flags & NCDE_FLAG_DEBUG_PROFILE) {  // phase-cycle counters -> workspace [n_wg][NW][4] u64
         if (!(e->shape.H == 32 && e->shape.C == 20 && p->interp == NCDE_INTERP_LINEAR && p->method == NCDE_RK4_38)) return NCDE_ERR_UNSUPPORTED;
@@ -2807,7 +2993,8 @@ int ncde_fast_forward(const NcdeProblem* p, float* out, float* stages, void* ws,
     hipLaunchKernelGGL(fn, dim3(y.n_wg), dim3(64 * (bf3 ? e->nw_bf3 : e->nw)), 0, st, a);
     if (hp && !(p->flags & NCDE_FLAG_DEBUG_PROFILE)) {  // re-execution of range-faulted tiles (normally none: every workgroup exits at once)
         a.only_faulted = 1;
-        hipLaunchKernelGGL(e->fwd_bf3(p->interp, p->method, p->n_layers, 0), dim3(y.n_wg), dim3(64 * e->nw_bf3), 0, st, a);
+        FwdFn fx = planned ? ncde_fast_plan_fwd(e->shape.H == 32 ? 0 : 1, p->interp, p->method, 0) : e->fwd_bf3(p->interp, p->method, p->n_layers, 0);
+        hipLaunchKernelGGL(fx, dim3(y.n_wg), dim3(64 * e->nw_bf3), 0, st, a);
     }
     return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
 }
@@ -2817,6 +3004,27 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
     if (use_h64(p, discrete ? 2 : 1)) return ncde_fast64_adjoint(p, z_out, grad_out, g, ws, ws_bytes, st, main_kernel_only, discrete);
     if (!ncde_fast_supported(p, discrete ? 2 : 1)) return NCDE_ERR_UNSUPPORTED;
     const FastEntry* e = find_entry(p);
+    if (p->output == NCDE_OUT_TIMES) {      // general time axis: the PLAN = 1 instances of the same kernel template, same launch protocol
+        if (discrete || !planned_ok(p, e, 1)) return NCDE_ERR_UNSUPPORTED;
+        const int hp = (p->flags & NCDE_FLAG_SPLIT_BF16) ? 0 : 2;
+        const Layout y = make_layout(p);
+        KArgs a;
+        fill_kargs(p, y, &a);
+        a.grad_out = grad_out; a.grad_z0 = g->grad_z0; a.z_out = z_out;
+        a.gpart = (float*)ws;
+        a.fault = hp ? reinterpret_cast<int*>(static_cast<char*>(ws) + ncde_fast_workspace_bytes(p, 1) - fault_bytes(y)) : nullptr;
+        for (int pass_hp : {hp, 0}) {
+            NcdeFastPlanKernel fn = ncde_fast_plan_adj3(p->n_layers, p->interp, p->method, pass_hp);
+            const size_t lds = ncde_fast_plan_adj3_lds(p->n_layers, p->interp, p->method, pass_hp);
+            if (!fn || ncde_lds_optin((const void*)fn, lds) != hipSuccess) return NCDE_ERR_HIP;
+            hipLaunchKernelGGL(fn, dim3(y.n_wg), dim3(512), lds, st, a);
+            if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
+            if (hp == 0) break;
+            a.only_faulted = 1;
+        }
+        if (main_kernel_only) return NCDE_OK;
+        return launch_reduce_partials(p, y, g, (const float*)ws, y.n_wg, st);
+    }
     if (use_nl(p, e, discrete ? 2 : 1)) {      // another layer count of the same kernel template: same launch protocol as below
         const int hp = nl_hp(p);
         const Layout y = make_layout(p);

@@ -166,15 +166,19 @@ constexpr int kF64MaxLayers = 4;
 #define F64_SYNC(k) __syncthreads();
 #endif
 
-__host__ __device__ constexpr int f64_lds_floats(int nl, int ns, bool cubic) {
+// plan_stages = S of a PLAN = 1 instance (the control-path region then holds [2][S][SP][4] instead of the ring of three pieces)
+__host__ __device__ constexpr int f64_lds_floats(int nl, int ns, bool cubic, int plan_stages = 0) {
     const int SP = 16 * ns, RS = SP + 4;
-    return 2 * 64 * RS + nl * 64 * RS + 256 * RS + 2 * 64 * RS + ns * 16 * 256 + 2 * ns * 4 * 256 + 3 * SP * (cubic ? 12 : 4) + 384 + 4;
+    const int dxr = plan_stages ? 2 * plan_stages * SP * 4 : 3 * SP * (cubic ? 12 : 4);
+    return 2 * 64 * RS + nl * 64 * RS + 256 * RS + 2 * 64 * RS + ns * 16 * 256 + 2 * ns * 4 * 256 + dxr + 384 + 4;
 }
 
 // HPF: 1 = forward-side GEMMs 2-way split-fp16 (default), 2 = everything fp32-input MFMA (NCDE_FLAG_FP32_MFMA / _SPLIT_BF16, and the
 // instance that re-executes range-faulted workgroups of HPF = 1: `only_faulted`)
-template <int METHOD, int NS, int HPF, int DISC>
+// PLAN = 1 (continuous adjoint only): the general time axis -- the reverse steps of a.plan's adjoint table, as in ncde_adj_fast3
+template <int METHOD, int NS, int HPF, int DISC, int PLAN = 0>
 __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
+    static_assert(PLAN == 0 || DISC == 0, "the planned discrete backward runs on the batch-tiled family");
     constexpr int S = kStages<METHOD>, SP = 16 * NS, RS = SP + 4, KS = 4 * NS;
     constexpr int NLM = kF64MaxLayers;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -187,12 +191,18 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
     float* gimg = dpT + 256 * RS;              // [2][64][RS]      w * dL/dpre_l, rows of wave q at 16 q (wave-private), by layer parity
     float* red = gimg + 2 * 64 * RS;           // [NS][4 src][4 tp][256]  per-wave partials of dL/dx_L
     float* exch = red + NS * 16 * 256;         // [2][NS][4][256]  lane-aligned exchange, double-buffered by phase parity
-    float* dxs = exch + 2 * NS * 4 * 256;      // [3][SP][DXW]     ring of control-path pieces
-    float* biasL = dxs + 3 * SP * DXW;         // [256] output-layer biases (prescaled) by row h C' + c, C' = 4;  [2][64] hidden biases
+    float* dxs = exch + 2 * NS * 4 * 256;      // [3][SP][DXW]     ring of control-path pieces  (PLAN: [2][S][SP][4], dX/dt per stage)
+    float* biasL = dxs + (PLAN ? 2 * S * SP * 4 : 3 * SP * DXW);         // [256] output-layer biases (prescaled) by row h C' + c, C' = 4;  [2][64] hidden biases
     int* fault_s = reinterpret_cast<int*>(biasL + 384);
     if constexpr (HPF != 1) {
         if (a.only_faulted && a.fault[blockIdx.x] == 0) return;
     }
+    if constexpr (PLAN != 0) {
+        if (a.plan == nullptr || !plan_header_ok(a, S)) return;      // (uniform: before the first barrier)
+    }
+    const int pw_ = plan_step_words(S);
+    const int* padj = PLAN ? a.plan + plan_off_adj(S, a.n_steps_fwd, a.n_out) : nullptr;
+    const int n_rsteps = PLAN ? a.n_steps_adj : a.T - 1;
     float mx = 0.0f;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -264,16 +274,51 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
             eprev[k] = enext[k];
         }
     };
-    const int p_hi = a.n_pieces - 1;
-    if (!cubic) {
+    constexpr int EPQ = PLAN ? (S * SP * 4 + 255) / 256 : 1;
+    float qn[EPQ];
+    auto plan_load = [&](const int* pstep) {      // element e = (stage j, sample es, channel c) of a reverse step
 #pragma unroll
-        for (int k = 0; k < EPT; ++k) eprev[k] = eok[k] ? eptr[k][(long long)(p_hi + 1) * a.cs_t] : 0.0f;
-    }
-    stage_load(p_hi);
-    stage_store(p_hi);
-    if (p_hi >= 1) {
-        stage_load(p_hi - 1);
-        stage_store(p_hi - 1);
+        for (int k = 0; k < EPQ; ++k) {
+            const int e = tid + k * 256;
+            const int j = e / (SP * 4), rem = e - j * (SP * 4), es = rem >> 2, c = rem & 3;
+            float v = 0.0f;
+            if (e < S * SP * 4 && c < a.Cc && b0 + es < a.B) {
+                const StageDesc sd = plan_stage(pstep, j);
+                const float* p = a.coeffs + (long long)(b0 + es) * a.cs_b + (long long)sd.idx * a.cs_t;
+                if (!cubic) {
+                    v = p[a.cs_t + c] - p[c];
+                    if (sd.kdt != 1.0f) v = v / sd.kdt;
+                } else {
+                    const float bb = p[a.Cc + c], cc = p[2 * a.Cc + c], dd = p[3 * a.Cc + c];
+                    const float inner = cc + dd * sd.frac;
+                    v = bb + inner * sd.frac;
+                }
+            }
+            qn[k] = v;
+        }
+    };
+    auto plan_store = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < EPQ; ++k) {
+            const int e = tid + k * 256;
+            if (e < S * SP * 4) dxs[buf * (S * SP * 4) + e] = qn[k];
+        }
+    };
+    const int p_hi = a.n_pieces - 1;
+    if constexpr (PLAN != 0) {
+        plan_load(padj);
+        plan_store(0);
+    } else {
+        if (!cubic) {
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) eprev[k] = eok[k] ? eptr[k][(long long)(p_hi + 1) * a.cs_t] : 0.0f;
+        }
+        stage_load(p_hi);
+        stage_store(p_hi);
+        if (p_hi >= 1) {
+            stage_load(p_hi - 1);
+            stage_store(p_hi - 1);
+        }
     }
 
     // ---- state: entries h = 16q + 4t + g of sample (hf, s) ---------------------------------------------------------------
@@ -363,20 +408,29 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
 #ifdef NCDE_F64_PROF
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #endif
-    for (int n = a.T - 1; n >= 1; --n) {
-        if (n - 3 >= 0) stage_load(n - 3);
+    for (int n = n_rsteps; n >= 1; --n) {
+        const int rs = n_rsteps - n;      // PLAN: index of this reverse step in the adjoint table
+        const int* pstep = PLAN ? padj + rs * pw_ : nullptr;
+        const float dt = PLAN ? __int_as_float(pstep[0]) : 1.0f;
+        const int reset_row = PLAN ? pstep[1] : -1;
+        if constexpr (PLAN != 0) {
+            if (n > 1) plan_load(pstep + pw_);
+        } else {
+            if (n - 3 >= 0) stage_load(n - 3);
+        }
 #pragma unroll 1
         for (int j = 0; j < S; ++j) {
             const float tt = DISC != 0 ? (float)(n - 1) + stage_offset(METHOD, S - 1 - j) : -(-(float)n + stage_offset(METHOD, j));
-            const int idx = piece_index(tt, a.n_pieces);
+            const int idx = PLAN ? 0 : piece_index(tt, a.n_pieces);
             const float frac = tt - (float)idx;
-            const float w = DISC != 0 ? 1.0f : stage_weight(METHOD, j);
-            const float* dxp = dxs + (idx % 3) * SP * DXW;
+            const float w = DISC != 0 ? 1.0f : stage_weight(METHOD, j) * dt;      // (dt = 1 on the default axis)
+            const float* dxp = PLAN ? dxs + ((rs & 1) * S + j) * SP * 4 : dxs + (idx % 3) * SP * DXW;
             if constexpr (DISC != 0) {
                 const int lin = (n - 1) * S + (S - 1 - j);
                 if (lin >= 1) rec_fetch(lin - 1);
             }
-            const bool at_knot = j == S - 1 && (a.output == NCDE_OUT_KNOTS || n == 1);
+            const bool at_knot = PLAN ? (j == S - 1 && reset_row >= 0) : (j == S - 1 && (a.output == NCDE_OUT_KNOTS || n == 1));
+            const bool reset_y = PLAN != 0 || a.output == NCDE_OUT_KNOTS;      // at such a point: y back to the stored value
             // Every phase below is written "read everything -> compute -> write everything" with the sample tile innermost: the two
             // tiles are independent, but their LDS reads and writes may alias as far as the compiler can tell, and a tile-by-tile body
             // was scheduled exactly so -- tile 1's reads behind tile 0's writes, every phase twice as long (measured with F64_TICK).
@@ -417,8 +471,8 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
 #pragma unroll
                 for (int hf = 0; hf < NS; ++hf) {
                     B[hf] = read_opB<HPF>(exch + (((NL + 1) & 1) * NS + hf) * 1024, lane);
-                    const float* dp = dxp + (16 * hf + s) * DXW;
-                    if (!cubic) {
+                    const float* dp = dxp + (16 * hf + s) * (PLAN ? 4 : DXW);
+                    if (!cubic || PLAN != 0) {      // (PLAN: the staged values ARE dX/dt of this stage)
                         dx[hf] = *reinterpret_cast<const f32x4*>(dp);
                     } else {      // b + (2c + 3d fr) fr  (interpolation_cubic.py:331-336)
                         const f32x4 cb = *reinterpret_cast<const f32x4*>(dp);
@@ -597,7 +651,7 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
                 // sequence outputs: the stored state / cotangent of knot n-1 (requested before the MFMAs below)
                 float zk[NS][4], gk[NS][4];
                 if (at_knot) {
-                    const int row = a.output == NCDE_OUT_KNOTS ? n - 1 : 0;
+                    const int row = PLAN ? reset_row : (a.output == NCDE_OUT_KNOTS ? n - 1 : 0);
 #pragma unroll
                     for (int hf = 0; hf < NS; ++hf)
 #pragma unroll
@@ -605,7 +659,7 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
                             const long long o = (brow[hf] + row) * Hr + 16 * q + 4 * t + g;
                             const bool live = valid[hf] && 16 * q + 4 * t + g < Hr;
                             gk[hf][t] = live ? a.grad_out[o] : 0.0f;
-                            zk[hf][t] = (DISC == 0 && a.output == NCDE_OUT_KNOTS && live) ? a.z_out[o] : 0.0f;
+                            zk[hf][t] = (DISC == 0 && reset_y && live) ? a.z_out[o] : 0.0f;
                         }
                 }
                 f32x4 vy[NS];
@@ -646,10 +700,16 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
                     } else {
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
-                            ys[hf][t] = Combine<METHOD>::apply(j, -kout[hf][t], y0[hf][t], ky1[hf][t], ky2[hf][t]);
-                            as_[hf][t] = Combine<METHOD>::apply(j, vy[hf][t], a0[hf][t], ka1[hf][t], ka2[hf][t]);
+                            if constexpr (PLAN != 0) {
+                                bool last;
+                                ys[hf][t] = StageCombine::apply(METHOD, j, -kout[hf][t], dt, y0[hf][t], ky1[hf][t], ky2[hf][t], last);
+                                as_[hf][t] = StageCombine::apply(METHOD, j, vy[hf][t], dt, a0[hf][t], ka1[hf][t], ka2[hf][t], last);
+                            } else {
+                                ys[hf][t] = Combine<METHOD>::apply(j, -kout[hf][t], y0[hf][t], ky1[hf][t], ky2[hf][t]);
+                                as_[hf][t] = Combine<METHOD>::apply(j, vy[hf][t], a0[hf][t], ka1[hf][t], ka2[hf][t]);
+                            }
                             if (at_knot) {
-                                if (a.output == NCDE_OUT_KNOTS) {      // reset y to the stored knot value, add dL/dz of that knot
+                                if (reset_y) {      // reset y to the stored value, add dL/dz of that output time
                                     y0[hf][t] = zk[hf][t];
                                     ys[hf][t] = y0[hf][t];
                                 }
@@ -668,7 +728,11 @@ __global__ __launch_bounds__(256, 1) void ncde_adj_h64(KArgs a) {
                     for (int t = 0; t < 4; ++t) zimg[((zp ^ 1) * 64 + 16 * q + 4 * t + g) * RS + 16 * hf + s] = ys[hf][t];
                     *reinterpret_cast<u32x4*>(exch + ((p & 1) * NS + hf) * 1024 + q * 256 + lane * 4) = piece[hf];
                 }
-                if (j == S - 1 && n - 3 >= 0) stage_store(n - 3);
+                if constexpr (PLAN != 0) {
+                    if (j == S - 1 && n > 1) plan_store((rs + 1) & 1);
+                } else {
+                    if (j == S - 1 && n - 3 >= 0) stage_store(n - 3);
+                }
                 zp ^= 1;
                 F64_SYNC(4)
             }
@@ -729,6 +793,12 @@ F64Fn pick_method(int method) {
     if (method == NCDE_MIDPOINT) return ncde_adj_h64<NCDE_MIDPOINT, NS, HPF, DISC>;
     return ncde_adj_h64<NCDE_EULER, NS, HPF, DISC>;
 }
+template <int HPF>
+F64Fn pick_planned(int method) {      // general time axis: one sample tile per workgroup, continuous adjoint
+    if (method == NCDE_RK4_38) return ncde_adj_h64<NCDE_RK4_38, 1, HPF, 0, 1>;
+    if (method == NCDE_MIDPOINT) return ncde_adj_h64<NCDE_MIDPOINT, 1, HPF, 0, 1>;
+    return ncde_adj_h64<NCDE_EULER, 1, HPF, 0, 1>;
+}
 F64Fn pick_kernel(int method, int ns, int hpf, bool disc) {
     if (disc) {
         if (ns == 2) return hpf == 1 ? pick_method<2, 1, 1>(method) : pick_method<2, 2, 1>(method);
@@ -738,14 +808,17 @@ F64Fn pick_kernel(int method, int ns, int hpf, bool disc) {
     return hpf == 1 ? pick_method<1, 1, 0>(method) : pick_method<1, 2, 0>(method);
 }
 
-size_t f64_lds_bytes(const NcdeProblem* p, int ns) { return sizeof(float) * (size_t)f64_lds_floats(p->n_layers, ns, p->interp != NCDE_INTERP_LINEAR); }
+size_t f64_lds_bytes(const NcdeProblem* p, int ns) {
+    const int S = p->method == NCDE_RK4_38 ? 4 : (p->method == NCDE_MIDPOINT ? 2 : 1);
+    return sizeof(float) * (size_t)f64_lds_floats(p->n_layers, ns, p->interp != NCDE_INTERP_LINEAR, p->output == NCDE_OUT_TIMES ? S : 0);
+}
 
 // sample tiles per workgroup.  Measured at cfg4 (B = 8192, MI355X): NS = 1 (512 workgroups, two rounds) 3.56 ms, NS = 2 (one workgroup
 // per CU, the two tiles interleaved in every wave) 3.7 - 4.8 ms: with both tiles' operands live the 512-register file spills and
 // the scheduler serialises the tiles again.  NS = 2 stays selectable (NCDE_FLAG_TILED_NS2; tested).
 int f64_ns(const NcdeProblem* p) {
     int ns = 1;
-    if (p->flags & NCDE_FLAG_TILED_NS2) ns = 2;
+    if ((p->flags & NCDE_FLAG_TILED_NS2) && p->output != NCDE_OUT_TIMES) ns = 2;
     if (ns == 2 && f64_lds_bytes(p, 2) > (size_t)kLdsLimit) ns = 1;
     return ns;
 }
@@ -757,7 +830,8 @@ int64_t f64_fault_bytes(int n_wg) { return ((int64_t)n_wg * 4 + 255) & ~(int64_t
 bool ncde_fast64_supported(const NcdeProblem* p, int pass) {
     if (pass != 1 && pass != 2) return false;
     if (p->hidden != 64 || p->channels > 4 || p->n_layers < 1 || p->n_layers > kF64MaxLayers) return false;
-    if (p->field_kind != NCDE_FIELD_ORIGINAL || p->field_input != NCDE_INPUT_MATMUL || p->output == NCDE_OUT_TIMES) return false;
+    if (p->field_kind != NCDE_FIELD_ORIGINAL || p->field_input != NCDE_INPUT_MATMUL) return false;
+    if (p->output == NCDE_OUT_TIMES && pass != 1) return false;      // general time axis: the continuous adjoint (PLAN instances)
     if (p->flags & (NCDE_FLAG_ADJOINT_V1 | NCDE_FLAG_ADJOINT_V2 | NCDE_FLAG_ADJOINT_V4 | NCDE_FLAG_DEBUG_PROFILE)) return false;
     for (int l = 0; l < p->n_layers; ++l) {
         if (p->layer_in[l] != 64 || p->layer_out[l] != 64) return false;
@@ -798,12 +872,13 @@ int ncde_fast64_adjoint(const NcdeProblem* p, const float* src, const float* gra
     a.gpart = (float*)ws;
     a.fault = hpf == 1 ? reinterpret_cast<int*>(static_cast<char*>(ws) + sizeof(float) * (size_t)n_wg * y.theta_size + 256) : nullptr;
     const size_t lds = f64_lds_bytes(p, ns);
-    F64Fn fn = pick_kernel(p->method, ns, hpf, discrete);
+    const bool planned = p->output == NCDE_OUT_TIMES;
+    F64Fn fn = planned ? (hpf == 1 ? pick_planned<1>(p->method) : pick_planned<2>(p->method)) : pick_kernel(p->method, ns, hpf, discrete);
     if (ncde_lds_optin((const void*)fn, lds) != hipSuccess) return NCDE_ERR_HIP;
     hipLaunchKernelGGL(fn, dim3(n_wg), dim3(256), lds, st, a);
     if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
     if (hpf == 1) {      // re-execution of range-faulted workgroups with fp32-input MFMA (normally none: every workgroup exits at once)
-        F64Fn fx = pick_kernel(p->method, ns, 2, discrete);
+        F64Fn fx = planned ? pick_planned<2>(p->method) : pick_kernel(p->method, ns, 2, discrete);
         if (ncde_lds_optin((const void*)fx, lds) != hipSuccess) return NCDE_ERR_HIP;
         a.only_faulted = 1;
         hipLaunchKernelGGL(fx, dim3(n_wg), dim3(256), lds, st, a);

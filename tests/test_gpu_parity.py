@@ -1156,7 +1156,8 @@ def test_general_time_axis_on_the_batch_tiled_family_vs_oracle(kind, interp, met
     if interp == "linear":
         g["knots"] = kn
     names = [n for n in ("W0", "b0", "W1", "b1", "Wg", "bg", "Wo", "bo") if n in p]
-    for wflags in (0, 3 << 16):                            # default budget, then NCDE_FLAG_TILED_WINDOW_STEPS(3)
+    for wflags in (0x8000, 0x8000 | (3 << 16)):            # NCDE_FLAG_FORCE_TILED (round 4: a shape this small would otherwise be zero-padded
+        # onto the plan-capable specialised kernels); default record budget, then NCDE_FLAG_TILED_WINDOW_STEPS(3)
         res = gpu_util.run_times_case(g, meta, adjoint=True, kind=kind, mode="matmul", params=p, flags=wflags)
         resd = gpu_util.run_times_case(g, meta, adjoint=False, kind=kind, mode="matmul", params=p, flags=wflags)
         assert gu.relerr(res["z_out"], z) <= TIGHT_Z, gu.relerr(res["z_out"], z)
@@ -1172,6 +1173,85 @@ def test_general_time_axis_on_the_batch_tiled_family_vs_oracle(kind, interp, met
     # sample's dL/dz0 by percents (seen here: one sample of 37 at 2e-2, the rest at 8e-8) -- so all but a few samples must agree
     per = np.abs(ref["dz0"] - dz0.numpy()).max(axis=1) / np.abs(dz0.numpy()).max()
     assert np.sum(per <= E2E_G) >= B - 2, np.sort(per)[-4:]
+
+
+@pytest.mark.parametrize("shape", [(20, 32, 32, 3), (4, 64, 64, 3), (5, 16, 15, 3), (3, 47, 32, 2), (20, 32, 32, 2)])
+@pytest.mark.parametrize("interp,method,step", [("linear", "rk4", 0.5), ("cubic", "midpoint", 0.4), ("cubic", "rk4", 0.75), ("linear", "euler", 1.3)])
+def test_general_time_axis_on_the_specialised_kernels_vs_oracle(shape, interp, method, step, gpu_lib):
+    """Round 4: the register-resident kernel sets walk the time plan -- any output times / step size / user knot grid -- instead of
+    leaving the general time axis to the batch-tiled family: `ncde_fwd_fast_bf3<..., time plan>` for both shapes (and everything
+    zero-padded onto them), `ncde_adj_fast3<..., time plan>` for (32, 32, 20) with nl = 3, `ncde_adj_h64` for H = 64.  Against the
+    oracle's general-time functions (pinned to the reference on g11): forward, continuous adjoint (one reverse solve per output
+    interval), and -- on whatever family takes it -- the exact discrete backward; ragged batch, split-bf16 variant as well."""
+    import ctypes
+    import gpu_util
+    import ncde_amd
+    import ncde_oracle as orc
+    from ncde_amd import _lib, solver
+    C, H, HH, nl = shape
+    B, L = 37, 9
+    rng = np.random.RandomState(7)
+    x = (gu.data.normal(61, B * L * C, stream=3).reshape(B, L, C) * 0.5).astype(np.float32)
+    if interp == "linear":      # user knot grid, spacing 0.6 .. 1.4
+        kn = np.cumsum(np.concatenate([[0.0], 0.6 + 0.8 * rng.rand(L - 1)])).astype(np.float32)
+        x[:, :, 0] = kn[None, :]
+        coeffs = x
+    else:
+        kn = np.arange(L, dtype=np.float32)
+        x[:, :, 0] = kn[None, :]
+        coeffs = gu.data.natural_cubic_coeffs(x)
+    p = gu.data.make_field_weights(H, HH, C, seed=29)
+    if nl == 1:
+        p = {k: v for k, v in p.items() if k not in ("W1", "b1")}
+    z0 = (gu.data.normal(63, B * H, stream=2).reshape(B, H) * 0.5).astype(np.float32)
+    tout = np.array([kn[0], 0.5 * (kn[1] + kn[2]), kn[4], kn[6] + 0.05, kn[-1] - 0.125], np.float32)
+    meta = {"kind": interp, "method": method, "step_size": step, "dims": {"nl": nl}}
+    field = orc.Field.variant(p, H, C, nl, "original", "matmul")
+    ctl = orc.Control(coeffs, interp, t=kn if interp == "linear" else None)
+    z = orc.solve_forward_times(ctl, field, z0, tout, method, step)
+    gout = (gu.data.normal(25, z.numel(), stream=1).reshape(z.shape) / 2.0).astype(np.float32)
+    dz0, gp = orc.solve_adjoint_times(ctl, field, tout, z, gout, method, step)
+    bdz0, bgp = orc.solve_discrete_backward_times(ctl, field, z0, tout, gout, method, step)
+    g = {"coeffs": coeffs, "z0": z0, "t_out": tout, "grad_out": gout}
+    if interp == "linear":
+        g["knots"] = kn
+    names = [n for n in ("W0", "b0", "W1", "b1", "Wo", "bo") if n in p]
+    # which kernels the planned problem dispatches to
+    cc = torch.from_numpy(coeffs).cuda()
+    X = (ncde_amd.LinearInterpolation if interp == "linear" else ncde_amd.NaturalCubicSpline)(cc, t=torch.from_numpy(kn).cuda() if interp == "linear" else None)
+    plan = solver._time_plan(X, torch.from_numpy(tout), method, step, cc.device)
+    func = gpu_util.CaseField(p, [("W0", "b0")] + [("W1", "b1")] * (nl - 1), "cuda")
+    prob = solver.build_problem(cc, interp, torch.from_numpy(z0).cuda(), func.fused_spec(), method, _lib.OUT_TIMES, 0, plan)
+    kn_ = [(_lib.lib().ncde_kernel_name(ctypes.byref(prob), k) or b"?").decode() for k in (0, 1, 2)]
+    big = H > 32 or HH > 32
+    assert kn_[0].startswith("ncde_fwd_fast_bf3<H64" if big else "ncde_fwd_fast_bf3<H32") and "time plan" in kn_[0], kn_
+    if big:
+        assert kn_[1].startswith("ncde_adj_h64"), kn_
+    elif nl == 3:
+        assert kn_[1].startswith("ncde_adj_fast3") and "time plan" in kn_[1], kn_
+    else:
+        assert kn_[1].startswith("ncde_adj_tiled"), kn_      # other layer counts of the planned adjoint: batch-tiled family
+    assert kn_[2].startswith("ncde_adj_tiled"), kn_
+    def check(res, want_dz0, want_gp, rows_off, tag):
+        # A pre-activation within rounding of zero flips a ReLU mask in one implementation and not the other, and moves ONE sample's
+        # row (seen: sample 22 of shape2-linear-rk4-0.5 at 1e-3 under the split-fp16 forward-side recompute, 2^-22 products, where
+        # the split-bf16 run of the SAME planned kernel agrees to 1e-7; and one row of shape1-cubic-rk4-0.75's discrete backward at
+        # 3e-5 on which all four GPU families agree with each other).  So: every row but `rows_off` within E2E_G, and the batch-summed
+        # parameter gradients within E2E_G whenever no row shows a flip (all rows at fp32 rounding).
+        per = np.abs(res["dz0"] - want_dz0.numpy()).max(axis=1) / np.abs(want_dz0.numpy()).max()
+        assert int((per > E2E_G).sum()) <= rows_off, (tag, np.sort(per)[-3:])
+        flipped = int((per > 1e-5).sum())
+        assert flipped <= 1, (tag, np.sort(per)[-3:])
+        for n_, g_ in zip(names, want_gp):
+            assert gu.relerr(res["grads"][n_], g_) <= (2e-2 if flipped else E2E_G), (tag, n_, gu.relerr(res["grads"][n_], g_))
+
+    for flags in (_lib.FLAG_SPLIT_BF16, 0):
+        res = gpu_util.run_times_case(g, meta, adjoint=True, params=p, flags=flags)
+        assert gu.relerr(res["z_out"], z) <= TIGHT_Z, (flags, gu.relerr(res["z_out"], z))
+        check(res, dz0, gp, 0 if flags else 1, ("adjoint", flags))
+    resd = gpu_util.run_times_case(g, meta, adjoint=False, params=p)      # recording forward (planned specialised kernel) + discrete backward
+    assert gu.relerr(resd["z_out"], z) <= TIGHT_Z
+    check(resd, bdz0, bgp, 0, "discrete")
 
 
 @pytest.mark.parametrize("kind,nl", [("original", 3), ("minimal", 3), ("original", 1)])

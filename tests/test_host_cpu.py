@@ -344,8 +344,13 @@ def test_general_time_axis_dispatches_to_the_plan_driven_families():
     p = _problem()                       # cfg2 shape: specialised kernels on the default axis ...
     assert (lib.ncde_kernel_name(ctypes.byref(p), 0) or b"").startswith(b"ncde_fwd_fast")
     p.output, p.time_plan, p.n_t_out, p.n_steps_fwd, p.n_steps_adj = _lib.OUT_TIMES, 0x9000, 5, 12, 14
-    assert lib.ncde_kernel_name(ctypes.byref(p), 0).startswith(b"ncde_fwd_tiled")     # ... a plan-driven family otherwise: batch-tiled
-    assert lib.ncde_kernel_name(ctypes.byref(p), 1).startswith(b"ncde_adj_tiled")     # where every width is a multiple of 16 (C of 4),
+    n0, n1 = lib.ncde_kernel_name(ctypes.byref(p), 0), lib.ncde_kernel_name(ctypes.byref(p), 1)     # ... and (round 4) their plan-walking
+    assert n0.startswith(b"ncde_fwd_fast_bf3<H32") and b"time plan" in n0, n0                        # instantiations otherwise;
+    assert n1.startswith(b"ncde_adj_fast3") and b"time plan" in n1, n1
+    assert lib.ncde_kernel_name(ctypes.byref(p), 2).startswith(b"ncde_adj_tiled")     # the exact discrete backward: batch-tiled family
+    p.flags = _lib.FLAG_FORCE_TILED
+    assert lib.ncde_kernel_name(ctypes.byref(p), 0).startswith(b"ncde_fwd_tiled")     # batch-tiled where every width is a multiple
+    assert lib.ncde_kernel_name(ctypes.byref(p), 1).startswith(b"ncde_adj_tiled")     # of 16 (C of 4),
     p.flags = _lib.FLAG_FORCE_GENERIC
     assert lib.ncde_kernel_name(ctypes.byref(p), 0) == b"ncde_fwd_generic"            # generic for any shape
     assert lib.ncde_kernel_name(ctypes.byref(p), 1) == b"ncde_adj_generic"
@@ -353,7 +358,7 @@ def test_general_time_axis_dispatches_to_the_plan_driven_families():
     assert lib.ncde_num_outputs(ctypes.byref(p)) == 5
     assert lib.ncde_stage_record_bytes(ctypes.byref(p)) == 4 * 12 * 4 * 32 * 32      # bytes: steps x stages x B x H
     p.flags = _lib.FLAG_FORCE_FAST
-    assert lib.ncde_workspace_bytes(ctypes.byref(p), 0) == -2
+    assert lib.ncde_workspace_bytes(ctypes.byref(p), 0) >= 0
     p.flags, p.n_steps_fwd = 0, 0
     assert lib.ncde_num_outputs(ctypes.byref(p)) == -1
 
