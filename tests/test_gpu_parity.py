@@ -1382,7 +1382,9 @@ def test_default_axis_through_the_time_plan_equals_the_default_kernels(gpu_lib):
     plan = solver._time_plan(X, torch.arange(T, dtype=torch.float32), "rk4", 1.0, coeffs.device)
     assert plan[1] == (T, T - 1, T - 1)
     # family by family: generic (flag 1) and batch-tiled (flag 0x8000; the plan-driven default for this aligned shape)
-    for fam, adjoint in ((1, True), (1, False), (0x8000, True), (0x8000, False)):
+    # ... and (round 4) the specialised register-resident kernels (flag 0: this shape zero-pads onto the (32, 32, 20) set; dt = 1
+    # multiplies exactly and the stage combinations are the same expressions)
+    for fam, adjoint in ((1, True), (1, False), (0x8000, True), (0x8000, False), (0, True), (0, False)):
         want = gpu_util.run_case(case, flags=fam, adjoint=adjoint)
         func = gpu_util.case_field(case, "cuda")
         z0 = torch.from_numpy(case["z0"]).cuda().requires_grad_(True)
@@ -1390,10 +1392,13 @@ def test_default_axis_through_the_time_plan_equals_the_default_kernels(gpu_lib):
                "func": None, "nfe_per_solve": 0, "nfe_adjoint": 0, "adjoint_param_ids": None}
         out = solver._FusedCdeint.apply(z0, coeffs, cfg, *func.fused_spec().unique_params())
         (out * torch.from_numpy(case["expect"]["grad_out"]).cuda()).sum().backward()
-        assert np.array_equal(out.detach().cpu().numpy(), want["z_out"])
-        assert np.array_equal(z0.grad.cpu().numpy(), want["dz0"])
+        assert np.array_equal(out.detach().cpu().numpy(), want["z_out"]), (fam, adjoint, gu.relerr(out.detach().cpu().numpy(), want["z_out"]))
+        # the planned exact discrete backward of the specialised family is the batch-tiled sweep, the default-axis one is
+        # ncde_adj_fast3<discrete>: two kernels, so equal to fp32 rounding there and bit for bit everywhere else
+        same = np.array_equal if (fam, adjoint) != (0, False) else (lambda a, b: gu.relerr(a, b) <= 2e-6)
+        assert same(z0.grad.cpu().numpy(), want["dz0"]), (fam, adjoint, gu.relerr(z0.grad.cpu().numpy(), want["dz0"]))
         for k, v in func.p.items():
-            assert np.array_equal(v.grad.cpu().numpy(), want["grads"][k]), k
+            assert same(v.grad.cpu().numpy(), want["grads"][k]), (fam, adjoint, k, gu.relerr(v.grad.cpu().numpy(), want["grads"][k]))
 
 
 def ncde_amd_mod():
