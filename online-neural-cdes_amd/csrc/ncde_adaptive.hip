@@ -734,7 +734,7 @@ extern "C" __global__ __launch_bounds__(GEN_THREADS) void ncde_dp_tape_finish(Dp
 namespace {
 
 struct DpPlan {
-    size_t off_ctrl, off_t, off_knots, off_xout, off_y0, off_yc, off_ky, off_a0, off_ac, off_ka, off_gp, off_kt, off_g0t, off_gct, off_pn, off_tr, off_wp;
+    size_t off_ctrl, off_t, off_knots, off_xout, off_y0, off_yc, off_ky, off_a0, off_ac, off_ka, off_gp, off_kt, off_g0t, off_gct, off_pn, off_tr, off_wp, off_segp;
     size_t total;
     int theta1, n_wg;
 };
@@ -758,12 +758,14 @@ DpPlan dp_plan(const NcdeProblem* p, const Layout& y, int n_t, bool adj) {
     w.off_ky = take(4 * 7 * BH);
     w.off_pn = take(sizeof(double) * 4 * w.n_wg);
     w.off_tr = take(sizeof(double) * 4 * kTraceCap + sizeof(double) * 2 * kTraceCap);      // trace rows, then the replay list
-    w.off_wp = take(4 * ncde_dpf_pack_floats(p));      // fused attempt kernels: per-lane weight image (0 bytes where they do not apply)
+    w.off_wp = take(4 * ncde_dpf_pack_floats(p, adj ? 1 : 0));      // fused attempt kernels: per-lane weight image (0 bytes where they do not apply)
     if (adj) {
         w.off_a0 = take(4 * BH);
         w.off_ac = take(4 * BH);
         w.off_ka = take(4 * 7 * BH);
-        w.off_gp = take(4 * (size_t)w.n_wg * w.theta1);
+        // fused: two weighted sums per workgroup, each [dWo in register order][parameter order]
+        w.off_gp = take(ncde_dpf_supported(p, 1) ? 4 * (size_t)w.n_wg * 2 * ncde_dpf_partial_floats(p, w.theta1) : 4 * (size_t)w.n_wg * w.theta1);
+        w.off_segp = take(sizeof(double) * 2 * (DP_MAXSEG + 1) * (size_t)ncde_dpf_reduce_blocks(p, w.theta1));
         w.off_kt = take(4 * 7 * (size_t)w.theta1);
         w.off_g0t = take(4 * (size_t)w.theta1);
         w.off_gct = take(4 * (size_t)w.theta1);
@@ -891,6 +893,7 @@ int ncde_dp_solve(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdapti
     d.PN = (double*)(base + w.off_pn);
     d.TR = (double*)(base + w.off_tr);
     d.WP = (float*)(base + w.off_wp);
+    if (adj) { d.SEGP = (double*)(base + w.off_segp); d.n_rblk = ncde_dpf_reduce_blocks(p, w.theta1); }
     d.trace_cap = op->trace && op->trace_capacity > 0 ? std::min(op->trace_capacity, kTraceCap) : 0;
     if (adj) {
         d.A0 = (float*)(base + w.off_a0); d.AC = (float*)(base + w.off_ac); d.KA = (float*)(base + w.off_ka);
@@ -1028,7 +1031,9 @@ int ncde_dp_solve(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdapti
     if (hc.error == 4) { snprintf(err, errn, "the record holds %d accepted steps and the solve needs more: pass a larger record", d.tape_cap); return NCDE_ERR_WORKSPACE; }
     if (adj) {
         // dL/dz0 = a at the start time; dL/dtheta = the parameter part, scattered into the caller's buffers
-        DP_TRY(hipMemcpyAsync(g->grad_z0, d.A0, sizeof(float) * BH, hipMemcpyDeviceToDevice, st));
+        const float* a_end = (d.fused && hc.cur) ? d.AC : d.A0;        // fused attempt kernels: the state is double-buffered
+        const float* g_end = (d.fused && hc.cur) ? d.GCT : d.G0T;
+        DP_TRY(hipMemcpyAsync(g->grad_z0, a_end, sizeof(float) * BH, hipMemcpyDeviceToDevice, st));
         // one "partial" of theta_size floats: a pure scatter into the destinations that exist
         ReduceSegs segs{};
         int n = 0;
@@ -1045,7 +1050,7 @@ int ncde_dp_solve(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdapti
         if (g->grad_bo) { segs.off[n] = y.gbo_off; segs.len[n] = y.rows; segs.dst[n] = g->grad_bo; ++n; }
         segs.n = n;
         if (n > 0) {
-            hipLaunchKernelGGL(ncde_reduce_partials, dim3((y.theta_size + 255) / 256), dim3(256), 0, st, (const float*)d.G0T, 1, y.theta_size, segs);
+            hipLaunchKernelGGL(ncde_reduce_partials, dim3((y.theta_size + 255) / 256), dim3(256), 0, st, g_end, 1, y.theta_size, segs);
             DP_TRY(hipGetLastError());
         }
     }

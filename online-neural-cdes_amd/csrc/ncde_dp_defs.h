@@ -12,7 +12,7 @@
 
 namespace {
 
-enum { DP_INIT0 = 0, DP_INIT1 = 1, DP_STEP = 2, DP_DONE = 3 };
+enum { DP_INIT0 = 0, DP_INIT1 = 1, DP_STEP = 2, DP_DONE = 3, DP_FIN = 4 };      // DP_FIN: fused adjoint only (dense output at an interval end)
 constexpr int DP_MAXSEG = 2 * NCDE_MAX_LAYERS + 8;
 
 struct DpCtrl {
@@ -83,7 +83,9 @@ struct DpArgs {
     int max_num_steps;
     int nseg, seg_off[DP_MAXSEG], seg_len[DP_MAXSEG];
     int lds_words_fwd, lds_words_adj, gacc_in_lds;
-    float* WP;               // fused attempt kernels: per-lane weight image (ncde_dpf_pack)
+    float* WP;               // fused attempt kernels: per-lane weight image (ncde_dpf_pack / ncde_dpa_pack)
+    double* SEGP;            // fused adjoint: [reduce block][2][DP_MAXSEG + 1] per-segment sums of squares of the parameter part
+    int n_rblk;              // number of reduce blocks
     int fused;               // 1: the fused attempt kernels drive the solve (state ping-pong by ctrl->cur, no commit launch)
 };
 
@@ -154,32 +156,29 @@ __device__ __forceinline__ float dp_poly(float y0, float y1, float ym, float f0,
 }
 
 
-// block-wide sum of a double (256 threads); every thread gets the total
+__device__ __forceinline__ double dp_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// block-wide sum / max of a double (256 threads = 4 waves); every thread gets the total.  Fixed order: butterfly inside a wave, then
+// (w0 + w1) + (w2 + w3).
 __device__ double dp_block_sum(double v, double* sh) {
     const int tid = threadIdx.x;
+    const double w = dp_wave_sum(v);
     __syncthreads();
-    sh[tid] = v;
+    if ((tid & 63) == 0) sh[tid >> 6] = w;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) sh[tid] += sh[tid + off];
-        __syncthreads();
-    }
-    const double r = sh[0];
-    __syncthreads();
-    return r;
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 __device__ double dp_block_max(double v, double* sh) {
     const int tid = threadIdx.x;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
     __syncthreads();
-    sh[tid] = v;
+    if ((tid & 63) == 0) sh[tid >> 6] = v;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) sh[tid] = fmax(sh[tid], sh[tid + off]);
-        __syncthreads();
-    }
-    const double r = sh[0];
-    __syncthreads();
-    return r;
+    return fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
 }
 
 // mixed norm of the parameter part (adjoint.py:239-242): max over parameter tensors of rms(v / scale), and |vjp_t| / scale.
@@ -218,6 +217,37 @@ __device__ double dp_theta_norm(const DpArgs& d, int which, float dtf, double* s
 }
 
 
+// the same from the per-block, per-segment sums ncde_dpf_reduce left (slot 0 / 1: the first / second norm of the phase)
+__device__ double dp_theta_norm_fused(const DpArgs& d, int slot, double* sh) {      // (256 threads; sh: >= 4 * 8 doubles)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double best = 0.0;
+    for (int s0 = 0; s0 <= d.nseg; s0 += 8) {      // eight segments per pass: per-thread sums over the reduce blocks, one exchange
+        double acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.0;
+        for (int b = tid; b < d.n_rblk; b += 256) {
+            const double* row = d.SEGP + ((long long)b * 2 + slot) * (DP_MAXSEG + 1) + s0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (s0 + i <= d.nseg) acc[i] += __hip_atomic_load(&row[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double w = dp_wave_sum(acc[i]);
+            if (lane == 0) sh[wave * 8 + i] = w;
+        }
+        __syncthreads();
+        for (int i = 0; i < 8 && s0 + i <= d.nseg; ++i) {
+            const int sg = s0 + i;
+            const double tot = (sh[i] + sh[8 + i]) + (sh[16 + i] + sh[24 + i]);
+            best = fmax(best, sg < d.nseg ? sqrt(tot / (double)d.seg_len[sg]) : sqrt(tot));
+        }
+        __syncthreads();
+    }
+    return best;
+}
+
 __device__ void dp_control_body(const DpArgs& d, double* sh, int* sh_flags, float* sh_xp) {
     int& sh_accept = sh_flags[0];
     int& sh_finish = sh_flags[1];
@@ -227,6 +257,24 @@ __device__ void dp_control_body(const DpArgs& d, double* sh, int* sh_flags, floa
     const int phase = c->phase;
     if (phase == DP_DONE || c->error != 0) {
         if (tid == 0) c->accepted_now = 0;
+        return;
+    }
+    if (phase == DP_FIN) {      // fused adjoint: the candidate buffers now hold (y, a, g_theta) at the interval end
+        if (tid == 0) {
+            c->cur ^= 1;
+            c->accepted_now = 0;
+            if (c->interval == 1) {
+                c->phase = DP_DONE;
+            } else {       // next output interval: a fresh solve (new f0, new initial step), adjoint.py:116-130
+                c->interval -= 1;
+                c->t0 = -d.t_out[c->interval];
+                c->t_goal = -d.t_out[c->interval - 1];
+                c->t1 = c->t0;
+                c->steps_this_solve = 0;
+                c->st[0] = dp_stage_desc(-(float)c->t0, d.knots, d.n_knots);
+                c->phase = DP_INIT0;
+            }
+        }
         return;
     }
     // batch-wide sums of squares from the stage kernels
@@ -243,12 +291,13 @@ __device__ void dp_control_body(const DpArgs& d, double* sh, int* sh_flags, floa
         if (d.adj) {
             d0 = fmax(d0, sqrt(tot[1] / nel));
             d1 = fmax(d1, sqrt(tot[3] / nel));
-            d0 = fmax(d0, dp_theta_norm(d, 0, dtf, sh));
-            d1 = fmax(d1, dp_theta_norm(d, 1, dtf, sh));
+            d0 = fmax(d0, d.fused ? dp_theta_norm_fused(d, 0, sh) : dp_theta_norm(d, 0, dtf, sh));
+            d1 = fmax(d1, d.fused ? dp_theta_norm_fused(d, 1, sh) : dp_theta_norm(d, 1, dtf, sh));
         }
         if (tid == 0) {
             const float d0f = (float)d0, d1f = (float)d1;
             c->nfe += 1;
+            c->st_k1 = c->st[0];      // fused adjoint: stage 1 of the first attempt is re-evaluated where f0 was
             c->h0d = d1;      // keep d1 for the second half of the rule
             float h0;
             if (d0f < 1e-5f || d1f < 1e-5f) h0 = 1e-6f;
@@ -277,7 +326,7 @@ __device__ void dp_control_body(const DpArgs& d, double* sh, int* sh_flags, floa
         double s2 = sqrt(tot[0] / nel);
         if (d.adj) {
             s2 = fmax(s2, sqrt(tot[1] / nel));
-            s2 = fmax(s2, dp_theta_norm(d, 2, dtf, sh));
+            s2 = fmax(s2, d.fused ? dp_theta_norm_fused(d, 0, sh) : dp_theta_norm(d, 2, dtf, sh));
         }
         if (tid == 0) {
             const float h0 = c->h0, d1f = (float)c->h0d;
@@ -302,7 +351,7 @@ __device__ void dp_control_body(const DpArgs& d, double* sh, int* sh_flags, floa
     double ratio = sqrt(tot[0] / nel);
     if (d.adj) {
         ratio = fmax(ratio, sqrt(tot[1] / nel));
-        ratio = fmax(ratio, dp_theta_norm(d, 3, dtf, sh));
+        ratio = fmax(ratio, d.fused ? dp_theta_norm_fused(d, 0, sh) : dp_theta_norm(d, 3, dtf, sh));
     }
     if (tid == 0) {
         const float ratiof = (float)ratio;
@@ -372,10 +421,13 @@ __device__ void dp_control_body(const DpArgs& d, double* sh, int* sh_flags, floa
         if (!(c->t0 + c->dt > c->t0) && !finish && c->error == 0) c->error = 1;      // 'underflow in dt' (rk_common.py:232)
         c->accepted_now = accept ? 1 : 0;
         c->finish_now = finish;
-        if (d.fused && accept) c->cur ^= 1;      // fused attempt kernels: the candidate buffers become the state
+        if (d.fused && accept && !(d.adj && finish)) c->cur ^= 1;      // fused attempt kernels: the candidate buffers become the state
+        if (d.fused && d.adj && accept && !finish) c->st_k1 = c->st[6];   // ... and stage 1 of the next attempt is this attempt's stage 7 (FSAL)
         sh_accept = accept ? 1 : 0;
         sh_finish = finish;
-        if (finish) {
+        if (finish && d.fused && d.adj) {
+            c->phase = DP_FIN;      // one more launch: the dense output at the interval end (same stages, other weights); then DP_FIN below
+        } else if (finish) {
             if (!d.adj || c->interval == 1) {
                 c->phase = DP_DONE;
             } else {       // next output interval: a fresh solve (new f0, new initial step), adjoint.py:116-130
@@ -392,7 +444,7 @@ __device__ void dp_control_body(const DpArgs& d, double* sh, int* sh_flags, floa
         }
     }
     __syncthreads();
-    if (d.adj && sh_accept) {      // roll the parameter part (every thread): candidate, or the dense output at the interval end
+    if (d.adj && sh_accept && !d.fused) {      // roll the parameter part (every thread): candidate, or the dense output at the interval end
         const float x = sh_x, dtc = c->dtf_commit;
         for (int k = tid; k < d.theta1; k += 256) {
             float g1 = d.GCT[k];
