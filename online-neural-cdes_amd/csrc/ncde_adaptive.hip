@@ -814,7 +814,7 @@ int tape_cap_of(const NcdeProblem* p, int n_t, size_t bytes) {
 }
 
 struct TapeWs {
-    size_t off_knots, off_kf, off_kb, off_dz0, off_f0b, off_scb, off_gp, off_pn2, total;
+    size_t off_knots, off_kf, off_kb, off_dz0, off_f0b, off_scb, off_gp, off_pn2, off_wp, total;
 };
 TapeWs tape_ws(const NcdeProblem* p, const Layout& y) {
     TapeWs w{};
@@ -829,6 +829,7 @@ TapeWs tape_ws(const NcdeProblem* p, const Layout& y) {
     w.off_scb = take(4 * BH);
     w.off_gp = take(4 * (size_t)y.n_wg * (y.theta_size + 1));
     w.off_pn2 = take(sizeof(double) * 4 * y.n_wg);
+    w.off_wp = take(4 * ncde_dpf_pack_floats(p, 1));      // fused sweep (ncde_dpf_tape): weight image (0 bytes where it does not apply)
     w.total = o;
     return w;
 }
@@ -1113,7 +1114,13 @@ int ncde_dp_tape_backward_run(const NcdeProblem* p, const NcdeTimeSpec* ts, cons
     if (d.gacc_in_lds) lds += sizeof(float) * (size_t)d.theta1;
     DP_TRY(ncde_lds_optin((const void*)ncde_dp_tape_backward, lds));
     DP_TRY(ncde_lds_optin((const void*)ncde_dp_tape_finish, lds));
-    hipLaunchKernelGGL(ncde_dp_tape_backward, dim3(y.n_wg), dim3(GEN_THREADS), lds, st, d);
+    if (ncde_dpf_tape_supported(p)) {      // the sweep on the fused stage machinery (ncde_adaptive_fast.hip); same hand-over to the finish launches
+        d.WP = (float*)(base + w.off_wp);
+        const int rc = ncde_dpf_tape_launch(p, &d, sizeof(d), st);
+        if (rc != NCDE_OK) { snprintf(err, errn, "fused taped sweep failed (%d)", rc); return rc; }
+    } else {
+        hipLaunchKernelGGL(ncde_dp_tape_backward, dim3(y.n_wg), dim3(GEN_THREADS), lds, st, d);
+    }
     if (hh.delta_active) hipLaunchKernelGGL(ncde_dp_tape_finish, dim3(y.n_wg), dim3(GEN_THREADS), lds, st, d, 1);
     hipLaunchKernelGGL(ncde_dp_tape_finish, dim3(y.n_wg), dim3(GEN_THREADS), lds, st, d, 2);
     DP_TRY(hipGetLastError());

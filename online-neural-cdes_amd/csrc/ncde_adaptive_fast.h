@@ -14,3 +14,6 @@ int ncde_dpf_reduce_blocks(const NcdeProblem* p, int theta1);
 int ncde_dpf_prepare(const NcdeProblem* p, const void* dp_args, size_t dp_args_bytes, int adj, hipStream_t st);
 // enqueue `rounds` attempt launches (launches of a finished solve exit at once); dp_args = the caller's DpArgs block
 int ncde_dpf_launch(const NcdeProblem* p, const void* dp_args, size_t dp_args_bytes, int adj, int rounds, hipStream_t st);
+// reverse sweep of a taped solve (adjoint=False) on the fused stage machinery; workspace: ncde_dpf_pack_floats(p, 1) floats at DpArgs.WP
+bool ncde_dpf_tape_supported(const NcdeProblem* p);
+int ncde_dpf_tape_launch(const NcdeProblem* p, const void* dp_args, size_t dp_args_bytes, hipStream_t st);

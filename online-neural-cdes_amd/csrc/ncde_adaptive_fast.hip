@@ -1060,6 +1060,539 @@ __global__ __launch_bounds__(256, 1) void ncde_dpf_adj(DpArgs d) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// reverse sweep of a TAPED solve (adjoint=False) on the same stage machinery: ncde_dp_tape_backward (ncde_adaptive.hip) restated
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent, one workgroup per 16-sample tile, over the accepted steps m = M-1 .. 0.  Per step: the seven stage derivatives are
+// recomputed from the recorded start state (forward part of the stage body only), the cotangents of the step's outputs are set up
+// (FSAL, transpose of the 4th-order dense output and of its fit, the time partials d/dt0 and d/d(dt_1)), then the six stages are
+// transposed in reverse, each a full stage body (forward recompute at the stage input + VJP with the stage's cotangent, ONE gradient
+// sum with weight 1).  Lane-local: a lane owns the entries u = 4 (wave NB + nb) + g of sample s for everything elementwise, exactly
+// as the attempt kernels do.  Hand-over to ncde_dp_tape_finish (DZ0, F0B, SCB, PN2, the parameter partial) as the per-launch kernel.
+template <int H, int HH, int C, int NL>
+__global__ __launch_bounds__(256, 1) void ncde_dpf_tape(DpArgs d) {
+    typedef DpaPack<H, HH, C, NL> PK;
+    constexpr int NW = 4, NT = 256;
+    constexpr int CP = PK::CP, CQ = PK::CQ, HB = PK::HB, HT = PK::HT, KH = PK::KH, NB = PK::NB, NTILE = PK::NTILE;
+    constexpr int HT0 = H / 16;
+    constexpr int XS = 20;
+    constexpr int R_Z = 0, R_X = 16, R_XL = R_X + 16 * (NL - 1), R_DP = R_XL + HH, PRIV = (R_DP + HH) * XS;
+    constexpr int EPT = (16 * CP + NT - 1) / NT;
+    static_assert(HT * HT == NW && HT * HT0 == NW, "one dW1 tile and one dW0 tile per wave");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* zx = lds;
+    float* dxs = zx + 2 * H * 16;
+    float* d2s = dxs + 2 * 16 * CP;
+    float* red = d2s + 2 * 16 * CP;
+    float* simg = red + NW * HH * 16;
+    float* privbase = simg + PK::IMGS;
+    double* sh = reinterpret_cast<double*>(privbase + NW * PRIV);      // [2][NW]
+    __shared__ StageDesc sds[8];
+    __shared__ double sh_dt;
+    __shared__ int sh_jb, sh_je;
+
+    const KArgs& a = d.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = lane & 15, g = lane >> 4;
+    const int b0 = blockIdx.x * NCDE_TILE;
+    const int bs = b0 + s;
+    const bool valid = bs < a.B;
+    const int Hr = a.H, HHr = a.dout[0], Cr = a.C;
+    const long long BH = (long long)a.B * Hr;
+    const bool cubic = a.interp == NCDE_INTERP_CUBIC;
+    float* priv = privbase + wave * PRIV;
+    float* zimg = priv + R_Z * XS;
+    float* xLimg = priv + R_XL * XS;
+    float* dpimg = priv + R_DP * XS;
+    float* dptile = dpimg;
+    const int tr1 = wave / HT, tc1 = wave - tr1 * HT;
+    const int tr0 = wave / HT0, tc0 = wave - tr0 * HT0;
+    const float* w0i = simg + PK::I_W0 + lane * 4;
+    const float* w1i = simg + PK::I_W1 + lane * 4;
+    const float* w1ti = simg + PK::I_W1T + lane * 4;
+    const float* w0ti = simg + PK::I_W0T + (wave * (KH / 4) * 64 + lane) * 4;
+    const float* woTw = simg + PK::I_WOT + wave * NTILE * HT * 256;
+    const float* boLw = simg + PK::I_BOL + wave * NTILE * 16;
+    const float* b0i = simg + PK::I_B0 + g * 4;
+    const float* b1i = simg + PK::I_B1 + g * 4;
+
+    float wo[NB][CQ][KH];
+    {
+        const float* wp = d.WP + (long long)wave * PK::WAVE + lane * 4;
+        float wreg[PK::LANE4 * 4];
+#pragma unroll
+        for (int i4 = 0; i4 < PK::LANE4; ++i4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wp + i4 * 256);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wreg[4 * i4 + q] = v[q];
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int cq = 0; cq < CQ; ++cq)
+#pragma unroll
+                for (int ks = 0; ks < KH; ++ks) wo[nb][cq][ks] = wreg[PK::O_WO + (nb * CQ + cq) * KH + ks];
+        const f32x4* src = reinterpret_cast<const f32x4*>(d.WP + (long long)NW * PK::WAVE);
+        f32x4* dst = reinterpret_cast<f32x4*>(simg);
+        for (int e = tid; e < PK::IMGS / 4; e += NT) dst[e] = src[e];
+    }
+    float dxv[EPT], d2v[EPT];
+    auto stage_load = [&](int j) {
+        const StageDesc sd = sds[j];
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = tid + q * NT;
+            const int es = e / CP, cc = e - es * CP;
+            float v = 0.0f, v2 = 0.0f;
+            if (e < 16 * CP && cc < Cr && b0 + es < a.B) {
+                const float* p = a.coeffs + (long long)(b0 + es) * a.cs_b + (long long)sd.idx * a.cs_t;
+                if (!cubic) {
+                    v = p[a.cs_t + cc] - p[cc];
+                    if (sd.kdt != 1.0f) v = v / sd.kdt;
+                } else {
+                    const float bb = p[Cr + cc], c2 = p[2 * Cr + cc], dd = p[3 * Cr + cc];
+                    const float inner = c2 + dd * sd.frac;
+                    v = bb + inner * sd.frac;
+                    v2 = inner + dd * sd.frac;
+                }
+            }
+            dxv[q] = v;
+            d2v[q] = v2;
+        }
+    };
+    auto stage_store = [&](int slot) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = tid + q * NT;
+            if (e < 16 * CP) {
+                dxs[(slot & 1) * 16 * CP + e] = dxv[q];
+                d2s[(slot & 1) * 16 * CP + e] = d2v[q];
+            }
+        }
+    };
+
+    // ---- gradient accumulators (one sum, weight 1) ---------------------------------------------------------------------------------
+    f32x4 gWo[NTILE][HT], gW1, gW0, gbo;
+    float gb1 = 0.0f, gb0 = 0.0f;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    gW1 = gW0 = gbo = zero4;
+#pragma unroll
+    for (int i = 0; i < NTILE; ++i)
+#pragma unroll
+        for (int t = 0; t < HT; ++t) gWo[i][t] = zero4;
+
+    float zreg[HB], ys[NB], as_[NB];
+    int zpar = 0, dpar = 0;
+    auto exchange = [&]() {
+        float* zw = zx + zpar * H * 16;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) zw[(4 * (wave * NB + nb) + g) * 16 + s] = ys[nb];
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < HB; ++ks) zreg[ks] = zw[(4 * ks + g) * 16 + s];
+        zpar ^= 1;
+    };
+    // One stage evaluation at the stage input now in zreg, with dX/dt in parity slot `dslot`: kout = f dX/dt for the owned entries; with
+    // `vjp`: also vy = as_^T df/dy, the parameter gradients (+= as_^T df/dtheta) and vt = as_^T (d/dt of f dX/dt) per lane.
+    float kout[NB], vt;
+    f32x4 vy;
+    auto stage = [&](int dslot, bool vjp) {
+        const float* dxp = dxs + (dslot & 1) * 16 * CP + s * CP;
+        const float* d2p = d2s + (dslot & 1) * 16 * CP + s * CP;
+        float xc[KH];
+        unsigned relu_mask = 0;
+        {
+            f32x4 acc[HT];
+#pragma unroll
+            for (int tt = 0; tt < HT; ++tt) acc[tt] = *reinterpret_cast<const f32x4*>(b0i + tt * 16);
+#pragma unroll
+            for (int q4 = 0; q4 < HB / 4; ++q4) {
+                f32x4 a4[HT];
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt) a4[tt] = *reinterpret_cast<const f32x4*>(w0i + (tt * (HB / 4) + q4) * 256);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt) acc[tt] = mfma16(a4[tt][i], zreg[4 * q4 + i], acc[tt]);
+            }
+#pragma unroll
+            for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xc[4 * tt + r] = relu_dev(acc[tt][r]);
+#pragma unroll
+            for (int l = 1; l < NL; ++l) {
+                if (vjp) {
+#pragma unroll
+                    for (int q4 = 0; q4 < KH / 4; ++q4)
+                        if (q4 == tc1) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) priv[((R_X + 16 * (l - 1)) + 4 * i + g) * XS + s] = xc[4 * q4 + i];
+                        }
+                }
+#pragma unroll
+                for (int ks = 0; ks < KH; ++ks) relu_mask |= (xc[ks] > 0.0f ? 1u : 0u) << (8 * (l - 1) + ks);
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt) acc[tt] = *reinterpret_cast<const f32x4*>(b1i + tt * 16);
+#pragma unroll
+                for (int q4 = 0; q4 < KH / 4; ++q4) {
+                    f32x4 a4[HT];
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt) a4[tt] = *reinterpret_cast<const f32x4*>(w1i + (tt * (KH / 4) + q4) * 256);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int tt = 0; tt < HT; ++tt) acc[tt] = mfma16(a4[tt][i], xc[4 * q4 + i], acc[tt]);
+                }
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xc[4 * tt + r] = relu_dev(acc[tt][r]);
+            }
+        }
+        f32x4 xB[HT];
+        if (vjp) {
+#pragma unroll
+            for (int q4 = 0; q4 < HB / 4; ++q4)
+                if (q4 == tc0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) zimg[(4 * i + g) * XS + s] = zreg[4 * q4 + i];
+                }
+#pragma unroll
+            for (int ks = 0; ks < KH; ++ks) xLimg[(4 * ks + g) * XS + s] = xc[ks];
+            wave_lds_order();
+#pragma unroll
+            for (int tt = 0; tt < HT; ++tt) xB[tt] = *reinterpret_cast<const f32x4*>(xLimg + (16 * tt + s) * XS + 4 * g);
+        }
+        f32x4 accJ[HT];
+#pragma unroll
+        for (int tt = 0; tt < HT; ++tt) accJ[tt] = zero4;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) kout[nb] = 0.0f;
+        vt = 0.0f;
+#pragma unroll
+        for (int cq = 0; cq < CQ; ++cq) {
+            f32x4 o[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) o[nb] = *reinterpret_cast<const f32x4*>(boLw + ((nb * CQ + cq) * 4 + g) * 4);
+#pragma unroll
+            for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) o[nb] = mfma16(wo[nb][cq][ks], xc[ks], o[nb]);
+            const f32x4 dx = *reinterpret_cast<const f32x4*>(dxp + 4 * cq);
+            const f32x4 d2 = *reinterpret_cast<const f32x4*>(d2p + 4 * cq);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int tau = nb * CQ + cq;
+                f32x4 dP;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float m = tanh_prescaled(o[nb][r]);
+                    kout[nb] = fmaf(m, dx[r], kout[nb]);
+                    dP[r] = (as_[nb] * dx[r]) * (1.0f - m * m);
+                    vt = fmaf(as_[nb] * m, d2[r], vt);
+                }
+                if (vjp) {
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt) {
+                        const f32x4 av = *reinterpret_cast<const f32x4*>(woTw + ((tau * HT + tt) * 64 + lane) * 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) accJ[tt] = mfma16(av[r], dP[r], accJ[tt]);
+                    }
+                    f32x4 sm;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sm[r] = row16_sum(dP[r]);
+                        dptile[(4 * g + r) * XS + s] = dP[r];
+                    }
+                    if (s == tau) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) gbo[r] += sm[r];
+                    }
+                    wave_lds_order();
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(dptile + s * XS + 4 * g);
+                    wave_lds_order();
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) gWo[tau][tt] = mfma16(av[q], xB[tt][q], gWo[tau][tt]);
+                }
+            }
+        }
+        vy = zero4;
+        if (!vjp) return;
+        float gpre[KH];
+#pragma unroll
+        for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave * HH * 16 + (4 * (4 * tt + r) + g) * 16 + s] = accJ[tt][r];
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) {
+            float v = red[(4 * ks + g) * 16 + s];
+#pragma unroll
+            for (int wv = 1; wv < NW; ++wv) v += red[wv * HH * 16 + (4 * ks + g) * 16 + s];
+            gpre[ks] = xc[ks] > 0.0f ? v : 0.0f;
+        }
+        auto bias_sum = [&](float& gb) {
+#pragma unroll
+            for (int ks = 0; ks < KH; ++ks) {
+                const float sm = row16_sum(gpre[ks]);
+                if (s == ks) gb += sm;
+                dpimg[(4 * ks + g) * XS + s] = gpre[ks];
+            }
+            wave_lds_order();
+        };
+        auto grad_tile = [&](f32x4& gw, int tr, const float* bimg) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(dpimg + (16 * tr + s) * XS + 4 * g);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bimg + s * XS + 4 * g);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gw = mfma16(av[q], bv[q], gw);
+            wave_lds_order();
+        };
+#pragma unroll
+        for (int l = NL - 1; l >= 1; --l) {
+            bias_sum(gb1);
+            grad_tile(gW1, tr1, priv + (R_X + 16 * (l - 1)) * XS);
+            f32x4 acc[HT];
+#pragma unroll
+            for (int tt = 0; tt < HT; ++tt) acc[tt] = zero4;
+#pragma unroll
+            for (int q4 = 0; q4 < KH / 4; ++q4) {
+                f32x4 a4[HT];
+#pragma unroll
+                for (int tt = 0; tt < HT; ++tt) a4[tt] = *reinterpret_cast<const f32x4*>(w1ti + (tt * (KH / 4) + q4) * 256);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt) acc[tt] = mfma16(a4[tt][i], gpre[4 * q4 + i], acc[tt]);
+            }
+#pragma unroll
+            for (int tt = 0; tt < HT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gpre[4 * tt + r] = ((relu_mask >> (8 * (l - 1) + 4 * tt + r)) & 1u) ? acc[tt][r] : 0.0f;
+        }
+        bias_sum(gb0);
+        grad_tile(gW0, tr0, zimg);
+#pragma unroll
+        for (int q4 = 0; q4 < KH / 4; ++q4) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(w0ti + q4 * 256);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vy = mfma16(a4[i], gpre[4 * q4 + i], vy);
+        }
+    };
+
+    // ---- per-lane state of the sweep ---------------------------------------------------------------------------------------------------
+    float y0[NB], kf[7][NB], kb[7][NB], yb0[NB], yb1[NB], YB1[NB], KBN[NB];
+    bool own[NB];
+    long long gi[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int u = 4 * (wave * NB + nb) + g;
+        own[nb] = valid && u < Hr;
+        gi[nb] = own[nb] ? (long long)bs * Hr + u : 0;
+        YB1[nb] = KBN[nb] = 0.0f;
+        as_[nb] = 0.0f;
+    }
+    double Tpart = 0.0, D1part = 0.0;      // per-thread partials of dL/d(t0 of the steps >= 2) and dL/d(dt_1)
+    const int M = d.tape->n_steps;
+    __syncthreads();      // operand images
+
+    for (int m = M - 1; m >= 0; --m) {
+        if (tid == 0) {
+            const DpStepRec r = d.tape_steps[m];
+            const double t1 = r.t0 + r.dt;
+            const float t0f = (float)r.t0, dtf0 = (float)r.dt, t1f = (float)t1;
+            sh_dt = r.dt;
+            sh_jb = r.j_begin;
+            sh_je = r.j_end;
+            sds[0] = dp_stage_desc(m == 0 ? t0f : nextafterf(t0f, -INFINITY), d.knots, d.n_knots);
+            for (int i = 0; i < 6; ++i) {
+                const float ti = kAlpha[i] == 1.0f ? nextafterf(t1f, -INFINITY) : t0f + kAlpha[i] * dtf0;
+                sds[i + 1] = dp_stage_desc(ti, d.knots, d.n_knots);
+            }
+        }
+        __syncthreads();
+        const double dt64 = sh_dt;
+        const float dtf = (float)dt64;
+        const int jb = sh_jb, je = sh_je;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            y0[nb] = own[nb] ? d.tape_y[(long long)m * BH + gi[nb]] : 0.0f;
+            ys[nb] = y0[nb];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) kf[q][nb] = kb[q][nb] = 0.0f;
+        }
+        // ---- the seven stage derivatives of the step -----------------------------------------------------------------------------------
+        stage_load(0);
+        stage_store(dpar);
+        exchange();
+        float y1[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) y1[nb] = 0.0f;
+#pragma unroll 1
+        for (int i = 0; i < 7; ++i) {
+            if (i + 1 < 7) stage_load(i + 1);
+            stage(dpar, false);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int q = 0; q < 7; ++q) kf[q][nb] = i == q ? kout[nb] : kf[q][nb];
+            if (i + 1 < 7) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int jq = 0; jq < 6; ++jq) acc += kf[jq][nb] * (kBeta[i][jq] * dtf);
+                    ys[nb] = own[nb] ? y0[nb] + acc : 0.0f;
+                    if (i == 5) y1[nb] = ys[nb];      // the input of the last stage = the step's solution
+                }
+                dpar ^= 1;
+                stage_store(dpar);
+                exchange();
+            }
+        }
+        // ---- cotangents: FSAL, dense output, interpolation fit -----------------------------------------------------------------------
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            yb0[nb] = 0.0f;
+            yb1[nb] = YB1[nb];
+            kb[6][nb] = KBN[nb];
+        }
+        if (je > jb) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                if (!own[nb]) continue;
+                const int u = 4 * (wave * NB + nb) + g;
+                const float k1 = kf[0][nb], k7 = kf[6][nb];
+                float ym = 0.0f, kmid = 0.0f;
+#pragma unroll
+                for (int jq = 0; jq < 7; ++jq) {
+                    ym += kf[jq][nb] * (dtf * kMid[jq]);
+                    kmid += kf[jq][nb] * kMid[jq];
+                }
+                ym = y0[nb] + ym;
+                const float ca = 2.0f * dtf * (k7 - k1) - 8.0f * (y1[nb] + y0[nb]) + 16.0f * ym;
+                const float cb = dtf * (5.0f * k1 - 3.0f * k7) + 18.0f * y0[nb] + 14.0f * y1[nb] - 32.0f * ym;
+                const float cc = dtf * (k7 - 4.0f * k1) - 11.0f * y0[nb] - 5.0f * y1[nb] + 16.0f * ym;
+                const float cd = dtf * k1;
+                float ab = 0.f, bb = 0.f, cbb = 0.f, db = 0.f, eb = 0.f;
+                for (int jr = jb; jr < je; ++jr) {
+                    const float x = d.tape_x[jr];
+                    const float gq = d.grad_out[((long long)bs * d.n_t + jr) * Hr + u];
+                    const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+                    eb += gq; db += x * gq; cbb += x2 * gq; bb += x3 * gq; ab += x4 * gq;
+                    const double xbar = (double)(gq * (cd + 2.0f * x * cc + 3.0f * x2 * cb + 4.0f * x3 * ca));
+                    if (m >= 1) Tpart += xbar * (-1.0 / dt64);
+                    else D1part += xbar * (-(double)x / dt64);
+                }
+                const float ymb = 16.0f * ab - 32.0f * bb + 16.0f * cbb;
+                yb0[nb] += -8.0f * ab + 18.0f * bb - 11.0f * cbb + eb + ymb;
+                yb1[nb] += -8.0f * ab + 14.0f * bb - 5.0f * cbb;
+                kb[0][nb] += dtf * (-2.0f * ab + 5.0f * bb - 4.0f * cbb + db);
+                kb[6][nb] += dtf * (2.0f * ab - 3.0f * bb + cbb);
+#pragma unroll
+                for (int jq = 0; jq < 7; ++jq) kb[jq][nb] += (dtf * kMid[jq]) * ymb;
+                if (m == 0)
+                    D1part += (double)(ab * 2.0f * (k7 - k1) + bb * (5.0f * k1 - 3.0f * k7) + cbb * (k7 - 4.0f * k1) + db * k1) + (double)(ymb * kmid);
+            }
+        }
+        // ---- the six stages in reverse: k_{i+1} = f(t_i, y_i), y_i = y0 + dt sum_j beta_ij k_j ------------------------------------------
+#pragma unroll 1
+        for (int i = 6; i >= 1; --i) {
+            stage_load(i);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                float acc = 0.0f, cot = 0.0f;
+#pragma unroll
+                for (int jq = 0; jq < 6; ++jq) acc += kf[jq][nb] * (kBeta[i - 1][jq] * dtf);
+#pragma unroll
+                for (int q = 0; q < 7; ++q) cot = i == q ? kb[q][nb] : cot;
+                ys[nb] = own[nb] ? y0[nb] + acc : 0.0f;
+                as_[nb] = own[nb] ? cot : 0.0f;
+            }
+            dpar ^= 1;
+            stage_store(dpar);
+            exchange();
+            stage(dpar, true);
+            if (cubic) {      // dL/d(t_i): t_i = t0 + alpha_i dt, t0 = t[0] + dt_1 + constants
+                if (m >= 1) Tpart += (double)vt;
+                else D1part += (double)kAlpha[i - 1] * (double)vt;
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float ybi = vy[nb] + (i == 6 ? yb1[nb] : 0.0f);
+                yb0[nb] += ybi;
+                float sbk = 0.0f;
+#pragma unroll
+                for (int jq = 0; jq < 6; ++jq) {
+                    const float bj = kBeta[i - 1][jq];
+                    kb[jq][nb] += (bj * dtf) * ybi;
+                    sbk += bj * kf[jq][nb];
+                }
+                if (m == 0) D1part += (double)(ybi * sbk);
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            YB1[nb] = yb0[nb];
+            KBN[nb] = kb[0][nb];
+        }
+        __syncthreads();      // sds is rewritten at the top of the next step
+    }
+    // ---- hand-over to the finish launches ------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        if (!own[nb]) continue;
+        const int u = 4 * (wave * NB + nb) + g;
+        d.DZ0[gi[nb]] = YB1[nb] + d.grad_out[((long long)bs * d.n_t) * Hr + u];      // the solution at t[0] is z0 itself
+        d.F0B[gi[nb]] = KBN[nb];
+        d.SCB[gi[nb]] = 0.0f;
+    }
+    const double Tw = wave_sum_d(Tpart), Dw = wave_sum_d(D1part);
+    __syncthreads();
+    if (lane == 0) { sh[wave] = Tw; sh[NW + wave] = Dw; }
+    __syncthreads();
+    if (tid == 0) {
+        d.PN2[(long long)blockIdx.x * 4 + 0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        d.PN2[(long long)blockIdx.x * 4 + 1] = (sh[NW] + sh[NW + 1]) + (sh[NW + 2] + sh[NW + 3]);
+        d.PN2[(long long)blockIdx.x * 4 + 2] = 0.0;
+        d.PN2[(long long)blockIdx.x * 4 + 3] = 0.0;
+    }
+    // the parameter partial in parameter order (once per solve): ncde_dp_tape_finish adds its own evaluations on top
+    float* gp = d.GP + (long long)blockIdx.x * d.theta1;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int cq = 0; cq < CQ; ++cq) {
+            const int tau = nb * CQ + cq;
+            const int hh = 4 * (wave * NB + nb) + g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cc = 4 * cq + r;
+                if (hh < Hr && cc < Cr) {
+#pragma unroll
+                    for (int tt = 0; tt < HT; ++tt)
+                        if (16 * tt + s < HHr) gp[a.gWo_off + (long long)(hh * Cr + cc) * HHr + 16 * tt + s] = gWo[tau][tt][r];
+                    if (s == tau) gp[a.gbo_off + hh * Cr + cc] = gbo[r];
+                }
+            }
+        }
+    if (NL > 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (16 * tr1 + 4 * g + r < HHr && 16 * tc1 + s < HHr) gp[a.gW_off[1] + (16 * tr1 + 4 * g + r) * HHr + 16 * tc1 + s] = gW1[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (16 * tr0 + 4 * g + r < HHr && 16 * tc0 + s < Hr) gp[a.gW_off[0] + (16 * tr0 + 4 * g + r) * Hr + 16 * tc0 + s] = gW0[r];
+    if (wave == 0 && s < KH && 4 * s + g < HHr) {
+        if (NL > 1) gp[a.gb_off[1] + 4 * s + g] = gb1;
+        gp[a.gb_off[0] + 4 * s + g] = gb0;
+    }
+    if (tid == 0) gp[a.theta_size] = 0.0f;
+}
+
 // Sum of the per-workgroup parameter-part partials, the parameter part of the mixed norm, and -- in the last workgroup -- the controller.
 // A block handles 64 consecutive entries of the PARTIAL vector ([dWo in register order][parameter order], see ncde_dpf_adj); its four
 // waves each sum a quarter of the workgroups (fixed order, coalesced 256-byte rows), the quarters are combined in a fixed order.
@@ -1191,7 +1724,7 @@ bool ncde_dpf_supported(const NcdeProblem* p, int adj) {
     if (p->flags & NCDE_FLAG_FORCE_GENERIC) return false;
     const int sh = dpf_shape(p);
     if (adj == 0) return sh != 0;
-    if (adj == 1) return sh == 1 && p->n_layers <= 4 && dpa_lds_bytes(p->n_layers) <= 160 * 1024;      // (32, 32, 20) set only
+    if (adj == 1) return sh == 1 && p->n_layers <= 4 && dpa_lds_bytes(p->n_layers) + 512 <= 160 * 1024;      // (32, 32, 20) set only; 512 B: static LDS
     return false;
 }
 
@@ -1225,6 +1758,22 @@ int ncde_dpf_prepare(const NcdeProblem* p, const void* dp_args, size_t dp_args_b
     } else {
         hipLaunchKernelGGL((ncde_dpf_pack<64, 64, 4>), dim3(1), dim3(256), 0, st, d);
     }
+    return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
+}
+
+// reverse sweep of a taped solve: weight image + the persistent sweep (the caller launches ncde_dp_tape_finish afterwards, as before)
+bool ncde_dpf_tape_supported(const NcdeProblem* p) { return ncde_dpf_supported(p, 1); }
+int ncde_dpf_tape_launch(const NcdeProblem* p, const void* dp_args, size_t dp_args_bytes, hipStream_t st) {
+    if (dp_args_bytes != sizeof(DpArgs) || !ncde_dpf_tape_supported(p)) return NCDE_ERR_UNSUPPORTED;
+    DpArgs d;
+    memcpy(&d, dp_args, sizeof(d));
+    const int nl = p->n_layers;
+    const DpfKernel k = nl == 1 ? (DpfKernel)ncde_dpf_tape<32, 32, 20, 1> : (nl == 2 ? (DpfKernel)ncde_dpf_tape<32, 32, 20, 2>
+                      : (nl == 3 ? (DpfKernel)ncde_dpf_tape<32, 32, 20, 3> : (DpfKernel)ncde_dpf_tape<32, 32, 20, 4>));
+    const size_t lds = dpa_lds_bytes(nl);
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NCDE_ERR_HIP;
+    hipLaunchKernelGGL((ncde_dpa_pack<32, 32, 20, 3>), dim3(1), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k, dim3(d.n_wg), dim3(256), lds, st, d);
     return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
 }
 
