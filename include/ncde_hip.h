@@ -226,6 +226,13 @@ typedef struct NcdeAdaptiveStats {
 } NcdeAdaptiveStats;
 
 int64_t ncde_dopri5_workspace_bytes(const NcdeProblem* p, const NcdeTimeSpec* ts, int pass /* 0 forward, 1 adjoint, 2 taped backward */);
+/* Which kernels a dopri5 call of this problem runs (static string; NULL + last error if the problem is not supported): the fused
+ * attempt kernels of round 4 -- one launch per attempt for the forward solve ("ncde_dpf_fwd<...>": hidden, hidden_hidden <= 32 with
+ * C <= 20, or <= 64 with C <= 4), an attempt + a reduce launch for the adjoint ("ncde_dpf_adj<...> + ncde_dpf_reduce") and the persistent
+ * reverse sweep of a taped solve ("ncde_dpf_tape<...>"; both: the (32, 32, 20) set, <= 3 layers) -- or the per-launch kernels
+ * ("ncde_dp_stage x 6 + ncde_dp_control + ncde_dp_commit", "ncde_dp_tape_backward") for every other shape and under
+ * NCDE_FLAG_FORCE_GENERIC. */
+const char* ncde_dopri5_kernel_name(const NcdeProblem* p, int pass /* 0 forward, 1 adjoint, 2 taped backward */);
 int ncde_dopri5_forward(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt, float* out, void* workspace,
                         size_t workspace_bytes, void* stream, NcdeAdaptiveStats* stats);
 int ncde_dopri5_adjoint(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt, const float* z_out,

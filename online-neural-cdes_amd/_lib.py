@@ -115,7 +115,7 @@ EXPORTS = (
     "ncde_prepare_workspace_bytes", "ncde_prepare_linear", "ncde_prepare_cubic", "ncde_prepare_linear_grid", "ncde_prepare_cubic_grid",
     "ncde_stage_record_bytes", "ncde_forward_record", "ncde_backward",
     "ncde_time_plan_build", "ncde_dopri5_workspace_bytes", "ncde_dopri5_forward", "ncde_dopri5_adjoint",
-    "ncde_dopri5_record_bytes", "ncde_dopri5_forward_record", "ncde_dopri5_backward",
+    "ncde_dopri5_record_bytes", "ncde_dopri5_forward_record", "ncde_dopri5_backward", "ncde_dopri5_kernel_name",
 )
 
 _LIB = None
@@ -195,6 +195,8 @@ def lib():
     h.ncde_dopri5_forward.restype = ctypes.c_int
     h.ncde_dopri5_adjoint.argtypes = [P, TS, AO, vp, vp, G, vp, sz, vp, AS]
     h.ncde_dopri5_adjoint.restype = ctypes.c_int
+    h.ncde_dopri5_kernel_name.argtypes = [P, ctypes.c_int]
+    h.ncde_dopri5_kernel_name.restype = ctypes.c_char_p
     h.ncde_dopri5_record_bytes.argtypes = [P, TS, AO]
     h.ncde_dopri5_record_bytes.restype = ctypes.c_int64
     h.ncde_dopri5_forward_record.argtypes = [P, TS, AO, vp, vp, sz, vp, sz, vp, AS]

@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "ncde_adaptive.h"
+#include "ncde_adaptive_fast.h"
 #include "ncde_common.h"
 #include "ncde_fast.h"
 #include "ncde_host.h"
@@ -454,6 +455,21 @@ int64_t ncde_dopri5_workspace_bytes(const NcdeProblem* p, const NcdeTimeSpec* ts
     const int rc = dopri5_prepare(p, ts, &o, pass == 2 ? 2 : (pass != 0), &q_);
     if (rc != NCDE_OK) return rc;
     return ncde_dp_workspace_bytes(&q_, ts->n_t, pass);
+}
+
+const char* ncde_dopri5_kernel_name(const NcdeProblem* p, int pass) {
+    NcdeProblem q_;
+    NcdeAdaptiveOptions o{};
+    o.rtol = 1e-4;
+    const double t2[2] = {0.0, 1.0};
+    NcdeTimeSpec ts{};
+    ts.n_t = 2;
+    ts.t = t2;
+    if (dopri5_prepare(p, &ts, &o, pass == 2 ? 2 : (pass != 0), &q_) != NCDE_OK) return nullptr;
+    if (pass == 2) return ncde_dpf_tape_supported(&q_) ? ncde_dpf_tape_kernel_name(&q_) : "ncde_dp_tape_backward";
+    const char* f = ncde_dpf_kernel_name(&q_, pass != 0);
+    if (f) return f;
+    return pass ? "ncde_dp_stage x 6 + ncde_dp_reduce_theta x 6 + ncde_dp_control + ncde_dp_commit" : "ncde_dp_stage x 6 + ncde_dp_control + ncde_dp_commit";
 }
 
 int64_t ncde_dopri5_record_bytes(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdaptiveOptions* opt) {

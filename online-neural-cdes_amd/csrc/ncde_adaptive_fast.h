@@ -16,4 +16,5 @@ int ncde_dpf_prepare(const NcdeProblem* p, const void* dp_args, size_t dp_args_b
 int ncde_dpf_launch(const NcdeProblem* p, const void* dp_args, size_t dp_args_bytes, int adj, int rounds, hipStream_t st);
 // reverse sweep of a taped solve (adjoint=False) on the fused stage machinery; workspace: ncde_dpf_pack_floats(p, 1) floats at DpArgs.WP
 bool ncde_dpf_tape_supported(const NcdeProblem* p);
+const char* ncde_dpf_tape_kernel_name(const NcdeProblem* p);
 int ncde_dpf_tape_launch(const NcdeProblem* p, const void* dp_args, size_t dp_args_bytes, hipStream_t st);

@@ -1763,6 +1763,7 @@ int ncde_dpf_prepare(const NcdeProblem* p, const void* dp_args, size_t dp_args_b
 
 // reverse sweep of a taped solve: weight image + the persistent sweep (the caller launches ncde_dp_tape_finish afterwards, as before)
 bool ncde_dpf_tape_supported(const NcdeProblem* p) { return ncde_dpf_supported(p, 1); }
+const char* ncde_dpf_tape_kernel_name(const NcdeProblem* p) { return ncde_dpf_tape_supported(p) ? "ncde_dpf_tape<H32,HH32,C20,fp32 MFMA>" : nullptr; }
 int ncde_dpf_tape_launch(const NcdeProblem* p, const void* dp_args, size_t dp_args_bytes, hipStream_t st) {
     if (dp_args_bytes != sizeof(DpArgs) || !ncde_dpf_tape_supported(p)) return NCDE_ERR_UNSUPPORTED;
     DpArgs d;

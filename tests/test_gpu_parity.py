@@ -1713,6 +1713,60 @@ def test_dopri5_forced_step_sequence_vs_oracle(interp, seq, gpu_lib):
         assert gu.relerr(func.p[n_].grad.cpu().numpy(), g_) <= E2E_G, n_
 
 
+@pytest.mark.parametrize("C,H,HH,nl,interp", [(20, 32, 32, 3, "linear"), (3, 48, 64, 2, "cubic"), (5, 16, 24, 1, "cubic"), (7, 40, 40, 2, "linear"),
+                                               (20, 32, 32, 4, "linear"), (4, 64, 64, 3, "linear")])
+def test_dopri5_every_kernel_set_forced_sequence_vs_oracle(C, H, HH, nl, interp, gpu_lib):
+    """Round 4: the fused attempt kernels (forward: (32, 32, 20) and (64, 64, 4) sets incl. zero-padded shapes; adjoint and taped
+    sweep: the (32, 32, 20) set up to three layers) and the per-launch kernels they fall back to, each on the forced step sequence
+    (first_step = min_step = max_step: GPU and oracle walk the same steps): forward at TIGHT_Z, adaptive adjoint and
+    `adjoint=False` gradients at E2E_G, ragged batch, sequence outputs (dense output inside steps: 0.75 does not divide the knots)."""
+    import ctypes
+    import gpu_util
+    import ncde_amd
+    import ncde_oracle as orc
+    from ncde_amd import _lib, solver
+    B, L = 21, 6
+    if interp == "linear":
+        coeffs = gu.data.make_rectilinear_coeffs(B, L, C - 1, missing=0.3, seed=95)
+        x0 = coeffs[:, 0]
+    else:
+        coeffs = gu.data.make_cubic_coeffs(B, 2 * L, C - 1, seed=96)
+        x0 = coeffs[:, 0, :C]
+    p = gu.data.make_field_weights(H, HH, C, seed=9)
+    rw = gu.data.make_readin_weights(H, C, 1, seed=9)
+    z0n = (x0 @ rw["Wi"].T + rw["bi"]).astype(np.float32)
+    opts = {"first_step": 0.75, "min_step": 0.75, "max_step": 0.75}
+    field = orc.Field.original(p, H, C, nl)
+    ctl = orc.Control(coeffs, interp)
+    tt = torch.arange(ctl.n_knots, dtype=torch.float32)
+    z = orc.dopri5_forward(ctl, field, z0n, tt, 1e-3, 1e-5, opts)
+    gout = (gu.data.normal(31, z.numel(), stream=1).reshape(z.shape) / np.sqrt(z.shape[1])).astype(np.float32)
+    dz0, gp = orc.dopri5_adjoint(ctl, field, tt, z, gout, 1e-3, 1e-5, opts)
+    _zb, bdz0, bgp = orc.dopri5_discrete_backward(ctl, field, z0n, tt, gout, 1e-3, 1e-5, opts)
+    names = ["W0", "b0"] + (["W1", "b1"] if nl > 1 else []) + ["Wo", "bo"]      # (one layer: W1 / b1 exist in `p` but are in no layer)
+    if nl == 1:
+        gp, bgp = [gp[0], gp[1]] + list(gp[-2:]), [bgp[0], bgp[1]] + list(bgp[-2:])
+    X = (ncde_amd.LinearInterpolation if interp == "linear" else ncde_amd.NaturalCubicSpline)(torch.from_numpy(coeffs).cuda())
+    layers = [("W0", "b0")] + [("W1", "b1")] * (nl - 1)
+    # which kernels
+    func = gpu_util.CaseField(p, layers, "cuda")
+    prob = solver.build_problem(torch.from_numpy(coeffs).cuda(), interp, torch.from_numpy(z0n).cuda(), func.fused_spec(), "rk4", _lib.OUT_INTERVAL, 0)
+    kn = [(_lib.lib().ncde_dopri5_kernel_name(ctypes.byref(prob), k) or b"?").decode() for k in (0, 1, 2)]
+    small, mid = max(H, HH) <= 32 and C <= 20, max(H, HH) <= 64 and C <= 4
+    assert kn[0].startswith("ncde_dpf_fwd<H32" if small else ("ncde_dpf_fwd<H64" if mid else "ncde_dp_stage")), kn
+    assert kn[1].startswith("ncde_dpf_adj" if small and nl <= 3 else "ncde_dp_stage"), kn
+    assert kn[2].startswith("ncde_dpf_tape" if small and nl <= 3 else "ncde_dp_tape_backward"), kn
+    for adjoint, want_dz0, want_gp in ((True, dz0, gp), (False, bdz0, bgp)):
+        func = gpu_util.CaseField(p, layers, "cuda")
+        z0 = torch.from_numpy(z0n).cuda().requires_grad_(True)
+        out = ncde_amd.cdeint(X, func, z0, X.grid_points, adjoint=adjoint, method="dopri5", rtol=1e-3, atol=1e-5, options=dict(opts))
+        assert gu.relerr(out.detach().cpu().numpy(), z) <= TIGHT_Z, (adjoint, gu.relerr(out.detach().cpu().numpy(), z))
+        (out * torch.from_numpy(gout).cuda()).sum().backward()
+        assert gu.relerr(z0.grad.cpu().numpy(), want_dz0) <= E2E_G, (adjoint, gu.relerr(z0.grad.cpu().numpy(), want_dz0))
+        for n_, g_ in zip(names, want_gp):
+            assert gu.relerr(func.p[n_].grad.cpu().numpy(), g_) <= E2E_G, (adjoint, n_, gu.relerr(func.p[n_].grad.cpu().numpy(), g_))
+
+
 def test_neuralcde_module_with_dopri5(gpu_lib):
     """NeuralCDE(solver='dopri5') no longer raises: forward + adaptive adjoint end to end, against the oracle run with the
     module's own parameters (same tolerance logic as above)."""

@@ -131,6 +131,25 @@ def test_kernel_family_selection():
     assert lib.ncde_workspace_bytes(ctypes.byref(un), 1) == -2
 
 
+def test_dopri5_kernel_selection():
+    """Round 4: the fused attempt kernels where the shape allows, the per-launch kernels elsewhere and under FORCE_GENERIC."""
+    lib = ncde_amd.lib()
+    name = lambda p, k: (lib.ncde_dopri5_kernel_name(ctypes.byref(p), k) or b"").decode()
+    p = _problem()                                    # BASELINE cfg2 shape
+    assert name(p, 0).startswith("ncde_dpf_fwd<H32") and name(p, 1).startswith("ncde_dpf_adj<H32") and name(p, 2).startswith("ncde_dpf_tape<H32")
+    q = _problem(C=5, H=16, HH=24)                    # smaller: the same kernels (weights read with their real extents)
+    assert [name(q, k) for k in (0, 1, 2)] == [name(p, k) for k in (0, 1, 2)]
+    w = _problem(C=3, H=48, HH=64, nl=2)              # (64, 64, 4) set: forward only
+    assert name(w, 0).startswith("ncde_dpf_fwd<H64") and name(w, 1).startswith("ncde_dp_stage") and name(w, 2) == "ncde_dp_tape_backward"
+    n4 = _problem(nl=4)                               # four layers: the adjoint's images do not fit in LDS
+    assert name(n4, 0).startswith("ncde_dpf_fwd<H32") and name(n4, 1).startswith("ncde_dp_stage")
+    big = _problem(C=21, H=47, HH=93)
+    assert all(name(big, k).startswith("ncde_dp_") for k in (0, 1, 2))
+    assert name(_problem(flags=_lib.FLAG_FORCE_GENERIC), 0).startswith("ncde_dp_stage")
+    ts = _lib.NcdeTimeSpec() if hasattr(_lib, "NcdeTimeSpec") else None
+    assert lib.ncde_dopri5_kernel_name(ctypes.byref(_problem(C=80, H=128, HH=512, nl=2)), 1) is None      # beyond the adjoint's LDS plan
+
+
 def test_control_paths_match_oracle_control():
     import ncde_oracle as orc
     lin = gu.data.make_rectilinear_coeffs(3, 6, 4, missing=0.3, seed=5)
