@@ -1002,7 +1002,7 @@ int ncde_dp_solve(const NcdeProblem* p, const NcdeTimeSpec* ts, const NcdeAdapti
             const double launched = (double)hc.n_attempts + 2.0;
             double remaining = done > 1e-3 ? launched * (1.0 - done) / done : 4.0 * launched;
             remaining = remaining * 1.05 + 6.0 + (adj ? 3.0 * (hc.interval - 1) : 0.0);
-            rounds = (int)std::min(1024.0, std::max(8.0, remaining));
+            rounds = (int)std::min(std::min(1024.0, 2.0 * rounds), std::max(8.0, remaining));      // (early estimates overshoot: first steps are short)
         }
     }
     for (long long guard = 0; !d.fused && guard < (1LL << 40); ++guard) {
