@@ -56,13 +56,17 @@ def _field_spec(func):
         "arbitrary Python vector fields are outside the fused MI355X path")
 
 
-def _unfused_reason(X, func, z0, t, adjoint, adjoint_params):
+def _unfused_reason(X, func, z0, t, adjoint, adjoint_params, method=None):
     """Why this call cannot run on the fused kernels (None = it can).  Such calls run on the unfused torch-op solver
     (unfused.py) -- on the GPU: CPU tensors stay refused, there is no CPU fallback."""
     if not torch.is_tensor(z0):
         return None      # tuple-valued z0: refused further down, on either path
     if not hasattr(func, "fused_spec"):
         return "func does not expose fused_spec()"
+    if method == "dopri5":      # the adaptive kernels evaluate the original field with the matmul input only
+        spec = func.fused_spec()
+        if spec.kind != "original" or spec.mode != "matmul":
+            return "method='dopri5' with a gated vector field or the evaluate / derivative input"
     tt = torch.as_tensor(t)
     if tt.dim() == 1 and tt.numel() >= 2 and bool(tt[0] > tt[1]):
         return "decreasing output times"
@@ -518,14 +522,22 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
         raise NotImplementedError("adjoint_method != method is outside the fused path")
     if not isinstance(X, (LinearInterpolation, NaturalCubicSpline)):
         raise NotImplementedError("X must be ncde_amd.LinearInterpolation or ncde_amd.NaturalCubicSpline")
-    reason = _unfused_reason(X, func, z0, t, adjoint, adjoint_params)
+    reason = _unfused_reason(X, func, z0, t, adjoint, adjoint_params, method)
     if reason is not None:
         # outside the fused kernels: the own unfused torch-op solver, same algorithms (unfused.py), on the tensors' device
         from . import unfused
         if not z0.is_cuda:
             raise NotImplementedError("cdeint needs tensors on the GPU (there is no CPU fallback); z0 is on %s" % z0.device)
-        if method not in _FIXED_METHODS:
-            raise NotImplementedError("method '%s' outside the fused path (%s): the unfused solver runs %s" % (method, reason, _FIXED_METHODS))
+        adaptive_cfg = None
+        if method == "dopri5":      # round 4: adaptive dopri5 on the unfused path too (same options as the fused one)
+            if options.pop("norm", None) is not None:
+                raise NotImplementedError("a custom error norm is not supported (the reference's rms / mixed norms are built in)")
+            aopt = {k: options.pop(k) for k in list(options) if k in _DOPRI5_OPTIONS and not k.startswith("_")}
+            for k in [k for k in options if k.startswith("_")]:
+                options.pop(k)
+            bopt = dict(aopt) if adjoint_options is None else {k: v for k, v in adjoint_options.items() if k in _DOPRI5_OPTIONS and not k.startswith("_")}
+            adaptive_cfg = {"rtol": rtol, "atol": atol, "options": aopt, "adjoint_rtol": rtol if adjoint_rtol is None else adjoint_rtol,
+                            "adjoint_atol": atol if adjoint_atol is None else adjoint_atol, "adjoint_options": bopt}
         step = options.pop("step_size", None)
         if "grid_constructor" in options:
             raise NotImplementedError("options['grid_constructor'] is not supported; give options={'step_size': h}")
@@ -541,7 +553,7 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
         unfused.warn_once(reason)
         if torch.is_tensor(step):
             step = step.item()
-        return unfused.cdeint_unfused(X, func, z0, t, adjoint, vector_field_type, method, step, adjoint_params)
+        return unfused.cdeint_unfused(X, func, z0, t, adjoint, vector_field_type, method, step, adjoint_params, adaptive_cfg)
     adaptive = method == "dopri5"
     if adaptive:
         for k in list(options):
