@@ -2132,6 +2132,13 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                             }
                         }
                 }
+                // From here on the activations are needed only as ReLU masks (x_L's B operand `xb` is already split): one bit each
+                // instead of 8 NL registers carried across the output tiles (round 4: the kernel's last 32 B / lane of scratch)
+                unsigned relu_mask = 0;
+#pragma unroll
+                for (int l = 0; l < NL; ++l)
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) relu_mask |= (x[l][jj] > 0.0f ? 1u : 0u) << (8 * l + jj);
                 // ---- output tiles: P, r = 1/(exp(2P)+1), f, dP -> LDS tile + flag -----------------------------------
                 float kout[NB];
                 float sdx = 0.0f;
@@ -2189,7 +2196,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                     float v = red[(8 * g + jj) * 16 + s];
 #pragma unroll
                     for (int wv = 1; wv < NW; ++wv) v += red[wv * HH * 16 + (8 * g + jj) * 16 + s];
-                    gpre[jj] = x[NL - 1][jj] > 0.0f ? v : 0.0f;
+                    gpre[jj] = ((relu_mask >> (8 * (NL - 1) + jj)) & 1u) ? v : 0.0f;
                 }
                 // ---- hidden layers backward (split-bf16) -----------------------------------------------------------------
 #pragma unroll
@@ -2209,7 +2216,7 @@ __global__ __launch_bounds__(512, 2) void ncde_adj_fast3(KArgs a) {
                     for (int tt = 0; tt < HT; ++tt) {
                         const f32x4 gq = SO::finish(acc[tt]);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) gpre[4 * tt + r] = x[l - 1][4 * tt + r] > 0.0f ? gq[r] : 0.0f;
+                        for (int r = 0; r < 4; ++r) gpre[4 * tt + r] = ((relu_mask >> (8 * (l - 1) + 4 * tt + r)) & 1u) ? gq[r] : 0.0f;
                     }
                 }
                 if (wq != 0.0f && pw == 0) {
