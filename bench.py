@@ -515,6 +515,13 @@ def main():
             "ms_allreduce": ms_allreduce,
             "allreduce_floats": int(w.bucket.flat.numel()),
         }
+        # where the step's time goes outside the two solver kernels (cdeint's per-call host work, the
+        # range-fault re-execution launches, the gradient reduction, read-in / read-out layers, loss, Adam -- and launch gaps)
+        kf, kb = roofs[0].get("ms_per_launch"), roofs[1].get("ms_per_launch")
+        if kf is not None and kb is not None:
+            rec["step_breakdown"] = {"forward_kernel_ms": kf, "backward_kernel_ms": kb, "other_ms": round(dt / args.steps * 1e3 - kf - kb, 4),
+                                     "note": "other = ms_per_step - the two solver kernels' own time (HIP events): everything cdeint, autograd, "
+                                             "the model's linear layers, the loss, the optimizer and launch gaps add per step"}
         if z_err is not None:
             rec["z_err_vs_golden"] = z_err
             rec["z_err_note"] = ("max-abs error of z_T from the timed default forward kernel (%s) on this full workload, relative to max |z_T|, "

@@ -35,6 +35,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu_lib):
     # the timed default forward kernel against the reference's own z_T on this very workload (golden g5), and the all-fp32-MFMA step
     assert 0 <= rec["z_err_vs_golden"] <= 1e-4, rec["z_err_vs_golden"]
     assert rec["fp32_mfma_ms_per_step"] >= 0.9 * rec["ms_per_step"]
+    sb = rec["step_breakdown"]      # the step outside the two solver kernels: host work, other launches, gaps
+    assert abs(sb["forward_kernel_ms"] + sb["backward_kernel_ms"] + sb["other_ms"] - rec["ms_per_step"]) < 1e-2 and -0.5 < sb["other_ms"] < 0.3 * rec["ms_per_step"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1.5
     assert "traffic" in r
     c = rec["cpu_baseline"]
