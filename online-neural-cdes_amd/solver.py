@@ -403,6 +403,8 @@ class _FusedDopri5(torch.autograd.Function):
         cfg["stats_backward"] = (stats.nfe, stats.n_accepted, stats.n_rejected)
         if cfg["func"] is not None and hasattr(cfg["func"], "nfe"):
             cfg["func"].nfe += stats.nfe
+        if ad.trace is not None and cfg["func"] is not None:      # diagnostics (tests): the reverse solve's own step sequence
+            cfg["func"].dopri5_trace_backward = ad.trace[:stats.n_accepted + stats.n_rejected].copy()
         grads = [gbuf[id(q)] if id(q) in live else None for q in params]
         return (grad_z0 if ctx.needs_input_grad[0] else None, None, None, *grads)
 
