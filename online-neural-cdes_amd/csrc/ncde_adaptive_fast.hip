@@ -1594,21 +1594,22 @@ __global__ __launch_bounds__(256, 1) void ncde_dpf_tape(DpArgs d) {
 }
 
 // Sum of the per-workgroup parameter-part partials, the parameter part of the mixed norm, and -- in the last workgroup -- the controller.
-// A block handles 64 consecutive entries of the PARTIAL vector ([dWo in register order][parameter order], see ncde_dpf_adj); its four
-// waves each sum a quarter of the workgroups (fixed order, coalesced 256-byte rows), the quarters are combined in a fixed order.
+// A block handles RED_EPB consecutive entries of the PARTIAL vector ([dWo in register order][parameter order], see ncde_dpf_adj); its
+// RED_NG thread groups each sum their share of the workgroups (fixed order, coalesced 256-byte rows), the quarters are combined in a fixed order.
+constexpr int RED_EPB = 128, RED_NG = 256 / RED_EPB;      // entries per block, groups of workgroups per block
 extern "C" __global__ __launch_bounds__(256) void ncde_dpf_reduce(DpArgs d) {
     typedef DpaPack<32, 32, 20, 3> PK;
     __shared__ double sh[256];
-    __shared__ float part[2][4][64];
+    __shared__ float part[2][RED_NG][RED_EPB];
     __shared__ int sh_flags[2], is_last;
     __shared__ float sh_x;
     DpCtrl* c = d.ctrl;
     const int phase = c->phase;
     if (phase == DP_DONE || c->error != 0) return;
     const KArgs& a = d.a;
-    const int tid = threadIdx.x, grp = tid >> 6, kk = tid & 63;
+    const int tid = threadIdx.x, grp = tid / RED_EPB, kk = tid % RED_EPB;
     const int PL = PK::WOT + d.theta1;
-    const int e = blockIdx.x * 64 + kk;
+    const int e = blockIdx.x * RED_EPB + kk;
     const float rtolf = (float)d.rtol, atolf = (float)d.atol;
     const int cur = c->cur;
     const float* G0 = cur ? d.GCT : d.G0T;
@@ -1632,14 +1633,14 @@ extern "C" __global__ __launch_bounds__(256) void ncde_dpf_reduce(DpArgs d) {
             const float* src = d.GP + (long long)q * PL + e;
             const long long row = 2LL * PL;
             int p = grp;
-            for (; p + 60 < d.n_wg; p += 64) {      // sixteen rows in flight; the order of the additions is fixed
+            for (; p + 15 * RED_NG < d.n_wg; p += 16 * RED_NG) {      // sixteen rows in flight; the order of the additions is fixed
                 float v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = src[(long long)(p + 4 * u) * row];
+                for (int u = 0; u < 16; ++u) v[u] = src[(long long)(p + RED_NG * u) * row];
 #pragma unroll
                 for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
             }
-            for (; p < d.n_wg; p += 4) s0 += src[(long long)p * row];
+            for (; p < d.n_wg; p += RED_NG) s0 += src[(long long)p * row];
         }
         part[q][grp][kk] = (s0 + s1) + (s2 + s3);
     }
@@ -1648,7 +1649,15 @@ extern "C" __global__ __launch_bounds__(256) void ncde_dpf_reduce(DpArgs d) {
     int seg = -1;
     if (grp == 0 && k >= 0) {
         float tot[2] = {0.0f, 0.0f};
-        for (int q = 0; q < nset; ++q) tot[q] = (part[q][0][kk] + part[q][1][kk]) + (part[q][2][kk] + part[q][3][kk]);
+        for (int q = 0; q < nset; ++q) {
+            float t4[RED_NG / 2];
+#pragma unroll
+            for (int u = 0; u < RED_NG / 2; ++u) t4[u] = part[q][2 * u][kk] + part[q][2 * u + 1][kk];
+            float tq = t4[0];
+#pragma unroll
+            for (int u = 1; u < RED_NG / 2; ++u) tq += t4[u];
+            tot[q] = tq;
+        }
         const float g0 = G0[k];
         if (phase == DP_INIT0) {
             d.KT[k] = tot[0];
@@ -1671,21 +1680,27 @@ extern "C" __global__ __launch_bounds__(256) void ncde_dpf_reduce(DpArgs d) {
             if (k >= off && k < off + len) seg = sg;
         }
     }
-    // per-segment sums of squares of this block -> SEGP[block][2][DP_MAXSEG + 1]  (wave 0 holds the terms; a block of 64 entries
+    // per-segment sums of squares of this block -> SEGP[block][2][DP_MAXSEG + 1]  (wave 0 holds the terms; a block of RED_EPB entries
     // touches few segments, so: one wave-wide sum per segment that occurs)
     double* segp = d.SEGP + (long long)blockIdx.x * 2 * (DP_MAXSEG + 1);
-    if (grp == 0) {
+    constexpr int RED_W0 = (RED_EPB + 63) / 64;      // waves that hold group 0's terms (the other lanes hold seg = -1)
+    __shared__ double segw[RED_W0][2][DP_MAXSEG + 1];
+    if (tid < 64 * RED_W0) {
         for (int sg = 0; sg <= d.nseg; ++sg) {
             double va = 0.0, vb = 0.0;
             if (__builtin_amdgcn_ballot_w64(seg == sg) != 0) {
                 va = wave_sum_d(seg == sg ? (double)qa * qa : 0.0);
                 vb = wave_sum_d(seg == sg ? (double)qb * qb : 0.0);
             }
-            if (kk == 0) {
-                __hip_atomic_store(&segp[sg], va, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&segp[(DP_MAXSEG + 1) + sg], vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if ((tid & 63) == 0) { segw[tid >> 6][0][sg] = va; segw[tid >> 6][1][sg] = vb; }
         }
+    }
+    __syncthreads();
+    if (tid <= d.nseg) {
+        double va = 0.0, vb = 0.0;
+        for (int w = 0; w < RED_W0; ++w) { va += segw[w][0][tid]; vb += segw[w][1][tid]; }
+        __hip_atomic_store(&segp[tid], va, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&segp[(DP_MAXSEG + 1) + tid], vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     dpf_finish_launch(d, sh, sh_flags, &sh_x, &is_last);
 }
@@ -1736,7 +1751,7 @@ const char* ncde_dpf_kernel_name(const NcdeProblem* p, int adj) {
 
 // fused adjoint: floats of one workgroup's partial vector (one weighted sum), and the number of blocks of ncde_dpf_reduce
 size_t ncde_dpf_partial_floats(const NcdeProblem* p, int theta1) { return ncde_dpf_supported(p, 1) ? (size_t)Dpa32::WOT + (size_t)theta1 : (size_t)theta1; }
-int ncde_dpf_reduce_blocks(const NcdeProblem* p, int theta1) { return (int)((ncde_dpf_partial_floats(p, theta1) + 63) / 64); }
+int ncde_dpf_reduce_blocks(const NcdeProblem* p, int theta1) { return (int)((ncde_dpf_partial_floats(p, theta1) + 127) / 128); }      // RED_EPB
 
 size_t ncde_dpf_pack_floats(const NcdeProblem* p, int adj) {
     if (!ncde_dpf_supported(p, adj)) return 0;
