@@ -1,0 +1,86 @@
+"""The unfused solver's adaptive dopri5 (online-neural-cdes_amd/unfused.py) against the oracle WITHOUT a GPU: `cdeint` refuses CPU
+tensors (no CPU fallback in the product path), but the solver itself is plain torch ops, so its algorithm -- tableau, step
+control, dense output, per-interval adaptive adjoint with the mixed norm, differentiable initial step -- can be pinned here by
+calling it directly.  The GPU twins are in tests/test_unfused_gpu.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+import golden_util as gu      # noqa: E402
+import ncde_amd               # noqa: E402
+import ncde_oracle as orc     # noqa: E402
+from ncde_amd import unfused  # noqa: E402
+
+
+def _setup(kind, mode, interp, dtype=torch.float32):
+    torch.manual_seed(0)
+    B, L, C, H, HH, nl = 5, 5, 4, 8, 12, 2
+    coeffs = gu.data.make_rectilinear_coeffs(B, L, C - 1, missing=0.3, seed=5) if interp == "linear" else gu.data.make_cubic_coeffs(B, 2 * L, C - 1, seed=6)
+    coeffs = coeffs.astype(np.float64 if dtype == torch.float64 else np.float32)
+    cls = {"original": ncde_amd.OriginalVectorField, "minimal": ncde_amd.MinimalGatedVectorField, "gru": ncde_amd.GRUGatedVectorField}[kind]
+    func = cls(C, H, HH, nl, vector_field_type=mode).to(dtype)
+    sp = func.fused_spec()
+    p = {"W0": sp.layers[0][0], "b0": sp.layers[0][1], "W1": sp.layers[1][0], "b1": sp.layers[1][1], "Wo": sp.Wo, "bo": sp.bo}
+    if sp.Wg is not None:
+        p["Wg"], p["bg"] = sp.Wg, sp.bg
+    if sp.Wr is not None:
+        p["Wr"], p["br"] = sp.Wr, sp.br
+    field = orc.Field.variant({k: v.detach().clone() for k, v in p.items()}, H, C, nl, kind, mode)
+    ctl = orc.Control(coeffs, interp)
+    X = (ncde_amd.LinearInterpolation if interp == "linear" else ncde_amd.NaturalCubicSpline)(torch.from_numpy(coeffs))
+    z0 = (torch.randn(B, H, dtype=dtype) * 0.3)
+    tt = torch.arange(ctl.n_knots, dtype=dtype)
+    return func, p, field, ctl, X, z0, tt
+
+
+@pytest.mark.parametrize("kind,mode,interp", [("minimal", "matmul", "linear"), ("gru", "evaluate", "cubic"), ("original", "derivative", "cubic")])
+def test_unfused_dopri5_forced_sequence_vs_oracle(kind, mode, interp):
+    func, p, field, ctl, X, z0, tt = _setup(kind, mode, interp)
+    opts = {"first_step": 0.75, "min_step": 0.75, "max_step": 0.75}
+    z = orc.dopri5_forward(ctl, field, z0.numpy(), tt, 1e-3, 1e-5, dict(opts))
+    gout = torch.from_numpy((gu.data.normal(31, z.numel(), stream=1).reshape(z.shape) / 3.0).astype(np.float32))
+    dz0, gp = orc.dopri5_adjoint(ctl, field, tt, z, gout, 1e-3, 1e-5, dict(opts), vjp="autograd")
+    ad = {"rtol": 1e-3, "atol": 1e-5, "options": dict(opts), "adjoint_rtol": 1e-3, "adjoint_atol": 1e-5, "adjoint_options": dict(opts)}
+    z0g = z0.clone().requires_grad_(True)
+    out = unfused.cdeint_unfused(X, func, z0g, tt, True, mode, "dopri5", None, None, ad)
+    assert gu.relerr(out.detach().numpy(), z.numpy()) <= 1e-5
+    (out * gout).sum().backward()
+    assert gu.relerr(z0g.grad.numpy(), dz0.numpy()) <= 1e-5
+    order = {id(q): i for i, q in enumerate(field.unique_params())}
+    fp = dict(zip(["W0", "b0", "W1", "b1", "Wo", "bo", "Wg", "bg", "Wr", "br"], [None] * 10))
+    for (w, b), (nw, nb) in zip(field.layers[:2], (("W0", "b0"), ("W1", "b1"))):
+        fp[nw], fp[nb] = w, b
+    fp["Wo"], fp["bo"] = field.Wo, field.bo
+    if kind in ("minimal", "gru"):
+        fp["Wg"], fp["bg"] = field.Wg, field.bg
+    if kind == "gru":
+        fp["Wr"], fp["br"] = field.Wr, field.br
+    for k, q in p.items():
+        assert gu.relerr(q.grad.numpy(), gp[order[id(fp[k])]].numpy()) <= 1e-4, k
+
+
+def test_unfused_dopri5_taped_gradient_in_fp64_vs_the_hand_derived_backward():
+    """adjoint=False = autograd through the solve, initial step of _select_initial_step included (differentiable, as in the reference):
+    free-running in fp64 both sides take the same steps, so the oracle's hand-derived backward of the taped solve -- pinned to the
+    reference's autograd on g12 -- must be matched at round-off."""
+    func, p, field, ctl, X, z0, tt = _setup("original", "matmul", "cubic", torch.float64)
+    field = orc.Field.original({k: v.detach().numpy() for k, v in p.items()}, 8, 4, 2)
+    opts = {"min_step": 0.25}
+    zfw = orc.dopri5_forward(ctl, field, z0.numpy(), tt, 1e-3, 1e-5, dict(opts))
+    gout = (gu.data.normal(31, zfw.numel(), stream=1).reshape(zfw.shape) / 3.0).astype(np.float64)
+    st = {}
+    z, dz0, gp = orc.dopri5_discrete_backward(ctl, field, z0.numpy(), tt, gout, 1e-3, 1e-5, dict(opts), stats=st)
+    assert st["delta_active"]
+    ad = {"rtol": 1e-3, "atol": 1e-5, "options": dict(opts), "adjoint_rtol": 1e-3, "adjoint_atol": 1e-5, "adjoint_options": dict(opts)}
+    z0g = z0.clone().requires_grad_(True)
+    out = unfused.cdeint_unfused(X, func, z0g, tt, False, "matmul", "dopri5", None, None, ad)
+    assert gu.relerr(out.detach().numpy(), np.asarray(z)) <= 1e-10
+    (out * torch.from_numpy(gout)).sum().backward()
+    assert gu.relerr(z0g.grad.numpy(), np.asarray(dz0)) <= 1e-10
+    for name, want in zip(["W0", "b0", "W1", "b1", "Wo", "bo"], gp):
+        assert gu.relerr(p[name].grad.numpy(), np.asarray(want)) <= 1e-10, name
