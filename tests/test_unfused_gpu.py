@@ -229,3 +229,34 @@ def test_unfused_dopri5_taped_gradient_includes_the_first_step_size(gpu_lib):
     assert gu.relerr(z0.grad.cpu().numpy(), np.asarray(dz0)) <= 1e-10, gu.relerr(z0.grad.cpu().numpy(), np.asarray(dz0))
     for name, want in zip(["W0", "b0", "W1", "b1", "Wo", "bo"], gp):
         assert gu.relerr(pd[name].grad.cpu().numpy(), np.asarray(want)) <= 1e-10, (name, gu.relerr(pd[name].grad.cpu().numpy(), np.asarray(want)))
+
+
+def test_neuralcde_module_with_a_gated_field_and_dopri5(gpu_lib):
+    """NeuralCDE(vector_field='minimal' | 'gru', solver='dopri5') -- the combination of the reference's 'interpolation' grid
+    (configurations.json5:187-191) -- end to end through the module: forward + adaptive adjoint, finite, and equal to the oracle's
+    free-running solve on the smooth (cubic) control at solver tolerance."""
+    import ncde_amd
+    import ncde_oracle as orc
+    B, L, C, H, HH, nl, OUT = 6, 6, 4, 8, 12, 2, 2
+    coeffs = gu.data.make_cubic_coeffs(B, 2 * L, C - 1, seed=6)
+    for vf in ("minimal", "gru"):
+        torch.manual_seed(3)
+        model = ncde_amd.NeuralCDE(C, H, OUT, hidden_hidden_dim=HH, num_layers=nl, interpolation="cubic", solver="dopri5", vector_field=vf,
+                                   adjoint=True, return_sequences=True).cuda()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = model(torch.from_numpy(coeffs).cuda())
+        assert out.shape[0] == B and out.shape[-1] == OUT and torch.isfinite(out).all()
+        out.square().sum().backward()
+        assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in model.parameters())
+        sp = model.func.fused_spec()
+        p = {"W0": sp.layers[0][0], "b0": sp.layers[0][1], "W1": sp.layers[1][0], "b1": sp.layers[1][1], "Wo": sp.Wo, "bo": sp.bo, "Wg": sp.Wg, "bg": sp.bg}
+        if sp.Wr is not None:
+            p["Wr"], p["br"] = sp.Wr, sp.br
+        field = orc.Field.variant({k: v.detach().cpu() for k, v in p.items()}, H, C, nl, vf, "matmul")
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        z0 = torch.from_numpy(coeffs[:, 0, :C]) @ sd["initial_linear.weight"].t() + sd["initial_linear.bias"]
+        ctl = orc.Control(coeffs, "cubic")
+        z = orc.dopri5_forward(ctl, field, z0, torch.arange(ctl.n_knots, dtype=torch.float32), 1e-3, 1e-5, {"min_step": 0.5})
+        want = z @ sd["final_linear.weight"].t() + sd["final_linear.bias"]
+        assert gu.relerr(out.detach().cpu().numpy(), want.numpy()) <= 2e-2
