@@ -181,6 +181,30 @@ __global__ __launch_bounds__(256, 1) void ncde_dpf_fwd(DpArgs d) {
     const float rtolf = (float)d.rtol, atolf = (float)d.atol;
     float mx = 0.0f;
 
+    // ---- dX/dt of every stage of the attempt: requested here, BEFORE the weight image (independent loads travel together), stored to
+    //      LDS [stage][sample][channel] after it
+    const int nst = phase == DP_STEP ? 6 : 1;
+    constexpr int EPQ = (6 * 16 * CP + NT - 1) / NT;
+    float qn[EPQ];
+#pragma unroll
+    for (int q = 0; q < EPQ; ++q) {
+        const int e = tid + q * NT;
+        const int j = e / (16 * CP), rem = e - j * (16 * CP), es = rem / CP, cc = rem - es * CP;
+        float v = 0.0f;
+        if (e < nst * 16 * CP && cc < Cr && b0 + es < a.B) {
+            const StageDesc sd = c->st[phase == DP_STEP ? j + 1 : 0];
+            const float* p = a.coeffs + (long long)(b0 + es) * a.cs_b + (long long)sd.idx * a.cs_t;
+            if (a.interp == NCDE_INTERP_LINEAR) {
+                v = p[a.cs_t + cc] - p[cc];
+                if (sd.kdt != 1.0f) v = v / sd.kdt;
+            } else {
+                const float bb = p[Cr + cc], c2 = p[2 * Cr + cc], dd = p[3 * Cr + cc];
+                const float inner = c2 + dd * sd.frac;
+                v = bb + inner * sd.frac;
+            }
+        }
+        qn[q] = v;
+    }
     // ---- weights -> split-bf16 A operands in registers, from the per-lane image ncde_dpf_pack wrote once per solve ----------------
     typedef SplitOps<0> SO;
     typedef typename SO::T SpT;
@@ -217,24 +241,11 @@ __global__ __launch_bounds__(256, 1) void ncde_dpf_fwd(DpArgs d) {
     }
 
     DPF_STAMP(1)
-    // ---- dX/dt of every stage of the attempt -> LDS [stage][sample][channel] ------------------------------------------------
-    const int nst = phase == DP_STEP ? 6 : 1;
-    for (int e = tid; e < nst * 16 * CP; e += NT) {
-        const int j = e / (16 * CP), rem = e - j * (16 * CP), es = rem / CP, cc = rem - es * CP;
-        float v = 0.0f;
-        if (cc < Cr && b0 + es < a.B) {
-            const StageDesc sd = c->st[phase == DP_STEP ? j + 1 : 0];
-            const float* p = a.coeffs + (long long)(b0 + es) * a.cs_b + (long long)sd.idx * a.cs_t;
-            if (a.interp == NCDE_INTERP_LINEAR) {
-                v = p[a.cs_t + cc] - p[cc];
-                if (sd.kdt != 1.0f) v = v / sd.kdt;
-            } else {
-                const float bb = p[Cr + cc], c2 = p[2 * Cr + cc], dd = p[3 * Cr + cc];
-                const float inner = c2 + dd * sd.frac;
-                v = bb + inner * sd.frac;
-            }
-        }
-        dxq[j][es * CP + cc] = v;
+    // ---- dX/dt -> LDS ----------------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < EPQ; ++q) {
+        const int e = tid + q * NT;
+        if (e < nst * 16 * CP) dxq[e / (16 * CP)][e % (16 * CP)] = qn[q];
     }
 
     // ---- state entries this lane owns: u = 4 (wave NB + nb) + g of sample s --------------------------------------------------
@@ -1396,6 +1407,9 @@ __global__ __launch_bounds__(256, 1) void ncde_dpf_tape(DpArgs d) {
     }
     double Tpart = 0.0, D1part = 0.0;      // per-thread partials of dL/d(t0 of the steps >= 2) and dL/d(dt_1)
     const int M = d.tape->n_steps;
+    float k1_later[NB];      // FSAL: k7 of step m IS k1 of step m + 1, evaluated one iteration ago (six evaluations per step, not seven)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) k1_later[nb] = 0.0f;
     __syncthreads();      // operand images
 
     for (int m = M - 1; m >= 0; --m) {
@@ -1430,9 +1444,10 @@ __global__ __launch_bounds__(256, 1) void ncde_dpf_tape(DpArgs d) {
         float y1[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) y1[nb] = 0.0f;
+        const int n_eval = m == M - 1 ? 7 : 6;      // the last step has no later step to take k7 from
 #pragma unroll 1
-        for (int i = 0; i < 7; ++i) {
-            if (i + 1 < 7) stage_load(i + 1);
+        for (int i = 0; i < n_eval; ++i) {
+            if (i + 1 < n_eval) stage_load(i + 1);
             stage(dpar, false);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
@@ -1447,11 +1462,19 @@ __global__ __launch_bounds__(256, 1) void ncde_dpf_tape(DpArgs d) {
                     ys[nb] = own[nb] ? y0[nb] + acc : 0.0f;
                     if (i == 5) y1[nb] = ys[nb];      // the input of the last stage = the step's solution
                 }
-                dpar ^= 1;
-                stage_store(dpar);
-                exchange();
+                if (i + 1 < n_eval) {
+                    dpar ^= 1;
+                    stage_store(dpar);
+                    exchange();
+                }
             }
         }
+        if (m < M - 1) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) kf[6][nb] = k1_later[nb];
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) k1_later[nb] = kf[0][nb];
         // ---- cotangents: FSAL, dense output, interpolation fit -----------------------------------------------------------------------
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -1596,7 +1619,10 @@ __global__ __launch_bounds__(256, 1) void ncde_dpf_tape(DpArgs d) {
 // Sum of the per-workgroup parameter-part partials, the parameter part of the mixed norm, and -- in the last workgroup -- the controller.
 // A block handles RED_EPB consecutive entries of the PARTIAL vector ([dWo in register order][parameter order], see ncde_dpf_adj); its
 // RED_NG thread groups each sum their share of the workgroups (fixed order, coalesced 256-byte rows), the quarters are combined in a fixed order.
-constexpr int RED_EPB = 128, RED_NG = 256 / RED_EPB;      // entries per block, groups of workgroups per block
+#ifndef NCDE_RED_EPB
+#define NCDE_RED_EPB 128
+#endif
+constexpr int RED_EPB = NCDE_RED_EPB, RED_NG = 256 / RED_EPB;      // entries per block, groups of workgroups per block
 extern "C" __global__ __launch_bounds__(256) void ncde_dpf_reduce(DpArgs d) {
     typedef DpaPack<32, 32, 20, 3> PK;
     __shared__ double sh[256];
@@ -1751,7 +1777,7 @@ const char* ncde_dpf_kernel_name(const NcdeProblem* p, int adj) {
 
 // fused adjoint: floats of one workgroup's partial vector (one weighted sum), and the number of blocks of ncde_dpf_reduce
 size_t ncde_dpf_partial_floats(const NcdeProblem* p, int theta1) { return ncde_dpf_supported(p, 1) ? (size_t)Dpa32::WOT + (size_t)theta1 : (size_t)theta1; }
-int ncde_dpf_reduce_blocks(const NcdeProblem* p, int theta1) { return (int)((ncde_dpf_partial_floats(p, theta1) + 127) / 128); }      // RED_EPB
+int ncde_dpf_reduce_blocks(const NcdeProblem* p, int theta1) { return (int)((ncde_dpf_partial_floats(p, theta1) + NCDE_RED_EPB - 1) / NCDE_RED_EPB); }
 
 size_t ncde_dpf_pack_floats(const NcdeProblem* p, int adj) {
     if (!ncde_dpf_supported(p, adj)) return 0;

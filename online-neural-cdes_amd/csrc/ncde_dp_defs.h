@@ -218,32 +218,43 @@ __device__ double dp_theta_norm(const DpArgs& d, int which, float dtf, double* s
 
 
 // the same from the per-block, per-segment sums ncde_dpf_reduce left (slot 0 / 1: the first / second norm of the phase)
-__device__ double dp_theta_norm_fused(const DpArgs& d, int slot, double* sh) {      // (256 threads; sh: >= 4 * 8 doubles)
+// ... in two halves, so that the controller can have these loads in flight together with those of the y / a partial sums: the per-thread
+// sums over the reduce blocks (dp_theta_norm_load, up to eight segments), then the exchange (dp_theta_norm_combine)
+__device__ __forceinline__ void dp_theta_norm_load(const DpArgs& d, int slot, int s0, double (&acc)[8]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.0;
+    for (int b = tid; b < d.n_rblk; b += 256) {
+        const double* row = d.SEGP + ((long long)b * 2 + slot) * (DP_MAXSEG + 1) + s0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (s0 + i <= d.nseg) acc[i] += __hip_atomic_load(&row[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ double dp_theta_norm_combine(const DpArgs& d, int s0, const double (&acc)[8], double* sh) {      // (256 threads; sh: >= 32 doubles)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double best = 0.0;
-    for (int s0 = 0; s0 <= d.nseg; s0 += 8) {      // eight segments per pass: per-thread sums over the reduce blocks, one exchange
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double w = dp_wave_sum(acc[i]);
+        if (lane == 0) sh[wave * 8 + i] = w;
+    }
+    __syncthreads();
+    for (int i = 0; i < 8 && s0 + i <= d.nseg; ++i) {
+        const int sg = s0 + i;
+        const double tot = (sh[i] + sh[8 + i]) + (sh[16 + i] + sh[24 + i]);
+        best = fmax(best, sg < d.nseg ? sqrt(tot / (double)d.seg_len[sg]) : sqrt(tot));
+    }
+    __syncthreads();
+    return best;
+}
+__device__ double dp_theta_norm_fused(const DpArgs& d, int slot, double* sh) {
+    double best = 0.0;
+    for (int s0 = 0; s0 <= d.nseg; s0 += 8) {      // eight segments per pass
         double acc[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = 0.0;
-        for (int b = tid; b < d.n_rblk; b += 256) {
-            const double* row = d.SEGP + ((long long)b * 2 + slot) * (DP_MAXSEG + 1) + s0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (s0 + i <= d.nseg) acc[i] += __hip_atomic_load(&row[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const double w = dp_wave_sum(acc[i]);
-            if (lane == 0) sh[wave * 8 + i] = w;
-        }
-        __syncthreads();
-        for (int i = 0; i < 8 && s0 + i <= d.nseg; ++i) {
-            const int sg = s0 + i;
-            const double tot = (sh[i] + sh[8 + i]) + (sh[16 + i] + sh[24 + i]);
-            best = fmax(best, sg < d.nseg ? sqrt(tot / (double)d.seg_len[sg]) : sqrt(tot));
-        }
-        __syncthreads();
+        dp_theta_norm_load(d, slot, s0, acc);
+        best = fmax(best, dp_theta_norm_combine(d, s0, acc, sh));
     }
     return best;
 }
@@ -281,6 +292,13 @@ __device__ void dp_control_body(const DpArgs& d, double* sh, int* sh_flags, floa
     double p[4] = {0, 0, 0, 0};
     for (int w = tid; w < d.n_wg; w += 256)      // (agent-scope loads: in a fused launch other workgroups of THIS launch wrote them)
         for (int q = 0; q < 4; ++q) p[q] += __hip_atomic_load(&d.PN[(long long)w * 4 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // fused adjoint: the parameter part's per-block sums, requested now so that both sets of write-through data travel together
+    const bool seg_pre = d.fused && d.adj && d.nseg < 8;
+    double seg0[8], seg1[8];
+    if (seg_pre) {
+        dp_theta_norm_load(d, 0, 0, seg0);
+        if (phase == DP_INIT0) dp_theta_norm_load(d, 1, 0, seg1);
+    }
     double tot[4];
     for (int q = 0; q < 4; ++q) tot[q] = dp_block_sum(p[q], sh);
     const double nel = (double)d.a.B * (double)d.a.H;
@@ -291,8 +309,8 @@ __device__ void dp_control_body(const DpArgs& d, double* sh, int* sh_flags, floa
         if (d.adj) {
             d0 = fmax(d0, sqrt(tot[1] / nel));
             d1 = fmax(d1, sqrt(tot[3] / nel));
-            d0 = fmax(d0, d.fused ? dp_theta_norm_fused(d, 0, sh) : dp_theta_norm(d, 0, dtf, sh));
-            d1 = fmax(d1, d.fused ? dp_theta_norm_fused(d, 1, sh) : dp_theta_norm(d, 1, dtf, sh));
+            d0 = fmax(d0, seg_pre ? dp_theta_norm_combine(d, 0, seg0, sh) : (d.fused ? dp_theta_norm_fused(d, 0, sh) : dp_theta_norm(d, 0, dtf, sh)));
+            d1 = fmax(d1, seg_pre ? dp_theta_norm_combine(d, 0, seg1, sh) : (d.fused ? dp_theta_norm_fused(d, 1, sh) : dp_theta_norm(d, 1, dtf, sh)));
         }
         if (tid == 0) {
             const float d0f = (float)d0, d1f = (float)d1;
@@ -326,7 +344,7 @@ __device__ void dp_control_body(const DpArgs& d, double* sh, int* sh_flags, floa
         double s2 = sqrt(tot[0] / nel);
         if (d.adj) {
             s2 = fmax(s2, sqrt(tot[1] / nel));
-            s2 = fmax(s2, d.fused ? dp_theta_norm_fused(d, 0, sh) : dp_theta_norm(d, 2, dtf, sh));
+            s2 = fmax(s2, seg_pre ? dp_theta_norm_combine(d, 0, seg0, sh) : (d.fused ? dp_theta_norm_fused(d, 0, sh) : dp_theta_norm(d, 2, dtf, sh)));
         }
         if (tid == 0) {
             const float h0 = c->h0, d1f = (float)c->h0d;
@@ -351,7 +369,7 @@ __device__ void dp_control_body(const DpArgs& d, double* sh, int* sh_flags, floa
     double ratio = sqrt(tot[0] / nel);
     if (d.adj) {
         ratio = fmax(ratio, sqrt(tot[1] / nel));
-        ratio = fmax(ratio, d.fused ? dp_theta_norm_fused(d, 0, sh) : dp_theta_norm(d, 3, dtf, sh));
+        ratio = fmax(ratio, seg_pre ? dp_theta_norm_combine(d, 0, seg0, sh) : (d.fused ? dp_theta_norm_fused(d, 0, sh) : dp_theta_norm(d, 3, dtf, sh)));
     }
     if (tid == 0) {
         const float ratiof = (float)ratio;
