@@ -253,7 +253,7 @@ class Workload:
 def _pmc_summary(config, B_local):
     """The committed rocprofv3 PMC summary of this config (bench.py cannot run the profiler on itself) -- only if it was taken on
     exactly the kernel sources this library is built from (fingerprint) and on this workload; otherwise None."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_%s_summary.json" % (rnd, config))
         try:
             with open(path) as fh:
@@ -280,8 +280,12 @@ def pmc_pass(name, config, B_local):
     if len(recs) != len(bases) or not all("hbm_read_MB_per_pass_corrected_x2" in r for r in recs):
         return None
     dom = max(recs, key=lambda r: r.get("SQ_WAVE_CYCLES", 0.0) * r.get("launches_per_pass", 1.0))
+    per_pass = lambda key: sum(r.get(key, 0.0) * r.get("launches_per_pass", 1.0) for r in recs)      # noqa: E731
     return {"traffic": round(sum(r["hbm_read_MB_per_pass_corrected_x2"] + r.get("hbm_write_MB_per_pass", 0.0) for r in recs) * 1e6),
             "launches_per_pass": {b: r.get("launches_per_pass") for b, r in zip(bases, recs)},
+            # dynamic instruction counters, summed over every launch of a pass (all waves of the chip)
+            "mfma_busy_cycles": per_pass("SQ_VALU_MFMA_BUSY_CYCLES"), "insts_mfma": per_pass("SQ_INSTS_MFMA"),
+            "insts_valu": per_pass("SQ_INSTS_VALU") if all("SQ_INSTS_VALU" in r for r in recs) else None,
             "mfma_busy": round(dom["MfmaUtil_pct"] / 100.0, 4) if "MfmaUtil_pct" in dom else None,
             "valu_active": round(dom["VALU_active_frac_of_wave_cycles"], 4) if "VALU_active_frac_of_wave_cycles" in dom else None,
             "wait": round(dom["wait_frac_of_wave_cycles"], 4) if "wait_frac_of_wave_cycles" in dom else None,
@@ -324,6 +328,35 @@ def dtype_note(names):
     return "fp32 throughout (fp32-input MFMA)"
 
 
+N_SIMD = 256 * 4
+CLOCK_HZ = 2.4e9
+_CENSUS_EXPECT = {"cfg2.forward": "ncde_fwd_fast_bf3<H32,HH32,C20,NW4,fp16x2>", "cfg2.backward": "ncde_adj_fast3<",
+                  "cfg4.forward": "ncde_fwd_fast_bf3<H64,HH64,C4,NW4,fp16x2>", "cfg4.backward": "ncde_adj_h64<H64,HH64,NS1"}
+
+
+def isa_census(config, which, name, B_local):
+    """Static ISA census of the dispatched kernel (tools/isa_census.py: instruction counts by issue class inside the step loop of the
+    built code object -> `valu_ceiling_ms`, `mfma_ceiling_ms`, `issue_ceiling_ms`), run LIVE on the objects this library was linked
+    from; None for kernels it has no loop model for (the batch-tiled family: data-dependent loop nests) or another batch."""
+    key = "%s.%s" % (config, which)
+    if key not in _CENSUS_EXPECT or not name.startswith(_CENSUS_EXPECT[key]) or B_local != CONFIGS[config]["B"]:
+        return None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import isa_census as ic
+        return ic.census_for([key])[key]
+    except Exception as e:      # no llvm-objdump / objects on this box: the committed census, if it is of these sources
+        try:
+            with open(os.path.join(ROOT, "profiles", "r05_isa_census.json")) as fh:
+                j = json.load(fh)
+            if j.get("_meta", {}).get("source_fingerprint") == _lib.source_fingerprint():
+                return j.get(key)
+        except (OSError, ValueError):
+            pass
+        sys.stderr.write("isa census unavailable for %s: %r\n" % (key, e))
+        return None
+
+
 def rooflines(model, c, coeffs, config, B_local, T):
     """(forward, backward) roofline records from HIP-event kernel times measured here + the committed PMC traffic."""
     ms_fwd, ms_adj, names = time_kernels(model, c, coeffs)
@@ -337,29 +370,68 @@ def rooflines(model, c, coeffs, config, B_local, T):
     def roof(ms, flops, nbytes, name, backward):
         tf_s = flops * steps_per_launch / (ms * 1e-3) / 1e12
         pm = pmc_pass(name, config, B_local)
+        cen = isa_census(config, "backward" if backward else "forward", name, B_local)
         pipe_peak, pipe_note = issued_pipe_peak(name, backward)
         alg = nbytes * steps_per_launch
-        # which unit the counters say the kernel is waiting on: the fp32 peak below is the contract's convention for `frac`
-        # (algorithmic fp32 flops / fp32 MFMA-vector peak), not a statement that the matrix pipe is the limiter
-        bound = "unmeasured"
+        trans_ms = tanh_per_step * steps_per_launch / TRANS_PER_S * 1e3
+        # ---- ceilings: the least time each unit needs for THIS kernel's instruction stream / bytes (floors on ms_per_launch) -------
+        # matrix pipe: busy cycles the SQ counted (dynamic: skipped branches are not in it) / 1024 SIMDs, else the static census
+        ceil = {"hbm": alg / (PEAK_HBM_GBS * 1e9) * 1e3}
+        src = {"hbm": "algorithmic bytes / 8 TB/s"}
+        if pm is not None and pm.get("mfma_busy_cycles"):
+            ceil["mfma"] = pm["mfma_busy_cycles"] / N_SIMD / CLOCK_HZ * 1e3
+            src["mfma"] = "SQ_VALU_MFMA_BUSY_CYCLES per pass / 1024 SIMDs / 2.4 GHz (%s)" % pm["source"]
+        elif cen is not None:
+            ceil["mfma"] = cen["mfma_ceiling_ms"]
+            src["mfma"] = "static ISA census (tools/isa_census.py): MFMAs in the step loop x their pipe cycles"
+        if cen is not None:
+            ceil["valu"] = cen["valu_ceiling_ms"]
+            ceil["issue"] = cen["issue_ceiling_ms"]
+            src["valu"] = "static ISA census: VALU 2 / packed-fp32 4 / transcendental 8 cycles per wave64 instruction, per SIMD"
+            src["issue"] = "static ISA census: every instruction of the longest wave x its 4-cycle issue slot"
+        elif pm is not None and pm.get("insts_valu"):
+            # dynamic: VALU instructions (all waves, MFMAs excluded) at 2 cycles + the quarter-rate surcharge of the tanh work
+            ceil["valu"] = (pm["insts_valu"] - (pm.get("insts_mfma") or 0.0)) * 2.0 / N_SIMD / CLOCK_HZ * 1e3 + 0.75 * trans_ms
+            src["valu"] = "SQ_INSTS_VALU - SQ_INSTS_MFMA per pass x 2 cycles / 1024 SIMDs + the transcendentals' quarter-rate surcharge"
+        # ---- which unit the counters show busiest; `wait` above it = the waves stall more than any unit works ----------------------
+        bound, stalled, busy = "unmeasured", None, {}
         if pm is not None and pm["mfma_busy"] is not None and pm["valu_active"] is not None:
-            if pm["traffic"] / (ms * 1e-3) / 1e9 > 0.5 * PEAK_HBM_GBS:
-                bound = "hbm"
-            else:
-                bound = "mfma" if pm["mfma_busy"] >= pm["valu_active"] else "valu"
-        r = {"bound": bound, "kernel": name, "achieved": round(tf_s, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-             "frac": round(tf_s / PEAK_FP32_TFLOPS, 4), "traffic": pm["traffic"] if pm else None,
+            busy = {"mfma": pm["mfma_busy"], "valu": pm["valu_active"], "hbm": pm["traffic"] / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+            bound = max(busy, key=busy.get)
+            stalled = pm["wait"] is not None and pm["wait"] > busy[bound]
+        elif "valu" in ceil and "mfma" in ceil:
+            bound = max(("mfma", "valu", "hbm"), key=lambda k: ceil[k])
+        frac = peak = None
+        if bound in ceil:
+            frac = min(ceil[bound] / ms, 1.0)
+            peak = tf_s / frac if frac > 0 else None
+        r = {"bound": bound, "kernel": name, "achieved": round(tf_s, 3), "peak": round(peak, 3) if peak else None, "unit": "TFLOP/s",
+             "frac": round(frac, 4) if frac is not None else None,
+             "traffic": pm["traffic"] if pm else None,
              "traffic_ratio": round(pm["traffic"] / alg, 3) if pm else None,
              "algorithmic_bytes_per_launch": alg, "ms_per_launch": round(ms, 4),
-             "hbm_algorithmic_GBs": round(alg / (ms * 1e-3) / 1e9, 2),
-             "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6),
+             "ceilings_ms": {k: round(v, 4) for k, v in ceil.items()},
+             "valu_ceiling_ms": round(ceil["valu"], 4) if "valu" in ceil else None,
+             "mfma_ceiling_ms": round(ceil["mfma"], 4) if "mfma" in ceil else None,
+             "issue_ceiling_ms": round(ceil["issue"], 4) if "issue" in ceil else None,
+             "tanh_ceiling_ms": round(trans_ms, 4),
+             "frac_of_issue_ceiling": round(min(ceil["issue"] / ms, 1.0), 4) if "issue" in ceil else None,
+             "ceiling_sources": src,
+             "stalled": stalled,
+             "busy": {k: round(v, 4) for k, v in busy.items()} if busy else None,
              "mfma_busy": pm["mfma_busy"] if pm else None, "valu_active": pm["valu_active"] if pm else None,
              "wait": pm["wait"] if pm else None,
-             "tanh_ceiling_ms": round(tanh_per_step * steps_per_launch / TRANS_PER_S * 1e3, 4),
-             "issued_pipe": pipe_note, "issued_pipe_peak": round(pipe_peak, 1), "frac_of_issued_pipe": round(tf_s / pipe_peak, 4),
-             "bound_note": "`frac` prices algorithmic fp32 flops against the fp32 MFMA/vector peak (SURVEY.md section 8d); `bound` is the "
-                           "unit the SQ counters show busiest (valu = VALU + transcendental issue), `frac_of_issued_pipe` the same flops "
-                           "against the matrix pipe the kernel really issues on"}
+             "hbm_algorithmic_GBs": round(alg / (ms * 1e-3) / 1e9, 2),
+             "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6),
+             "x_fp32_peak": round(tf_s / PEAK_FP32_TFLOPS, 4), "fp32_peak": PEAK_FP32_TFLOPS,
+             "issued_pipe": pipe_note, "issued_pipe_peak": round(pipe_peak, 1), "frac_of_issued_pipe": round(min(tf_s / pipe_peak, 1.0), 4),
+             "bound_note": "`bound` = the unit the SQ / TCC counters show busiest (mfma: matrix-pipe busy cycles, valu: VALU + transcendental "
+                           "issue, hbm: counter bytes against 8 TB/s); `frac` = that unit's ceiling for this kernel's own instruction "
+                           "stream / bytes (`ceilings_ms`) over the measured ms_per_launch, never above 1; `peak` = achieved / frac = the "
+                           "algorithmic TFLOP/s the kernel would deliver with that unit saturated; `stalled` = the waves wait "
+                           "(SQ_WAIT_INST_ANY) more than the busiest unit works: latency-, not throughput-bound; `x_fp32_peak` = the same "
+                           "algorithmic fp32 flops as MULTIPLES of the 157.3 TFLOP/s fp32 MFMA / vector peak (SURVEY.md section 8d "
+                           "convention; above 1 where the arithmetic runs as split-fp16 on the 2.5 PF pipe)"}
         if pm is not None:
             r["traffic_unit"] = "HBM bytes per pass, summed over all launches of all kernels of the pass (rocprofv3 PMC passes on these kernel sources, %s)" % pm["source"]
             r["launches_per_pass"] = pm["launches_per_pass"]

@@ -72,6 +72,9 @@ typedef enum NcdeOutput { NCDE_OUT_INTERVAL = 0, NCDE_OUT_KNOTS = 1, NCDE_OUT_TI
 #define NCDE_FLAG_ADJOINT_SPLIT_FP16 128u /* development builds (-DNCDE_DEV_KNOBS) only, ignored otherwise: split-fp16 GEMMs on the cotangent
                                        side of the specialised adjoint too (not reproducible run to run) */
 #define NCDE_FLAG_DEBUG_PROFILE 0x100u /* development: instrumented kernel variant, cycle counters land in the workspace */
+#define NCDE_FLAG_NO_COOP 0x400u       /* batch-tiled backward: do not use the XCD-cooperative, weight-stationary output phase (round 5, large
+                                          hidden sizes: workgroups of one launch exchange activations through L2 and spin on each other --
+                                          it needs every workgroup resident, i.e. the GPU's CUs not held by another process's persistent kernel) */
 #define NCDE_FLAG_TILED_NS1 0x1000u    /* batch-tiled forward: force 1 / 2 / 4 sixteen-sample tiles per workgroup     */
 #define NCDE_FLAG_TILED_NS2 0x2000u    /*   (default: the largest that still gives >= 256 workgroups)                 */
 #define NCDE_FLAG_TILED_NS4 0x4000u
@@ -142,7 +145,7 @@ typedef struct NcdeProblem {
     int32_t n_t_out;
     int32_t n_steps_fwd;
     int32_t n_steps_adj;
-    int32_t reserved_;
+    int32_t reserved_;      /* padding; NOT an input -- the library ignores whatever the caller leaves here (it is zeroed on entry) */
 } NcdeProblem;
 
 typedef enum NcdeFieldKind { NCDE_FIELD_ORIGINAL = 0, NCDE_FIELD_MINIMAL = 1, NCDE_FIELD_GRU = 2 } NcdeFieldKind;
@@ -229,7 +232,8 @@ int64_t ncde_dopri5_workspace_bytes(const NcdeProblem* p, const NcdeTimeSpec* ts
 /* Which kernels a dopri5 call of this problem runs (static string; NULL + last error if the problem is not supported): the fused
  * attempt kernels of round 4 -- one launch per attempt for the forward solve ("ncde_dpf_fwd<...>": hidden, hidden_hidden <= 32 with
  * C <= 20, or <= 64 with C <= 4), an attempt + a reduce launch for the adjoint ("ncde_dpf_adj<...> + ncde_dpf_reduce") and the persistent
- * reverse sweep of a taped solve ("ncde_dpf_tape<...>"; both: the (32, 32, 20) set, <= 3 layers) -- or the per-launch kernels
+ * reverse sweep of a taped solve ("ncde_dpf_tape<...>"; both: the (32, 32, 20) set, <= 3 layers -- a fourth layer's LDS images do
+ * not fit 160 KB, so the library caps n_layers at 3 there) -- or the per-launch kernels
  * ("ncde_dp_stage x 6 + ncde_dp_control + ncde_dp_commit", "ncde_dp_tape_backward") for every other shape and under
  * NCDE_FLAG_FORCE_GENERIC. */
 const char* ncde_dopri5_kernel_name(const NcdeProblem* p, int pass /* 0 forward, 1 adjoint, 2 taped backward */);

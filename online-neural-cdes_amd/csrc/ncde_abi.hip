@@ -49,6 +49,9 @@ int normalize(const NcdeProblem* in, NcdeProblem* out) {
     // input, default time axis)
     memcpy(out, in, in->abi_version >= 3 ? sizeof(NcdeProblem) : (in->abi_version == 2 ? offsetof(NcdeProblem, time_plan) : offsetof(NcdeProblem, field_kind)));
     out->abi_version = NCDE_ABI_VERSION;
+    // reserved_ is NOT an input: whatever the caller left there (an uninitialised stack struct, say) is dropped.  Internally the
+    // field carries the real extents of a zero-padded problem, and only make_pad_plan() -- after this point -- ever sets it.
+    out->reserved_ = 0;
     return NCDE_OK;
 }
 

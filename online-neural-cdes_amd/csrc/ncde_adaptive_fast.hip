@@ -1758,14 +1758,14 @@ size_t dpa_lds_bytes(int nl) {
 }
 template <int NL>
 DpfKernel dpa_kernel() { return (DpfKernel)ncde_dpf_adj<32, 32, 20, NL>; }
-DpfKernel dpa_pick(int nl) { return nl == 1 ? dpa_kernel<1>() : (nl == 2 ? dpa_kernel<2>() : (nl == 3 ? dpa_kernel<3>() : (nl == 4 ? dpa_kernel<4>() : nullptr))); }
+DpfKernel dpa_pick(int nl) { return nl == 1 ? dpa_kernel<1>() : (nl == 2 ? dpa_kernel<2>() : (nl == 3 ? dpa_kernel<3>() : nullptr)); }      // (NL = 4 does not fit the 160 KB of LDS)
 }  // namespace
 
 bool ncde_dpf_supported(const NcdeProblem* p, int adj) {
     if (p->flags & NCDE_FLAG_FORCE_GENERIC) return false;
     const int sh = dpf_shape(p);
     if (adj == 0) return sh != 0;
-    if (adj == 1) return sh == 1 && p->n_layers <= 4 && dpa_lds_bytes(p->n_layers) + 512 <= 160 * 1024;      // (32, 32, 20) set only; 512 B: static LDS
+    if (adj == 1) return sh == 1 && p->n_layers <= 3 && dpa_lds_bytes(p->n_layers) + 512 <= 160 * 1024;      // (32, 32, 20) set, <= 3 layers (include/ncde_hip.h); 512 B: static LDS
     return false;
 }
 
@@ -1811,7 +1811,7 @@ int ncde_dpf_tape_launch(const NcdeProblem* p, const void* dp_args, size_t dp_ar
     memcpy(&d, dp_args, sizeof(d));
     const int nl = p->n_layers;
     const DpfKernel k = nl == 1 ? (DpfKernel)ncde_dpf_tape<32, 32, 20, 1> : (nl == 2 ? (DpfKernel)ncde_dpf_tape<32, 32, 20, 2>
-                      : (nl == 3 ? (DpfKernel)ncde_dpf_tape<32, 32, 20, 3> : (DpfKernel)ncde_dpf_tape<32, 32, 20, 4>));
+                                                                             : (DpfKernel)ncde_dpf_tape<32, 32, 20, 3>);      // nl <= 3 (ncde_dpf_supported)
     const size_t lds = dpa_lds_bytes(nl);
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NCDE_ERR_HIP;
     hipLaunchKernelGGL((ncde_dpa_pack<32, 32, 20, 3>), dim3(1), dim3(256), 0, st, d);

@@ -72,6 +72,13 @@ struct KArgs {
     // grad_z0 / the stage record (units >= Hr are not read or written; they stay exactly 0), Cc = channels of the coefficient
     // tensor (channels >= Cc have dX/dt = X = 0).  Unpadded: Hr = H, Cc = C.
     int Hr, Cc;
+    // XCD-cooperative output phase of the batch-tiled sweep (ncde_coop.h): packed register images of Wo per group member, the
+    // inter-workgroup exchange area, the group counters + abort word, {sw, 1/sw}, members per group, number of groups
+    const unsigned* coop_img;
+    float* coop_x;
+    unsigned* coop_sync;
+    const float* coop_scale;
+    int coop_M, coop_G;
 };
 
 // ---- time plan (built on the host by ncde_time_plan_build, csrc/ncde_timeplan.hip; layout in 4-byte words) -------------

@@ -3,8 +3,11 @@ backed by the fused HIP kernels behind the C-ABI of include/ncde_hip.h.
 
 What the reference does per call -- wrap (X, func) in a vector field, hand it to torchdiffeq's Python
 time loop (solvers.py:94-119) and, for the backward pass, to OdeintAdjointMethod (adjoint.py:37-145)
--- happens here in ONE kernel launch per direction.  There is no unfused or CPU fallback: a request
-outside the fused path raises NotImplementedError naming the reason.
+-- happens here in ONE kernel launch per direction.  There is no CPU fallback.  What the fused kernels do
+not cover but the reference accepts (an arbitrary ``func``, decreasing output times, gradients of the control
+path or of ``t``, non-fp32 tensors, shapes no fused kernel exists for -- hidden widths beyond 128 in training)
+runs on the package's own UNFUSED torch-op solver on the GPU (unfused.py) behind a one-time UserWarning naming
+the reason; what neither path covers raises NotImplementedError.
 """
 import ctypes
 import warnings
@@ -51,9 +54,8 @@ class FieldSpec:
 def _field_spec(func):
     if hasattr(func, "fused_spec"):
         return func.fused_spec()
-    raise NotImplementedError(
-        "cdeint: `func` must expose fused_spec() (e.g. ncde_amd.OriginalVectorField or ncde_amd.MLPField); "
-        "arbitrary Python vector fields are outside the fused MI355X path")
+    raise NotImplementedError(      # (not reached from cdeint: a func without fused_spec() is routed to the unfused solver)
+        "a fused kernel call needs `func` to expose fused_spec() (e.g. ncde_amd.OriginalVectorField or ncde_amd.MLPField)")
 
 
 def _unfused_reason(X, func, z0, t, adjoint, adjoint_params, method=None):
@@ -67,9 +69,12 @@ def _unfused_reason(X, func, z0, t, adjoint, adjoint_params, method=None):
         spec = func.fused_spec()
         if spec.kind != "original" or spec.mode != "matmul":
             return "method='dopri5' with a gated vector field or the evaluate / derivative input"
-    tt = torch.as_tensor(t)
-    if tt.dim() == 1 and tt.numel() >= 2 and bool(tt[0] > tt[1]):
-        return "decreasing output times"
+    # decreasing output times?  X.interval / X.grid_points are tagged and known to increase: no device sync for them
+    # (ADVICE round 4); any other tensor is copied to the host ONCE (_host_times, shared with _time_mode / _time_plan).
+    if not _is_tagged_time(X, t):
+        tv = _host_times(t)
+        if tv.dim() == 1 and tv.numel() >= 2 and bool(tv[0] > tv[1]):
+            return "decreasing output times"
     if torch.is_tensor(t) and t.requires_grad:
         return "the output times require gradients"
     ap = set(id(q) for q in adjoint_params) if adjoint_params is not None else set()
@@ -81,14 +86,34 @@ def _unfused_reason(X, func, z0, t, adjoint, adjoint_params, method=None):
     return None
 
 
+def _is_tagged_time(X, t):
+    """True for X's own interval / grid_points tensors (tagged by interpolation.py; a weakref, so a recycled id() of a dead
+    control can never match): their values are known without looking at the device."""
+    kind = getattr(t, "_ncde_kind", None)
+    owner = getattr(t, "_ncde_owner", None)
+    return kind is not None and owner is not None and owner() is X and t.numel() == (X.n_knots if kind == "knots" else 2)
+
+
+def _host_times(t):
+    """Host copy (fp64) of the output times: at most ONE device-to-host copy per tensor version, kept on the tensor object."""
+    if not torch.is_tensor(t):
+        return torch.as_tensor(t).detach().double()
+    hit = getattr(t, "_ncde_host", None)
+    if hit is not None and hit[0] == t._version:
+        return hit[1]
+    tv = t.detach().cpu().double()
+    try:
+        t._ncde_host = (t._version, tv)
+    except Exception:      # (a tensor subclass that refuses attributes)
+        pass
+    return tv
+
+
 def _time_mode(X, t):
     """-> _lib.OUT_INTERVAL / OUT_KNOTS.  Tagged tensors from X.interval / X.grid_points avoid a device sync."""
-    kind = getattr(t, "_ncde_kind", None)
-    owner = getattr(t, "_ncde_owner", None)      # a weakref: a recycled id() of a dead control can never match
-    if X._default_grid and kind is not None and owner is not None and owner() is X and \
-            t.numel() == (X.n_knots if kind == "knots" else 2):     # a control on a user knot grid always takes the time plan
-        return _lib.OUT_KNOTS if kind == "knots" else _lib.OUT_INTERVAL
-    tv = torch.as_tensor(t).detach().cpu().double()
+    if X._default_grid and _is_tagged_time(X, t):     # a control on a user knot grid always takes the time plan
+        return _lib.OUT_KNOTS if t._ncde_kind == "knots" else _lib.OUT_INTERVAL
+    tv = _host_times(t)
     assert tv.dim() == 1, "t must be one dimensional"
     assert (tv[1:] > tv[:-1]).all(), "t must be strictly increasing or decreasing"  # misc.py:336-343
     n = X.n_knots
@@ -108,7 +133,7 @@ def _time_plan(X, t, method, step, device):
     reference's grid / stage-time / knot-index arithmetic on the host (solvers.py:78-87, 103-117; one device sync for t)."""
     tt = torch.as_tensor(t).detach()
     f64 = tt.dtype == torch.float64
-    tv = np.ascontiguousarray(tt.cpu().double().numpy())
+    tv = np.ascontiguousarray(_host_times(t).numpy())
     kn = None if X._default_grid else np.ascontiguousarray(X._t.detach().cpu().double().numpy())
     key = (method, float(step), tv.tobytes(), f64, None if kn is None else kn.tobytes(), X.n_knots, str(device))
     hit = _PLAN_CACHE.get(key)
@@ -239,7 +264,7 @@ class _FusedCdeint(torch.autograd.Function):
         else:
             n_out = coeffs.shape[1] + (1 if cfg["interp"] == "cubic" else 0) if cfg["output"] == _lib.OUT_KNOTS else 2
         out = torch.empty(z0.shape[0], n_out, z0.shape[1], dtype=torch.float32, device=z0.device)
-        record = (not cfg["adjoint"]) and any(ctx.needs_input_grad)
+        record = (not cfg["adjoint"]) and cfg.get("needs_grad", True) and any(ctx.needs_input_grad)
         stages = None
         with torch.cuda.device(z0.device):   # the C-ABI launches on the calling thread's current device / stream
             ws = _workspace(p, 0, z0.device)
@@ -424,7 +449,7 @@ class _FusedDopri5Taped(torch.autograd.Function):
         lib = _lib.lib()
         stats = _lib.NcdeAdaptiveStats()
         # nothing to differentiate (torch.no_grad(), frozen inputs): the plain solve, no step record at all
-        taped = any(ctx.needs_input_grad)
+        taped = cfg.get("needs_grad", True) and any(ctx.needs_input_grad)
         rec = None
         with torch.cuda.device(z0.device):
             need = _lib.check(lib.ncde_dopri5_workspace_bytes(ctypes.byref(p), ctypes.byref(ad.ts), 0), "ncde_dopri5_workspace_bytes")
@@ -491,14 +516,72 @@ _DOPRI5_OPTIONS = ("min_step", "max_step", "first_step", "safety", "ifactor", "d
                    "_record_bytes")      # _record_bytes: initial size of the step record of adjoint=False (default: the library's estimate)
 
 
+def _run_unfused(reason, X, func, z0, t, adjoint, vector_field_type, method, options, adjoint_params, rtol, atol, adjoint_rtol,
+                 adjoint_atol, adjoint_options):
+    """Outside the fused kernels: the own unfused torch-op solver, same algorithms (unfused.py), on the tensors' device."""
+    from . import unfused
+    options = dict(options)
+    if not z0.is_cuda:
+        raise NotImplementedError("cdeint needs tensors on the GPU (there is no CPU fallback); z0 is on %s" % z0.device)
+    adaptive_cfg = None
+    if method == "dopri5":      # adaptive dopri5 on the unfused path too (same options as the fused one)
+        if options.pop("norm", None) is not None:
+            raise NotImplementedError("a custom error norm is not supported (the reference's rms / mixed norms are built in)")
+        aopt = {k: options.pop(k) for k in list(options) if k in _DOPRI5_OPTIONS and not k.startswith("_")}
+        for k in [k for k in options if k.startswith("_")]:
+            options.pop(k)
+        bopt = dict(aopt) if adjoint_options is None else {k: v for k, v in adjoint_options.items() if k in _DOPRI5_OPTIONS and not k.startswith("_")}
+        adaptive_cfg = {"rtol": rtol, "atol": atol, "options": aopt, "adjoint_rtol": rtol if adjoint_rtol is None else adjoint_rtol,
+                        "adjoint_atol": atol if adjoint_atol is None else adjoint_atol, "adjoint_options": bopt}
+    step = options.pop("step_size", None)
+    if "grid_constructor" in options:
+        raise NotImplementedError("options['grid_constructor'] is not supported; give options={'step_size': h}")
+    options.pop("perturb", None)
+    for k in options:
+        warnings.warn("cdeint: Unexpected arguments {}".format({k: options[k]}))
+    if adjoint:
+        ids = set(id(q) for q in adjoint_params) if adjoint_params is not None else set()
+        for buffer in X.buffers():
+            if buffer.requires_grad and id(buffer) not in ids:      # the reference's warning (solver.py:207-221)
+                warnings.warn("One of the inputs to the control path X requires gradients but is not listed in "
+                              "`options['adjoint_params']`. It will not receive a gradient when using the adjoint method.")
+    unfused.warn_once(reason)
+    if torch.is_tensor(step):
+        step = step.item()
+    return unfused.cdeint_unfused(X, func, z0, t, adjoint, vector_field_type, method, step, adjoint_params, adaptive_cfg)
+
+
+def _no_kernel_reason(p, passes, dopri5_ts=None):
+    """None if the library has a fused kernel for every pass in `passes` (0 forward, 1 continuous adjoint, 2 exact discrete
+    backward) of problem `p`, else a sentence naming the shape.  Asked BEFORE the forward runs: a model
+    the reference trains -- hidden_dim up to 256, hidden_hidden_dim up to 196, configurations.json5:34-35 -- must not pass its
+    forward and then fail inside loss.backward()."""
+    lib = _lib.lib()
+    for ps in passes:
+        if dopri5_ts is not None:
+            rc = lib.ncde_dopri5_workspace_bytes(ctypes.byref(p), ctypes.byref(dopri5_ts), ps)
+        else:
+            rc = lib.ncde_workspace_bytes(ctypes.byref(p), ps)
+        if rc == -2:      # NCDE_ERR_UNSUPPORTED (anything else is reported by the call itself)
+            what = ("forward", "continuous adjoint", "exact discrete backward")[ps]
+            widths = [int(p.layer_out[l]) for l in range(p.n_layers)]
+            return "no fused %s kernel for hidden=%d, layer widths %s, channels=%d: %s" % (
+                what, p.hidden, widths, p.channels, (lib.ncde_last_error_string() or b"").decode())
+    return None
+
+
 def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
     r"""Solve ``z_t = z_{t_0} + \int f(z_s) dX_s``; returns ``[batch, len(t), hidden]`` like the reference.
 
-    Same arguments as ``torchcde.cdeint`` (solver.py:140).  Requirements: X a LinearInterpolation /
-    NaturalCubicSpline (default integer grid or a user knot grid), ``func`` exposing ``fused_spec()``, ``method`` in
-    {euler, midpoint, rk4} with ``options={'step_size': h}``, fp32 CUDA tensors, ``t`` any increasing times.
-    The reference's NeuralCDE setting -- default grid, step 1, t = X.interval or X.grid_points -- runs on the
-    shape-specialised / batch-tiled kernels; any other time axis on the plan-driven generic kernels.
+    Same arguments as ``torchcde.cdeint`` (solver.py:140): X a LinearInterpolation / NaturalCubicSpline (default integer grid
+    or a user knot grid), ``func`` any ``nn.Module (t, z) -> [..., H, C]``, ``method`` in {euler, midpoint, rk4} (with
+    ``options={'step_size': h}``) or dopri5, CUDA tensors, ``t`` any monotone times.
+    The FUSED kernels run when ``func`` exposes ``fused_spec()`` (the package's vector fields), tensors are fp32, ``t``
+    increases and nothing upstream of the control path needs a gradient: the reference's NeuralCDE setting -- default grid,
+    step 1, t = X.interval or X.grid_points -- on the shape-specialised / batch-tiled kernels, any other time axis on their
+    plan-driven forms.  Every other request the reference accepts -- and shapes no fused kernel covers (training with hidden
+    widths > 128, checked here before the forward) -- runs on the unfused torch-op solver on the GPU (unfused.py), with one
+    UserWarning per reason.
     """
     if vector_field_type not in ("matmul", "evaluate", "derivative"):
         raise ValueError("vector_field_type string not recognised")
@@ -506,6 +589,7 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
     kwargs.setdefault("rtol", 1e-4)
     method = kwargs.pop("method", None)
     options = dict(kwargs.pop("options", None) or {})
+    options_in = dict(options)      # (as given: what the unfused solver is handed if the call ends up there)
     flags = kwargs.pop("kernel_flags", 0)
     adjoint_params = kwargs.pop("adjoint_params", None)
     atol, rtol = kwargs.pop("atol"), kwargs.pop("rtol")
@@ -519,43 +603,21 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
     if method not in _ALL_METHODS:
         raise ValueError('Invalid method "{}". Must be one of {}'.format(method, '{"' + '", "'.join(_ALL_METHODS) + '"}.'))
     if method not in _FIXED_METHODS and method != "dopri5":
-        raise NotImplementedError("method '%s': the fixed-step solvers %s and adaptive dopri5 run on the fused path" % (method, _FIXED_METHODS))
+        raise NotImplementedError("method '%s': the fixed-step solvers %s and adaptive dopri5 are implemented" % (method, _FIXED_METHODS))
     if adjoint_method is not None and adjoint_method != method:
-        raise NotImplementedError("adjoint_method != method is outside the fused path")
+        raise NotImplementedError("adjoint_method != method is not implemented")
     if not isinstance(X, (LinearInterpolation, NaturalCubicSpline)):
         raise NotImplementedError("X must be ncde_amd.LinearInterpolation or ncde_amd.NaturalCubicSpline")
+
+    z0_in = z0      # (z0 is flattened further down; the unfused solver takes it as given)
+
+    def unfused_(reason):
+        return _run_unfused(reason, X, func, z0_in, t, adjoint, vector_field_type, method, options_in, adjoint_params, rtol, atol,
+                            adjoint_rtol, adjoint_atol, adjoint_options)
+
     reason = _unfused_reason(X, func, z0, t, adjoint, adjoint_params, method)
     if reason is not None:
-        # outside the fused kernels: the own unfused torch-op solver, same algorithms (unfused.py), on the tensors' device
-        from . import unfused
-        if not z0.is_cuda:
-            raise NotImplementedError("cdeint needs tensors on the GPU (there is no CPU fallback); z0 is on %s" % z0.device)
-        adaptive_cfg = None
-        if method == "dopri5":      # round 4: adaptive dopri5 on the unfused path too (same options as the fused one)
-            if options.pop("norm", None) is not None:
-                raise NotImplementedError("a custom error norm is not supported (the reference's rms / mixed norms are built in)")
-            aopt = {k: options.pop(k) for k in list(options) if k in _DOPRI5_OPTIONS and not k.startswith("_")}
-            for k in [k for k in options if k.startswith("_")]:
-                options.pop(k)
-            bopt = dict(aopt) if adjoint_options is None else {k: v for k, v in adjoint_options.items() if k in _DOPRI5_OPTIONS and not k.startswith("_")}
-            adaptive_cfg = {"rtol": rtol, "atol": atol, "options": aopt, "adjoint_rtol": rtol if adjoint_rtol is None else adjoint_rtol,
-                            "adjoint_atol": atol if adjoint_atol is None else adjoint_atol, "adjoint_options": bopt}
-        step = options.pop("step_size", None)
-        if "grid_constructor" in options:
-            raise NotImplementedError("options['grid_constructor'] is not supported; give options={'step_size': h}")
-        options.pop("perturb", None)
-        for k in options:
-            warnings.warn("cdeint: Unexpected arguments {}".format({k: options[k]}))
-        if adjoint:
-            ids = set(id(q) for q in adjoint_params) if adjoint_params is not None else set()
-            for buffer in X.buffers():
-                if buffer.requires_grad and id(buffer) not in ids:      # the reference's warning (solver.py:207-221)
-                    warnings.warn("One of the inputs to the control path X requires gradients but is not listed in "
-                                  "`options['adjoint_params']`. It will not receive a gradient when using the adjoint method.")
-        unfused.warn_once(reason)
-        if torch.is_tensor(step):
-            step = step.item()
-        return unfused.cdeint_unfused(X, func, z0, t, adjoint, vector_field_type, method, step, adjoint_params, adaptive_cfg)
+        return unfused_(reason)
     adaptive = method == "dopri5"
     if adaptive:
         for k in list(options):
@@ -620,14 +682,24 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
         ap = ap & set(id(q) for q in uniq)
     else:
         ap = None
+    # does anything need a gradient?  (torch.no_grad() evaluation with trainable parameters does not: needs_input_grad inside an
+    # autograd.Function mirrors requires_grad whatever the grad mode, so the decision is taken here -- ADVICE round 4)
+    needs_grad = torch.is_grad_enabled() and (z0.requires_grad or any(q.requires_grad for q in uniq))
+    # (a family pinned by a development flag keeps the old contract -- the forward runs, a missing backward kernel is reported when a
+    # backward is actually asked for: the caller named the kernels, rerouting to the unfused solver would not be what was asked)
+    pinned = flags & (_lib.FLAG_FORCE_GENERIC | _lib.FLAG_FORCE_FAST | _lib.FLAG_FORCE_TILED)
+    passes = (0,) + (((1,) if adjoint else (2,)) if (needs_grad and not pinned) else ())
     if adaptive:
         if spec.kind != "original" or spec.mode != "matmul":
             raise NotImplementedError("method='dopri5' runs the original vector field with the matmul input only")
         bopt = dict(ad_options) if adjoint_options is None else {k: v for k, v in adjoint_options.items() if k in _DOPRI5_OPTIONS}
-        cfg = {"spec": spec, "interp": X.interp_name, "flags": flags, "func": func, "adjoint_param_ids": ap,
+        cfg = {"spec": spec, "interp": X.interp_name, "flags": flags, "func": func, "adjoint_param_ids": ap, "needs_grad": needs_grad,
                "adaptive": _AdaptiveSpec(X, t, rtol, atol, ad_options), "record_bytes": ad_options.get("_record_bytes"),
                "adaptive_backward": _AdaptiveSpec(X, t, rtol if adjoint_rtol is None else adjoint_rtol,
                                                   atol if adjoint_atol is None else adjoint_atol, bopt)}
+        why = _no_kernel_reason(build_problem(coeffs, X.interp_name, z0.detach(), spec, "rk4", _lib.OUT_INTERVAL, flags), passes, cfg["adaptive"].ts)
+        if why is not None:
+            return unfused_(why)
         out = (_FusedDopri5 if adjoint else _FusedDopri5Taped).apply(z0, coeffs.detach(), cfg, *uniq)
         if len(batch_shape) != 1:
             out = out.reshape(*batch_shape, out.shape[-2], out.shape[-1])
@@ -643,7 +715,10 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
         nfe, nfe_adj = stages * plan[1][1], stages * plan[1][2]
     else:
         nfe = nfe_adj = stages * (X.n_knots - 1)
-    cfg = {"spec": spec, "interp": X.interp_name, "method": method, "output": output, "flags": flags, "plan": plan,
+    why = _no_kernel_reason(build_problem(coeffs, X.interp_name, z0.detach(), spec, method, output, flags, plan), passes)
+    if why is not None:
+        return unfused_(why)
+    cfg = {"spec": spec, "interp": X.interp_name, "method": method, "output": output, "flags": flags, "plan": plan, "needs_grad": needs_grad,
            "adjoint": bool(adjoint), "func": func, "nfe_per_solve": nfe, "nfe_adjoint": nfe_adj, "adjoint_param_ids": ap}
     out = _FusedCdeint.apply(z0, coeffs.detach(), cfg, *uniq)
     if hasattr(func, "nfe"):

@@ -268,15 +268,23 @@ class _AdjointDopri5(torch.autograd.Function):
                 vp = tuple(torch.zeros_like(p) if v is None else v for p, v in zip(params, vj[2:]))
                 return (vt, fe.detach(), vy) + vp
 
+            t_needs = ctx.needs_input_grad[2]
             state = [torch.zeros((), dtype=y.dtype, device=y.device), y[-1], grad_y[-1]] + [torch.zeros_like(p) for p in params]
+            time_vjps = torch.empty(t.numel(), dtype=t.dtype, device=t.device) if t_needs else None
             for i in range(t.numel() - 1, 0, -1):
+                if t_needs:      # dL/dt_i through the end point of the interval: f(t_i, y_i) . dL/dy_i  (adjoint.py:112-123, every solver)
+                    dcur = (field(t[i].to(y.dtype), y[i]).reshape(-1) * grad_y[i].reshape(-1)).sum()
+                    state[0] = state[0] - dcur
+                    time_vjps[i] = dcur
                 sol = solve_dopri5(aug, tuple(state), t[i - 1:i + 1].flip(0), cfg["adjoint_rtol"], cfg["adjoint_atol"], cfg["adjoint_options"],
                                    _mixed_norm, cfg["stats_backward"])
                 state = [s_[1] for s_ in sol]
                 state[1] = y[i - 1]
                 state[2] = state[2] + grad_y[i - 1]
+            if t_needs:
+                time_vjps[0] = state[0]      # adjoint.py:136
         gp = [g if need else None for g, need in zip(state[3:], ctx.needs_input_grad[3:])]
-        return (None, state[2] if ctx.needs_input_grad[1] else None, None, *gp)
+        return (None, state[2] if ctx.needs_input_grad[1] else None, time_vjps, *gp)
 
 
 class _Adjoint(torch.autograd.Function):

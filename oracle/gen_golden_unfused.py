@@ -30,7 +30,11 @@ CASES = [  # name, interp, knots on a user grid?, output times, method, step_siz
     ("decreasing_midpoint", "linear", False, [9.0, 6.5, 2.25, 0.0], "midpoint", 0.75, True),
     ("decreasing_euler_tape", "linear", False, [8.0, 3.0, 1.0], "euler", 0.4, False),
     ("interior_rk4_adj", "linear", False, [0.5, 2.0, 7.3, 9.0], "rk4", 1.0, True),
+    # round 5: the adaptive solver's continuous adjoint also returns dL/dt (adjoint.py:112-136 computes time_vjps for
+    # every solver).  Forced step sequence (first_step = min_step = max_step) so that both sides walk the same steps.
+    ("dopri5_adj_tgrad", "cubic", False, [0.0, 2.5, 9.0], "dopri5", None, True),
 ]
+DOPRI5_OPTS = {"first_step": 0.5, "min_step": 0.5, "max_step": 0.5}
 
 out = {}
 g = torch.Generator().manual_seed(20261002)
@@ -49,6 +53,9 @@ for name, interp, user_grid, tt, method, step, adjoint in CASES:
     t = torch.tensor(tt, requires_grad=True)
     kw = {"adjoint_params": tuple(f.parameters()) + (coeffs, kn)} if adjoint else {}
     opts = {} if step is None else {"step_size": step}
+    if method == "dopri5":
+        opts = dict(DOPRI5_OPTS)
+        kw.update(rtol=1e-3, atol=1e-5)
     z = torchcde.cdeint(X, f, z0, t, adjoint=adjoint, method=method, options=opts, **kw)
     w = torch.rand(z.shape, generator=g) - 0.5
     (z * w).sum().backward()

@@ -978,6 +978,12 @@ _SWEEP = [  # (B, L, C, H, HH, nl, interp, method, seq)  -- whatever family the 
     (70, 3, 4, 64, 64, 3, "linear", "midpoint", False),  # cfg4 dims, linear control
     (16, 2, 16, 16, 128, 2, "linear", "rk4", False),     # a single step, wide hidden layers
     (3, 12, 2, 16, 16, 1, "cubic", "euler", True),       # time + one channel
+    # round 5: beyond 80 channels and beyond 128 state units on the batch-tiled backward
+    (22, 5, 100, 64, 64, 3, "linear", "rk4", True),      # C = 100: dX/dt read in the sweep's bookkeeping phase (B = 21 has one knife-edge ReLU sample)
+    (18, 3, 84, 48, 32, 2, "cubic", "euler", False),     # C = 84, cubic control
+    (19, 4, 20, 160, 128, 3, "linear", "rk4", False),    # H = 160: the one-wave-per-SIMD instantiation of the sweep (BIGH)
+    (11, 3, 7, 256, 128, 2, "cubic", "midpoint", True),  # H = 256, C = 7 -> 8 (zero-padded), sequence outputs
+    (35, 2, 12, 208, 64, 3, "linear", "rk4", True),      # H = 208, last width 64
 ]
 
 
@@ -1935,3 +1941,90 @@ def test_integration_md_stub_with_version1_struct(gpu_lib):
             ref = ncde_amd.cdeint(X, func, z0, X.grid_points if every_knot else X.interval, method="rk4", options={"step_size": 1})
         torch.cuda.synchronize()
         assert torch.equal(out, ref)
+
+
+def test_training_beyond_the_fused_backward_kernels_runs_on_the_unfused_solver(gpu_lib):
+    """NeuralCDE(hidden_dim=256) -- inside the reference's hyper-parameter range (configurations.json5:34-35,
+    adjoint: false) -- used to pass its forward and raise inside loss.backward().  cdeint now asks for the backward kernel before the
+    forward and routes the call to the unfused torch-op solver with a warning naming the shape; the result is the solve the oracle
+    computes (forward and both kinds of gradient), and evaluation under no_grad keeps the fused forward kernel."""
+    import warnings
+    import ncde_amd
+    import ncde_oracle as orc
+    from ncde_amd import unfused
+    B, L, C, H, HH, nl = 9, 5, 6, 256, 196, 2
+    coeffs = gu.data.make_rectilinear_coeffs(B, L, C - 1, missing=0.3, seed=77)
+    for adjoint in (False, True):
+        torch.manual_seed(3)
+        model = ncde_amd.NeuralCDE(C, H, 3, hidden_hidden_dim=HH, num_layers=nl, interpolation="rectilinear", adjoint=adjoint).cuda()
+        x = torch.from_numpy(coeffs).cuda()
+        unfused._WARNED.clear()
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            out = model(x)
+        assert any("unfused torch-op solver" in str(w.message) and "hidden=256" in str(w.message) for w in rec), [str(w.message) for w in rec]
+        out.square().sum().backward()      # (used to raise NotImplementedError here)
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+        # same numbers as the oracle's restatement of the reference
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        field = orc.Field([(sd["func.net_to_hh.0.weight"], sd["func.net_to_hh.0.bias"])] + [(sd["func.net_to_hh.2.weight"], sd["func.net_to_hh.2.bias"])] * (nl - 1),
+                          sd["func.tanh_output_layer.0.weight"], sd["func.tanh_output_layer.0.bias"], H, C)
+        z0 = torch.from_numpy(coeffs[:, 0]) @ sd["initial_linear.weight"].t() + sd["initial_linear.bias"]
+        ctl = orc.Control(coeffs, "linear")
+        z = orc.solve_forward(ctl, field, z0, "rk4", False)
+        ref = z[:, -1] @ sd["final_linear.weight"].t() + sd["final_linear.bias"]
+        assert gu.relerr(out.detach().cpu().numpy(), ref.numpy()) <= 2e-5
+        gz = torch.zeros_like(z)
+        gz[:, -1] = (2 * ref) @ sd["final_linear.weight"]
+        if adjoint:
+            dz0, gp = orc.solve_adjoint(ctl, field, z, gz, "rk4", False)
+        else:
+            dz0, gp = orc.solve_discrete_backward(ctl, field, z0, gz, "rk4", False)[-2:]
+        got = model.func.tanh_output_layer[0].weight.grad.cpu().numpy()
+        assert gu.relerr(got, np.asarray(gp[-2])) <= 2e-4
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("error")      # no gradient needed: the fused forward kernel, no warning
+            out2 = model(x)
+        assert gu.relerr(out2.cpu().numpy(), ref.numpy()) <= 2e-5
+
+
+@pytest.mark.parametrize("B,L,C,H,HH,nl,interp,method,seq", [
+    (123, 3, 40, 64, 128, 2, "linear", "rk4", False),       # 8 sample tiles = ONE group of 8 members (2 state-unit blocks each), ragged last tile
+    (256, 3, 20, 128, 128, 3, "cubic", "midpoint", True),   # 16 tiles = two groups of 8 (4 blocks per member, one wave each), sequence outputs
+    (512, 2, 80, 128, 128, 3, "linear", "rk4", True),       # cfg5 dims: 32 tiles = one group of 32 (one block per member)
+])
+def test_cooperative_output_phase_vs_oracle(B, L, C, H, HH, nl, interp, method, seq, gpu_lib):
+    """Round 5: the XCD-cooperative, weight-stationary output phase of the batch-tiled sweep (csrc/ncde_coop.h) --
+    each workgroup keeps 20 row tiles of Wo in registers and applies them to every sample tile of its group, activations and partial
+    sums travel through L2 with write-through stores / L1-bypassing loads and monotonic group counters.  Continuous adjoint and exact
+    discrete backward on the oracle's forward solution at the tight tolerances, against the per-workgroup sweep (NCDE_FLAG_NO_COOP),
+    and bit-reproducible run to run."""
+    import gpu_util
+    from ncde_amd import _lib
+    case = _seeded_case(interp, method, seq, B=B, L=L, C=C, H=H, HH=HH, nl=nl, seed=900 + C)
+    ex = case["expect"]
+    names = gpu_util.kernel_names(case)
+    assert "coop" in names[1] and "coop" in names[2], names
+    assert "coop" not in gpu_util.kernel_names(case, flags=_lib.FLAG_NO_COOP)[1]
+    iso = gpu_util.run_adjoint_direct(case, ex["z_out"])
+    for k, e in _grad_errors(case, iso).items():
+        assert e <= TIGHT_G, ("cooperative adjoint", k, e)
+    old = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_NO_COOP)
+    assert gu.relerr(iso["dz0"], old["dz0"]) <= 2e-5
+    for k in iso["grads"]:
+        assert gu.relerr(iso["grads"][k], old["grads"][k]) <= 2e-5, k
+    again = gpu_util.run_adjoint_direct(case, ex["z_out"])
+    assert np.array_equal(again["dz0"], iso["dz0"]) and all(np.array_equal(again["grads"][k], iso["grads"][k]) for k in iso["grads"])
+    isod = gpu_util.run_adjoint_direct(case, ex["z_out"], stages=case["stage_record"])
+    oldd = gpu_util.run_adjoint_direct(case, ex["z_out"], stages=case["stage_record"], flags=_lib.FLAG_NO_COOP)
+    assert gu.relerr(isod["dz0"], oldd["dz0"]) <= 2e-5
+    for k in isod["grads"]:
+        assert gu.relerr(isod["grads"][k], oldd["grads"][k]) <= 2e-5, k
+    if B != 512:      # (the 512-sample case has ONE sample whose ReLU mask flips between any two fp32 implementations -- both sweeps deviate
+        for k, e in _grad_errors(case, isod, "bp_").items():      # from the oracle there by the same 1e-3 --, see DESIGN.md 5.5d)
+            assert e <= TIGHT_G, ("cooperative discrete backward", k, e)
+    # several time windows (records of two steps at a time): the state, the hidden-layer partial and the group counters carry over
+    win = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=_lib.FLAG_TILED_WINDOW_STEPS(2))
+    assert gu.relerr(win["dz0"], iso["dz0"]) <= 1e-6
+    for k in iso["grads"]:
+        assert gu.relerr(win["grads"][k], iso["grads"][k]) <= 2e-6, k

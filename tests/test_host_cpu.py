@@ -131,6 +131,31 @@ def test_kernel_family_selection():
     assert lib.ncde_workspace_bytes(ctypes.byref(un), 1) == -2
 
 
+def test_reserved_field_of_the_problem_is_not_an_input():
+    """NcdeProblem.reserved_ carries the real extents of a zero-padded problem INSIDE the library; whatever a caller
+    leaves in it (an uninitialised stack struct) must be ignored, not read as row strides."""
+    lib = ncde_amd.lib()
+    for shape in (dict(), dict(C=5, H=16, HH=24), dict(C=21, H=47, HH=93)):
+        clean, dirty = _problem(**shape), _problem(**shape)
+        dirty.reserved_ = (777 << 12) | 333
+        for k in (0, 1, 2):
+            assert lib.ncde_kernel_name(ctypes.byref(dirty), k) == lib.ncde_kernel_name(ctypes.byref(clean), k)
+            assert lib.ncde_workspace_bytes(ctypes.byref(dirty), k) == lib.ncde_workspace_bytes(ctypes.byref(clean), k)
+
+
+def test_shapes_without_a_backward_kernel_are_known_before_the_forward():
+    """cdeint asks the library for every pass it will need BEFORE launching the forward (solver._no_kernel_reason)
+    and sends a shape no fused kernel covers to the unfused solver, instead of failing inside loss.backward()."""
+    big = _problem(C=20, H=196, HH=196, nl=3)          # the reference's hyper-parameter range (configurations.json5:34-35)
+    assert solver._no_kernel_reason(big, (0,)) is None                       # the forward exists ...
+    why = solver._no_kernel_reason(big, (0, 2))                              # ... the exact discrete backward does not
+    assert why is not None and "hidden=196" in why and "discrete backward" in why
+    assert "continuous adjoint" in solver._no_kernel_reason(big, (0, 1))
+    assert solver._no_kernel_reason(_problem(), (0, 1, 2)) is None           # BASELINE cfg2: every pass
+    assert solver._no_kernel_reason(_problem(C=100, H=64, HH=64), (0, 1, 2)) is None      # round 5: more than 80 channels on the batch-tiled backward
+    assert solver._no_kernel_reason(_problem(C=20, H=160, HH=128), (0, 1, 2)) is None     # round 5: hidden > 128 with a last width <= 128
+
+
 def test_dopri5_kernel_selection():
     """Round 4: the fused attempt kernels where the shape allows, the per-launch kernels elsewhere and under FORCE_GENERIC."""
     lib = ncde_amd.lib()

@@ -84,3 +84,34 @@ def test_unfused_dopri5_taped_gradient_in_fp64_vs_the_hand_derived_backward():
     assert gu.relerr(z0g.grad.numpy(), np.asarray(dz0)) <= 1e-10
     for name, want in zip(["W0", "b0", "W1", "b1", "Wo", "bo"], gp):
         assert gu.relerr(p[name].grad.numpy(), np.asarray(want)) <= 1e-10, name
+
+
+def test_unfused_dopri5_adjoint_returns_the_time_gradient_of_the_reference():
+    """torchdiffeq's adjoint computes dL/dt for every solver (adjoint.py:112-136); the adaptive one here dropped it.
+    Golden produced by the imported reference (oracle/gen_golden_unfused.py, case dopri5_adj_tgrad: forced step sequence)."""
+    f = np.load(os.path.join(gu.GOLD, "g13_unfused.npz"))
+    name = "dopri5_adj_tgrad"
+    g = lambda k: torch.from_numpy(f[name + "__" + k])      # noqa: E731
+
+    class Func(torch.nn.Module):      # the reference tests' inline field (test_tricks.py:6-18)
+        def __init__(self, variable):
+            super().__init__()
+            self.variable = torch.nn.Parameter(variable)
+
+        def forward(self, t, z):
+            return z.sigmoid().unsqueeze(-1) + self.variable
+
+    coeffs, kn = g("coeffs").requires_grad_(True), g("knots").requires_grad_(True)
+    X = ncde_amd.NaturalCubicSpline(coeffs, kn)
+    func = Func(g("variable"))
+    z0, t = g("z0").requires_grad_(True), g("t").requires_grad_(True)
+    opts = {"first_step": 0.5, "min_step": 0.5, "max_step": 0.5}
+    ad = {"rtol": 1e-3, "atol": 1e-5, "options": dict(opts), "adjoint_rtol": 1e-3, "adjoint_atol": 1e-5, "adjoint_options": dict(opts)}
+    z = unfused.cdeint_unfused(X, func, z0, t, True, "matmul", "dopri5", None, tuple(func.parameters()) + (coeffs, kn), ad)
+    (z * g("w")).sum().backward()
+    got = {"z": z, "d_z0": z0.grad, "d_variable": func.variable.grad, "d_coeffs": coeffs.grad, "d_t": t.grad, "d_knots": kn.grad}
+    for k, v in got.items():
+        ref = f[name + "__" + k]
+        assert v is not None, k
+        err = np.abs(v.detach().numpy() - ref).max() / (np.abs(ref).max() + 1e-30)
+        assert err <= 2e-5, (k, err)

@@ -23,7 +23,9 @@ class _Func(torch.nn.Module):      # the reference tests' inline field (test_tri
         return z.sigmoid().unsqueeze(-1) + self.variable
 
 
-CASES = ["tricks_rk4_adj", "tricks_rk4_tape", "detach_rk4_half", "decreasing_midpoint", "decreasing_euler_tape", "interior_rk4_adj"]
+CASES = ["tricks_rk4_adj", "tricks_rk4_tape", "detach_rk4_half", "decreasing_midpoint", "decreasing_euler_tape", "interior_rk4_adj",
+         "dopri5_adj_tgrad"]      # (round 5: dL/dt of the adaptive adjoint, forced step sequence)
+DOPRI5_OPTS = {"first_step": 0.5, "min_step": 0.5, "max_step": 0.5}
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -41,6 +43,9 @@ def test_unfused_matches_reference_golden(name, gpu_lib):
     t = g("t").requires_grad_(True)
     kw = {"adjoint_params": tuple(func.parameters()) + (coeffs, kn)} if adjoint else {}
     opts = {} if step is None else {"step_size": step}
+    if method == "dopri5":
+        opts = dict(DOPRI5_OPTS)
+        kw.update(rtol=1e-3, atol=1e-5)
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
         z = ncde_amd.cdeint(X, func, z0, t, adjoint=adjoint, method=method, options=opts, **kw)
@@ -51,7 +56,7 @@ def test_unfused_matches_reference_golden(name, gpu_lib):
         ref = f[name + "__" + k]
         assert v is not None, k
         err = np.abs(v.detach().cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30)
-        assert err <= 1e-6, (name, k, err)
+        assert err <= (2e-5 if method == "dopri5" else 1e-6), (name, k, err)
 
 
 def test_unfused_warns_once_and_refuses_cpu(gpu_lib):
