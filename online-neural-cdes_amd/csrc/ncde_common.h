@@ -76,6 +76,7 @@ struct KArgs {
     // inter-workgroup exchange area, the group counters + abort word, {sw, 1/sw}, members per group, number of groups
     const unsigned* coop_img;
     float* coop_x;
+    float* coop_state;      // [n_workgroups][6][state slice]: the Butcher registers (y0, k.. / a0, k..) between bookkeeping phases
     unsigned* coop_sync;
     const float* coop_scale;
     int coop_M, coop_G;

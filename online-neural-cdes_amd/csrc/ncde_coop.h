@@ -60,12 +60,17 @@ struct CoopDims {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t coop_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7ffffffc, 0x00020000);
 }
-// write-through 16-byte store / L1-bypassing 16-byte load (byte offsets from the exchange base; 2 GB window)
-__device__ __forceinline__ void coop_st16(__amdgpu_buffer_rsrc_t r, long long float_off, u32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(float_off * 4), 0, 16);
+// Payload stores.  `same` (uniform over the group, decided once per launch by coop_same_xcd): every member of the group runs on ONE
+// XCD, whose L2 they share -- a plain store is in that L2 once the storing wave's vmcnt has drained, and the readers' sc1 loads
+// (L1 bypassed) find it there at L2-hit latency.  Otherwise the store is written through (sc1) so that readers on another XCD see
+// it: correct under any placement, at fabric latency.  (byte offsets from the exchange base; 2 GB window)
+__device__ __forceinline__ void coop_st16(__amdgpu_buffer_rsrc_t r, float* base, bool same, long long float_off, u32x4 v) {
+    if (same) *reinterpret_cast<u32x4*>(base + float_off) = v;
+    else __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(float_off * 4), 0, 16);
 }
-__device__ __forceinline__ void coop_st4(__amdgpu_buffer_rsrc_t r, long long float_off, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)(float_off * 4), 0, 16);
+__device__ __forceinline__ void coop_st4(__amdgpu_buffer_rsrc_t r, float* base, bool same, long long float_off, float v) {
+    if (same) base[float_off] = v;
+    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)(float_off * 4), 0, 16);
 }
 __device__ __forceinline__ u32x4 coop_ld16(__amdgpu_buffer_rsrc_t r, long long float_off) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, (int)(float_off * 4), 0, 16);
@@ -86,11 +91,13 @@ __device__ __forceinline__ float coop_pow2_scale(float m) {
 }
 __device__ __forceinline__ float coop_pow2_inv(float s) { return __uint_as_float((254u - ((__float_as_uint(s) >> 23) & 255u)) << 23); }
 
-// sync words: [0 .. G-1] group counters (monotonic within a launch), [G] abort word
+// sync words: [0 .. G-1] group counters (monotonic within a launch), [G] abort word, [G+1 .. 2G] the groups' start-up counters,
+// [2G+1 .. 2G+n_tiles] XCC id + 1 of every workgroup (all zeroed by the host before every launch)
 struct CoopSync {
     unsigned* words;
     int G;
 };
+__host__ __device__ inline int coop_sync_words(int G, int n_tiles) { return 2 * G + 1 + n_tiles; }
 // Every storing wave has drained (s_waitcnt vmcnt(0)) and the workgroup has barrier-synced before this is called by thread 0.
 __device__ __forceinline__ void coop_arrive(const CoopSync& sy, int g) {
     __hip_atomic_fetch_add(sy.words + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -119,42 +126,64 @@ __device__ __forceinline__ bool coop_wait(const CoopSync& sy, int g, unsigned ta
     return ok;
 }
 
-// The keeper's resident weights: 20 row tiles of Wo per workgroup, 5 per wave.
-struct CoopWeights {
-    u32x4 P[COOP_NRT][COOP_NCH][2];      // row-major fragments (A operand of P = Wo x_L): [tile][K chunk][piece]
-    u32x4 T[2][8][2];                    // K-major fragments of tile pairs (0,1), (2,3): [pair][column tile][piece], K = the 32 rows of the pair
-    u32x2c T1[8][2];                     // ... of tile 4 alone (K = 16: v_mfma_f32_16x16x16_f16)
-};
-
-// words of the packed images per workgroup
-__host__ __device__ constexpr int coop_p_words() { return 4 * COOP_NRT * COOP_NCH * 2 * 64 * 4; }
-__host__ __device__ constexpr int coop_t_words() { return 4 * (2 * 8 * 2 * 64 * 4 + 8 * 2 * 64 * 2); }
-
-__device__ __forceinline__ void coop_load_weights(CoopWeights& w, const unsigned* img, int member, int wave, int lane) {
-    const unsigned* p = img + (long long)member * (coop_p_words() + coop_t_words());
-    const unsigned* pw = p + wave * (COOP_NRT * COOP_NCH * 2 * 64 * 4);
-#pragma unroll
-    for (int q = 0; q < COOP_NRT; ++q)
-#pragma unroll
-        for (int c = 0; c < COOP_NCH; ++c)
-#pragma unroll
-            for (int pc = 0; pc < 2; ++pc) w.P[q][c][pc] = *reinterpret_cast<const u32x4*>(pw + (((q * COOP_NCH + c) * 2 + pc) * 64 + lane) * 4);
-    const unsigned* t = p + coop_p_words() + wave * (2 * 8 * 2 * 64 * 4 + 8 * 2 * 64 * 2);
-#pragma unroll
-    for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-            for (int pc = 0; pc < 2; ++pc) w.T[pr][ct][pc] = *reinterpret_cast<const u32x4*>(t + (((pr * 8 + ct) * 2 + pc) * 64 + lane) * 4);
-    const unsigned* t1 = t + 2 * 8 * 2 * 64 * 4;
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-        for (int pc = 0; pc < 2; ++pc) w.T1[ct][pc] = *reinterpret_cast<const u32x2c*>(t1 + ((ct * 2 + pc) * 64 + lane) * 2);
+// Do all M members of this workgroup's group run on the same XCD (= share an L2)?  Every member publishes its XCC id with an
+// agent-scope store, arrives on the group's start-up counter, waits for the M arrivals and reads the M ids back: every member sees
+// the same M words, so the answer is uniform over the group.  -1 on timeout / abort.
+__device__ __forceinline__ int coop_same_xcd(const CoopSync& sy, int g, int member, int M, int n_tiles_per_launch, int* flag_lds, int tid) {
+    (void)n_tiles_per_launch;
+    unsigned* ids = sy.words + 2 * sy.G + 1;
+    if (tid == 0) {
+        const unsigned me = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) + 1u;      // HW_REG_XCC_ID[3:0] + 1
+        __hip_atomic_store(ids + g + sy.G * member, me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(sy.words + sy.G + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int res = 1;
+        unsigned spins = 0;
+        for (;;) {
+            if (__hip_atomic_load(sy.words + sy.G + 1 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)M) break;
+            if (++spins > COOP_SPIN_LIMIT) {
+                __hip_atomic_store(sy.words + sy.G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                res = -1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (res >= 0)
+            for (int mm = 0; mm < M; ++mm)
+                if (__hip_atomic_load(ids + g + sy.G * mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != me) res = 0;
+        *flag_lds = res;
+    }
+    __syncthreads();
+    const int res = *flag_lds;
+    __syncthreads();
+    return res;
 }
 
-__device__ __forceinline__ f32x4 coop_mfma_k16(u32x2c a, u32x2c b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
+// The keeper's resident weights: 20 row tiles of Wo per workgroup, 160 registers per wave.  The workgroup has 8 waves, two per SIMD:
+//   * waves 0..3 ("P role") hold ROW-major fragments of 5 row tiles each and compute P = Wo x_L, tanh, the f.dX slice and dP;
+//   * waves 4..7 ("T role") hold K-major fragments of 2 COLUMN tiles of the 128 hidden units each, over all 20 row tiles (10 K-pairs),
+//     and compute Wo^T dP one sample tile BEHIND the P role, from the dP the P role left in LDS.
+// A P wave and a T wave share each SIMD: the tanh / split / LDS work of one runs under the MFMAs of the other.
+struct CoopWeights {
+    u32x4 f[40];      // P role: [row tile q][K chunk c][piece] = f[(q * 4 + c) * 2 + piece];  T role: [pair][column tile][piece] = f[(pr * 2 + ci) * 2 + piece]
+};
+
+// words of the packed images per workgroup: [P role: 4 waves x 40 fragments][T role: 4 waves x 40 fragments], 64 lanes x 4 words each
+__host__ __device__ constexpr int coop_p_words() { return 4 * 40 * 64 * 4; }
+__host__ __device__ constexpr int coop_t_words() { return 4 * 40 * 64 * 4; }
+
+// Fragments [0, COOP_PIN) stay in registers for the whole launch; the other 40 - COOP_PIN are re-read from the packed image at the start
+// of every keeper phase.  Measured at cfg5 (s_memtime phase counters, cycles per stage of 8 waves): all 40 pinned --
+// the owner phases run out of registers, the compiler parks nine fragments in scratch and reloads them INSIDE the keeper loops (every
+// scratch reload is an in-order vmcnt wait): 292k cycles in those loops, 478k per stage; 30 pinned + 10 re-read: the same nine reloads;
+// all 40 re-read (the shipped setting): clean loops, 168k, but 10 MB per XCD and stage do not fit the 4 MB L2 and come from the
+// Infinity Cache / HBM: +40k cycles waiting for them, 410k per stage (the per-workgroup sweep: 469k).
+#define COOP_PIN 0
+template <int K0, int K1>
+__device__ __forceinline__ void coop_load_weights(CoopWeights& w, const unsigned* img, int member, int wave, int lane) {
+    const unsigned* p = img + (long long)member * (coop_p_words() + coop_t_words()) + wave * (40 * 64 * 4);      // (waves 4..7: behind the P images)
+#pragma unroll
+    for (int k = K0; k < K1; ++k) w.f[k] = *reinterpret_cast<const u32x4*>(p + (k * 64 + lane) * 4);
 }
 
 // 8 (or 4) fp32 values -> split-fp16 pieces (no range tracking: the caller has scaled them into [-1, 1])
@@ -194,13 +223,13 @@ __global__ __launch_bounds__(256) void ncde_coop_pack(const float* __restrict__ 
                                                       float* __restrict__ scale, int C, int dlast, int M) {
     const float sw = coop_pow2_scale(__uint_as_float(*absmax));
     if (blockIdx.x == 0 && threadIdx.x == 0) { scale[0] = sw; scale[1] = coop_pow2_inv(sw); }
-    constexpr int PF = COOP_NRT * COOP_NCH, TF = 2 * 8, T1F = 8;      // fragments (both pieces handled by one thread) per wave
-    const long long n = (long long)M * 4 * (PF + TF + T1F) * 64;
+    constexpr int PF = COOP_NRT * COOP_NCH, TF = (COOP_RPM / 2) * 2;      // fragments (both pieces handled by one thread) per wave
+    const long long n = (long long)M * 4 * (PF + TF) * 64;
     for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < n; v += (long long)gridDim.x * 256) {
         const int lane = (int)(v & 63);
         long long f = v >> 6;
-        const int frag = (int)(f % (PF + TF + T1F));
-        f /= (PF + TF + T1F);
+        const int frag = (int)(f % (PF + TF));
+        f /= (PF + TF);
         const int wave = (int)(f & 3), member = (int)(f >> 2);
         const int li = lane & 15, kg = lane >> 4;
         const int rt0 = member * COOP_RPM + wave * COOP_NRT;
@@ -217,26 +246,16 @@ __global__ __launch_bounds__(256) void ncde_coop_pack(const float* __restrict__ 
             unsigned* dst = base + wave * (PF * 2 * 64 * 4) + ((frag * 2) * 64 + lane) * 4;
             *reinterpret_cast<u32x4*>(dst) = (u32x4){h[0], h[1], h[2], h[3]};
             *reinterpret_cast<u32x4*>(dst + 256) = (u32x4){l[0], l[1], l[2], l[3]};
-        } else if (frag < PF + TF) {
-            const int ft = frag - PF, pr = ft >> 3, ct = ft & 7;
+        } else {      // K-major: rows (tile 2 pr + (e >> 2), row 4 kg + (e & 3)) of the workgroup's pair pr, column 16 ct + li, ct = 2 wave + ci
+            const int ft = frag - PF, pr = ft >> 1, ci = ft & 1, ct = 2 * wave + ci;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = W[coop_row(rt0 + 2 * pr + (e >> 2), 4 * kg + (e & 3), C) * dlast + 16 * ct + li] * sw;
+            for (int e = 0; e < 8; ++e) x[e] = W[coop_row(member * COOP_RPM + 2 * pr + (e >> 2), 4 * kg + (e & 3), C) * dlast + 16 * ct + li] * sw;
             unsigned h[4], l[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) coop_split2(x[2 * e], x[2 * e + 1], h[e], l[e]);
-            unsigned* dst = base + coop_p_words() + wave * (TF * 2 * 64 * 4 + T1F * 2 * 64 * 2) + ((ft * 2) * 64 + lane) * 4;
+            unsigned* dst = base + coop_p_words() + wave * (TF * 2 * 64 * 4) + ((ft * 2) * 64 + lane) * 4;
             *reinterpret_cast<u32x4*>(dst) = (u32x4){h[0], h[1], h[2], h[3]};
             *reinterpret_cast<u32x4*>(dst + 256) = (u32x4){l[0], l[1], l[2], l[3]};
-        } else {
-            const int ct = frag - PF - TF;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = W[coop_row(rt0 + 4, 4 * kg + e, C) * dlast + 16 * ct + li] * sw;
-            unsigned h[2], l[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) coop_split2(x[2 * e], x[2 * e + 1], h[e], l[e]);
-            unsigned* dst = base + coop_p_words() + wave * (TF * 2 * 64 * 4 + T1F * 2 * 64 * 2) + TF * 2 * 64 * 4 + ((ct * 2) * 64 + lane) * 2;
-            *reinterpret_cast<u32x2c*>(dst) = (u32x2c){h[0], h[1]};
-            *reinterpret_cast<u32x2c*>(dst + 128) = (u32x2c){l[0], l[1]};
         }
     }
 }

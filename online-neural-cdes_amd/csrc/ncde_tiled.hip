@@ -164,11 +164,14 @@ __device__ __forceinline__ void tl_dense_relu_pk(const float* __restrict__ W, co
         }
     }
 }
-template <int NS, int NWV, int ACT = 0, int XH = 0>
+// MAXPK: largest panel (k-blocks per 16-byte-per-lane load group) to use -- a panel is 4 PK registers, two are in flight
+template <int NS, int NWV, int ACT = 0, int XH = 0, int MAXPK = 8>
 __device__ __forceinline__ void tl_dense_relu(const float* __restrict__ W, const float* __restrict__ bias, int N, int K,
                                               const float* in, float* out, int wave, int lane, unsigned* xb = nullptr, int ld = 0,
                                               float* mxp = nullptr) {
-    switch (tl_panel_k(K >> 4)) {
+    int pk_ = tl_panel_k(K >> 4);
+    if (pk_ > MAXPK) pk_ = MAXPK;      // (powers of two: a smaller panel still divides K / 16)
+    switch (pk_) {
         case 8: tl_dense_relu_pk<NS, 8, NWV, ACT, XH>(W, bias, N, K, in, out, wave, lane, xb, ld, mxp); break;
         case 4: tl_dense_relu_pk<NS, 4, NWV, ACT, XH>(W, bias, N, K, in, out, wave, lane, xb, ld, mxp); break;
         case 2: tl_dense_relu_pk<NS, 2, NWV, ACT, XH>(W, bias, N, K, in, out, wave, lane, xb, ld, mxp); break;
@@ -1181,11 +1184,11 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     static_assert(BF == 0 || (RES != 1 && PK >= 2), "split record: streamed output tiles, last hidden width a multiple of 32");
     static_assert(DIRECT == 0 || (RES == 0 && BF == 0), "direct heads: streamed fp32 layers");
     static_assert(BIGH == 0 || (RES == 0 && DIRECT == 0 && NWV == 4), "wide state: streamed weights, matmul input, one wave per SIMD");
-    static_assert(COOP == 0 || (PK == 2 * COOP_NCH && NWV == 4 && RES == 0 && GATED == 0 && BF == 1 && DIRECT == 0 && BIGH == 0),
-                  "cooperative output phase: original field, last hidden width 128, split records, one wave per SIMD");
+    static_assert(COOP == 0 || (PK == 2 * COOP_NCH && NWV == 8 && RES == 0 && GATED == 0 && BF == 1 && DIRECT == 0 && BIGH == 0),
+                  "cooperative output phase: original field, last hidden width 128, split records, two waves per SIMD (P role / T role)");
     constexpr int NT = 64 * NWV, TL_EADJ = RES ? (16 * 16 * PK + NT - 1) / NT : (BIGH ? 4096 : 2048) / NT;
     constexpr int TL_DWT = COOP ? 1 : (RES ? (PK * PK + NWV - 1) / NWV : (BIGH ? 128 : 64) / NWV);   // hidden dW tiles per wave and weight slot
-    constexpr int COOP_LDS = 2 * 4 * 2048 + 2 * 4 * 64 + 3 * 4 * 16 + 64 + 8;      // floats: partial exchange, f.dX exchange, maxima, scales, flag
+    constexpr int COOP_LDS = 2 * 10 * 2 * 64 * 4 + 2 * 8 * 64 * 4 + 2 * 80 * 16 + 2 * 256 + 2 * 64 + 2 * 4 * 64 + 2 * 16 + 8;      // floats, see CDP .. CFL below
     constexpr int NSP = 16, SCW = (16 * (16 * PK + 4) > 16 * PK * NSP) ? 16 * (16 * PK + 4) : 16 * PK * NSP;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1219,7 +1222,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     // plan mode is pinned to the reference
     // (the all-resident variant, RES = 1, is the latency-critical one -- cfg4: +6 % with the plan's extra live state -- and runs
     // the default axis only: the host sends planned problems to RES = 2 / streamed kernels)
-    const bool planned = RES != 1 && a.plan != nullptr;
+    const bool planned = RES != 1 && COOP == 0 && a.plan != nullptr;      // (the cooperative sweep runs the default axis: the host's choice)
     if (planned && !plan_header_ok(a, S)) return;      // (uniform: before the first barrier)
     const int pw_ = plan_step_words(S);
     const int* pfwd = planned ? a.plan + plan_off_fwd() : nullptr;
@@ -1347,18 +1350,30 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     CoopSync csy{};
     __amdgpu_buffer_rsrc_t crs = coop_rsrc(a.coop_x);      // (a NULL base outside the cooperative mode: never dereferenced)
     int c_grp = 0, c_mem = 0, c_hbw = 0;
-    float* const CXB = SC;                                   // [2][4][2048] per-wave partials of dL/dx_L (also: parking area of the state)
-    float* const CKX = CXB + 2 * 4 * 2048;                   // [2][4][64]  per-wave f.dX partials
-    float* const CMX = CKX + 2 * 4 * 64;                     // [3][4][16]  per-wave maxima of |x_L|, |a|, |dX/dt| per sample
-    float* const CSG = CMX + 3 * 4 * 16;                     // [4][16]     sx, 1/(sx sw), sd, 1/(sd sw) of this tile
-    int* const CFL = reinterpret_cast<int*>(CSG + 64);       // barrier outcome
+    bool c_same = false;      // every member of the group on one XCD: plain payload stores (see coop_st16)
+    // exchange area (floats): dP operands of the group tile in flight [2][10 pairs][2 pieces][64 lanes][4], then the STAGED inputs of
+    // the next tile -- x_L image [2][8][64][4], dX/dt [2][C x 16], the a-rows of this member's state units [2][256], scales [2][64] --,
+    // the waves' f.dX partials [2][4][64] and the barrier flag.  The maxima / scales of the owner phase alias the head of the dP area.
+    float* const CDP = SC;
+    float* const CBX = CDP + 2 * 10 * 2 * 64 * 4;
+    float* const CDX = CBX + 2 * 8 * 64 * 4;
+    float* const CAS = CDX + 2 * 80 * 16;
+    float* const CSC = CAS + 2 * 256;
+    float* const CKX = CSC + 2 * 64;
+    float* const CIS = CKX + 2 * 4 * 64;                     // [2][16]     1/(sd sw) of the tile the T role is working on
+    int* const CFL = reinterpret_cast<int*>(CIS + 2 * 16);
+    float* const CMX = CDP;                                  // [3][8][16]  per-wave maxima of |x_L|, |a|, |dX/dt| per sample
+    float* const CSG = CDP + 3 * 8 * 16;                     // [4][16]     sx, 1/(sx sw), sd, 1/(sd sw) of this tile
     if constexpr (COOP != 0) {
         cd.H = H; cd.C = C; cd.dlast = dlast; cd.M = a.coop_M; cd.G = a.coop_G;
         csy.words = a.coop_sync; csy.G = a.coop_G;
         c_grp = blockIdx.x % a.coop_G;
         c_mem = blockIdx.x / a.coop_G;
-        c_hbw = (c_mem * COOP_RPM + wave * COOP_NRT) / (C >> 2);      // the state-unit block every row tile of this wave belongs to
-        coop_load_weights(cw, a.coop_img, c_mem, wave, lane);
+        c_hbw = (c_mem * COOP_RPM + (wave & 3) * COOP_NRT) / (C >> 2);      // P role: the state-unit block every row tile of this wave belongs to
+        coop_load_weights<0, COOP_PIN>(cw, a.coop_img, c_mem, wave, lane);      // the pinned part of this wave's 40 fragments
+        const int same = coop_same_xcd(csy, c_grp, c_mem, a.coop_M, (int)gridDim.x, CFL, tid);
+        if (same < 0) return;      // (another workgroup never arrived: the launch is abandoned, grad_z0 keeps the caller's fill)
+        c_same = same != 0;
     }
 
     // dX/dt (and, for the discrete backward, the recorded stage input) of stage (n, j) are fetched into registers one
@@ -1370,6 +1385,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     // itself -- one exposed global round trip per stage -- instead of one stage ahead through registers
     const bool wide_c = C > DXMAXC;
     StageDesc sdn;      // descriptor of the stage whose inputs are being fetched
+    const float* recn = nullptr;      // discrete backward: its recorded stage input
     auto stage_desc = [&](int n, int j) {
         if (planned) return plan_stage(step_of(n), disc ? S - 1 - j : j);
         return default_stage(a.method, disc ? (float)(n - 1) + stage_offset(a.method, S - 1 - j) : -(-(float)n + stage_offset(a.method, j)), a.n_pieces);
@@ -1410,9 +1426,10 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                 dxn[q] = e < NSP * C ? dx_value(e, sdn) : 0.0f;
             }
         }
+        recn = disc ? a.stages + ((long long)((n - 1) * S + (S - 1 - j)) * a.B + b0) * a.Hr : nullptr;
         if (disc) {
             const int Hr = a.Hr;
-            const float* rec = a.stages + ((long long)((n - 1) * S + (S - 1 - j)) * a.B + b0) * Hr;
+            const float* rec = recn;
 #pragma unroll
             for (int q = 0; q < YSE; ++q) {
                 const int e = tid + q * NT;
@@ -1458,6 +1475,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     int sc = 0;      // stage counter within this time window = record index
 #ifdef NCDE_TL_PROF
     unsigned long long tprof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();      // 8 .. 11: cooperative phases
+    unsigned long long kprof[3] = {0, 0, 0}, klast = 0;      // keeper loop: compute | DMA wait | barrier
 #endif
     for (int n = a.win_hi; n > a.win_lo; --n) {
         const int* pstep = step_of(n);
@@ -1499,11 +1517,57 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                     }
                 } else {
                     const TlW wr_ = tl_wref(lds, DIRECT != 0 ? a.tres[l] : 0, a.W[l], a.b[l], a.dout[l], a.din[l]);
-                    tl_dense_relu<1, NWV>(wr_.W, wr_.b, a.dout[l], a.din[l], in, outb, wave, lane, (BF != 0 && l == L - 1) ? XBA : nullptr, wr_.ld);
+                    tl_dense_relu<1, NWV, 0, 0, COOP ? 4 : 8>(wr_.W, wr_.b, a.dout[l], a.din[l], in, outb, wave, lane, (BF != 0 && l == L - 1) ? XBA : nullptr, wr_.ld);
                 }
                 TL_SYNC(0)
                 in = outb;
             }
+            auto write_records = [&]() {
+                    const long long tile = (long long)sc * n_st + blockIdx.x;
+                    float* ra = a.recA + tile * (BF != 0 ? dlast * 24 : dlast * NSP);
+                    float* rc = a.recC + tile * (H * NSP);
+                    float* rd = a.recD + tile * (C * NSP);
+                    if constexpr (BF != 0) {
+                        for (int e = tid; e < dlast * 6; e += NT)
+                            reinterpret_cast<u32x4*>(ra)[e] = reinterpret_cast<const u32x4*>(XBA)[e];
+                        // record B, split and PAIRED: sample tiles 2i and 2i+1 share one block, the K = 32 samples of the bf16 MFMA
+                        // that accumulates dWo in pass B.  Word ((jt * 3 + piece) * 64 + lane) * 4 + 2 half + d of the pair's block
+                        // holds x_L[k = 16 jt + (lane & 15)][samples 4 (lane >> 4) + 2 d, + 1] of tile `half`.
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        unsigned* rbp = reinterpret_cast<unsigned*>(a.recB) + ((long long)sc * ((n_st + 1) >> 1) + (blockIdx.x >> 1)) * (dlast * 48);
+                        const int half = blockIdx.x & 1;
+                        for (int e = tid; e < dlast * 4; e += NT) {
+                            const int k = e >> 2, kg = e & 3, ln = (k & 15) + 16 * kg;
+                            float v[4];
+    #pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] = in[((k >> 2) * NSP + 4 * kg + q) * 4 + (k & 3)];
+                            unsigned h0, m0, l0, h1, m1, l1;
+                            split_pair(v[0], v[1], h0, m0, l0);
+                            split_pair(v[2], v[3], h1, m1, l1);
+                            unsigned* dst = rbp + (((k >> 4) * 3) * 64 + ln) * 4 + 2 * half;
+                            *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
+                            *reinterpret_cast<u32x2*>(dst + 256) = (u32x2){m0, m1};
+                            *reinterpret_cast<u32x2*>(dst + 512) = (u32x2){l0, l1};
+                            if (half == 0 && blockIdx.x + 1 == n_st) {      // odd tile count: the missing partner contributes zeros
+                                *reinterpret_cast<u32x2*>(dst + 2) = (u32x2){0u, 0u};
+                                *reinterpret_cast<u32x2*>(dst + 258) = (u32x2){0u, 0u};
+                                *reinterpret_cast<u32x2*>(dst + 514) = (u32x2){0u, 0u};
+                            }
+                        }
+                    } else {
+                        float* rb = a.recB + tile * (dlast * NSP);
+                        for (int e = tid; e < dlast * NSP; e += NT) {
+                            ra[e] = in[e];
+                            const int jj = e >> 4, s = e & 15;
+                            rb[e] = in[((jj >> 2) * NSP + s) * 4 + (jj & 3)];
+                        }
+                    }
+                    for (int e = tid; e < H * NSP; e += NT) {
+                        const int hh = e >> 4, s = e & 15;
+                        rc[e] = w * AS[((hh >> 2) * NSP + s) * 4 + (hh & 3)];
+                    }
+                    for (int e = tid; e < C * NSP; e += NT) rd[e] = DX[e];
+            };
             if constexpr (DIRECT != 0) {
                 // ---- direct heads: m = tanh(Wo x_L + bo) (x sigmoid(Wg x_L + bg)) IS dz/dt; cotangents of the two pre-activations ----
                 float* DPT = G0;      // dL/dPt  [H][16]
@@ -1559,25 +1623,29 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                         md = fmaxf(md, __shfl_xor(md, 1, 64)); md = fmaxf(md, __shfl_xor(md, 2, 64));
                         if ((lane & 3) == 0) {
                             const int s_ = (lane >> 2) & 15;
-                            CMX[(0 * 4 + wave) * 16 + s_] = mx; CMX[(1 * 4 + wave) * 16 + s_] = ma; CMX[(2 * 4 + wave) * 16 + s_] = md;
+                            CMX[(0 * 8 + wave) * 16 + s_] = mx; CMX[(1 * 8 + wave) * 16 + s_] = ma; CMX[(2 * 8 + wave) * 16 + s_] = md;
                         }
                     }
                     __syncthreads();
                     if (tid < 16) {
                         float m3[3];
 #pragma unroll
-                        for (int k = 0; k < 3; ++k)
-                            m3[k] = fmaxf(fmaxf(CMX[(k * 4 + 0) * 16 + tid], CMX[(k * 4 + 1) * 16 + tid]), fmaxf(CMX[(k * 4 + 2) * 16 + tid], CMX[(k * 4 + 3) * 16 + tid]));
+                        for (int k = 0; k < 3; ++k) {
+                            float m_ = 0.0f;
+#pragma unroll
+                            for (int wv = 0; wv < 8; ++wv) m_ = fmaxf(m_, CMX[(k * 8 + wv) * 16 + tid]);
+                            m3[k] = m_;
+                        }
                         const float sw_inv = a.coop_scale[1];
                         const float sx = coop_pow2_scale(m3[0]), sd = coop_pow2_scale(m3[1] * m3[2]);
                         const float isx = coop_pow2_inv(sx) * sw_inv, isd = coop_pow2_inv(sd) * sw_inv;
                         CSG[tid] = sx; CSG[16 + tid] = isx; CSG[32 + tid] = sd; CSG[48 + tid] = isd;
-                        coop_st4(crs, my_base + cd.off_sc() + tid, sx); coop_st4(crs, my_base + cd.off_sc() + 16 + tid, isx);
-                        coop_st4(crs, my_base + cd.off_sc() + 32 + tid, sd); coop_st4(crs, my_base + cd.off_sc() + 48 + tid, isd);
+                        coop_st4(crs, a.coop_x, c_same, my_base + cd.off_sc() + tid, sx); coop_st4(crs, a.coop_x, c_same, my_base + cd.off_sc() + 16 + tid, isx);
+                        coop_st4(crs, a.coop_x, c_same, my_base + cd.off_sc() + 32 + tid, sd); coop_st4(crs, a.coop_x, c_same, my_base + cd.off_sc() + 48 + tid, isd);
                     }
                     __syncthreads();
                     // -- OWNER: publish x_L (scaled, split-fp16, B-operand order), a, dX/dt ------------------------------------
-                    {
+                    if (wave < 4) {
                         const int c = wave, ub = 32 * c + 8 * lk;      // K chunk c of this wave; units ub .. ub + 7 of sample li
                         const f32x4 v0 = *reinterpret_cast<const f32x4*>(in + (((ub >> 2)) * NSP + li) * 4);
                         const f32x4 v1 = *reinterpret_cast<const f32x4*>(in + (((ub >> 2) + 1) * NSP + li) * 4);
@@ -1585,26 +1653,28 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                         unsigned h[4], l[4];
                         coop_split2(v0[0] * sx, v0[1] * sx, h[0], l[0]); coop_split2(v0[2] * sx, v0[3] * sx, h[1], l[1]);
                         coop_split2(v1[0] * sx, v1[1] * sx, h[2], l[2]); coop_split2(v1[2] * sx, v1[3] * sx, h[3], l[3]);
-                        coop_st16(crs, my_base + ((c * 2 + 0) * 64 + lane) * 4, (u32x4){h[0], h[1], h[2], h[3]});
-                        coop_st16(crs, my_base + ((c * 2 + 1) * 64 + lane) * 4, (u32x4){l[0], l[1], l[2], l[3]});
-                        for (int e = tid; e < HS / 4; e += NT) coop_st16(crs, my_base + cd.off_as() + e * 4, *reinterpret_cast<const u32x4*>(AS + e * 4));
-                        for (int e = tid; e < C * NSP / 4; e += NT) coop_st16(crs, my_base + cd.off_dx() + e * 4, *reinterpret_cast<const u32x4*>(DX + e * 4));
+                        coop_st16(crs, a.coop_x, c_same, my_base + ((c * 2 + 0) * 64 + lane) * 4, (u32x4){h[0], h[1], h[2], h[3]});
+                        coop_st16(crs, a.coop_x, c_same, my_base + ((c * 2 + 1) * 64 + lane) * 4, (u32x4){l[0], l[1], l[2], l[3]});
+                    }
+                    {
+                        for (int e = tid; e < HS / 4; e += NT) coop_st16(crs, a.coop_x, c_same, my_base + cd.off_as() + e * 4, *reinterpret_cast<const u32x4*>(AS + e * 4));
+                        for (int e = tid; e < C * NSP / 4; e += NT) coop_st16(crs, a.coop_x, c_same, my_base + cd.off_dx() + e * 4, *reinterpret_cast<const u32x4*>(DX + e * 4));
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
                     if (tid == 0) coop_arrive(csy, c_grp);
                     TL_TICK(8)
-                    // park the Butcher k-registers in the LDS arrays that are dead until the reduction (KOY, KOA, G0, G1)
-                    {
-                        float* park = KOY;      // KOY | KOA contiguous: 2 HS floats; then G0 | G1: 2 DS floats
+                    write_records();      // (needs a, dX/dt, x_L and its split image: all final -- and dead for this stage afterwards)
+                    __syncthreads();
+                    coop_load_weights<COOP_PIN, 40>(cw, a.coop_img, c_mem, wave, lane);      // the re-read part (in flight while the group assembles)
+                    // the Butcher k-registers wait in LDS arrays that are dead until the reduction (KOY, KOA, G0, G1: 2048 floats each)
 #pragma unroll
-                        for (int q = 0; q < TL_EADJ; ++q) {
-                            if (q * NT < HS) {      // (H < 128: the upper slots of the state slice are unused, and KOY / KOA are HS floats)
-                                KOY[q * NT + tid] = ky1[q]; KOA[q * NT + tid] = ky2[q];
-                                G0[q * NT + tid] = ka1[q]; G1[q * NT + tid] = ka2[q];
-                            }
+                    for (int q = 0; q < TL_EADJ; ++q) {
+                        if (q * NT < HS) {      // (H < 128: the upper slots of the state slice are unused, the LDS arrays hold HS floats)
+                            KOY[q * NT + tid] = ky1[q]; KOA[q * NT + tid] = ky2[q];
+                            G0[q * NT + tid] = ka1[q]; G1[q * NT + tid] = ka2[q];
+                            AS[q * NT + tid] = y0[q]; reinterpret_cast<float*>(XBA)[q * NT + tid] = a0[q];      // (a and the split image: recorded above)
                         }
-                        (void)park;
                     }
                     if (!coop_wait(csy, c_grp, bar1, CFL, tid)) {      // timeout / another workgroup gave up: poison this tile's gradient
                         for (int e = tid; e < NSP * a.Hr; e += NT)
@@ -1612,147 +1682,201 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                         return;
                     }
                     TL_TICK(9)
+#ifdef NCDE_TL_PROF
+                    tprof[6] += c_same ? 1000 : 0;      // (development: column 6 = 1000 when the group shares an XCD)
+#endif
                     // -- KEEPER: the rows of Wo this workgroup holds x every sample tile of the group -----------------------------
-                    const int ncq = C >> 2, jh = COOP_RPM / ncq, wph = 4 / jh;      // state-unit blocks per member, waves per block
-                    int cqs[COOP_NRT];
+                    // Iteration `it` of the loop: the P role (waves 0..3) takes sample tile it -- P over its 5 row tiles, tanh, f.dX
+                    // partial, dP -> LDS as the split-fp16 B operands of the 10 row-tile pairs -- while the T role (waves 4..7)
+                    // takes tile it - 1: Wo^T dP over its 2 column tiles x all 10 pairs -> the member's partial of dL/dx_L straight to
+                    // the exchange area.  All threads fetch tile it + 1's inputs into LDS meanwhile.  One workgroup barrier per
+                    // iteration; dP, the staged inputs and the small exchange arrays are double-buffered by the parity of `it`.
+                    const int ncq = C >> 2, jh = COOP_RPM / ncq, wph = 4 / jh;      // state-unit blocks per member, P waves per block
+                    const bool prole = wave < 4;
+                    const int rw = wave & 3;      // wave index within its role
+                    const int cq0 = (c_mem * COOP_RPM + rw * COOP_NRT) % ncq;      // first channel quad of this wave's row tiles (5 | ncq: no wrap)
+                    // staging of one tile's inputs: thread t moves piece t of the x_L image (512) and one piece of {dX/dt (<= 320) |
+                    // the a-rows of this member's state units (<= 64, threads 320 ..) | the scales (16, threads 384 ..)}
+                    const int n_dx4 = C * NSP / 4, n_as4 = jh * 16;
+                    // LDS-DMA (global_load_lds_dwordx4, sc1): a wave's 64 lanes land in 1 KB of LDS starting at a wave-uniform base, no
+                    // register in between; the issuing wave's vmcnt covers it, the workgroup barrier publishes it
+                    typedef const __attribute__((address_space(1))) void* gptr_t;
+                    typedef __attribute__((address_space(3))) void* lptr_t;
+                    auto stage_load = [&](int tile, int buf, int tid) {
+                        const float* src = a.coop_x + (long long)tile * cd.per_tile();
+                        const int w64 = (tid >> 6) * 64;      // first thread of this wave
+                        __builtin_amdgcn_global_load_lds((gptr_t)(src + tid * 4), (lptr_t)(CBX + buf * 2048 + w64 * 4), 16, 0, 16);
+                        if (tid < n_dx4) __builtin_amdgcn_global_load_lds((gptr_t)(src + cd.off_dx() + tid * 4), (lptr_t)(CDX + buf * 1280 + w64 * 4), 16, 0, 16);
+                        else if (tid >= 320 && tid < 320 + n_as4)
+                            __builtin_amdgcn_global_load_lds((gptr_t)(src + cd.off_as() + (c_mem * jh * NSP) * 4 + (tid - 320) * 4), (lptr_t)(CAS + buf * 256), 16, 0, 16);
+                        else if (tid >= 384 && tid < 400)
+                            __builtin_amdgcn_global_load_lds((gptr_t)(src + cd.off_sc() + (tid - 384) * 4), (lptr_t)(CSC + buf * 64), 16, 0, 16);
+                    };
+                    auto stage_store = [&](int, int) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+                    stage_load(c_grp, 0, tid);
+                    stage_store(0, tid);
+                    __syncthreads();
+                    const int tid_outer = tid;
+#ifdef NCDE_TL_PROF
+                    klast = __builtin_readcyclecounter();
+#endif
+                    const int hl_w = rw / wph;      // P role: which of this member's state-unit blocks this wave's row tiles belong to
+                    // (one loop per role -- same trip count, same barriers -- so that neither carries the other's live registers)
+                    if (prole) {
+                        for (int it = 0; it <= cd.M; ++it) {
+                            // (thread-id derived offsets are re-derived from an opaque copy every iteration: hoisted out of the loop they were
+                            // spilled, and every scratch reload waits -- vmcnt is in order -- for the staging loads of the NEXT tile too)
+                            int tid = tid_outer;
+                            asm volatile("" : "+v"(tid));
+                            const int lane = tid & 63, li = tid & 15, lk = (tid >> 4) & 3;
+                            const int buf = it & 1;
+                            if (it + 1 < cd.M) stage_load(c_grp + cd.G * (it + 1), buf ^ 1, tid);
+                            if (it < cd.M) {
+                                const float* bxs = CBX + buf * 2048;
+                                const float isx = CSC[buf * 64 + 16 + li], sd = CSC[buf * 64 + 32 + li];
+                                if (wave == 0 && lane < 16) CIS[buf * 16 + lane] = CSC[buf * 64 + 48 + lane];
+                                const float sxw = coop_pow2_inv(isx);      // sx sw: the bias joins the scaled accumulator exactly
+                                const float aval = CAS[buf * 256 + (hl_w * NSP + li) * 4 + lk];
+                                float kk = 0.0f;
+                                unsigned* dpx = reinterpret_cast<unsigned*>(CDP) + buf * (10 * 2 * 64 * 4);
+                                // P = Wo x_L on the f16 matrix cores, main (h1 h1, starts at the scaled bias) and cross (h1 h2 + h2 h1)
+                                // accumulators; the wave's five row tiles in two batches (3 + 2) to keep the accumulators at 24 registers
+                                auto p_batch = [&](auto q0c, auto nqc) {
+                                    constexpr int Q0 = decltype(q0c)::value, NQ = decltype(nqc)::value;
+                                    f32x4 pm[NQ], px[NQ];
 #pragma unroll
-                    for (int q = 0; q < COOP_NRT; ++q) cqs[q] = (c_mem * COOP_RPM + wave * COOP_NRT + q) % ncq;
-                    u32x4 Bx[COOP_NCH][2];
-                    {
-                        const long long tb = (long long)c_grp * cd.per_tile();
+                                    for (int i = 0; i < NQ; ++i) {
+                                        const f32x4 bsv = *reinterpret_cast<const f32x4*>(a.bo + (4 * c_hbw + lk) * C + 4 * (cq0 + Q0 + i));
 #pragma unroll
-                        for (int c = 0; c < COOP_NCH; ++c)
+                                        for (int r = 0; r < 4; ++r) pm[i][r] = bsv[r] * sxw;
+                                        px[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                                    }
+                                    u32x4 b0_ = *reinterpret_cast<const u32x4*>(bxs + lane * 4), b1_ = *reinterpret_cast<const u32x4*>(bxs + (64 + lane) * 4);
 #pragma unroll
-                            for (int pc = 0; pc < 2; ++pc) Bx[c][pc] = coop_ld16(crs, tb + ((c * 2 + pc) * 64 + lane) * 4);
-                    }
-                    for (int mm = 0; mm < cd.M; ++mm) {
-                        const int tt = c_grp + cd.G * mm, buf = mm & 1;
-                        const long long tb = (long long)tt * cd.per_tile();
-                        const float isx = coop_ld4(crs, tb + cd.off_sc() + 16 + li), sd = coop_ld4(crs, tb + cd.off_sc() + 32 + li),
-                                    isd = coop_ld4(crs, tb + cd.off_sc() + 48 + li);
-                        const float aval = coop_ld4(crs, tb + cd.off_as() + (c_hbw * NSP + li) * 4 + lk);
-                        f32x4 dxv[COOP_NRT], bsv[COOP_NRT];
+                                    for (int c = 0; c < COOP_NCH; ++c) {
+                                        const u32x4 c0_ = b0_, c1_ = b1_;
+                                        if (c + 1 < COOP_NCH) {      // the next chunk's operand is read while this chunk multiplies
+                                            b0_ = *reinterpret_cast<const u32x4*>(bxs + (((c + 1) * 2 + 0) * 64 + lane) * 4);
+                                            b1_ = *reinterpret_cast<const u32x4*>(bxs + (((c + 1) * 2 + 1) * 64 + lane) * 4);
+                                        }
 #pragma unroll
-                        for (int q = 0; q < COOP_NRT; ++q) {
-                            dxv[q] = coop_ld16f(crs, tb + cd.off_dx() + (cqs[q] * NSP + li) * 4);
-                            bsv[q] = *reinterpret_cast<const f32x4*>(a.bo + (4 * c_hbw + lk) * C + 4 * cqs[q]);
-                        }
-                        // P = Wo x_L on the f16 matrix cores: main (h1 h1) and cross (h1 h2 + h2 h1) accumulators, tiles interleaved
-                        f32x4 pm[COOP_NRT], px[COOP_NRT];
+                                        for (int i = 0; i < NQ; ++i) pm[i] = mfma_h(cw.f[((Q0 + i) * 4 + c) * 2 + 0], c0_, pm[i]);
 #pragma unroll
-                        for (int q = 0; q < COOP_NRT; ++q) pm[q] = px[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                                        for (int i = 0; i < NQ; ++i) px[i] = mfma_h(cw.f[((Q0 + i) * 4 + c) * 2 + 1], c0_, px[i]);
 #pragma unroll
-                        for (int c = 0; c < COOP_NCH; ++c) {
+                                        for (int i = 0; i < NQ; ++i) px[i] = mfma_h(cw.f[((Q0 + i) * 4 + c) * 2 + 0], c1_, px[i]);
+                                    }
 #pragma unroll
-                            for (int q = 0; q < COOP_NRT; ++q) pm[q] = mfma_h(cw.P[q][c][0], Bx[c][0], pm[q]);
+                                    for (int i = 0; i < NQ; ++i) {
+                                        const f32x4 pc4 = h2_combine(pm[i], px[i]);
+                                        const f32x4 dxv = *reinterpret_cast<const f32x4*>(CDX + buf * 1280 + ((cq0 + Q0 + i) * NSP + li) * 4);
+                                        float dps[4];
 #pragma unroll
-                            for (int q = 0; q < COOP_NRT; ++q) px[q] = mfma_h(cw.P[q][c][1], Bx[c][0], px[q]);
-#pragma unroll
-                            for (int q = 0; q < COOP_NRT; ++q) px[q] = mfma_h(cw.P[q][c][0], Bx[c][1], px[q]);
-                        }
-                        float kk = 0.0f;
-                        float dps[COOP_NRT][4];
-#pragma unroll
-                        for (int q = 0; q < COOP_NRT; ++q) {
-                            const f32x4 pc4 = h2_combine(pm[q], px[q]);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float th = tanh_dev(__builtin_fmaf(pc4[r], isx, bsv[q][r]));
-                                kk = fmaf(th, dxv[q][r], kk);
-                                dps[q][r] = ((aval * dxv[q][r]) * (1.0f - th * th)) * sd;
+                                        for (int r = 0; r < 4; ++r) {
+                                            const float th = tanh_dev(pc4[r] * isx);
+                                            kk = fmaf(th, dxv[r], kk);
+                                            dps[r] = ((aval * dxv[r]) * (1.0f - th * th)) * sd;
+                                        }
+                                        // this tile's half of its pair's B operand: the lane's own four values (k = 8 g + 4 (tile & 1) + r)
+                                        const int rtl = rw * COOP_NRT + Q0 + i, pr = rtl >> 1, half = rtl & 1;
+                                        unsigned h0, l0, h1, l1;
+                                        coop_split2(dps[0], dps[1], h0, l0);
+                                        coop_split2(dps[2], dps[3], h1, l1);
+                                        *reinterpret_cast<u32x2c*>(dpx + ((pr * 2 + 0) * 64 + lane) * 4 + 2 * half) = (u32x2c){h0, h1};
+                                        *reinterpret_cast<u32x2c*>(dpx + ((pr * 2 + 1) * 64 + lane) * 4 + 2 * half) = (u32x2c){l0, l1};
+                                    }
+                                };
+                                p_batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+                                p_batch(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+                                CKX[(buf * 4 + rw) * 64 + lane] = kk;
                             }
+#ifdef NCDE_TL_PROF
+                            { const unsigned long long n_ = __builtin_readcyclecounter(); kprof[0] += n_ - klast; klast = n_; }
+#endif
+                            if (it + 1 < cd.M) stage_store(buf ^ 1, tid);      // (requested at the top of the iteration)
+#ifdef NCDE_TL_PROF
+                            { const unsigned long long n_ = __builtin_readcyclecounter(); kprof[1] += n_ - klast; klast = n_; }
+#endif
+                            __syncthreads();
+#ifdef NCDE_TL_PROF
+                            { const unsigned long long n_ = __builtin_readcyclecounter(); kprof[2] += n_ - klast; klast = n_; }
+#endif
                         }
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (mm + 1 < cd.M) {      // the next tile's B operand: its registers are free until the next P
-                            const long long nb = (long long)(tt + cd.G) * cd.per_tile();
+                    } else {
+                        for (int it = 0; it <= cd.M; ++it) {
+                            // (thread-id derived offsets are re-derived from an opaque copy every iteration: hoisted out of the loop they were
+                            // spilled, and every scratch reload waits -- vmcnt is in order -- for the staging loads of the NEXT tile too)
+                            int tid = tid_outer;
+                            asm volatile("" : "+v"(tid));
+                            const int lane = tid & 63, li = tid & 15, lk = (tid >> 4) & 3;
+                            const int buf = it & 1;
+                            if (it + 1 < cd.M) stage_load(c_grp + cd.G * (it + 1), buf ^ 1, tid);
+                            if (it >= 1) {
+                                // T role, tile it - 1: this wave's two column tiles of the 128 hidden units over the 10 row-tile pairs
+                                const int pb = buf ^ 1, tt = c_grp + cd.G * (it - 1);
+                                const long long tb = (long long)tt * cd.per_tile();
+                                const unsigned* dpx = reinterpret_cast<const unsigned*>(CDP) + pb * (10 * 2 * 64 * 4);
+                                const float isd = CIS[pb * 16 + li];
+                                f32x4 tm[2], tx[2];
 #pragma unroll
-                            for (int c = 0; c < COOP_NCH; ++c)
+                                for (int ci = 0; ci < 2; ++ci) tm[ci] = tx[ci] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                                u32x4 nh = *reinterpret_cast<const u32x4*>(dpx + lane * 4), nl = *reinterpret_cast<const u32x4*>(dpx + (64 + lane) * 4);
 #pragma unroll
-                                for (int pc = 0; pc < 2; ++pc) Bx[c][pc] = coop_ld16(crs, nb + ((c * 2 + pc) * 64 + lane) * 4);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        // Wo^T dP over this wave's rows: the lane's own eight dP values of a tile pair ARE the B operand (k = 8 g + 4 tile + r)
-                        u32x4 bh[2], bl[2];
+                                for (int pr = 0; pr < COOP_RPM / 2; ++pr) {
+                                    const u32x4 bh = nh, bl = nl;
+                                    if (pr + 1 < COOP_RPM / 2) {      // the next pair's operand is read while this pair multiplies
+                                        nh = *reinterpret_cast<const u32x4*>(dpx + (((pr + 1) * 2 + 0) * 64 + lane) * 4);
+                                        nl = *reinterpret_cast<const u32x4*>(dpx + (((pr + 1) * 2 + 1) * 64 + lane) * 4);
+                                    }
 #pragma unroll
-                        for (int pr = 0; pr < 2; ++pr) {
-                            unsigned h[4], l[4];
-                            coop_split2(dps[2 * pr][0], dps[2 * pr][1], h[0], l[0]); coop_split2(dps[2 * pr][2], dps[2 * pr][3], h[1], l[1]);
-                            coop_split2(dps[2 * pr + 1][0], dps[2 * pr + 1][1], h[2], l[2]); coop_split2(dps[2 * pr + 1][2], dps[2 * pr + 1][3], h[3], l[3]);
-                            bh[pr] = (u32x4){h[0], h[1], h[2], h[3]};
-                            bl[pr] = (u32x4){l[0], l[1], l[2], l[3]};
-                        }
-                        u32x2c b4h, b4l;
-                        {
-                            unsigned h[2], l[2];
-                            coop_split2(dps[4][0], dps[4][1], h[0], l[0]); coop_split2(dps[4][2], dps[4][3], h[1], l[1]);
-                            b4h = (u32x2c){h[0], h[1]};
-                            b4l = (u32x2c){l[0], l[1]};
-                        }
-                        float* xb = CXB + (buf * 4 + wave) * 2048;
+                                    for (int ci = 0; ci < 2; ++ci) tm[ci] = mfma_h(cw.f[(pr * 2 + ci) * 2 + 0], bh, tm[ci]);
 #pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            f32x4 tm[4], tx[4];
+                                    for (int ci = 0; ci < 2; ++ci) tx[ci] = mfma_h(cw.f[(pr * 2 + ci) * 2 + 1], bh, tx[ci]);
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) tm[i] = tx[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                                    for (int ci = 0; ci < 2; ++ci) tx[ci] = mfma_h(cw.f[(pr * 2 + ci) * 2 + 0], bl, tx[ci]);
+                                }
 #pragma unroll
-                            for (int pr = 0; pr < 2; ++pr) {
+                                for (int ci = 0; ci < 2; ++ci) {
+                                    f32x4 o = h2_combine(tm[ci], tx[ci]);
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) tm[i] = mfma_h(cw.T[pr][4 * half + i][0], bh[pr], tm[i]);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) tx[i] = mfma_h(cw.T[pr][4 * half + i][1], bh[pr], tx[i]);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) tx[i] = mfma_h(cw.T[pr][4 * half + i][0], bl[pr], tx[i]);
+                                    for (int r = 0; r < 4; ++r) o[r] *= isd;
+                                    // units 16 ct + 4 lk + r of sample li, ct = 2 rw + ci, in the activation layout [unit / 4][16][4]
+                                    coop_st16(crs, a.coop_x, c_same, tb + cd.off_part() + (long long)c_mem * (dlast * NSP) + ((4 * (2 * rw + ci) + lk) * NSP + li) * 4,
+                                              __builtin_bit_cast(u32x4, o));
+                                }
+                                if (tid - 256 < 64 * jh) {      // f.dX of this member's state units: sum of the P waves that hold their channel tiles
+                                    const int hl = (tid - 256) >> 6, ln = tid & 63;
+                                    float ksum = 0.0f;
+                                    for (int wv = hl * wph; wv < (hl + 1) * wph; ++wv) ksum += CKX[(pb * 4 + wv) * 64 + ln];
+                                    coop_st4(crs, a.coop_x, c_same, tb + cd.off_ko() + ((c_mem * jh + hl) * NSP + (ln & 15)) * 4 + (ln >> 4), ksum);
+                                }
                             }
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) tm[i] = coop_mfma_k16(cw.T1[4 * half + i][0], b4h, tm[i]);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) tx[i] = coop_mfma_k16(cw.T1[4 * half + i][1], b4h, tx[i]);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) tx[i] = coop_mfma_k16(cw.T1[4 * half + i][0], b4l, tx[i]);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                f32x4 o = h2_combine(tm[i], tx[i]);
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) o[r] *= isd;
-                                *reinterpret_cast<f32x4*>(xb + ((4 * (4 * half + i) + lk) * NSP + li) * 4) = o;      // units 16 ct + 4 lk + r
-                            }
-                        }
-                        CKX[(buf * 4 + wave) * 64 + lane] = kk;
-                        __syncthreads();
-                        // sum of the four waves' partials (fixed order) -> this member's partial of tile tt; f.dX slices of its state units
-                        {
-                            const float* x0 = CXB + (buf * 4) * 2048;
-#pragma unroll
-                            for (int i = 0; i < 2; ++i) {
-                                const int e4 = (tid + i * NT) * 4;
-                                const f32x4 p0 = *reinterpret_cast<const f32x4*>(x0 + e4), p1 = *reinterpret_cast<const f32x4*>(x0 + 2048 + e4);
-                                const f32x4 p2 = *reinterpret_cast<const f32x4*>(x0 + 4096 + e4), p3 = *reinterpret_cast<const f32x4*>(x0 + 6144 + e4);
-                                f32x4 sum;
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) sum[r] = (p0[r] + p1[r]) + (p2[r] + p3[r]);
-                                coop_st16(crs, tb + cd.off_part() + (long long)c_mem * (dlast * NSP) + e4, __builtin_bit_cast(u32x4, sum));
-                            }
-                            if (tid < 64 * jh) {
-                                const int hl = tid >> 6, ln = tid & 63;
-                                float ksum = 0.0f;
-                                for (int wv = hl * wph; wv < (hl + 1) * wph; ++wv) ksum += CKX[(buf * 4 + wv) * 64 + ln];
-                                coop_st4(crs, tb + cd.off_ko() + ((c_mem * jh + hl) * NSP + (ln & 15)) * 4 + (ln >> 4), ksum);
-                            }
+#ifdef NCDE_TL_PROF
+                            { const unsigned long long n_ = __builtin_readcyclecounter(); kprof[0] += n_ - klast; klast = n_; }
+#endif
+                            if (it + 1 < cd.M) stage_store(buf ^ 1, tid);      // (requested at the top of the iteration)
+#ifdef NCDE_TL_PROF
+                            { const unsigned long long n_ = __builtin_readcyclecounter(); kprof[1] += n_ - klast; klast = n_; }
+#endif
+                            __syncthreads();
+#ifdef NCDE_TL_PROF
+                            { const unsigned long long n_ = __builtin_readcyclecounter(); kprof[2] += n_ - klast; klast = n_; }
+#endif
                         }
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
                     if (tid == 0) coop_arrive(csy, c_grp);
                     TL_TICK(10)
-                    // the k-registers back (their LDS arrays are about to be reused)
 #pragma unroll
                     for (int q = 0; q < TL_EADJ; ++q) {
                         if (q * NT < HS) {
                             ky1[q] = KOY[q * NT + tid]; ky2[q] = KOA[q * NT + tid];
                             ka1[q] = G0[q * NT + tid]; ka2[q] = G1[q * NT + tid];
+                            y0[q] = AS[q * NT + tid]; a0[q] = reinterpret_cast<const float*>(XBA)[q * NT + tid];
                         }
                     }
-                    {   // next stage's inputs (COOP: requested here instead of at the top of the stage)
+                    {   // next stage's inputs (requested here, not at the top of the stage: the keeper phase needs the registers)
                         const int jn = j + 1 < S ? j + 1 : 0, nn = j + 1 < S ? n : n - 1;
                         if (nn > a.win_lo) prefetch(nn, jn);
                     }
@@ -1760,52 +1884,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                 tl_output_vjp<PK, NWV, RES, GATED, (BF != 0 && GATED == 0) ? 1 : 0>(a, in, AS, DX, KOY, scr, wave, lane, wo, XBA);
                 TL_TICK(1)
                 // ---- records for pass B (x_L twice, weighted cotangent, dX/dt) --------------------------------------------
-                {
-                    const long long tile = (long long)sc * n_st + blockIdx.x;
-                    float* ra = a.recA + tile * (BF != 0 ? dlast * 24 : dlast * NSP);
-                    float* rc = a.recC + tile * (H * NSP);
-                    float* rd = a.recD + tile * (C * NSP);
-                    if constexpr (BF != 0) {
-                        for (int e = tid; e < dlast * 6; e += NT)
-                            reinterpret_cast<u32x4*>(ra)[e] = reinterpret_cast<const u32x4*>(XBA)[e];
-                        // record B, split and PAIRED: sample tiles 2i and 2i+1 share one block, the K = 32 samples of the bf16 MFMA
-                        // that accumulates dWo in pass B.  Word ((jt * 3 + piece) * 64 + lane) * 4 + 2 half + d of the pair's block
-                        // holds x_L[k = 16 jt + (lane & 15)][samples 4 (lane >> 4) + 2 d, + 1] of tile `half`.
-                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                        unsigned* rbp = reinterpret_cast<unsigned*>(a.recB) + ((long long)sc * ((n_st + 1) >> 1) + (blockIdx.x >> 1)) * (dlast * 48);
-                        const int half = blockIdx.x & 1;
-                        for (int e = tid; e < dlast * 4; e += NT) {
-                            const int k = e >> 2, kg = e & 3, ln = (k & 15) + 16 * kg;
-                            float v[4];
-    #pragma unroll
-                            for (int q = 0; q < 4; ++q) v[q] = in[((k >> 2) * NSP + 4 * kg + q) * 4 + (k & 3)];
-                            unsigned h0, m0, l0, h1, m1, l1;
-                            split_pair(v[0], v[1], h0, m0, l0);
-                            split_pair(v[2], v[3], h1, m1, l1);
-                            unsigned* dst = rbp + (((k >> 4) * 3) * 64 + ln) * 4 + 2 * half;
-                            *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
-                            *reinterpret_cast<u32x2*>(dst + 256) = (u32x2){m0, m1};
-                            *reinterpret_cast<u32x2*>(dst + 512) = (u32x2){l0, l1};
-                            if (half == 0 && blockIdx.x + 1 == n_st) {      // odd tile count: the missing partner contributes zeros
-                                *reinterpret_cast<u32x2*>(dst + 2) = (u32x2){0u, 0u};
-                                *reinterpret_cast<u32x2*>(dst + 258) = (u32x2){0u, 0u};
-                                *reinterpret_cast<u32x2*>(dst + 514) = (u32x2){0u, 0u};
-                            }
-                        }
-                    } else {
-                        float* rb = a.recB + tile * (dlast * NSP);
-                        for (int e = tid; e < dlast * NSP; e += NT) {
-                            ra[e] = in[e];
-                            const int jj = e >> 4, s = e & 15;
-                            rb[e] = in[((jj >> 2) * NSP + s) * 4 + (jj & 3)];
-                        }
-                    }
-                    for (int e = tid; e < H * NSP; e += NT) {
-                        const int hh = e >> 4, s = e & 15;
-                        rc[e] = w * AS[((hh >> 2) * NSP + s) * 4 + (hh & 3)];
-                    }
-                    for (int e = tid; e < C * NSP; e += NT) rd[e] = DX[e];
-                }
+                if constexpr (COOP == 0) write_records();      // (COOP: written while the group assembles, see above)
                 TL_SYNC(2)
                 // ---- dL/dpre_L = (sum of the 8 partials) * relu'(x_L) ---------------------------------------------------------
                 if constexpr (COOP != 0) {      // ... of the group's M partials of this tile, in member order; f.dX from its keepers' slices
@@ -1980,6 +2059,8 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
 #ifdef NCDE_TL_PROF
     if (lane == 0 && sc > 0)
         for (int k = 0; k < 12; ++k) a.grad_z0[(long long)b0 * a.Hr + wave * 12 + k] = (float)tprof[k] / (float)sc;      // (over the tile's dz0 rows)
+    if (lane == 0 && sc > 0)
+        for (int k = 0; k < 3; ++k) a.grad_z0[(long long)b0 * a.Hr + 96 + wave * 3 + k] = (float)kprof[k] / (float)sc;
 #endif
     {
         const int li = lane & 15, lk = lane >> 4;
@@ -2583,7 +2664,7 @@ struct CoopPlan {
     bool ok;
     int M, G;      // members per group, groups
 };
-constexpr int kCoopLdsFloats = 2 * 4 * 2048 + 2 * 4 * 64 + 3 * 4 * 16 + 64 + 8;      // = COOP_LDS of ncde_adj_tiled
+constexpr int kCoopLdsFloats = 2 * 10 * 2 * 64 * 4 + 2 * 8 * 64 * 4 + 2 * 80 * 16 + 2 * 256 + 2 * 64 + 2 * 4 * 64 + 2 * 16 + 8;      // = COOP_LDS of ncde_adj_tiled
 size_t tiled_coop_lds(const NcdeProblem* p) {
     int D = 16;
     for (int l = 0; l < p->n_layers; ++l) D = std::max(D, p->layer_out[l]);
@@ -2604,7 +2685,7 @@ int tiled_device_cus() {
 CoopPlan tiled_coop_plan(const NcdeProblem* p) {
     CoopPlan c{false, 0, 0};
     if (p->flags & (NCDE_FLAG_NO_COOP | NCDE_FLAG_FP32_MFMA | NCDE_FLAG_DEBUG_PROFILE)) return c;
-    if (p->field_kind != NCDE_FIELD_ORIGINAL || p->field_input != NCDE_INPUT_MATMUL || p->n_layers < 1) return c;
+    if (p->field_kind != NCDE_FIELD_ORIGINAL || p->field_input != NCDE_INPUT_MATMUL || p->n_layers < 1 || p->output == NCDE_OUT_TIMES) return c;
     if (p->layer_out[p->n_layers - 1] != 128 || p->hidden > 128 || p->hidden % 16 || p->channels % 4) return c;
     const int ncq = p->channels / 4;
     if (ncq != 5 && ncq != 10 && ncq != 20) return c;
@@ -2654,7 +2735,7 @@ struct TiledAdjPlan {
     // cooperative output phase: packed weight images, exchange area, {absmax bits, sw, 1/sw}, sync words
     bool coop;
     int coop_M, coop_G;
-    long long coop_img, coop_x, coop_scale, coop_sync;
+    long long coop_img, coop_x, coop_scale, coop_sync, coop_state;
 };
 
 // Record budget of one time window.  The continuous adjoint exists to be O(1) in memory (torchcde README: "slower but more
@@ -2725,7 +2806,8 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
         t.coop_img = off; off += (long long)cp.M * (coop_p_words() + coop_t_words());
         t.coop_x = off; off += d.per_tile() * t.n_st;
         t.coop_scale = off; off += 64;
-        t.coop_sync = off; off += 64 + cp.G;
+        t.coop_state = off; off += (long long)t.n_st * 2 * 8 * 512 * 4;      // the sweep's hidden-dW accumulators while its registers hold Wo: 2 x TL_DWT x NT float4 per workgroup
+        t.coop_sync = off; off += 64 + coop_sync_words(cp.G, t.n_st);
     }
     t.total = off + 64;
     return t;
@@ -2958,20 +3040,21 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     int nwv_launch = nwv;
     size_t lds_launch = tiled_adj_lds(p);
     if (t.coop) {      // XCD-cooperative output phase: weights resident in registers, activations exchanged through L2 (ncde_coop.h)
-        fa = ncde_adj_tiled<8, 4, 0, 0, 1, 0, 0, 1>;
-        nwv_launch = 4;
+        fa = ncde_adj_tiled<8, 8, 0, 0, 1, 0, 0, 1>;
+        nwv_launch = 8;
         lds_launch = tiled_coop_lds(p);
         unsigned* amax = reinterpret_cast<unsigned*>(w + t.coop_scale + 8);
         if (hipMemsetAsync(amax, 0, sizeof(unsigned), st) != hipSuccess) return NCDE_ERR_HIP;
+        // the hidden-layer weight gradients accumulate in the workgroups' global partials from the first stage on
+        if (hipMemsetAsync(w + t.gpartA, 0, sizeof(float) * (size_t)t.n_st * t.gstride, st) != hipSuccess) return NCDE_ERR_HIP;
         const long long nw = (long long)p->hidden * p->channels * 128;
         hipLaunchKernelGGL(ncde_coop_absmax, dim3(512), dim3(256), 0, st, a.Wo, nw, amax);
         hipLaunchKernelGGL(ncde_coop_pack, dim3(1024), dim3(256), 0, st, a.Wo, (const unsigned*)amax, reinterpret_cast<unsigned*>(w + t.coop_img),
                            w + t.coop_scale, p->channels, 128, t.coop_M);
-        // the hidden-layer weight gradients accumulate in the workgroups' global partials from the first stage on
-        if (hipMemsetAsync(w + t.gpartA, 0, sizeof(float) * (size_t)t.n_st * t.gstride, st) != hipSuccess) return NCDE_ERR_HIP;
         a.coop_img = reinterpret_cast<const unsigned*>(w + t.coop_img);
         a.coop_x = w + t.coop_x;
         a.coop_scale = w + t.coop_scale;
+        a.coop_state = w + t.coop_state;
         a.coop_sync = reinterpret_cast<unsigned*>(w + t.coop_sync);
         a.coop_M = t.coop_M;
         a.coop_G = t.coop_G;
@@ -2987,7 +3070,7 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     for (int hi = n_rsteps, first = 1; hi >= 1; hi -= t.window, first = 0) {
         const int lo = std::max(0, hi - t.window);
         a.win_hi = hi; a.win_lo = lo; a.resume = first ? 0 : 1;
-        if (t.coop && hipMemsetAsync(a.coop_sync, 0, sizeof(unsigned) * (size_t)(t.coop_G + 1), st) != hipSuccess) return NCDE_ERR_HIP;
+        if (t.coop && hipMemsetAsync(a.coop_sync, 0, sizeof(unsigned) * (size_t)coop_sync_words(t.coop_G, t.n_st), st) != hipSuccess) return NCDE_ERR_HIP;
         hipLaunchKernelGGL(fa, dim3(t.n_st), dim3(64 * nwv_launch), lds, st, a);
         const int n_sc = (hi - lo) * t.S;
         hipLaunchKernelGGL(fb, gridB, dim3(256), 0, st, a, n_sc, t.n_st, gB);

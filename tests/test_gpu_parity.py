@@ -352,7 +352,17 @@ def test_full_batch_cfg4_cfg5_sample_independence(cfg, gpu_lib):
     sub = dict(big, coeffs=coeffs[sel].copy(), z0=z0[sel].copy(), expect={"grad_out": gout[sel].copy()})
     rs = gpu_util.run_case(sub)
     assert np.array_equal(rs["z_out"], rb["z_out"][sel])
-    assert np.array_equal(rs["dz0"], rb["dz0"][sel])
+    if "coop" in rb["kernels"][1]:
+        # round 5: the full cfg5 batch runs the XCD-cooperative sweep (fp16-split transposed product), a 32-sample batch the
+        # per-workgroup sweep (fp32 transposed product): two kernels, fp32 round-off apart; the per-workgroup sweep keeps the bitwise property
+        from ncde_amd import _lib
+        assert gu.relerr(rs["dz0"], rb["dz0"][sel]) <= 2e-5
+        rbo = gpu_util.run_case(big, flags=_lib.FLAG_NO_COOP)
+        assert "coop" not in rbo["kernels"][1] and np.array_equal(rs["dz0"], rbo["dz0"][sel])
+        for k in names:
+            assert gu.relerr(rb["grads"][k], rbo["grads"][k]) <= 2e-4, k      # (batch-summed over 4096 samples x 3192 stages)
+    else:
+        assert np.array_equal(rs["dz0"], rb["dz0"][sel])
     assert all(np.isfinite(g).all() for g in rb["grads"].values())
     rb2 = gpu_util.run_case(big)
     assert all(np.array_equal(rb2["grads"][k], rb["grads"][k]) for k in names)

@@ -29,9 +29,13 @@ for flags, label in ((_lib.FLAG_FORCE_TILED, "default"), (_lib.FLAG_FORCE_TILED 
     ms = ctypes.c_float()
     _lib.check(lib.ncde_time_kernel(ctypes.byref(p), 1, out.data_ptr(), gout.data_ptr(), ctypes.byref(g), ws.data_ptr(), ws.numel(), None, 1, ctypes.byref(ms)), "time")
     name = (lib.ncde_kernel_name(ctypes.byref(p), 1) or b"?").decode()
-    nwv = 4 if "coop" in name else 8
+    nwv = 8
     per = gz0.view(B // 16, 16 * H)[:, :nwv * 12].view(-1, nwv, 12).cpu().numpy().mean(axis=0)
     T = coeffs.shape[1] + (1 if interp == "cubic" else 0)
     print("%s  %s: backward %.2f ms (%.1f us per stage incl. pass B); sweep cycles per stage by wave x [fwd recompute | output tiles + VJP | records | "
           "partial sum / reduce | hidden bwd | bookkeeping | - | workgroup-barrier wait | coop: scales + publish | wait B1 | keeper loop | wait B2]" % (label, name, ms.value, ms.value * 1e3 / ((T - 1) * bench.stages_of(c["solver"]))))
     print(np.array2string(per, precision=0, suppress_small=True), " total", per.sum(axis=1).round())
+    if "coop" in name:
+        kp = gz0.view(B // 16, 16 * H)[:, 96:120].view(-1, 8, 3).cpu().numpy().mean(axis=0)
+        print("keeper loop per stage by wave x [compute | DMA wait | barrier]:")
+        print(np.array2string(kp, precision=0, suppress_small=True))
