@@ -611,7 +611,11 @@ def main():
         elif other is not None:
             rec[other["scaling"]] = other
         if not args.no_cpu_baseline and world == 1:
-            rec["cpu_baseline"] = cpu_baseline(c, w.fw, w.rw, args.cpu_sample)
+            # a BOUNDED sample: the same CPU work as 1024 samples of cfg2 (10 - 30 s with the repetitions) whatever the config -- cfg5 is
+            # 113 x the flops per sample (798 steps of a 128-wide field over 80 channels): 16 samples there
+            per_sample = lambda cc: flops_forward_per_sample_step(cc) * ((cc["L"] * 2 - 1 if cc["interpolation"] == "rectilinear" else cc["L"]) - 1)
+            cpu_B = int(min(args.cpu_sample, max(16, 16 * round(args.cpu_sample * per_sample(CONFIGS["cfg2"]) / per_sample(c) / 16))))
+            rec["cpu_baseline"] = cpu_baseline(c, w.fw, w.rw, cpu_B)
             rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
         if world == 1 and args.config == "cfg2" and not args.no_extras and not args.batch:
             # the other BASELINE shapes, OUTSIDE the headline's timed region: a few steps each so that the driver's record carries

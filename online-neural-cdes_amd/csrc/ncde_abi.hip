@@ -131,7 +131,10 @@ __global__ __launch_bounds__(256) void ncde_pad_params(PadSegs sg, int dir) {
     }
 }
 
-inline int pad_width(int w) { return w <= 16 ? 16 : (w <= 32 ? 32 : (w <= 64 ? 64 : (w <= 128 ? 128 : hru16(w)))); }
+// (the backward's output phase is instantiated for last widths 16 .. 256 in powers of two; the forward takes any multiple of 16 above 128)
+inline int pad_width(int w, int pass) {
+    return w <= 16 ? 16 : (w <= 32 ? 32 : (w <= 64 ? 64 : (w <= 128 ? 128 : ((pass != 0 && w <= 256) ? 256 : hru16(w)))));
+}
 
 struct PadPlan {
     bool ok;
@@ -187,7 +190,7 @@ PadPlan make_pad_plan(const NcdeProblem* p, int pass, int target = 0) {
     };
     int din = q.hidden;
     for (int l = 0; l < p->n_layers; ++l) {
-        const int dout = target == 0 ? pad_width(p->layer_out[l]) : tHH;
+        const int dout = target == 0 ? pad_width(p->layer_out[l], pass) : tHH;
         q.layer_in[l] = din; q.layer_out[l] = dout;
         P.slot_W[l] = add(p->layer_W[l], 1, p->layer_out[l], p->layer_in[l], 1, dout, din);
         P.slot_b[l] = add(p->layer_b[l], 1, 1, p->layer_out[l], 1, 1, dout);

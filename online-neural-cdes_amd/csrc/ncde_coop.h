@@ -9,9 +9,13 @@
 // share an L2).  Inside a group every workgroup plays two roles per stage:
 //   * OWNER of its own 16-sample tile, exactly as before: hidden layers forward, Butcher bookkeeping, hidden layers backward,
 //     records for the output-layer gradient pass;
-//   * KEEPER of 1/M of the ROWS of Wo (20 row tiles = 4 state units x 80 channels at cfg5), held for the whole launch in REGISTERS
-//     in both MFMA operand forms (row-major fragments for P = Wo x_L, K-major fragments for Wo^T dP; 2-way split-fp16, 320 of the
-//     wave's 512 registers), which it applies to the x_L of ALL M sample tiles of the group.
+//   * KEEPER of 1/M of the ROWS of Wo (20 row tiles = 4 state units x 80 channels at cfg5) in both MFMA operand forms (row-major
+//     fragments for P = Wo x_L, K-major fragments for Wo^T dP; 2-way split-fp16, packed once per launch by ncde_coop_pack into a
+//     per-member, per-wave fragment image of 40 KB), which it applies to the x_L of ALL M sample tiles of the group.  The 8 waves
+//     split in two roles: waves 0-3 compute P / tanh / dP of tile i (5 row tiles each) and hand dP over through LDS, waves 4-7
+//     form the partial of dL/dx_L of tile i-1 (2 column tiles each).  A wave's 40 fragments (160 registers) are re-read from the
+//     image at the start of every stage's keeper loop and stay in registers over its M tiles: keeping them over the whole launch
+//     (COOP_PIN) costs more in scratch reloads of the owner phase than the 40 KB L2 read per stage (measured, see COOP_PIN below).
 // Per stage: owners publish (x_L as a scaled split-fp16 B-operand image, the cotangent a, dX/dt) -> group barrier -> keepers loop
 // over the M tiles: P, tanh, f.dX slice, dP, partial of dL/dx_L over their rows -> publish -> group barrier -> owners sum the M
 // partials of their tile in a fixed order.  L2 traffic per stage and CU drops from 13 MB of weights to ~1 MB of activations, the
@@ -24,9 +28,12 @@
 // column's maximum keep an ABSOLUTE error of 2^-36 of that maximum -- below the fp32 rounding of the sums they enter.
 //
 // Inter-workgroup protocol (MI355X_MICROARCH.md, "inter-workgroup visibility"; cdna_hip_programming.md Guideline 16): payload is
-// stored write-through (`sc1` buffer stores), every storing wave drains (`s_waitcnt vmcnt(0)`), the workgroup barrier-syncs, ONE lane
-// adds 1 to the group's monotonic counter with an agent-scope atomic; consumers poll that ONE word with relaxed agent-scope loads
-// (+ s_sleep), then read the payload with `sc1` loads (L1 bypassed).  Correct for ANY workgroup placement; same-XCD placement
+// stored write-through (`sc1` buffer stores) -- or, when the members of the group found themselves on ONE XCD at start-up
+// (coop_same_xcd: they exchange HW_REG_XCC_ID), with plain stores into the L2 they share --, every storing wave drains
+// (`s_waitcnt vmcnt(0)`), the workgroup barrier-syncs, ONE lane adds 1 to the group's monotonic counter with an agent-scope atomic;
+// consumers poll that ONE word with relaxed agent-scope loads
+// (+ s_sleep), then read the payload with `sc1` loads (L1 bypassed; the keeper's x_L / dX/dt / a staging goes global -> LDS directly,
+// `global_load_lds_dwordx4 ... sc1`, double-buffered one tile ahead).  Correct for ANY workgroup placement; same-XCD placement
 // (block b -> XCD b % 8, observed) only makes it faster.  Every spin is bounded: on a timeout the workgroup raises the launch's
 // abort word, every workgroup leaves at its next check, and the caller's gradients are poisoned with NaN (never silently wrong).
 // All n_tiles workgroups must be co-resident (one per CU: the kernel takes ~157 KB of LDS): the host only selects this path for
@@ -35,7 +42,7 @@
 #include "ncde_bf3.h"
 #include "ncde_common.h"
 
-#define COOP_NRT 5                      // row tiles of Wo per wave (x 4 waves = 20 per workgroup)
+#define COOP_NRT 5                      // row tiles of Wo per P-role wave (x 4 waves = 20 per workgroup)
 #define COOP_RPM (4 * COOP_NRT)         // row tiles per member
 #define COOP_NCH 4                      // K chunks of 32: last hidden width 128
 #define COOP_SPIN_LIMIT (1 << 22)       // polls of a group counter before giving up (~1-2 s)

@@ -939,13 +939,19 @@ using WoTile = TlTile<PK, 0>;
 // BFP = 1 (original field, streamed weights): P from the split-bf16 copy of the tile (prefetched a tile ahead) and the split
 // image xb of x_L; the fp32 copy of the SAME tile, needed only for the transposed products, is requested at the top of the
 // step and lands under the P MFMAs and the tanh.
+// PK = 16 (round 5: last hidden width 256): the transposed product goes through a HALF-size scratch (8 k-blocks at a time), and the
+// wave's partial of dL/dx_L does not go to a scratch of its own (4 x 16 KB that the LDS plan does not have) but is added into `gsum` by
+// the waves in turn -- wave 0 stores, 1 .. NWV-2 add, the last adds and applies relu'(x_L): same order every run.
 template <int PK, int NWV, int RES, int GATED, int BFP = 0>
 __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, const float* AS, const float* DX, float* KOY,
-                                              float* scr, int wave, int lane, const WoTile<PK>* res, const unsigned* xb = nullptr) {
+                                              float* scr, int wave, int lane, const WoTile<PK>* res, const unsigned* xb = nullptr,
+                                              float* gsum = nullptr) {
     static_assert(!(RES == 1 && GATED != 0), "resident output tiles are built for the original field only");
     static_assert(BFP == 0 || (RES != 1 && GATED == 0 && PK >= 2), "split-bf16 P: original field, streamed output tiles");
+    static_assert(PK <= 8 || (PK == 16 && RES == 0 && GATED == 0 && BFP == 0), "256-wide last layer: original field, streamed fp32 tiles");
     constexpr int NCH = PK >= 2 ? PK / 2 : 1;
-    constexpr int NSP = 16, SCS = 16 * PK + 4;
+    constexpr int PKH = PK > 8 ? 8 : PK;      // k-blocks per pass through the scratch
+    constexpr int NSP = 16, SCS = 16 * PKH + 4;
     const int li = lane & 15, lk = lane >> 4;
     const int C = a.C, nhb = a.H >> 2, ncq = C >> 2;
     f32x4 accJ[PK];
@@ -989,7 +995,7 @@ __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, c
             for (int i = 0; i < PK; ++i) *reinterpret_cast<f32x4*>(scr + li * SCS + 16 * i + 4 * lk) = Pf.v[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < PK; ++i) *reinterpret_cast<f32x4*>(scr + li * SCS + 16 * i + 4 * lk) = t.P.v[i];
+            for (int i = 0; i < PKH; ++i) *reinterpret_cast<f32x4*>(scr + li * SCS + 16 * i + 4 * lk) = t.P.v[i];
             acc[0] = t.bias;
             tl_mma_panel<1, PK>(t.P, xL, 0, li, lk, acc);
         }
@@ -1020,9 +1026,19 @@ __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, c
         KOY[(hb * NSP + li) * 4 + lk] = kk;      // running sum; the last channel quad leaves the total
         // dL/dx_L[j][s] += sum_u Wo[u][j] dP[u][s]: the tile's 16 rows are the K dim, k = 4 (lane>>4) + r
 #pragma unroll
-        for (int jt = 0; jt < PK; ++jt)
+        for (int jt = 0; jt < PKH; ++jt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) accJ[jt] = mfma16(scr[(4 * lk + r) * SCS + 16 * jt + li], dP[r], accJ[jt]);
+        if constexpr (PK > 8) {         // k-blocks 8 .. 15 through the same scratch (fp32 tiles only: t.P is the tile)
+            if constexpr (BFP == 0) {
+#pragma unroll
+                for (int i = 0; i < PKH; ++i) *reinterpret_cast<f32x4*>(scr + li * SCS + 16 * i + 4 * lk) = t.P.v[PKH + i];
+            }
+#pragma unroll
+            for (int jt = 0; jt < PKH; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accJ[PKH + jt] = mfma16(scr[(4 * lk + r) * SCS + 16 * jt + li], dP[r], accJ[PKH + jt]);
+        }
         if constexpr (GATED != 0) {     // ... + sum_u Wg[u][j] dPg[u][s], through the same scratch
 #pragma unroll
             for (int i = 0; i < PK; ++i) *reinterpret_cast<f32x4*>(scr + li * SCS + 16 * i + 4 * lk) = t.G.v[i];
@@ -1053,6 +1069,31 @@ __device__ __forceinline__ void tl_output_vjp(const KArgs& a, const float* xL, c
             }
             if (nq & 1) step(TA);
         }
+    }
+    if constexpr (PK > 8) {
+        // the waves' partials, added in wave order into gsum (which may alias the scratches: they are dead behind the first barrier)
+        for (int wv = 0; wv < NWV; ++wv) {
+            __syncthreads();
+            if (wave == wv) {
+#pragma unroll
+                for (int jt = 0; jt < PK; ++jt) {
+                    const int o = ((4 * jt + lk) * NSP + li) * 4;
+                    f32x4 g = accJ[jt];
+                    if (wv > 0) {
+                        const f32x4 q = *reinterpret_cast<const f32x4*>(gsum + o);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) g[r] = q[r] + g[r];
+                    }
+                    if (wv == NWV - 1) {
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(xL + o);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) g[r] = xv[r] > 0.0f ? g[r] : 0.0f;
+                    }
+                    *reinterpret_cast<f32x4*>(gsum + o) = g;
+                }
+            }
+        }
+        return;
     }
     // this wave's partial of dL/dx_L -> its scratch, in the activation layout
 #pragma unroll
@@ -1184,12 +1225,17 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     static_assert(BF == 0 || (RES != 1 && PK >= 2), "split record: streamed output tiles, last hidden width a multiple of 32");
     static_assert(DIRECT == 0 || (RES == 0 && BF == 0), "direct heads: streamed fp32 layers");
     static_assert(BIGH == 0 || (RES == 0 && DIRECT == 0 && NWV == 4), "wide state: streamed weights, matmul input, one wave per SIMD");
+    static_assert(PK <= 8 || (PK == 16 && BIGH == 1 && GATED == 0 && BF == 0 && COOP == 0), "256-wide last layer: the wide instantiation, fp32 records");
     static_assert(COOP == 0 || (PK == 2 * COOP_NCH && NWV == 8 && RES == 0 && GATED == 0 && BF == 1 && DIRECT == 0 && BIGH == 0),
                   "cooperative output phase: original field, last hidden width 128, split records, two waves per SIMD (P role / T role)");
     constexpr int NT = 64 * NWV, TL_EADJ = RES ? (16 * 16 * PK + NT - 1) / NT : (BIGH ? 4096 : 2048) / NT;
-    constexpr int TL_DWT = COOP ? 1 : (RES ? (PK * PK + NWV - 1) / NWV : (BIGH ? 128 : 64) / NWV);   // hidden dW tiles per wave and weight slot
+    // W16 (round 5): last hidden width 256.  Up to 256 hidden-dW tiles per matrix do not fit the register file either: like the cooperative
+    // sweep it accumulates them in the workgroup's global partial (DWG), and the output phase's per-wave scratches alias the cotangent
+    // buffers (see the LDS plan below and tl_output_vjp)
+    constexpr bool W16 = PK == 16, DWG = COOP != 0 || W16;
+    constexpr int TL_DWT = DWG ? 1 : (RES ? (PK * PK + NWV - 1) / NWV : (BIGH ? 128 : 64) / NWV);   // hidden dW tiles per wave and weight slot
     constexpr int COOP_LDS = 2 * 10 * 2 * 64 * 4 + 2 * 8 * 64 * 4 + 2 * 80 * 16 + 2 * 256 + 2 * 64 + 2 * 4 * 64 + 2 * 16 + 8;      // floats, see CDP .. CFL below
-    constexpr int NSP = 16, SCW = (16 * (16 * PK + 4) > 16 * PK * NSP) ? 16 * (16 * PK + 4) : 16 * PK * NSP;
+    constexpr int NSP = 16, SCW = W16 ? 16 * (16 * 8 + 4) : ((16 * (16 * PK + 4) > 16 * PK * NSP) ? 16 * (16 * PK + 4) : 16 * PK * NSP);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1204,12 +1250,14 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     float* YS = lds;               // stage input y (= x_0)
     float* AS = YS + US;           // stage cotangent
     float* KOY = AS + HS;          // f(y).dX of the stage
-    float* KOA = KOY + HS;         // J^T cotangent of the stage
-    float* X = KOA + US;           // x_1 .. x_L
+    // W16: J^T cotangent behind the cotangent ping-pong buffers, so that [G0 | G1 | KOA] -- all dead during the output phase -- is one
+    // area of 2 DS + HS >= NWV SCW floats for the waves' scratches (the host checks that)
+    float* X = KOY + HS + (W16 ? 0 : US);           // x_1 .. x_L
     float* G0 = X + L * DS;
     float* G1 = G0 + DS;
-    float* DX = G1 + DS;           // [C/4][16][4]
-    float* SC = DX + C * NSP;      // per-wave scratch (COOP: the exchange area instead)
+    float* KOA = W16 ? G1 + DS : KOY + HS;         // J^T cotangent of the stage
+    float* DX = G1 + DS + (W16 ? HS : 0);           // [C/4][16][4]
+    float* SC = W16 ? G0 : DX + C * NSP;      // per-wave scratch (COOP: the exchange area instead)
     float* scr = SC + (COOP ? 0 : wave * SCW);
     unsigned* XBA = reinterpret_cast<unsigned*>(SC + (COOP ? COOP_LDS : NWV * SCW));   // BF: split image of x_L (24 words per unit)
     const bool disc = a.discrete != 0;
@@ -1289,7 +1337,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
             const int l = slot == 0 ? 0 : l1;
             if (l < 0) continue;
             const int N = a.dout[l], K = a.din[l], nit = K >> 4, ntile = (N >> 4) * nit;
-            if constexpr (COOP == 0) {
+            if constexpr (!DWG) {
 #pragma unroll
                 for (int q = 0; q < TL_DWT; ++q) {
                     const int tt = wave + NWV * q;
@@ -1881,7 +1929,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                         if (nn > a.win_lo) prefetch(nn, jn);
                     }
                 } else
-                tl_output_vjp<PK, NWV, RES, GATED, (BF != 0 && GATED == 0) ? 1 : 0>(a, in, AS, DX, KOY, scr, wave, lane, wo, XBA);
+                tl_output_vjp<PK, NWV, RES, GATED, (BF != 0 && GATED == 0) ? 1 : 0>(a, in, AS, DX, KOY, scr, wave, lane, wo, XBA, G1);
                 TL_TICK(1)
                 // ---- records for pass B (x_L twice, weighted cotangent, dX/dt) --------------------------------------------
                 if constexpr (COOP == 0) write_records();      // (COOP: written while the group assembles, see above)
@@ -1913,7 +1961,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                         *reinterpret_cast<f32x4*>(G1 + e4) = g;
                     }
                     for (int e4 = tid * 4; e4 < HS; e4 += NT * 4) *reinterpret_cast<f32x4*>(KOY + e4) = coop_ld16f(crs, my_base + cd.off_ko() + e4);
-                } else
+                } else if constexpr (!W16)      // (W16: tl_output_vjp left the masked sum in G1)
                 for (int e = tid; e < dlast * NSP; e += NT) {
                     float g = 0.0f;
     #pragma unroll
@@ -1930,7 +1978,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                 const float* xin = l == 0 ? YS : X + (l - 1) * DS;
                 if (w != 0.0f) {
                     const bool slot0 = a.gW_off[l] == a.gW_off[0];
-                    if constexpr (COOP != 0) tl_dw_rmw<NWV>(gpre, xin, N, K, w, a.gpart + (long long)blockIdx.x * a.gstride + a.gW_off[l], wave, lane);
+                    if constexpr (DWG) tl_dw_rmw<NWV>(gpre, xin, N, K, w, a.gpart + (long long)blockIdx.x * a.gstride + a.gW_off[l], wave, lane);
                     else if (slot0) tl_dw_acc<NWV, TL_DWT>(gpre, xin, N, K, w, dw0, wave, lane);
                     else tl_dw_acc<NWV, TL_DWT>(gpre, xin, N, K, w, dw1, wave, lane);
                     if (tid < N) {
@@ -2073,7 +2121,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
             if (l < 0) continue;
             const int N = a.dout[l], K = a.din[l], nit = K >> 4, ntile = (N >> 4) * nit;
 #pragma unroll
-            for (int q = 0; q < (COOP ? 0 : TL_DWT); ++q) {
+            for (int q = 0; q < (DWG ? 0 : TL_DWT); ++q) {
                 const int tt = wave + NWV * q;
                 if (tt < ntile) {
                     const int jt = tt / nit, it = tt - jt * nit;
@@ -2124,8 +2172,10 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
 template <int PK, int HEAD = 0, int NRT = 1>
 __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_st, float* gpartB) {
     // n_sc = stages recorded in this time window; a.resume != 0: add to the partial the earlier windows left in gpartB
+    // (the waves' accumulators are summed PKR column tiles at a time: 16 x 256 floats x 4 waves would not fit the 64 KB of static LDS)
+    constexpr int PKR = PK > 8 ? 8 : PK;
     __shared__ float patch[4][NRT][16 * 17];
-    __shared__ __attribute__((aligned(16))) float red[4][PK * 256 + 64];
+    __shared__ __attribute__((aligned(16))) float red[4][PKR * 256 + 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
@@ -2245,27 +2295,32 @@ __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_s
     float* gp = gpartB + (long long)blockIdx.y * theta_o;
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) {
-        if (rt > 0) __syncthreads();
 #pragma unroll
-        for (int jt = 0; jt < PK; ++jt) *reinterpret_cast<f32x4*>(&red[wave][(jt * 64 + lane) * 4]) = gW[rt][jt];
+        for (int j0 = 0; j0 < PK; j0 += PKR) {
+            if (rt > 0 || j0 > 0) __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = gb[rt][r];
-            v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
-            if (li == 0) red[wave][PK * 256 + 4 * lk + r] = v;
-        }
-        __syncthreads();
-        for (int e = tid; e < PK * 256; e += 256) {
-            const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-            const int r = e & 3, ln = (e >> 2) & 63, jt = e >> 8;
-            const int row = (4 * hb[rt] + (ln >> 4)) * C + 4 * cq[rt] + r;
-            float* dst = gp + (long long)row * dlast + 16 * jt + (ln & 15);
-            *dst = a.resume ? *dst + v : v;
-        }
-        if (tid < 16) {
-            const float v = (red[0][PK * 256 + tid] + red[1][PK * 256 + tid]) + (red[2][PK * 256 + tid] + red[3][PK * 256 + tid]);
-            float* dst = gp + wo_sz + (4 * hb[rt] + (tid >> 2)) * C + 4 * cq[rt] + (tid & 3);
-            *dst = a.resume ? *dst + v : v;
+            for (int jt = 0; jt < PKR; ++jt) *reinterpret_cast<f32x4*>(&red[wave][(jt * 64 + lane) * 4]) = gW[rt][j0 + jt];
+            if (j0 == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = gb[rt][r];
+                    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+                    if (li == 0) red[wave][PKR * 256 + 4 * lk + r] = v;
+                }
+            }
+            __syncthreads();
+            for (int e = tid; e < PKR * 256; e += 256) {
+                const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+                const int r = e & 3, ln = (e >> 2) & 63, jt = j0 + (e >> 8);
+                const int row = (4 * hb[rt] + (ln >> 4)) * C + 4 * cq[rt] + r;
+                float* dst = gp + (long long)row * dlast + 16 * jt + (ln & 15);
+                *dst = a.resume ? *dst + v : v;
+            }
+            if (j0 == 0 && tid < 16) {
+                const float v = (red[0][PKR * 256 + tid] + red[1][PKR * 256 + tid]) + (red[2][PKR * 256 + tid] + red[3][PKR * 256 + tid]);
+                float* dst = gp + wo_sz + (4 * hb[rt] + (tid >> 2)) * C + 4 * cq[rt] + (tid & 3);
+                *dst = a.resume ? *dst + v : v;
+            }
         }
     }
 }
@@ -2536,9 +2591,9 @@ int tiled_fwd_split(const NcdeProblem* p) { return !tiled_fwd_bf(p) ? 0 : ((p->f
 int64_t tiled_fault_floats(const NcdeProblem* p) { return (((int64_t)(p->batch + 15) / 16 + 1) + 63) & ~(int64_t)63; }   // one word per tile + the weights' word
 // Floats of the fragment-ordered copy of the output layer (and of the gate head): 0 when the last hidden width is not one
 // of the whole-panel cases the kernels read packed.  The split-bf16 copy (forward, pass 0) takes 1.5 x.
-int64_t tiled_pack_floats(const NcdeProblem* p, bool bf) {
+int64_t tiled_pack_floats(const NcdeProblem* p, bool bf, bool adj = false) {
     const int dl = p->layer_out[p->n_layers - 1];
-    if (dl != 16 && dl != 32 && dl != 64 && dl != 128) return 0;
+    if (dl != 16 && dl != 32 && dl != 64 && dl != 128 && !(dl == 256 && adj)) return 0;      // (256: the backward's W16 mode only)
     const int64_t n = (int64_t)p->hidden * p->channels * dl * (p->field_kind == NCDE_FIELD_MINIMAL ? 2 : 1);
     return bf ? n + n / 2 : n;
 }
@@ -2619,7 +2674,8 @@ int tiled_fwd_ns(const NcdeProblem* p) {
 // ---- adjoint / exact backward -------------------------------------------------------------------------------------
 int tiled_adj_pk(const NcdeProblem* p) {
     const int dlast = p->layer_out[p->n_layers - 1];
-    return (dlast == 128) ? 8 : (dlast == 64 ? 4 : (dlast == 32 ? 2 : (dlast == 16 ? 1 : 0)));
+    // (round 5: 256 -- the W16 mode of the wide instantiation, original field / matmul input only: see tiled_adj_ok)
+    return (dlast == 256) ? 16 : ((dlast == 128) ? 8 : (dlast == 64 ? 4 : (dlast == 32 ? 2 : (dlast == 16 ? 1 : 0))));
 }
 
 // small square models: every weight fragment register-resident (see ncde_adj_tiled, RES)
@@ -2631,7 +2687,8 @@ bool tiled_adj_res(const NcdeProblem* p) {
     return res;
 }
 // round 5: 128 < H <= 256 over hidden widths <= 128 runs the BIGH instantiation of the sweep: 4 waves (one per SIMD, 512 registers)
-bool tiled_adj_bigh(const NcdeProblem* p) { return p->hidden > 128; }
+// ... and so does a last hidden width of 256 (PK = 16: hidden widths 129 .. 256 are zero-padded to it, ncde_abi.hip) at any H <= 256
+bool tiled_adj_bigh(const NcdeProblem* p) { return p->hidden > 128 || p->layer_out[p->n_layers - 1] == 256; }
 int tiled_adj_nwv(const NcdeProblem* p) { return tiled_adj_bigh(p) ? 4 : TL_ADJ_NW; }
 size_t tiled_adj_lds_base(const NcdeProblem* p) {
     const int pk = p->field_input != NCDE_INPUT_MATMUL ? 1 : tiled_adj_pk(p);      // direct modes run the PK = 1 instantiation
@@ -2643,6 +2700,8 @@ size_t tiled_adj_lds_base(const NcdeProblem* p) {
     }
     int D = 16;      // x_1 .. x_L and the cotangent ping-pong buffers: rows = the widest LAYER (see ncde_adj_tiled)
     for (int l = 0; l < p->n_layers; ++l) D = std::max(D, p->layer_out[l]);
+    if (pk == 16)      // W16: the waves' scratches alias [G0 | G1 | KOA]
+        return sizeof(float) * (size_t)(4 * p->hidden * 16 + (p->n_layers + 2) * D * 16 + p->channels * 16);
     return sizeof(float) * (size_t)(4 * p->hidden * 16 + (p->n_layers + 2) * D * 16 + p->channels * 16 + tiled_adj_nwv(p) * scw);
 }
 // hidden matrices resident, output tiles streamed (RES = 2): small square hidden stacks that do not qualify for RES = 1
@@ -2656,7 +2715,7 @@ bool tiled_adj_res2(const NcdeProblem* p) {
 // x_L in the sweep's LDS, and the caller did not ask for plain fp32-input MFMA
 bool tiled_adj_bf(const NcdeProblem* p) {
     const int pk = tiled_adj_pk(p);
-    return !(p->flags & NCDE_FLAG_FP32_MFMA) && pk >= 2 && !tiled_adj_res(p) && p->field_input == NCDE_INPUT_MATMUL &&
+    return !(p->flags & NCDE_FLAG_FP32_MFMA) && pk >= 2 && pk <= 8 && !tiled_adj_res(p) && p->field_input == NCDE_INPUT_MATMUL &&
            tiled_adj_lds_base(p) + (size_t)pk * 16 * 16 * 6 <= (size_t)kLdsLimit;
 }
 // ---- XCD-cooperative output phase (ncde_coop.h) --------------------------------------------------------------------------------------
@@ -2715,7 +2774,11 @@ bool tiled_adj_ok(const NcdeProblem* p) {
     if (bigh && (direct || p->field_kind != NCDE_FIELD_ORIGINAL || tiled_adj_pk(p) < 2)) return false;
     int l1 = -1;
     if (direct && (p->hidden / 16) * (p->layer_out[p->n_layers - 1] / 16) > 64) return false;      // direct heads: [H][dlast] tiles
-    const int max_dw_tiles = bigh ? 128 : 64;      // hidden-dW accumulator tiles per matrix (registers of the sweep)
+    // hidden-dW accumulator tiles per matrix (registers of the sweep; W16 keeps them in its global partial: no limit)
+    const int max_dw_tiles = tiled_adj_pk(p) == 16 ? 1 << 30 : (bigh ? 128 : 64);
+    if (tiled_adj_pk(p) == 16) {      // the 4 scratches of 16 x 132 floats fit [G0 | G1 | KOA] (D = 256 here: always)
+        if (2 * 256 * 16 + p->hidden * 16 < 4 * 16 * 132) return false;
+    }
     for (int l = 0; l < p->n_layers; ++l) {
         if (p->layer_out[l] > 64 * tiled_adj_nwv(p) || (p->layer_out[l] / 16) * ((p->layer_in[l] + 15) / 16) > max_dw_tiles) return false;
         for (int q = 0; q < l; ++q)
@@ -2791,11 +2854,12 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
     // row tiles per wave of pass B (original field; the gated heads keep one: two weight panels per tile)
     // (PK = 8: four tiles no longer fit the register file -- measured at cfg5: 1 tile 1382 ms, 2 tiles 1335 ms, 4 tiles 1725 ms)
     t.nrt = p->field_kind == NCDE_FIELD_MINIMAL ? 1 : (row_tiles % 4 == 0 && row_tiles >= 64 && dlast < 128 ? 4 : (row_tiles % 2 == 0 && row_tiles >= 32 ? 2 : 1));
+    if (dlast == 256) t.nrt = 1;      // (one tile's weights, accumulators and two record fragments of 256 columns are the register file)
     t.parts = 1;
     while (t.parts < 64 && (row_tiles / t.nrt) * 4 * t.parts < 4096 && 4 * t.parts * 2 <= t.n_st) t.parts *= 2;
     t.gpartB = off; off += (long long)t.parts * t.theta_o * (p->field_kind == NCDE_FIELD_MINIMAL ? 2 : 1);
     t.carry = off; off += 2LL * t.n_st * p->hidden * 16;
-    t.pack = off; off += tiled_pack_floats(p, false);
+    t.pack = off; off += tiled_pack_floats(p, false, true);
     t.pack_bf = off; off += (bf && p->field_kind != NCDE_FIELD_MINIMAL) ? tiled_pack_floats(p, true) : 0;
     const CoopPlan cp = bf ? tiled_coop_plan(p) : CoopPlan{false, 0, 0};
     t.coop = cp.ok;
@@ -3033,7 +3097,11 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
         }
     }
     const int nwv = tiled_adj_nwv(p);
-    if (tiled_adj_bigh(p)) {      // (tiled_adj_ok: original field, matmul input, pk >= 2)
+    if (pk == 16) {      // last hidden width 256: fp32 records, hidden dW in the workgroups' global partials (zero before the first window)
+        fa = ncde_adj_tiled<16, 4, 0, 0, 0, 0, 1>;
+        fb = ncde_dwo_tiled<16, 0, 1>;
+        if (hipMemsetAsync(w + t.gpartA, 0, sizeof(float) * (size_t)t.n_st * t.gstride, st) != hipSuccess) return NCDE_ERR_HIP;
+    } else if (tiled_adj_bigh(p)) {      // (tiled_adj_ok: original field, matmul input, pk >= 2)
         if (bf) fa = pk == 8 ? ncde_adj_tiled<8, 4, 0, 0, 1, 0, 1> : (pk == 4 ? ncde_adj_tiled<4, 4, 0, 0, 1, 0, 1> : ncde_adj_tiled<2, 4, 0, 0, 1, 0, 1>);
         else fa = pk == 8 ? ncde_adj_tiled<8, 4, 0, 0, 0, 0, 1> : (pk == 4 ? ncde_adj_tiled<4, 4, 0, 0, 0, 0, 1> : ncde_adj_tiled<2, 4, 0, 0, 0, 0, 1>);
     }

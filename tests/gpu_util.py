@@ -89,7 +89,8 @@ def run_adjoint_direct(case, z_out, flags=_lib.FLAG_AUTO, device="cuda", stages=
                                      ws.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(rc, "ncde_adjoint")
     torch.cuda.synchronize()
-    return {"dz0": gz0.cpu().numpy(), "grads": {k: gbuf[id(v)].cpu().numpy() for k, v in func.p.items() if id(v) in gbuf}}
+    name = (_lib.lib().ncde_kernel_name(ctypes.byref(p), 2 if stages is not None else 1) or b"?").decode()
+    return {"dz0": gz0.cpu().numpy(), "kernel": name, "grads": {k: gbuf[id(v)].cpu().numpy() for k, v in func.p.items() if id(v) in gbuf}}
 
 
 def kernel_names(case, flags=_lib.FLAG_AUTO, device="cuda"):

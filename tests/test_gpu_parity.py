@@ -324,6 +324,60 @@ def test_full_size_cfg4_all_samples_vs_oracle(gpu_lib):
                 assert err[k] <= max(2.0 * ref[k], TOL_DTHETA), (disc, flags, k, err[k], ref[k])
 
 
+def test_full_size_cfg5_1024_samples_vs_oracle(gpu_lib):
+    """BASELINE config 5 at its full length (T = 799, RK4: 3192 stages; C = 80, H = HH = 128) on 1024 samples -- the XCD-cooperative sweep
+    (two groups of 32 workgroups) + the paired gradient pass, against the oracle on ALL samples: z_T, the
+    per-sample dL/dz0 rows (on the oracle's z) and the batch-summed parameter gradients.  The continuous adjoint re-integrates y backwards
+    over 798 steps, so ANY two fp32 implementations of it differ by what each differs from the exact (fp64) result of the same scheme: a
+    few ReLU masks flip, 1e-4 .. 1.5e-3 in the max norm of a gradient.  That band is measured here on the first 64 samples (fp32 oracle vs
+    the oracle run in fp64 -- the fp64 run on all 1024 would take the test to ten minutes) and is the yardstick: rows and sums within
+    2 x of the fp32 oracle's own distance from fp64 (floors: 5e-5 for the 99th percentile of the rows, 5e-4 for the sums, as in
+    test_full_size_cfg4_cfg5_sample_subset_vs_oracle)."""
+    import gpu_util
+    import ncde_oracle as orc
+    B, L, C, H, HH, nl, interp, method = 1024, 400, 80, 128, 128, 3, "linear", "rk4"
+    coeffs = gu.data.make_rectilinear_coeffs(B, L, C - 1, missing=0.6, seed=1234)
+    p = gu.data.make_field_weights(H, HH, C, seed=0)
+    rw = gu.data.make_readin_weights(H, C, 1, seed=0)
+    z0 = (coeffs[:, 0] @ rw["Wi"].T + rw["bi"]).astype(np.float32)
+    names = ["W0", "b0", "W1", "b1", "Wo", "bo"]
+    meta = {"kind": interp, "method": method, "sequence": False, "param_names": names, "field": "original",
+            "dims": {"C": C, "H": H, "HH": HH, "nl": nl}}
+    gout = (gu.data.normal(3, B * 2 * H, stream=1).reshape(B, 2, H) / np.sqrt(2.0)).astype(np.float32)
+    big = {"meta": meta, "coeffs": coeffs, "z0": z0, "params": p, "layers": [("W0", "b0")] + [("W1", "b1")] * (nl - 1),
+           "H": H, "C": C, "expect": {"grad_out": gout}}
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    rb = gpu_util.run_case(big, need_grads=False)
+    field, ctl = gu.oracle_field(big), orc.Control(coeffs, interp)
+    z = orc.solve_forward(ctl, field, z0, method, False)
+    assert gu.relerr(rb["z_out"], z) <= TIGHT_Z
+    d32, g32 = orc.solve_adjoint(ctl, field, z, gout, method, False)
+    d32 = d32.numpy()
+    scale = np.abs(d32).max()
+    # the yardstick: fp32 oracle vs fp64 oracle on the first 64 samples
+    n64 = 64
+    c64 = dict(big, params={k: v.astype(np.float64) for k, v in p.items()})
+    f64, ctl64 = gu.oracle_field(c64), orc.Control(coeffs[:n64].astype(np.float64), interp)
+    z64 = orc.solve_forward(ctl64, f64, z0[:n64].astype(np.float64), method, False)
+    d64, g64 = orc.solve_adjoint(ctl64, f64, z64, gout[:n64].astype(np.float64), method, False)
+    ctls = orc.Control(coeffs[:n64], interp)
+    ds, gs = orc.solve_adjoint(ctls, field, z[:n64], gout[:n64], method, False)
+    ref_rows = np.abs(ds.numpy() - d64.numpy()).max(1) / scale
+    ref = {n: gu.relerr(a.numpy(), b.numpy()) for n, a, b in zip(names, gs, g64)}
+    iso = gpu_util.run_adjoint_direct(big, z.numpy())
+    assert "coop" in iso["kernel"], iso["kernel"]
+    rows = np.abs(iso["dz0"] - d32).max(1) / scale
+    err = {n: gu.relerr(iso["grads"][n], g.numpy()) for n, g in zip(names, g32)}
+    print("cfg5, 1024 samples, %s: dz0 rows vs the fp32 oracle median %.2e p99 %.2e max %.2e (%d rows > 5e-5); fp32 oracle vs fp64 on %d samples: "
+          "median %.2e p99 %.2e max %.2e;" % (iso["kernel"], np.median(rows), np.quantile(rows, 0.99), rows.max(), int((rows > 5e-5).sum()), n64,
+                                              np.median(ref_rows), np.quantile(ref_rows, 0.99), ref_rows.max()),
+          {k: "%.1e (fp32 vs fp64 oracle, %d samples: %.1e)" % (err[k], n64, ref[k]) for k in err})
+    assert np.median(rows) <= max(2.0 * np.median(ref_rows), 1e-6)
+    assert np.quantile(rows, 0.99) <= max(2.0 * np.quantile(ref_rows, 0.99), 5e-5) and rows.max() <= 2e-2, (np.quantile(rows, 0.99), rows.max())
+    for k in err:
+        assert err[k] <= max(2.0 * ref[k], 5e-4), (k, err[k], ref[k])
+
+
 @pytest.mark.parametrize("cfg", ["cfg4", "cfg5"])
 def test_full_batch_cfg4_cfg5_sample_independence(cfg, gpu_lib):
     """cfg4 at B = 8192 and cfg5 at B = 4096 (their full batch AND length, through forward and backward, i.e. the full
@@ -354,13 +408,17 @@ def test_full_batch_cfg4_cfg5_sample_independence(cfg, gpu_lib):
     assert np.array_equal(rs["z_out"], rb["z_out"][sel])
     if "coop" in rb["kernels"][1]:
         # round 5: the full cfg5 batch runs the XCD-cooperative sweep (fp16-split transposed product), a 32-sample batch the
-        # per-workgroup sweep (fp32 transposed product): two kernels, fp32 round-off apart; the per-workgroup sweep keeps the bitwise property
+        # per-workgroup sweep (fp32 transposed product): two kernels, fp32 round-off apart (the per-workgroup sweep keeps the bitwise property),
+        # and over cfg5's 3192 re-integrated stages that is the 1e-4 .. 1.5e-3 band any two fp32 implementations of this sweep sit in
+        # (measured against the fp64 oracle in test_full_size_cfg4_cfg5_sample_subset_vs_oracle below)
         from ncde_amd import _lib
-        assert gu.relerr(rs["dz0"], rb["dz0"][sel]) <= 2e-5
+        per = np.abs(rs["dz0"] - rb["dz0"][sel]).max(1) / np.abs(rs["dz0"]).max()
+        print("cfg5 full batch, cooperative vs per-workgroup sweep: dz0 rows median %.2e max %.2e" % (np.median(per), per.max()))
+        assert per.max() <= 1.5e-3 and np.median(per) <= 3e-4, (np.median(per), per.max())
         rbo = gpu_util.run_case(big, flags=_lib.FLAG_NO_COOP)
         assert "coop" not in rbo["kernels"][1] and np.array_equal(rs["dz0"], rbo["dz0"][sel])
         for k in names:
-            assert gu.relerr(rb["grads"][k], rbo["grads"][k]) <= 2e-4, k      # (batch-summed over 4096 samples x 3192 stages)
+            assert gu.relerr(rb["grads"][k], rbo["grads"][k]) <= 1.5e-3, k      # (batch-summed over 4096 samples x 3192 stages; the same band)
     else:
         assert np.array_equal(rs["dz0"], rb["dz0"][sel])
     assert all(np.isfinite(g).all() for g in rb["grads"].values())
@@ -428,6 +486,13 @@ def test_full_size_cfg4_cfg5_sample_subset_vs_oracle(cfg, gpu_lib):
         print("flags", flags, {k: "%.1e (fp32 oracle %.1e)" % (err[k], ref[k]) for k in err})
         for k in err:
             assert err[k] <= max(2.0 * ref[k], 5e-4), (flags, k, err[k], ref[k])
+    # round 5: the 1024-sample batch takes the XCD-cooperative sweep (the 32-sample one cannot: two sample tiles); its rows of dL/dz0 meet the
+    # same bar against the fp64 oracle at the full length
+    itc = gpu_util.run_adjoint_direct(big, rb["z_out"])
+    assert "coop" in itc["kernel"] and "coop" not in iso["kernel"], (itc["kernel"], iso["kernel"])
+    e = gu.relerr(itc["dz0"][sel], dz64.numpy())
+    print("cooperative sweep, 1024 samples, rows %d..%d of dz0 vs fp64 oracle: %.1e (fp32 oracle %.1e)" % (sel.start, sel.stop, e, ref["dz0"]))
+    assert e <= max(2.0 * ref["dz0"], 5e-4), (e, ref["dz0"])
 
 
 def test_ragged_batch_and_determinism(gpu_lib):
@@ -994,6 +1059,11 @@ _SWEEP = [  # (B, L, C, H, HH, nl, interp, method, seq)  -- whatever family the 
     (19, 4, 20, 160, 128, 3, "linear", "rk4", False),    # H = 160: the one-wave-per-SIMD instantiation of the sweep (BIGH)
     (11, 3, 7, 256, 128, 2, "cubic", "midpoint", True),  # H = 256, C = 7 -> 8 (zero-padded), sequence outputs
     (35, 2, 12, 208, 64, 3, "linear", "rk4", True),      # H = 208, last width 64
+    # hidden widths beyond 128 (zero-padded to 256 in the backward: the W16 mode of the wide sweep, fp32 records, ncde_dwo_tiled<16>)
+    (19, 4, 20, 196, 196, 2, "linear", "rk4", False),    # the reference's largest hidden_hidden_dim (configurations.json5:35)
+    (13, 3, 7, 256, 160, 3, "cubic", "midpoint", True),  # H = 256, HH = 160
+    (34, 2, 5, 64, 256, 2, "linear", "euler", False),    # H = 64 under a 256-wide stack (no padding)
+    (17, 3, 20, 196, 196, 3, "linear", "rk4", True),     # three layers, sequence outputs
 ]
 
 
@@ -1962,7 +2032,7 @@ def test_training_beyond_the_fused_backward_kernels_runs_on_the_unfused_solver(g
     import ncde_amd
     import ncde_oracle as orc
     from ncde_amd import unfused
-    B, L, C, H, HH, nl = 9, 5, 6, 256, 196, 2
+    B, L, C, H, HH, nl = 9, 5, 6, 256, 272, 2      # (round 5: hidden widths up to 256 have fused backward kernels; 272 does not)
     coeffs = gu.data.make_rectilinear_coeffs(B, L, C - 1, missing=0.3, seed=77)
     for adjoint in (False, True):
         torch.manual_seed(3)
