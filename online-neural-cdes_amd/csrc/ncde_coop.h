@@ -62,6 +62,7 @@ struct CoopDims {
     __host__ __device__ int off_ko() const { return off_sc() + 64; }
     __host__ __device__ int off_part() const { return off_ko() + H * 16; }
     __host__ __device__ long long per_tile() const { return (long long)off_part() + (long long)M * dlast * 16; }
+    __host__ __device__ long long per_tile_fwd() const { return (long long)off_part(); }      // the forward exchanges no partials
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t coop_rsrc(const void* p) {
@@ -191,6 +192,17 @@ __device__ __forceinline__ void coop_load_weights(CoopWeights& w, const unsigned
     const unsigned* p = img + (long long)member * (coop_p_words() + coop_t_words()) + wave * (40 * 64 * 4);      // (waves 4..7: behind the P images)
 #pragma unroll
     for (int k = K0; k < K1; ++k) w.f[k] = *reinterpret_cast<const u32x4*>(p + (k * 64 + lane) * 4);
+}
+
+// The bias of the member's 20 row tiles as the P-role waves read it: dst[((rw * 5 + i) * 4 + lk) * 4 + r] = bo[row] for row tile
+// rw * 5 + i of the member, state unit 4 hb + lk, channel 4 cq + r.  (LDS, not a global load in the keeper loop: `vmcnt` is in order, so
+// a global load there waits for the staging loads of the NEXT tile issued just before it -- an L2 round trip per bias vector.)
+__device__ __forceinline__ void coop_fill_bias(const float* bo, int C, int member, float* dst, int tid) {
+    if (tid < 4 * COOP_NRT * 16) {
+        const int r = tid & 3, lk = (tid >> 2) & 3, i = (tid >> 4) % COOP_NRT, rw = tid / (16 * COOP_NRT);
+        const int ncq = C >> 2, t0 = member * COOP_RPM + rw * COOP_NRT;
+        dst[tid] = bo[(4 * (t0 / ncq) + lk) * C + 4 * (t0 % ncq + i) + r];
+    }
 }
 
 // 8 (or 4) fp32 values -> split-fp16 pieces (no range tracking: the caller has scaled them into [-1, 1])

@@ -689,9 +689,22 @@ __global__ __launch_bounds__(256) void ncde_pack_panels_h2(const float* __restri
 // DIRECT = 1: the evaluate / derivative input modes (solver.py:112-137): the field input is u = [z, X(t)] or [z, dX/dt(t)]
 // (H + C rows; layer 0 arrives zero-padded to a multiple of 16 columns, a.din[0]) and the heads are H-row dense layers with no
 // channel contraction, dz/dt = tanh(Wo x_L + bo) (x sigmoid(Wg x_L + bg)).
-template <int NS, int NWV, int EM, int GATED = 0, int BF = 0, int RESH = 0, int DIRECT = 0>
+#ifdef NCDE_TL_PROF
+#define FW_TICK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); fprof[k] += now_ - flast; flast = now_; }
+#else
+#define FW_TICK(k)
+#endif
+// COOP = 1 (round 5): the output phase is XCD-cooperative and weight-stationary like the reverse sweep's (ncde_coop.h): this workgroup
+// owns one sample tile (hidden layers, Butcher bookkeeping) and KEEPS 20 row tiles of Wo as split-fp16 A fragments, which it applies to
+// the x_L of every sample tile of its group -- two tiles per keeper iteration, waves 0..3 the even one, waves 4..7 the odd one, each
+// wave five row tiles.  Per stage: owners publish x_L (scaled by an exact power of two per sample, split-fp16, B-operand order) ->
+// group barrier -> keepers: P, tanh, f.dX slice of their state units -> exchange area -> group barrier -> owners read their tile's
+// f.dX.  The weight stream of the per-workgroup kernel (5.2 MB per stage and CU from L2 at cfg5) becomes 13 KB per tile of
+// activations; no range fault can occur (exact scaling), so the fault words stay 0.
+template <int NS, int NWV, int EM, int GATED = 0, int BF = 0, int RESH = 0, int DIRECT = 0, int COOP = 0>
 __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
     static_assert(DIRECT == 0 || (BF == 0 && RESH == 0), "direct heads: plain fp32 dense layers");
+    static_assert(COOP == 0 || (NS == 1 && NWV == 8 && GATED == 0 && BF == 2 && RESH == 0 && DIRECT == 0), "cooperative output phase: original field, one sample tile, 8 waves");
     static_assert(BF == 0 || NS == 1, "the split-bf16 / split-fp16 output tiles are built for one sample tile per workgroup");
     static_assert(RESH == 0 || (NS == 1 && RESH <= NWV), "resident hidden fragments: one sample tile, one row tile per wave");
     // BF = 1: 3-way split-bf16 output tiles; BF = 2 (default since round 4): 2-way split-fp16 ones, range faults per sample tile
@@ -718,6 +731,47 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
     float* KO = ACT1 + DS;      // f(z).dX of the stage
     float* DX = KO + HS;        // [C/4][NSP][4]
     unsigned* XB = reinterpret_cast<unsigned*>(DX + a.C * NSP);   // BF: x_L as three bf16 pieces, B-operand order
+    // COOP: staged inputs of the two group tiles of a keeper iteration, double-buffered by the iteration's parity (instead of XB):
+    // x_L images [2][2][8 x 64 x 4], dX/dt [2][2][C x 16 <= 1280], scales [2][2][64], the waves' f.dX partials [2][8][64], the per-wave
+    // maxima of |x_L| [8][16], this tile's scales [64], the barrier flag
+    float* const CBX = reinterpret_cast<float*>(XB);
+    float* const CDX = CBX + 2 * 2 * 2048;
+    float* const CSC = CDX + 2 * 2 * 1280;
+    float* const CKX = CSC + 2 * 2 * 64;
+    float* const CMX = CKX + 2 * 8 * 64;
+    float* const CSG = CMX + 8 * 16;
+    float* const CBO = CSG + 64;      // [4 waves of a role][5 row tiles][4 lk][4]: the bias of this member's rows (see coop_fill_bias)
+    // fragments FWD_KREG .. 39 of each wave's 40 wait in LDS, not in registers: with all 160 registers pinned the allocator kept one
+    // fragment in scratch and reloaded it inside the MFMA chain of every keeper iteration -- and a scratch reload waits (vmcnt is in
+    // order) for the staging loads of the next tiles issued just before it: one exposed L2 round trip per iteration
+    constexpr int FWD_KREG = 36;
+    unsigned* const CWL = reinterpret_cast<unsigned*>(CBO + 320);      // [4][40 - FWD_KREG][64 lanes][4]
+    int* const CFL = reinterpret_cast<int*>(CWL + 4 * (40 - FWD_KREG) * 256);
+    CoopWeights cw;
+    CoopDims cd{};
+    CoopSync csy{};
+    __amdgpu_buffer_rsrc_t crs = coop_rsrc(a.coop_x);      // (a NULL base outside the cooperative mode: never dereferenced)
+    int c_grp = 0, c_mem = 0;
+    bool c_same = false;
+    if constexpr (COOP != 0) {
+        cd.H = H; cd.C = a.C; cd.dlast = 128; cd.M = a.coop_M; cd.G = a.coop_G;
+        csy.words = a.coop_sync; csy.G = a.coop_G;
+        c_grp = blockIdx.x % a.coop_G;
+        c_mem = blockIdx.x / a.coop_G;
+        coop_fill_bias(a.bo, a.C, c_mem, CBO, tid);      // (visible after the barriers below)
+        const int same = coop_same_xcd(csy, c_grp, c_mem, a.coop_M, (int)gridDim.x, CFL, tid);
+        if (same < 0) return;      // (another workgroup never arrived: the launch is abandoned; the solution keeps the caller's fill)
+        c_same = same != 0;
+        // this wave's 5 x 4 x 2 fragments of Wo stay in registers for the whole launch: the owner phases of the FORWARD (hidden layers in
+        // panels of 4, twelve state registers) fit beside the 160 -- unlike the reverse sweep's, which re-reads them every stage
+        coop_load_weights<0, FWD_KREG>(cw, a.coop_img, c_mem, wave & 3, lane);
+        if (wave < 4) {
+            const unsigned* wp = a.coop_img + (long long)c_mem * (coop_p_words() + coop_t_words()) + wave * (40 * 64 * 4);
+#pragma unroll
+            for (int k = FWD_KREG; k < 40; ++k)
+                *reinterpret_cast<u32x4*>(CWL + ((wave * (40 - FWD_KREG) + (k - FWD_KREG)) * 64 + lane) * 4) = *reinterpret_cast<const u32x4*>(wp + (k * 64 + lane) * 4);
+        }
+    }
     if constexpr (DIRECT != 0) {
         for (int e = HS + tid; e < US; e += NT) YS[e] = 0.0f;      // rows H + C .. of the padded input stay zero
         tl_fill_resident<NT>(a, lds, tid);                           // small matrices -> LDS (visible after the first barrier below)
@@ -763,19 +817,34 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
     if (planned && !plan_header_ok(a, S)) return;      // (uniform: before the first barrier)
     const int n_steps = planned ? a.n_steps_fwd : a.T - 1;
     const int* pout = planned ? a.plan + plan_off_out(S, a.n_steps_fwd) : nullptr;
+    int sc = 0;      // stage counter of the launch (COOP: the group barriers count in it)
+#ifdef NCDE_TL_PROF
+    // development: cycles per stage by phase -> the head of this tile's rows of the solution (garbage solution in such a build):
+    // 0 dX/dt + record | 1 hidden layers | 2 scales + publish | 3 wait B1 | 4 keeper loop | 5 arrive + wait B2 | 6 f.dX read | 7 bookkeeping
+    unsigned long long fprof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, flast = __builtin_readcyclecounter();
+    unsigned long long kprof[3] = {0, 0, 0}, klast = 0;      // keeper loop: compute + f.dX stores | DMA wait | barrier
+#endif
     for (int n = 0; n < n_steps; ++n) {
         const int* pstep = planned ? a.plan + plan_off_fwd() + n * plan_step_words(S) : nullptr;
         const float dt = planned ? __int_as_float(pstep[0]) : 1.0f;
-        for (int j = 0; j < S; ++j) {
+        for (int j = 0; j < S; ++j, ++sc) {
             const StageDesc sd = planned ? plan_stage(pstep, j) : default_stage(a.method, (float)n + stage_offset(a.method, j), a.n_pieces);
             const int idx = sd.idx;
+            bool dx_new = false;
             if constexpr (DIRECT != 0) {
                 tl_load_cin<NS, NT>(a, b0, sd, a.field_input == NCDE_INPUT_EVALUATE, YS, H, tid);
             } else if (a.interp != NCDE_INTERP_LINEAR || idx != cur_idx) {
                 tl_load_dx<NS, NT>(a, b0, idx, sd.frac, sd.kdt, DX, tid);
                 cur_idx = idx;
+                dx_new = true;
             }
             __syncthreads();
+            if constexpr (COOP != 0) {      // this tile's dX/dt for the keepers (a linear control: once per piece; it stays in the exchange area)
+                if (dx_new) {
+                    const long long my_base = (long long)blockIdx.x * cd.per_tile_fwd();
+                    for (int e = tid; e < a.C * NSP / 4; e += NT) coop_st16(crs, a.coop_x, c_same, my_base + cd.off_dx() + e * 4, *reinterpret_cast<const u32x4*>(DX + e * 4));
+                }
+            }
             if (a.stages) {  // record the stage input for the exact discrete backward
                 const int Hr = a.Hr;
                 float* rec = a.stages + ((long long)(n * S + j) * a.B + b0) * Hr;
@@ -784,6 +853,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                     if (b0 + s < a.B) rec[e] = YS[((u >> 2) * NSP + s) * 4 + (u & 3)];
                 }
             }
+            FW_TICK(0)
             const float* in = YS;
             for (int l = 0; l < a.n_layers; ++l) {
                 float* outb = (l & 1) ? ACT1 : ACT0;
@@ -823,7 +893,9 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                     }
                 } else {
                     const TlW wr_ = tl_wref(lds, DIRECT != 0 ? a.tres[l] : 0, a.W[l], a.b[l], a.dout[l], a.din[l]);
-                    if constexpr (BF == 2)
+                    if constexpr (COOP != 0)      // (the scaled split image is formed at publication; panels of 4: the registers wait for Wo)
+                        tl_dense_relu<NS, NWV, 0, 0, 4>(wr_.W, wr_.b, a.dout[l], a.din[l], in, outb, wave, lane, nullptr, wr_.ld);
+                    else if constexpr (BF == 2)
                         tl_dense_relu<NS, NWV, 0, 1>(wr_.W, wr_.b, a.dout[l], a.din[l], in, outb, wave, lane,
                                                      l == a.n_layers - 1 ? XB : nullptr, wr_.ld, &mx);
                     else
@@ -833,6 +905,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                 __syncthreads();
                 in = outb;
             }
+            FW_TICK(1)
             float* KG = in == ACT0 ? ACT1 : ACT0;      // direct gated head: the free ping-pong buffer takes sigmoid(Wg x_L + bg)
             if constexpr (DIRECT != 0) {
                 const TlW wo_ = tl_wref(lds, a.tres_o, a.Wo, a.bo, H, dlast);
@@ -841,6 +914,150 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                     const TlW wg_ = tl_wref(lds, a.tres_g, a.Wg, a.bg, H, dlast);
                     tl_dense_relu<NS, NWV, 2>(wg_.W, wg_.b, H, dlast, in, KG, wave, lane, nullptr, wg_.ld);
                 }
+            } else
+            if constexpr (COOP != 0) {
+                const int li = lane & 15, lk = lane >> 4, C = a.C;
+                const long long my_base = (long long)blockIdx.x * cd.per_tile_fwd();
+                const unsigned bar1 = (2u * (unsigned)sc + 1u) * (unsigned)cd.M, bar2 = bar1 + (unsigned)cd.M;
+                // -- OWNER: per-sample maximum of |x_L| -> power-of-two scale; publish the scaled split image ---------------------------
+                {
+                    float mxl = 0.0f;      // this thread's elements all belong to sample (tid >> 2) & 15
+                    for (int e = tid; e < 128 * NSP; e += NT) mxl = fmaxf(mxl, fabsf(in[e]));
+                    mxl = fmaxf(mxl, __shfl_xor(mxl, 1, 64)); mxl = fmaxf(mxl, __shfl_xor(mxl, 2, 64));
+                    if ((lane & 3) == 0) CMX[wave * 16 + ((lane >> 2) & 15)] = mxl;
+                }
+                __syncthreads();
+                if (tid < 16) {
+                    float m_ = 0.0f;
+#pragma unroll
+                    for (int wv = 0; wv < 8; ++wv) m_ = fmaxf(m_, CMX[wv * 16 + tid]);
+                    const float sx = coop_pow2_scale(m_), isx = coop_pow2_inv(sx) * a.coop_scale[1];
+                    CSG[tid] = sx; CSG[16 + tid] = isx;
+                    coop_st4(crs, a.coop_x, c_same, my_base + cd.off_sc() + tid, sx); coop_st4(crs, a.coop_x, c_same, my_base + cd.off_sc() + 16 + tid, isx);
+                }
+                __syncthreads();
+                if (wave < 4) {
+                    const int c = wave, ub = 32 * c + 8 * lk;      // K chunk c of this wave; units ub .. ub + 7 of sample li
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(in + (((ub >> 2)) * NSP + li) * 4);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(in + (((ub >> 2) + 1) * NSP + li) * 4);
+                    const float sx = CSG[li];
+                    unsigned h[4], l[4];
+                    coop_split2(v0[0] * sx, v0[1] * sx, h[0], l[0]); coop_split2(v0[2] * sx, v0[3] * sx, h[1], l[1]);
+                    coop_split2(v1[0] * sx, v1[1] * sx, h[2], l[2]); coop_split2(v1[2] * sx, v1[3] * sx, h[3], l[3]);
+                    coop_st16(crs, a.coop_x, c_same, my_base + ((c * 2 + 0) * 64 + lane) * 4, (u32x4){h[0], h[1], h[2], h[3]});
+                    coop_st16(crs, a.coop_x, c_same, my_base + ((c * 2 + 1) * 64 + lane) * 4, (u32x4){l[0], l[1], l[2], l[3]});
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) coop_arrive(csy, c_grp);
+                FW_TICK(2)
+                if (!coop_wait(csy, c_grp, bar1, CFL, tid)) return;      // timeout / another workgroup gave up: the solution keeps the caller's fill from here on
+                FW_TICK(3)
+                // -- KEEPER: iteration `it` takes the group's tiles 2 it (waves 0..3) and 2 it + 1 (waves 4..7); the f.dX slices of iteration
+                // it - 1 are summed over the waves that hold their channel tiles and stored meanwhile; all threads fetch iteration it + 1's inputs
+                const int ncq = C >> 2, jh = COOP_RPM / ncq, wph = 4 / jh;
+                const int rw = wave & 3, half_w = wave >> 2;
+                const int cq0 = (c_mem * COOP_RPM + rw * COOP_NRT) % ncq;
+                const int n_dx4 = C * NSP / 4, n_it = cd.M / 2;
+                typedef const __attribute__((address_space(1))) void* gptr_t;
+                typedef __attribute__((address_space(3))) void* lptr_t;
+                auto stage_load = [&](int it_, int buf, int tid) {      // both tiles of iteration it_ -> LDS (global_load_lds_dwordx4, sc1)
+                    const int w64 = (tid >> 6) * 64;
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const float* src = a.coop_x + (long long)(c_grp + cd.G * (2 * it_ + hf)) * cd.per_tile_fwd();
+                        __builtin_amdgcn_global_load_lds((gptr_t)(src + tid * 4), (lptr_t)(CBX + (buf * 2 + hf) * 2048 + w64 * 4), 16, 0, 16);
+                        if (tid < n_dx4) __builtin_amdgcn_global_load_lds((gptr_t)(src + cd.off_dx() + tid * 4), (lptr_t)(CDX + (buf * 2 + hf) * 1280 + w64 * 4), 16, 0, 16);
+                        else if (tid >= 384 && tid < 400)
+                            __builtin_amdgcn_global_load_lds((gptr_t)(src + cd.off_sc() + (tid - 384) * 4), (lptr_t)(CSC + (buf * 2 + hf) * 64), 16, 0, 16);
+                    }
+                };
+                stage_load(0, 0, tid);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const int tid_outer = tid;
+#ifdef NCDE_TL_PROF
+                klast = __builtin_readcyclecounter();
+#endif
+                for (int it = 0; it <= n_it; ++it) {
+                    int tid = tid_outer;      // (offsets re-derived from an opaque copy every iteration: see the reverse sweep's keeper loops)
+                    asm volatile("" : "+v"(tid));
+                    const int lane = tid & 63, li = tid & 15, lk = (tid >> 4) & 3;
+                    const int buf = it & 1;
+                    if (it + 1 < n_it) stage_load(it + 1, buf ^ 1, tid);
+                    if (it < n_it) {
+                        const float* bxs = CBX + (buf * 2 + half_w) * 2048;
+                        const float isx = CSC[(buf * 2 + half_w) * 64 + 16 + li];
+                        const float sxw = coop_pow2_inv(isx);      // sx sw: the bias joins the scaled accumulator exactly
+                        float kk = 0.0f;
+                        // (k is a compile-time constant after unrolling: fragments below FWD_KREG are registers, the rest LDS reads)
+                        auto wfr = [&](int k) -> u32x4 {
+                            if (k < FWD_KREG) return cw.f[k];
+                            return *reinterpret_cast<const u32x4*>(CWL + ((rw * (40 - FWD_KREG) + (k - FWD_KREG)) * 64 + lane) * 4);
+                        };
+                        auto p_batch = [&](auto q0c, auto nqc) {
+                            constexpr int Q0 = decltype(q0c)::value, NQ = decltype(nqc)::value;
+                            f32x4 pm[NQ], px[NQ];
+#pragma unroll
+                            for (int i = 0; i < NQ; ++i) {
+                                const f32x4 bsv = *reinterpret_cast<const f32x4*>(CBO + ((rw * COOP_NRT + Q0 + i) * 4 + lk) * 4);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) pm[i][r] = bsv[r] * sxw;
+                                px[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            }
+                            u32x4 b0_ = *reinterpret_cast<const u32x4*>(bxs + lane * 4), b1_ = *reinterpret_cast<const u32x4*>(bxs + (64 + lane) * 4);
+#pragma unroll
+                            for (int c = 0; c < COOP_NCH; ++c) {
+                                const u32x4 c0_ = b0_, c1_ = b1_;
+                                if (c + 1 < COOP_NCH) {
+                                    b0_ = *reinterpret_cast<const u32x4*>(bxs + (((c + 1) * 2 + 0) * 64 + lane) * 4);
+                                    b1_ = *reinterpret_cast<const u32x4*>(bxs + (((c + 1) * 2 + 1) * 64 + lane) * 4);
+                                }
+#pragma unroll
+                                for (int i = 0; i < NQ; ++i) pm[i] = mfma_h(wfr(((Q0 + i) * 4 + c) * 2 + 0), c0_, pm[i]);
+#pragma unroll
+                                for (int i = 0; i < NQ; ++i) px[i] = mfma_h(wfr(((Q0 + i) * 4 + c) * 2 + 1), c0_, px[i]);
+#pragma unroll
+                                for (int i = 0; i < NQ; ++i) px[i] = mfma_h(wfr(((Q0 + i) * 4 + c) * 2 + 0), c1_, px[i]);
+                            }
+#pragma unroll
+                            for (int i = 0; i < NQ; ++i) {
+                                const f32x4 pc4 = h2_combine(pm[i], px[i]);
+                                const f32x4 dxv = *reinterpret_cast<const f32x4*>(CDX + (buf * 2 + half_w) * 1280 + ((cq0 + Q0 + i) * NSP + li) * 4);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) kk = fmaf(tanh_dev(pc4[r] * isx), dxv[r], kk);
+                            }
+                        };
+                        p_batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+                        p_batch(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+                        CKX[(buf * 8 + wave) * 64 + lane] = kk;
+                    }
+                    if (it >= 1 && tid < 2 * 64 * jh) {      // f.dX of this member's state units for the two tiles of iteration it - 1
+                        const int hf = tid / (64 * jh), hl = (tid >> 6) % jh, ln = tid & 63, pb = buf ^ 1;
+                        float ksum = 0.0f;
+                        for (int wv = hl * wph; wv < (hl + 1) * wph; ++wv) ksum += CKX[(pb * 8 + 4 * hf + wv) * 64 + ln];
+                        const long long tb = (long long)(c_grp + cd.G * (2 * (it - 1) + hf)) * cd.per_tile_fwd();
+                        coop_st4(crs, a.coop_x, c_same, tb + cd.off_ko() + ((c_mem * jh + hl) * NSP + (ln & 15)) * 4 + (ln >> 4), ksum);
+                    }
+#ifdef NCDE_TL_PROF
+                    { const unsigned long long n_ = __builtin_readcyclecounter(); kprof[0] += n_ - klast; klast = n_; }
+#endif
+                    if (it + 1 < n_it) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the next iteration's inputs: requested at the top)
+#ifdef NCDE_TL_PROF
+                    { const unsigned long long n_ = __builtin_readcyclecounter(); kprof[1] += n_ - klast; klast = n_; }
+#endif
+                    __syncthreads();
+#ifdef NCDE_TL_PROF
+                    { const unsigned long long n_ = __builtin_readcyclecounter(); kprof[2] += n_ - klast; klast = n_; }
+#endif
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                FW_TICK(4)
+                if (tid == 0) coop_arrive(csy, c_grp);
+                if (!coop_wait(csy, c_grp, bar2, CFL, tid)) return;
+                FW_TICK(5)
+                for (int e4 = tid * 4; e4 < HS; e4 += NT * 4) *reinterpret_cast<f32x4*>(KO + e4) = coop_ld16f(crs, my_base + cd.off_ko() + e4);
             } else
             if constexpr (BF == 2) {
                 switch (nkb_o) {
@@ -866,6 +1083,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                     break;
             }
             __syncthreads();
+            FW_TICK(6)
             // Butcher bookkeeping (same operation order as ncde_generic.hip's StageCombine)
 #pragma unroll
             for (int q = 0; q < EM; ++q) {
@@ -893,8 +1111,19 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                     }
                 }
             }
+            FW_TICK(7)
         }
     }
+#ifdef NCDE_TL_PROF
+    __syncthreads();
+    if (lane == 0 && sc > 0)
+        for (int k = 0; k < 8; ++k) a.out[(long long)b0 * a.n_out * a.Hr + wave * 8 + k] = (float)fprof[k] / (float)sc;
+    if (lane == 0 && sc > 0)
+        for (int k = 0; k < 3; ++k) a.out[(long long)b0 * a.n_out * a.Hr + 64 + wave * 3 + k] = (float)kprof[k] / (float)sc;
+#endif
+    if constexpr (COOP != 0) {      // exact scaling: no range fault can occur
+        if (a.fault != nullptr && tid == 0) a.fault[blockIdx.x] = 0;
+    } else
     if constexpr (BF == 2) {      // range fault of this sample tile (or of the weights: the pack kernel's word behind the tiles')
         if (a.fault != nullptr) {
             if (tid == 0) fault_s = a.fault[gridDim.x];
@@ -1410,6 +1639,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     float* const CKX = CSC + 2 * 64;
     float* const CIS = CKX + 2 * 4 * 64;                     // [2][16]     1/(sd sw) of the tile the T role is working on
     int* const CFL = reinterpret_cast<int*>(CIS + 2 * 16);
+    float* const CBO = reinterpret_cast<float*>(XBA) + 2048;      // [4][5][4][4] bias of this member's rows (keeper phase only; behind the parked a0)
     float* const CMX = CDP;                                  // [3][8][16]  per-wave maxima of |x_L|, |a|, |dX/dt| per sample
     float* const CSG = CDP + 3 * 8 * 16;                     // [4][16]     sx, 1/(sx sw), sd, 1/(sd sw) of this tile
     if constexpr (COOP != 0) {
@@ -1724,6 +1954,9 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                             AS[q * NT + tid] = y0[q]; reinterpret_cast<float*>(XBA)[q * NT + tid] = a0[q];      // (a and the split image: recorded above)
                         }
                     }
+                    // the bias of this member's rows -> the free tail of the split-image area (rewritten by the last hidden layer every stage):
+                    // a global load inside the keeper loop would wait -- vmcnt is in order -- for the staging loads of the next tile
+                    coop_fill_bias(a.bo, C, c_mem, CBO, tid);
                     if (!coop_wait(csy, c_grp, bar1, CFL, tid)) {      // timeout / another workgroup gave up: poison this tile's gradient
                         for (int e = tid; e < NSP * a.Hr; e += NT)
                             if (b0 + e / a.Hr < a.B) a.grad_z0[(long long)b0 * a.Hr + e] = __builtin_nanf("");
@@ -1768,7 +2001,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
 #ifdef NCDE_TL_PROF
                     klast = __builtin_readcyclecounter();
 #endif
-                    const int hl_w = rw / wph;      // P role: which of this member's state-unit blocks this wave's row tiles belong to
+                    const int hl_w_outer = rw / wph, cq0_outer = cq0;      // P role: which of this member's state-unit blocks this wave's row tiles belong to
                     // (one loop per role -- same trip count, same barriers -- so that neither carries the other's live registers)
                     if (prole) {
                         for (int it = 0; it <= cd.M; ++it) {
@@ -1778,6 +2011,8 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                             asm volatile("" : "+v"(tid));
                             const int lane = tid & 63, li = tid & 15, lk = (tid >> 4) & 3;
                             const int buf = it & 1;
+                            int hl_w = hl_w_outer, cq0 = cq0_outer;      // (opaque copies too: an address base derived from them was hoisted and spilled)
+                            asm volatile("" : "+v"(hl_w), "+v"(cq0));
                             if (it + 1 < cd.M) stage_load(c_grp + cd.G * (it + 1), buf ^ 1, tid);
                             if (it < cd.M) {
                                 const float* bxs = CBX + buf * 2048;
@@ -1794,7 +2029,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                                     f32x4 pm[NQ], px[NQ];
 #pragma unroll
                                     for (int i = 0; i < NQ; ++i) {
-                                        const f32x4 bsv = *reinterpret_cast<const f32x4*>(a.bo + (4 * c_hbw + lk) * C + 4 * (cq0 + Q0 + i));
+                                        const f32x4 bsv = *reinterpret_cast<const f32x4*>(CBO + ((rw * COOP_NRT + Q0 + i) * 4 + lk) * 4);
 #pragma unroll
                                         for (int r = 0; r < 4; ++r) pm[i][r] = bsv[r] * sxw;
                                         px[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -2765,6 +3000,34 @@ size_t tiled_adj_lds(const NcdeProblem* p) {
     return tiled_adj_lds_base(p) + (tiled_adj_bf(p) ? (size_t)tiled_adj_pk(p) * 16 * 16 * 6 : 0);
 }
 
+// The forward's cooperative output phase (ncde_fwd_tiled<.., COOP>): same groups, same packed weight images, an exchange area without
+// the partials.  Workspace regions (float offsets) behind the split-fp16 forward's own [h2 copy | bf16 copy | fault words].
+struct FwdCoopPlan {
+    bool ok;
+    int M, G;
+    long long img, x, scale, sync, end;
+};
+constexpr int kFwdCoopLdsFloats = 2 * 2 * 2048 + 2 * 2 * 1280 + 2 * 2 * 64 + 2 * 8 * 64 + 8 * 16 + 64 + 320 + 4 * 4 * 256 + 8;      // = CBX .. CFL of ncde_fwd_tiled
+FwdCoopPlan tiled_fwd_coop_plan(const NcdeProblem* p) {
+    FwdCoopPlan f{};
+    if (p->field_input != NCDE_INPUT_MATMUL || tiled_fwd_split(p) != 2 || tiled_fwd_ns(p) != 1) return f;
+    const CoopPlan c = tiled_coop_plan(p);
+    if (!c.ok) return f;
+    const size_t lds = sizeof(float) * ((size_t)16 * (size_t)(2 * p->hidden + 2 * tiled_dmax(p) + p->channels) + (size_t)kFwdCoopLdsFloats);
+    if (lds > (size_t)kLdsLimit) return f;
+    const int n_tiles = (p->batch + 15) / 16;
+    const CoopDims d{p->hidden, p->channels, 128, c.M, c.G};
+    long long off = 64 + tiled_pack_floats(p, false) + tiled_pack_floats(p, true) + tiled_fault_floats(p);
+    off = (off + 63) & ~63LL;
+    f.img = off; off += (long long)c.M * (coop_p_words() + coop_t_words());
+    f.x = off; off += d.per_tile_fwd() * n_tiles;
+    f.scale = off; off += 64;
+    f.sync = off; off += 64 + coop_sync_words(c.G, n_tiles);
+    f.end = off + 64;
+    f.ok = true; f.M = c.M; f.G = c.G;
+    return f;
+}
+
 bool tiled_adj_ok(const NcdeProblem* p) {
     const bool direct = p->field_input != NCDE_INPUT_MATMUL;
     const bool bigh = tiled_adj_bigh(p);
@@ -2933,6 +3196,7 @@ const char* ncde_tiled_kernel_name(const NcdeProblem* p, int pass) {
     if (pass == 2) return gated ? "ncde_adj_tiled<gated,discrete>+ncde_dwo_tiled" : "ncde_adj_tiled<discrete>+ncde_dwo_tiled";
     if (p->field_input != NCDE_INPUT_MATMUL) return gated ? "ncde_fwd_tiled<NS1,gated,direct>" : "ncde_fwd_tiled<NS1,direct>";
     const int ns = tiled_fwd_ns(p);
+    if (!gated && tiled_fwd_coop_plan(p).ok) return "ncde_fwd_tiled<NS1,coop,fp16x2>";
     if (tiled_fwd_split(p) == 2) return gated ? "ncde_fwd_tiled<NS1,gated,fp16x2>" : "ncde_fwd_tiled<NS1,fp16x2>";
     if (tiled_fwd_bf(p)) return gated ? "ncde_fwd_tiled<NS1,gated,bf16>" : "ncde_fwd_tiled<NS1,bf16>";
     if (gated) return ns == 4 ? "ncde_fwd_tiled<NS4,gated>" : (ns == 2 ? "ncde_fwd_tiled<NS2,gated>" : "ncde_fwd_tiled<NS1,gated>");
@@ -2944,6 +3208,8 @@ int64_t ncde_tiled_workspace_bytes(const NcdeProblem* p, int pass) {
     if (pass == 0 && p->field_input != NCDE_INPUT_MATMUL) return 256 + (int64_t)sizeof(float) * p->layer_out[0] * ((p->layer_in[0] + 15) & ~15);
     if (pass == 0) {
         const int split = tiled_fwd_split(p);      // split-fp16: its own copy + the split-bf16 copy of the re-execution launch + fault words
+        const FwdCoopPlan fc = tiled_fwd_coop_plan(p);
+        if (fc.ok) return (int64_t)sizeof(float) * fc.end;
         if (split == 2) return 256 + (tiled_pack_floats(p, false) + tiled_pack_floats(p, true) + tiled_fault_floats(p)) * (int64_t)sizeof(float);
         return 256 + tiled_pack_floats(p, split == 1) * (int64_t)sizeof(float);
     }
@@ -3008,10 +3274,31 @@ int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws
         if (p->field_kind == NCDE_FIELD_MINIMAL) fn = small ? ncde_fwd_tiled<1, TL_NW, 4, 1, 0, 0, 1> : ncde_fwd_tiled<1, TL_NW, 16, 1, 0, 0, 1>;
         else fn = small ? ncde_fwd_tiled<1, TL_NW, 4, 0, 0, 0, 1> : ncde_fwd_tiled<1, TL_NW, 16, 0, 0, 0, 1>;
     }
-    if (ncde_lds_optin((const void*)fn, lds) != hipSuccess) return NCDE_ERR_HIP;
+    const FwdCoopPlan fc = direct ? FwdCoopPlan{} : tiled_fwd_coop_plan(p);
+    size_t lds_launch = lds;
+    if (fc.ok) {      // XCD-cooperative, weight-stationary output phase (ncde_coop.h): the reverse sweep's groups and weight images
+        float* w = (float*)ws;
+        unsigned* amax = reinterpret_cast<unsigned*>(w + fc.scale + 8);
+        if (hipMemsetAsync(amax, 0, sizeof(unsigned), st) != hipSuccess) return NCDE_ERR_HIP;
+        const int n_tiles = (p->batch + 15) / 16;
+        if (hipMemsetAsync(w + fc.sync, 0, sizeof(unsigned) * (size_t)coop_sync_words(fc.G, n_tiles), st) != hipSuccess) return NCDE_ERR_HIP;
+        const long long nw = (long long)p->hidden * p->channels * 128;
+        hipLaunchKernelGGL(ncde_coop_absmax, dim3(512), dim3(256), 0, st, a.Wo, nw, amax);
+        hipLaunchKernelGGL(ncde_coop_pack, dim3(1024), dim3(256), 0, st, a.Wo, (const unsigned*)amax, reinterpret_cast<unsigned*>(w + fc.img), w + fc.scale,
+                           p->channels, 128, fc.M);
+        a.coop_img = reinterpret_cast<const unsigned*>(w + fc.img);
+        a.coop_x = w + fc.x;
+        a.coop_scale = w + fc.scale;
+        a.coop_sync = reinterpret_cast<unsigned*>(w + fc.sync);
+        a.coop_M = fc.M;
+        a.coop_G = fc.G;
+        fn = ncde_fwd_tiled<1, TL_NW, 4, 0, 2, 0, 0, 1>;
+        lds_launch = sizeof(float) * ((size_t)16 * (size_t)(2 * p->hidden + 2 * tiled_dmax(p) + p->channels) + (size_t)kFwdCoopLdsFloats);
+    }
+    if (ncde_lds_optin((const void*)fn, lds_launch) != hipSuccess) return NCDE_ERR_HIP;
     const int nwg = (p->batch + ns * 16 - 1) / (ns * 16);
-    hipLaunchKernelGGL(fn, dim3(nwg), dim3(TL_THREADS), lds, st, a);
-    if (split == 2) {      // re-execution of range-faulted sample tiles in split-bf16 (normally none: every workgroup exits at once)
+    hipLaunchKernelGGL(fn, dim3(nwg), dim3(TL_THREADS), lds_launch, st, a);
+    if (split == 2 && !fc.ok) {      // re-execution of range-faulted sample tiles in split-bf16 (normally none: every workgroup exits at once)
         tiled_pack_launch(p, &a, pack_bf, true, st);
         a.only_faulted = 1;
         if (ncde_lds_optin((const void*)fx, lds) != hipSuccess) return NCDE_ERR_HIP;

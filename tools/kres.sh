@@ -4,7 +4,9 @@
 #                                    (VERDICT round 3, item 9); exit code 1 otherwise
 C=/root/repo/online-neural-cdes_amd/csrc
 table() {
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I/root/repo/include -c $1 -o /tmp/kres.o -Rpass-analysis=kernel-resource-usage 2>&1 \
+  # (the files the Makefile builds with MFMA results in VGPRs get the same flag here)
+  case $(basename $1) in ncde_fast.hip|ncde_fast_nl.hip|ncde_fast_plan.hip|ncde_adaptive_fast.hip|ncde_adaptive.hip|ncde_variant.hip|ncde_generic.hip) X="-mllvm -amdgpu-mfma-vgpr-form";; *) X="";; esac
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $X -I/root/repo/include -c $1 -o /tmp/kres.o -Rpass-analysis=kernel-resource-usage 2>&1 \
    | grep -E "Function Name|VGPRs:|AGPRs:|ScratchSize|Occupancy|LDS Size" | sed -E 's/.*remark: +//; s/ \[-Rpass.*//' \
    | awk '/Function Name/{if(line)print line; line=$3; next}{line=line" | "$0}END{print line}'
 }
