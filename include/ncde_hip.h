@@ -72,7 +72,7 @@ typedef enum NcdeOutput { NCDE_OUT_INTERVAL = 0, NCDE_OUT_KNOTS = 1, NCDE_OUT_TI
 #define NCDE_FLAG_ADJOINT_SPLIT_FP16 128u /* development builds (-DNCDE_DEV_KNOBS) only, ignored otherwise: split-fp16 GEMMs on the cotangent
                                        side of the specialised adjoint too (not reproducible run to run) */
 #define NCDE_FLAG_DEBUG_PROFILE 0x100u /* development: instrumented kernel variant, cycle counters land in the workspace */
-#define NCDE_FLAG_NO_COOP 0x400u       /* batch-tiled backward: do not use the XCD-cooperative, weight-stationary output phase (round 5, large
+#define NCDE_FLAG_NO_COOP 0x400u       /* batch-tiled forward and backward: do not use the XCD-cooperative, weight-stationary output phase (round 5, large
                                           hidden sizes: workgroups of one launch exchange activations through L2 and spin on each other --
                                           it needs every workgroup resident, i.e. the GPU's CUs not held by another process's persistent kernel) */
 #define NCDE_FLAG_TILED_NS1 0x1000u    /* batch-tiled forward: force 1 / 2 / 4 sixteen-sample tiles per workgroup     */

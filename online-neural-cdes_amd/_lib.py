@@ -17,7 +17,7 @@ FIELD_INPUT = {"matmul": 0, "evaluate": 1, "derivative": 2}
 FLAG_AUTO, FLAG_FORCE_GENERIC, FLAG_FORCE_FAST, FLAG_FP32_MFMA, FLAG_ADJOINT_V1, FLAG_ADJOINT_V2 = 0, 1, 2, 4, 8, 16
 FLAG_ADJOINT_V4 = 32
 FLAG_SPLIT_BF16 = 64        # specialised forward kernels: 3-way split-bf16 GEMMs instead of the default 2-way split-fp16 ones
-FLAG_NO_COOP = 0x400          # batch-tiled backward: per-workgroup sweep instead of the XCD-cooperative output phase (round 5)
+FLAG_NO_COOP = 0x400          # batch-tiled forward / backward: per-workgroup kernels instead of the XCD-cooperative output phase (round 5)
 FLAG_ADJOINT_SPLIT_FP16 = 128   # development builds of the library only (ignored otherwise): see DESIGN.md 5.4c
 
 

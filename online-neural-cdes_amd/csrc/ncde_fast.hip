@@ -16,6 +16,7 @@
 #include "ncde_fast4.h"
 #include "ncde_fast64.h"
 #include "ncde_fast_nl.h"
+#include "ncde_fast_fwd3.h"
 #include "ncde_fast_plan.h"
 // HP = 2 (the default adjoint): hidden-layer dW/db of the previous stage behind barrier A (dL/dpre images double-buffered) / all five
 // dWo blocks behind barrier A -- both shorten what the gradient waves do before barrier A, where the chain waves wait for them
@@ -2723,8 +2724,10 @@ FwdFn pick_fwd(int interp, int method) {
 
 template <int H, int HH, int C, int NW, int HP>
 FwdFn pick_fwd_split(int interp, int method, int n_layers) {
+    // (the unrolled three-layer instantiations live in ncde_fast_fwd3.hip: the one unit built with MFMA results in VGPRs)
+    if (n_layers == 3 && NW == 4 && ((H == 32 && HH == 32 && C == 20) || (H == 64 && HH == 64 && C == 4))) return ncde_fast_fwd3(H, interp, method, HP);
 #define NCDE_PICK(I, M) \
-    if (interp == I && method == M) return n_layers == 3 ? ncde_fwd_fast_bf3<H, HH, C, NW, I, M, 0, 3, HP> : ncde_fwd_fast_bf3<H, HH, C, NW, I, M, 0, 0, HP>;
+    if (interp == I && method == M) return ncde_fwd_fast_bf3<H, HH, C, NW, I, M, 0, 0, HP>;
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_RK4_38)
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_MIDPOINT)
     NCDE_PICK(NCDE_INTERP_LINEAR, NCDE_EULER)

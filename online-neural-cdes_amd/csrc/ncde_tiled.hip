@@ -760,7 +760,11 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
         c_mem = blockIdx.x / a.coop_G;
         coop_fill_bias(a.bo, a.C, c_mem, CBO, tid);      // (visible after the barriers below)
         const int same = coop_same_xcd(csy, c_grp, c_mem, a.coop_M, (int)gridDim.x, CFL, tid);
-        if (same < 0) return;      // (another workgroup never arrived: the launch is abandoned; the solution keeps the caller's fill)
+        if (same < 0) {      // (another workgroup never arrived: the launch is abandoned, this tile's rows of the solution are NaN)
+            for (long long e = tid; e < (long long)NSP * a.n_out * a.Hr; e += NT)
+                if (b0 + (int)(e / ((long long)a.n_out * a.Hr)) < a.B) a.out[(long long)b0 * a.n_out * a.Hr + e] = __builtin_nanf("");
+            return;
+        }
         c_same = same != 0;
         // this wave's 5 x 4 x 2 fragments of Wo stay in registers for the whole launch: the owner phases of the FORWARD (hidden layers in
         // panels of 4, twelve state registers) fit beside the 160 -- unlike the reverse sweep's, which re-reads them every stage
@@ -951,7 +955,13 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                 __syncthreads();
                 if (tid == 0) coop_arrive(csy, c_grp);
                 FW_TICK(2)
-                if (!coop_wait(csy, c_grp, bar1, CFL, tid)) return;      // timeout / another workgroup gave up: the solution keeps the caller's fill from here on
+                // timeout / another workgroup gave up: the launch is abandoned and this tile's rows of the solution are NaN (never silently wrong)
+                auto poison = [&]() {
+                    const float qnan = __builtin_nanf("");
+                    for (long long e = tid; e < (long long)NSP * a.n_out * a.Hr; e += NT)
+                        if (b0 + (int)(e / ((long long)a.n_out * a.Hr)) < a.B) a.out[(long long)b0 * a.n_out * a.Hr + e] = qnan;
+                };
+                if (!coop_wait(csy, c_grp, bar1, CFL, tid)) { poison(); return; }
                 FW_TICK(3)
                 // -- KEEPER: iteration `it` takes the group's tiles 2 it (waves 0..3) and 2 it + 1 (waves 4..7); the f.dX slices of iteration
                 // it - 1 are summed over the waves that hold their channel tiles and stored meanwhile; all threads fetch iteration it + 1's inputs
@@ -1055,7 +1065,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                 __syncthreads();
                 FW_TICK(4)
                 if (tid == 0) coop_arrive(csy, c_grp);
-                if (!coop_wait(csy, c_grp, bar2, CFL, tid)) return;
+                if (!coop_wait(csy, c_grp, bar2, CFL, tid)) { poison(); return; }
                 FW_TICK(5)
                 for (int e4 = tid * 4; e4 < HS; e4 += NT * 4) *reinterpret_cast<f32x4*>(KO + e4) = coop_ld16f(crs, my_base + cd.off_ko() + e4);
             } else

@@ -256,14 +256,14 @@ def table():
     T2, T4 = 399, 182
     return {
         # cfg2: B = 4096 -> 256 workgroups of 16 samples.  Forward: ONE loop = the 398 steps, its body = the 4 stages unrolled.
-        "cfg2.forward": dict(obj="ncde_fast", frag="ncde_fwd_fast_bf3ILi32ELi32ELi20ELi4ELi0ELi2ELi0ELi3ELi1ELi0E", waves_per_simd=1, n_wg=256, wg_per_cu=1,
+        "cfg2.forward": dict(obj="ncde_fast_fwd3", frag="ncde_fwd_fast_bf3ILi32ELi32ELi20ELi4ELi0ELi2ELi0ELi3ELi1ELi0E", waves_per_simd=1, n_wg=256, wg_per_cu=1,
                              trips=[T2 - 1]),
         # adjoint: loop 0 prologue fill; loops 1-2 = the gradient waves' step / stage loops; 3-8 their flag polls; 9-10 = the chain
         # waves' step / stage loops.  One wave of each role per SIMD.
         "cfg2.backward": dict(obj="ncde_fast", frag="ncde_adj_fast3ILi3ELi20ELi0ELi2ELi0ELi0ELi2ELi0E", waves_per_simd=2, n_wg=256, wg_per_cu=1,
                               trips=[1, T2 - 1, 4, 1, 1, 1, 1, 1, 1, T2 - 1, 4], roles=[[1, 2, 3, 4, 5, 6, 7, 8], [9, 10]]),
         # cfg4: B = 8192 -> 512 workgroups; forward 2 per CU (4 waves each), backward 1 per CU (two rounds); midpoint: 2 stages
-        "cfg4.forward": dict(obj="ncde_fast", frag="ncde_fwd_fast_bf3ILi64ELi64ELi4ELi4ELi1ELi1ELi0ELi3ELi1ELi0E", waves_per_simd=1, n_wg=512, wg_per_cu=2,
+        "cfg4.forward": dict(obj="ncde_fast_fwd3", frag="ncde_fwd_fast_bf3ILi64ELi64ELi4ELi4ELi1ELi1ELi0ELi3ELi1ELi0E", waves_per_simd=1, n_wg=512, wg_per_cu=2,
                              trips=[T4 - 1]),
         "cfg4.backward": dict(obj="ncde_fast64", frag="ncde_adj_h64ILi1ELi1ELi1ELi0ELi0E", waves_per_simd=1, n_wg=512, wg_per_cu=1, trips=[T4 - 1, 2]),
     }

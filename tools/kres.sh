@@ -4,8 +4,8 @@
 #                                    (VERDICT round 3, item 9); exit code 1 otherwise
 C=/root/repo/online-neural-cdes_amd/csrc
 table() {
-  # (the files the Makefile builds with MFMA results in VGPRs get the same flag here)
-  case $(basename $1) in ncde_fast.hip|ncde_fast_nl.hip|ncde_fast_plan.hip|ncde_adaptive_fast.hip|ncde_adaptive.hip|ncde_variant.hip|ncde_generic.hip) X="-mllvm -amdgpu-mfma-vgpr-form";; *) X="";; esac
+  # (the one unit the Makefile builds with MFMA results in VGPRs gets the same flag here)
+  case $(basename $1) in ncde_fast_fwd3.hip) X="-mllvm -amdgpu-mfma-vgpr-form";; *) X="";; esac
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $X -I/root/repo/include -c $1 -o /tmp/kres.o -Rpass-analysis=kernel-resource-usage 2>&1 \
    | grep -E "Function Name|VGPRs:|AGPRs:|ScratchSize|Occupancy|LDS Size" | sed -E 's/.*remark: +//; s/ \[-Rpass.*//' \
    | awk '/Function Name/{if(line)print line; line=$3; next}{line=line" | "$0}END{print line}'
@@ -22,10 +22,10 @@ check() {  # file, name fragment
   s=$(echo "$line" | sed -E 's/.*ScratchSize \[bytes\/lane\]: ([0-9]+).*/\1/')
   if [ "$s" != "0" ]; then echo "SCRATCH $s B  $2"; rc=1; else echo "ok       $2"; fi
 }
-for f in ncde_fast ncde_fast64 ncde_adaptive_fast; do table $C/$f.hip > /tmp/kres_$f.txt; done
-check ncde_fast "ncde_fwd_fast_bf3ILi32ELi32ELi20ELi4ELi0ELi2ELi0ELi3ELi1ELi0E"
+for f in ncde_fast ncde_fast_fwd3 ncde_fast64 ncde_adaptive_fast; do table $C/$f.hip > /tmp/kres_$f.txt; done
+check ncde_fast_fwd3 "ncde_fwd_fast_bf3ILi32ELi32ELi20ELi4ELi0ELi2ELi0ELi3ELi1ELi0E"
 check ncde_fast "ncde_adj_fast3ILi3ELi20ELi0ELi2ELi0ELi0ELi2ELi0E"
-check ncde_fast "ncde_fwd_fast_bf3ILi64ELi64ELi4ELi4ELi1ELi1ELi0ELi3ELi1ELi0E"
+check ncde_fast_fwd3 "ncde_fwd_fast_bf3ILi64ELi64ELi4ELi4ELi1ELi1ELi0ELi3ELi1ELi0E"
 check ncde_fast64 "ncde_adj_h64ILi1ELi1ELi1ELi0ELi0E"
 check ncde_adaptive_fast "ncde_dpf_fwdILi32ELi32ELi20E"
 check ncde_adaptive_fast "ncde_dpf_tapeILi32ELi32ELi20ELi3E"
