@@ -3042,9 +3042,9 @@ bool tiled_adj_ok(const NcdeProblem* p) {
     const bool direct = p->field_input != NCDE_INPUT_MATMUL;
     const bool bigh = tiled_adj_bigh(p);
     // (round 5: any channel count -- beyond 80 / 160 the sweep reads dX/dt in its bookkeeping phase instead of a stage ahead; hidden
-    // sizes up to 256 on the BIGH instantiation: original field, matmul input, streamed weights, last width 32 / 64 / 128)
+    // sizes up to 256 on the BIGH instantiation: original field, matmul input, streamed weights, last width 16 .. 256)
     if ((!direct && tiled_adj_pk(p) == 0) || p->hidden * 16 > 4096 || p->channels > 4095) return false;
-    if (bigh && (direct || p->field_kind != NCDE_FIELD_ORIGINAL || tiled_adj_pk(p) < 2)) return false;
+    if (bigh && (direct || p->field_kind != NCDE_FIELD_ORIGINAL || tiled_adj_pk(p) < 1)) return false;
     int l1 = -1;
     if (direct && (p->hidden / 16) * (p->layer_out[p->n_layers - 1] / 16) > 64) return false;      // direct heads: [H][dlast] tiles
     // hidden-dW accumulator tiles per matrix (registers of the sweep; W16 keeps them in its global partial: no limit)
@@ -3400,7 +3400,7 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
         if (hipMemsetAsync(w + t.gpartA, 0, sizeof(float) * (size_t)t.n_st * t.gstride, st) != hipSuccess) return NCDE_ERR_HIP;
     } else if (tiled_adj_bigh(p)) {      // (tiled_adj_ok: original field, matmul input, pk >= 2)
         if (bf) fa = pk == 8 ? ncde_adj_tiled<8, 4, 0, 0, 1, 0, 1> : (pk == 4 ? ncde_adj_tiled<4, 4, 0, 0, 1, 0, 1> : ncde_adj_tiled<2, 4, 0, 0, 1, 0, 1>);
-        else fa = pk == 8 ? ncde_adj_tiled<8, 4, 0, 0, 0, 0, 1> : (pk == 4 ? ncde_adj_tiled<4, 4, 0, 0, 0, 0, 1> : ncde_adj_tiled<2, 4, 0, 0, 0, 0, 1>);
+        else fa = pk == 8 ? ncde_adj_tiled<8, 4, 0, 0, 0, 0, 1> : (pk == 4 ? ncde_adj_tiled<4, 4, 0, 0, 0, 0, 1> : (pk == 2 ? ncde_adj_tiled<2, 4, 0, 0, 0, 0, 1> : ncde_adj_tiled<1, 4, 0, 0, 0, 0, 1>));
     }
     int nwv_launch = nwv;
     size_t lds_launch = tiled_adj_lds(p);

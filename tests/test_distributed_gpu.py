@@ -103,20 +103,22 @@ def test_two_rank_neuralcde_data_parallel_on_one_gpu(adjoint, seq, tmp_path, gpu
     assert ep <= 1e-3, ep
 
 
-def test_two_rank_data_parallel_at_the_benchmarked_shape(tmp_path, gpu_lib):
+@pytest.mark.parametrize("adjoint", [True, False])
+def test_two_rank_data_parallel_at_the_benchmarked_shape(adjoint, tmp_path, gpu_lib):
     """The same two-rank run at BASELINE cfg2/cfg3's per-sample shape (200 observations -> 399 rectilinear knots, C = 20, H = HH = 32),
     512 samples per rank: the flat-bucket all-reduce runs with the kernels the benchmark times (ncde_fwd_fast_bf3 / ncde_adj_fast3),
-    replicas stay bit-identical and the first-step gradient equals the single-process one on the 1024-sample batch."""
+    replicas stay bit-identical and the first-step gradient equals the single-process one on the 1024-sample batch.  adjoint=False
+    (VERDICT round 4, item 8): the recording forward + exact discrete backward, the mode every shipped experiment of the reference trains in."""
     shape = {"B": 1024, "L": 200}
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path), True, False, shape), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), adjoint, False, shape), nprocs=2, join=True)
     r0 = torch.load(tmp_path / "rank0.pt")
     r1 = torch.load(tmp_path / "rank1.pt")
     assert torch.equal(r0["params"], r1["params"]) and torch.equal(r0["grad"], r1["grad"])
     SHAPE.update(shape)
     try:
         x, y = _data(0, 1024, False)
-        flat, grad, _ = _train(_make_model(True, False), x, y)
+        flat, grad, _ = _train(_make_model(adjoint, False), x, y)
     finally:
         SHAPE.update({"B": B, "L": L})
     eg = float((grad - r0["grad"]).abs().max()) / float(grad.abs().max())

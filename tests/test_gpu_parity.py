@@ -1076,6 +1076,7 @@ _SWEEP = [  # (B, L, C, H, HH, nl, interp, method, seq)  -- whatever family the 
     (13, 3, 7, 256, 160, 3, "cubic", "midpoint", True),  # H = 256, HH = 160
     (34, 2, 5, 64, 256, 2, "linear", "euler", False),    # H = 64 under a 256-wide stack (no padding)
     (17, 3, 20, 196, 196, 3, "linear", "rk4", True),     # three layers, sequence outputs
+    (20, 3, 4, 160, 15, 1, "linear", "midpoint", False), # H = 160 over the reference's default hidden_hidden_dim = 15 (-> 16): last width 16 on the wide sweep
 ]
 
 

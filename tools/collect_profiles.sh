@@ -5,6 +5,7 @@
 set -u
 CFG=${1:-cfg2}; shift || true
 ROUND=${ROUND:-r05}
+DEFB=4096; [ "$CFG" = cfg4 ] && DEFB=8192      # (per-GPU batch of the config: bench.py matches the summary on it)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$CFG
 rm -rf $OUT; mkdir -p $OUT
@@ -15,5 +16,5 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > /dev/null 2> $OUT/pmc_write.err
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $ROOT/gpurun_out/${ROUND}_bench_${CFG}_kernel_stats.csv
-cd $ROOT && python3 tools/pmc_summary.py $OUT $ROOT/gpurun_out/${ROUND}_pmc_${CFG}_summary.json --config $CFG --batch ${PMC_BATCH:-4096} --passes 8 --note "rocprofv3 --kernel-trace --pmc, three separate passes (SQ counters | FETCH_SIZE | WRITE_SIZE) of: $BENCH" > /dev/null
+cd $ROOT && python3 tools/pmc_summary.py $OUT $ROOT/gpurun_out/${ROUND}_pmc_${CFG}_summary.json --config $CFG --batch ${PMC_BATCH:-$DEFB} --passes 8 --note "rocprofv3 --kernel-trace --pmc, three separate passes (SQ counters | FETCH_SIZE | WRITE_SIZE) of: $BENCH" > /dev/null
 tail -c 400 $OUT/bench_trace.json; echo; head -6 $ROOT/gpurun_out/${ROUND}_bench_${CFG}_kernel_stats.csv | cut -c1-160
