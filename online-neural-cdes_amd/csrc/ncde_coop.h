@@ -38,6 +38,11 @@
 // abort word, every workgroup leaves at its next check, and the caller's gradients are poisoned with NaN (never silently wrong).
 // All n_tiles workgroups must be co-resident (one per CU: the kernel takes ~157 KB of LDS): the host only selects this path for
 // n_tiles <= the device's CU count, and a GPU shared with another process's persistent kernels is outside its contract.
+//
+// The FORWARD (ncde_fwd_tiled<.., COOP>) uses the same groups, weight images and protocol for its output phase P = Wo x_L: it has no
+// transposed product, so all 8 waves play the P role (waves 0-3 on the group's even tiles, 4-7 on the odd ones, two tiles per keeper
+// iteration), the exchange carries no partial sums (30 KB per tile: it stays in the XCD's L2), and -- its owner phases being light -- the
+// fragments stay in registers for the whole launch (36 of a wave's 40; the last four wait in LDS).
 #pragma once
 #include "ncde_bf3.h"
 #include "ncde_common.h"

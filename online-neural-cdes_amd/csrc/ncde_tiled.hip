@@ -971,14 +971,15 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                 const int n_dx4 = C * NSP / 4, n_it = cd.M / 2;
                 typedef const __attribute__((address_space(1))) void* gptr_t;
                 typedef __attribute__((address_space(3))) void* lptr_t;
+                const int n_dxw = (n_dx4 + 63) >> 6;      // (wave-uniform choice of the extra piece: see the reverse sweep's stage_load)
                 auto stage_load = [&](int it_, int buf, int tid) {      // both tiles of iteration it_ -> LDS (global_load_lds_dwordx4, sc1)
-                    const int w64 = (tid >> 6) * 64;
+                    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), w64 = wv * 64;
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
                         const float* src = a.coop_x + (long long)(c_grp + cd.G * (2 * it_ + hf)) * cd.per_tile_fwd();
                         __builtin_amdgcn_global_load_lds((gptr_t)(src + tid * 4), (lptr_t)(CBX + (buf * 2 + hf) * 2048 + w64 * 4), 16, 0, 16);
-                        if (tid < n_dx4) __builtin_amdgcn_global_load_lds((gptr_t)(src + cd.off_dx() + tid * 4), (lptr_t)(CDX + (buf * 2 + hf) * 1280 + w64 * 4), 16, 0, 16);
-                        else if (tid >= 384 && tid < 400)
+                        if (wv < n_dxw) __builtin_amdgcn_global_load_lds((gptr_t)(src + cd.off_dx() + tid * 4), (lptr_t)(CDX + (buf * 2 + hf) * 1280 + w64 * 4), 16, 0, 16);
+                        else if (wv == 6 && tid < 400)
                             __builtin_amdgcn_global_load_lds((gptr_t)(src + cd.off_sc() + (tid - 384) * 4), (lptr_t)(CSC + (buf * 2 + hf) * 64), 16, 0, 16);
                     }
                 };
@@ -1952,9 +1953,9 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                     __syncthreads();
                     if (tid == 0) coop_arrive(csy, c_grp);
                     TL_TICK(8)
+                    coop_load_weights<COOP_PIN, 40>(cw, a.coop_img, c_mem, wave, lane);      // the re-read part: in flight under the records and while the group assembles
                     write_records();      // (needs a, dX/dt, x_L and its split image: all final -- and dead for this stage afterwards)
                     __syncthreads();
-                    coop_load_weights<COOP_PIN, 40>(cw, a.coop_img, c_mem, wave, lane);      // the re-read part (in flight while the group assembles)
                     // the Butcher k-registers wait in LDS arrays that are dead until the reduction (KOY, KOA, G0, G1: 2048 floats each)
 #pragma unroll
                     for (int q = 0; q < TL_EADJ; ++q) {
@@ -1993,14 +1994,20 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                     // register in between; the issuing wave's vmcnt covers it, the workgroup barrier publishes it
                     typedef const __attribute__((address_space(1))) void* gptr_t;
                     typedef __attribute__((address_space(3))) void* lptr_t;
+                    // Which extra piece a wave fetches is WAVE-uniform (scalar branches, no exec-mask sequences in the loop): waves below
+                    // n_dxw whole 1 KB blocks of dX/dt (lanes past C x 16 floats read on into the tile's scale / f.dX area: never used, and
+                    // the 1280-float slot holds five blocks), wave 5 the 64 a-rows from this member's first state unit on (jh x 16 of them
+                    // are its own), wave 6 -- its first 16 lanes -- the scales
+                    const int n_dxw = (n_dx4 + 63) >> 6;
+                    (void)n_as4;
                     auto stage_load = [&](int tile, int buf, int tid) {
                         const float* src = a.coop_x + (long long)tile * cd.per_tile();
-                        const int w64 = (tid >> 6) * 64;      // first thread of this wave
+                        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), w64 = wv * 64;      // (this wave; its first thread)
                         __builtin_amdgcn_global_load_lds((gptr_t)(src + tid * 4), (lptr_t)(CBX + buf * 2048 + w64 * 4), 16, 0, 16);
-                        if (tid < n_dx4) __builtin_amdgcn_global_load_lds((gptr_t)(src + cd.off_dx() + tid * 4), (lptr_t)(CDX + buf * 1280 + w64 * 4), 16, 0, 16);
-                        else if (tid >= 320 && tid < 320 + n_as4)
+                        if (wv < n_dxw) __builtin_amdgcn_global_load_lds((gptr_t)(src + cd.off_dx() + tid * 4), (lptr_t)(CDX + buf * 1280 + w64 * 4), 16, 0, 16);
+                        else if (wv == 5)
                             __builtin_amdgcn_global_load_lds((gptr_t)(src + cd.off_as() + (c_mem * jh * NSP) * 4 + (tid - 320) * 4), (lptr_t)(CAS + buf * 256), 16, 0, 16);
-                        else if (tid >= 384 && tid < 400)
+                        else if (wv == 6 && tid < 400)
                             __builtin_amdgcn_global_load_lds((gptr_t)(src + cd.off_sc() + (tid - 384) * 4), (lptr_t)(CSC + buf * 64), 16, 0, 16);
                     };
                     auto stage_store = [&](int, int) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
@@ -2191,12 +2198,13 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                     const long long my_base = (long long)blockIdx.x * cd.per_tile();
                     for (int e4 = tid * 4; e4 < dlast * NSP; e4 += NT * 4) {
                         f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        for (int mm = 0; mm < cd.M; mm += 4) {      // four partials in flight (M is a multiple of 4)
-                            f32x4 p[4];
+                        for (int mm = 0; mm < cd.M; mm += 16) {      // sixteen partials in flight (four were eight dependent L2 round trips at M = 32)
+                            f32x4 p[16];
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) p[k] = coop_ld16f(crs, my_base + cd.off_part() + (long long)(mm + k) * (dlast * NSP) + e4);
+                            for (int k = 0; k < 16; ++k)
+                                p[k] = mm + k < cd.M ? coop_ld16f(crs, my_base + cd.off_part() + (long long)(mm + k) * (dlast * NSP) + e4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                            for (int k = 0; k < 4; ++k)
+                            for (int k = 0; k < 16; ++k)      // (member order, as before: the zeros past M change nothing)
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) g[r] += p[k][r];
                         }
