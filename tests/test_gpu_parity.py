@@ -1221,6 +1221,60 @@ def test_user_knot_grid_with_the_controls_own_time_tensors(gpu_lib):
     assert np.array_equal(a["z_out"], b["z_out"]) and np.array_equal(a["dz0"], b["dz0"])
 
 
+@pytest.mark.parametrize("C,H,HH,nl,interp,method,step", [(8, 160, 32, 2, "linear", "rk4", 0.5),        # H = 160: the one-wave-per-SIMD sweep (BIGH), split records
+                                                          (4, 48, 160, 2, "cubic", "midpoint", 0.4),     # HH = 160 -> 256: its W16 mode, fp32 records
+                                                          (100, 32, 64, 3, "linear", "euler", 0.25),     # C = 100: dX/dt read in the bookkeeping phase
+                                                          (7, 256, 196, 2, "cubic", "rk4", 0.75)])       # H = 256, HH = 196, C = 7 -> 8: everything padded
+def test_general_time_axis_on_the_wide_sweeps_vs_oracle(C, H, HH, nl, interp, method, step, gpu_lib):
+    """Round 5: the batch-tiled backward's new instantiations (H up to 256, hidden widths up to 256, any channel count) walk the time plan
+    like the rest of the family: any output times / step size / user knot grid against the oracle's general-time functions -- forward,
+    continuous adjoint (one reverse solve per output interval) and exact discrete backward, with one and with several time windows."""
+    import gpu_util
+    import ncde_oracle as orc
+    B, L = 21, 7
+    rng = np.random.RandomState(7)
+    x = (gu.data.normal(51, B * L * C, stream=3).reshape(B, L, C) * 0.5).astype(np.float32)
+    if interp == "linear":      # user knot grid, spacing 0.6 .. 1.4
+        kn = np.cumsum(np.concatenate([[0.0], 0.6 + 0.8 * rng.rand(L - 1)])).astype(np.float32)
+        x[:, :, 0] = kn[None, :]
+        coeffs = x
+    else:
+        kn = np.arange(L, dtype=np.float32)
+        x[:, :, 0] = kn[None, :]
+        coeffs = gu.data.natural_cubic_coeffs(x)
+    p = gu.data.make_field_weights(H, HH, C, seed=29)
+    if nl == 1:
+        p = {k: v for k, v in p.items() if k not in ("W1", "b1")}
+    z0 = (gu.data.normal(53, B * H, stream=2).reshape(B, H) * 0.5).astype(np.float32)
+    tout = np.array([kn[0], 0.5 * (kn[1] + kn[2]), kn[3], kn[4] + 0.05, kn[-1] - 0.125], np.float32)
+    meta = {"kind": interp, "method": method, "step_size": step, "dims": {"nl": nl}}
+    field = orc.Field.variant(p, H, C, nl, "original", "matmul")
+    ctl = orc.Control(coeffs, interp, t=kn if interp == "linear" else None)
+    z = orc.solve_forward_times(ctl, field, z0, tout, method, step)
+    gout = (gu.data.normal(27, z.numel(), stream=1).reshape(z.shape) / 2.0).astype(np.float32)
+    dz0, gp = orc.solve_adjoint_times(ctl, field, tout, z, gout, method, step)
+    bdz0, bgp = orc.solve_discrete_backward_times(ctl, field, z0, tout, gout, method, step)
+    g = {"coeffs": coeffs, "z0": z0, "t_out": tout, "grad_out": gout}
+    if interp == "linear":
+        g["knots"] = kn
+    names = [n for n in ("W0", "b0", "W1", "b1", "Wo", "bo") if n in p]
+    import warnings
+    from ncde_amd import unfused
+    unfused._WARNED.clear()
+    for wflags in (0, 3 << 16):            # default record budget, then NCDE_FLAG_TILED_WINDOW_STEPS(3)
+        with warnings.catch_warnings():      # (a shape without a fused backward would be routed to the unfused solver WITH a warning: not here)
+            warnings.filterwarnings("error", message=".*unfused.*")
+            res = gpu_util.run_times_case(g, meta, adjoint=True, kind="original", mode="matmul", params=p, flags=wflags)
+            resd = gpu_util.run_times_case(g, meta, adjoint=False, kind="original", mode="matmul", params=p, flags=wflags)
+        assert gu.relerr(res["z_out"], z) <= TIGHT_Z, gu.relerr(res["z_out"], z)
+        assert gu.relerr(res["dz0"], dz0) <= E2E_G, gu.relerr(res["dz0"], dz0)
+        for n_, g_ in zip(names, gp):
+            assert gu.relerr(res["grads"][n_], g_) <= E2E_G, (n_, gu.relerr(res["grads"][n_], g_))
+        assert gu.relerr(resd["dz0"], bdz0) <= E2E_G
+        for n_, g_ in zip(names, bgp):
+            assert gu.relerr(resd["grads"][n_], g_) <= E2E_G, ("discrete", n_, gu.relerr(resd["grads"][n_], g_))
+
+
 @pytest.mark.parametrize("kind,interp,method,step", [("original", "linear", "rk4", 0.5), ("original", "cubic", "midpoint", 0.4),
                                                      ("minimal", "linear", "euler", 0.25), ("original", "cubic", "rk4", 0.75)])
 def test_general_time_axis_on_the_batch_tiled_family_vs_oracle(kind, interp, method, step, gpu_lib):
@@ -2079,6 +2133,46 @@ def test_training_beyond_the_fused_backward_kernels_runs_on_the_unfused_solver(g
             warnings.simplefilter("error")      # no gradient needed: the fused forward kernel, no warning
             out2 = model(x)
         assert gu.relerr(out2.cpu().numpy(), ref.numpy()) <= 2e-5
+
+
+@pytest.mark.parametrize("adjoint", [False, True])
+def test_neuralcde_hidden_256_trains_on_the_fused_kernels(adjoint, gpu_lib):
+    """VERDICT round 4, item 1 (done criterion): NeuralCDE(hidden_dim=256, hidden_hidden_dim=196) -- the corner of the reference's
+    hyper-parameter range (configurations.json5:34-35), `adjoint: false` as its experiments train -- runs forward and backward on fused,
+    non-generic kernels (no unfused-solver warning) and gets the oracle's numbers."""
+    import warnings
+    import ncde_amd
+    import ncde_oracle as orc
+    from ncde_amd import unfused
+    B, L, C, H, HH, nl = 9, 5, 6, 256, 196, 2
+    coeffs = gu.data.make_rectilinear_coeffs(B, L, C - 1, missing=0.3, seed=78)
+    torch.manual_seed(4)
+    model = ncde_amd.NeuralCDE(C, H, 3, hidden_hidden_dim=HH, num_layers=nl, interpolation="rectilinear", adjoint=adjoint).cuda()
+    x = torch.from_numpy(coeffs).cuda()
+    unfused._WARNED.clear()
+    with warnings.catch_warnings():
+        warnings.filterwarnings("error", message=".*unfused.*")
+        out = model(x)
+        out.square().sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    field = orc.Field([(sd["func.net_to_hh.0.weight"], sd["func.net_to_hh.0.bias"])] + [(sd["func.net_to_hh.2.weight"], sd["func.net_to_hh.2.bias"])] * (nl - 1),
+                      sd["func.tanh_output_layer.0.weight"], sd["func.tanh_output_layer.0.bias"], H, C)
+    z0 = torch.from_numpy(coeffs[:, 0]) @ sd["initial_linear.weight"].t() + sd["initial_linear.bias"]
+    ctl = orc.Control(coeffs, "linear")
+    z = orc.solve_forward(ctl, field, z0, "rk4", False)
+    ref = z[:, -1] @ sd["final_linear.weight"].t() + sd["final_linear.bias"]
+    assert gu.relerr(out.detach().cpu().numpy(), ref.numpy()) <= 2e-5
+    gz = torch.zeros_like(z)
+    gz[:, -1] = (2 * ref) @ sd["final_linear.weight"]
+    if adjoint:
+        dz0, gp = orc.solve_adjoint(ctl, field, z, gz, "rk4", False)
+    else:
+        dz0, gp = orc.solve_discrete_backward(ctl, field, z0, gz, "rk4", False)[-2:]
+    got = model.func.tanh_output_layer[0].weight.grad.cpu().numpy()
+    assert gu.relerr(got, np.asarray(gp[-2])) <= 2e-4, gu.relerr(got, np.asarray(gp[-2]))
+    got0 = model.func.net_to_hh[0].weight.grad.cpu().numpy()
+    assert gu.relerr(got0, np.asarray(gp[0])) <= 2e-4, gu.relerr(got0, np.asarray(gp[0]))
 
 
 @pytest.mark.parametrize("B,L,C,H,HH,nl,interp,method,seq", [
