@@ -5,7 +5,7 @@ What the reference does per call -- wrap (X, func) in a vector field, hand it to
 time loop (solvers.py:94-119) and, for the backward pass, to OdeintAdjointMethod (adjoint.py:37-145)
 -- happens here in ONE kernel launch per direction.  There is no CPU fallback.  What the fused kernels do
 not cover but the reference accepts (an arbitrary ``func``, decreasing output times, gradients of the control
-path or of ``t``, non-fp32 tensors, shapes no fused kernel exists for -- hidden widths beyond 128 in training)
+path or of ``t``, non-fp32 tensors, shapes no fused kernel exists for -- hidden widths beyond 256 in training)
 runs on the package's own UNFUSED torch-op solver on the GPU (unfused.py) behind a one-time UserWarning naming
 the reason; what neither path covers raises NotImplementedError.
 """
@@ -580,7 +580,7 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
     increases and nothing upstream of the control path needs a gradient: the reference's NeuralCDE setting -- default grid,
     step 1, t = X.interval or X.grid_points -- on the shape-specialised / batch-tiled kernels, any other time axis on their
     plan-driven forms.  Every other request the reference accepts -- and shapes no fused kernel covers (training with hidden
-    widths > 128, checked here before the forward) -- runs on the unfused torch-op solver on the GPU (unfused.py), with one
+    widths > 256, checked here before the forward) -- runs on the unfused torch-op solver on the GPU (unfused.py), with one
     UserWarning per reason.
     """
     if vector_field_type not in ("matmul", "evaluate", "derivative"):
