@@ -149,7 +149,7 @@ struct PadPlan {
 };
 
 // Would padding bring `p` into the batch-tiled family (target 0: original / minimal-gated field, matmul input), or onto one of the
-// shape-specialised kernel sets (target 1: (H, HH, C) = (32, 32, 20), target 2: (64, 64, 4); original field, default time axis, ONE
+// shape-specialised kernel sets (target 1: (H, HH, C) = (32, 32, 20), target 2: (64, 64, 4), target 3: (32, 32, 40) forward only; original field, default time axis, ONE
 // shared inner layer as the reference's fields have)?  Measured at B = 4096, T = 99 (profiles/r04_shape_sweep_perf.txt): the
 // specialised kernels at their full padded size take no longer than the SMALLEST batch-tiled shapes (forward 0.6 - 0.9 ms vs 0.7 ms,
 // adjoint 1.8 - 2.0 ms vs 2.1 ms at (4, 32, 16)), so a shape they can hold is always sent there.
@@ -159,7 +159,9 @@ PadPlan make_pad_plan(const NcdeProblem* p, int pass, int target = 0) {
     P.inner = target == 0 ? 2 : 1;
     if (p->n_layers < 1 || p->field_input != NCDE_INPUT_MATMUL || p->field_kind == NCDE_FIELD_GRU) return P;
     if (p->hidden > 2048 || p->channels > 4095) return P;
-    const int tH = target == 1 ? 32 : 64, tHH = tH, tC = target == 1 ? 20 : 4;
+    // (target 3, round 5: (32, 32, 40) -- a forward-only kernel set: pass 0 on the default time axis)
+    const int tH = target == 2 ? 64 : 32, tHH = tH, tC = target == 1 ? 20 : (target == 2 ? 4 : 40);
+    if (target == 3 && (pass != 0 || p->output == NCDE_OUT_TIMES)) return P;
     if (target != 0) {
         if (p->field_kind != NCDE_FIELD_ORIGINAL || p->hidden > tH || p->channels > tC) return P;
         // (any batch-tiled knob is a request for that family; the non-default adjoint variants exist for the exact shapes only)
@@ -218,7 +220,7 @@ PadPlan make_pad_plan(const NcdeProblem* p, int pass, int target = 0) {
 }
 // the padded plan a problem takes, if any: a shape-specialised kernel set first, then the batch-tiled family
 PadPlan pick_pad_plan(const NcdeProblem* p, int pass, bool allow_tiled) {
-    for (int target = 1; target <= 2; ++target) {
+    for (int target = 1; target <= 3; ++target) {
         PadPlan P = make_pad_plan(p, pass, target);
         if (P.ok) return P;
     }

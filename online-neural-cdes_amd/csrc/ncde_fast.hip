@@ -2883,6 +2883,12 @@ const FastEntry kFast[] = {
     {{64, 64, 4}, 4, pick_fwd<64, 64, 4, 4>, "ncde_fwd_fast<H64,HH64,C4,NW4>",
      pick_fwd_bf3<64, 64, 4, 4>, "ncde_fwd_fast_bf3<H64,HH64,C4,NW4,bf16x3>", "ncde_fwd_fast_bf3<H64,HH64,C4,NW4,fp16x2>", 4, 0, nullptr, nullptr, nullptr,
      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
+    // round 5: the forward alone for up to 40 channels at H, HH <= 32 (its 160 + 80 registers of output-layer operands fit the one
+    // wave per SIMD the forward runs at; the adjoint's chain / gradient waves, two per SIMD, have no room for them): inference and the
+    // forward half of a training step of such shapes leave the batch-tiled family.  Default time axis only.
+    {{32, 32, 40}, 4, pick_fwd<32, 32, 40, 4>, "ncde_fwd_fast<H32,HH32,C40,NW4>",
+     pick_fwd_bf3<32, 32, 40, 4>, "ncde_fwd_fast_bf3<H32,HH32,C40,NW4,bf16x3>", "ncde_fwd_fast_bf3<H32,HH32,C40,NW4,fp16x2>", 4, 0, nullptr, nullptr, nullptr,
+     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
 };
 
 const FastEntry* find_entry(const NcdeProblem* p) {
@@ -2920,6 +2926,7 @@ static bool use_h64(const NcdeProblem* p, int pass) { return pass >= 1 && ncde_f
 // runtime layer count), continuous adjoint of (32, 32, 20) with nl = 3; (64, 64, <= 4): ncde_fast64.hip's own planned instances
 static bool planned_ok(const NcdeProblem* p, const FastEntry* e, int pass) {
     if (p->flags & (NCDE_FLAG_FP32_MFMA | NCDE_FLAG_ADJOINT_V1 | NCDE_FLAG_ADJOINT_V2 | NCDE_FLAG_ADJOINT_V4 | NCDE_FLAG_DEBUG_PROFILE | 0x200u)) return false;
+    if (e != nullptr && e->shape.C == 40) return false;      // (the forward-only C <= 40 set has no plan-walking instances)
     if (pass == 0) return e != nullptr && ncde_fast_plan_fwd(e->shape.H == 32 ? 0 : 1, p->interp, p->method, 1) != nullptr;
     if (pass == 1) return e != nullptr && e->shape.H == 32 && ncde_fast_plan_adj3(p->n_layers, p->interp, p->method, 2) != nullptr;
     return false;

@@ -799,6 +799,35 @@ def test_fast_forward_with_other_layer_counts(nl, gpu_lib):
             assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), (nl, C, k, e)
 
 
+@pytest.mark.parametrize("shape", [(40, 32, 32, 3), (21, 32, 32, 2), (33, 20, 15, 1), (24, 32, 32, 4)])
+@pytest.mark.parametrize("interp,method,seq", [("linear", "rk4", True), ("cubic", "midpoint", False), ("linear", "euler", False)])
+def test_forward_only_kernel_set_for_up_to_40_channels(shape, interp, method, seq, gpu_lib):
+    """Round 5: 20 < C <= 40 at H, HH <= 32 runs its FORWARD on the register-resident kernel (zero-padded to
+    (32, 32, 40): `ncde_fwd_fast_bf3<H32,HH32,C40,..>`), the backward on the batch-tiled family: forward against the oracle (split-fp16
+    default, split-bf16, fp32-input MFMA, and against the batch-tiled forward), the recording forward of adjoint=False bit-identical, and
+    both kinds of gradient end to end."""
+    import gpu_util
+    from ncde_amd import _lib
+    C, H, HH, nl = shape
+    case = _seeded_case(interp, method, seq, B=37, L=7, C=C, H=H, HH=HH, nl=nl, seed=1300 + 7 * C + H)
+    ex = case["expect"]
+    res = gpu_util.run_case(case)
+    assert res["kernels"][0].startswith("ncde_fwd_fast_bf3<H32,HH32,C40") and res["kernels"][1].startswith("ncde_adj_tiled"), res["kernels"]
+    assert gu.relerr(res["z_out"], ex["z_out"]) <= TIGHT_Z, gu.relerr(res["z_out"], ex["z_out"])
+    for k, e in _grad_errors(case, res).items():
+        assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), ("end-to-end", k, e)
+    resd = gpu_util.run_case(case, adjoint=False)      # the recording forward writes the record the batch-tiled discrete backward reads
+    assert np.array_equal(resd["z_out"], res["z_out"])
+    for k, e in _grad_errors(case, resd, "bp_").items():
+        assert e <= (TOL_DZ0 if k == "dz0" else TOL_DTHETA), ("discrete end-to-end", k, e)
+    rbf = gpu_util.run_case(case, flags=_lib.FLAG_SPLIT_BF16, need_grads=False)
+    assert "bf16x3" in rbf["kernels"][0] and gu.relerr(rbf["z_out"], ex["z_out"]) <= TIGHT_Z, rbf["kernels"]
+    r32 = gpu_util.run_case(case, flags=_lib.FLAG_FP32_MFMA, need_grads=False)
+    assert r32["kernels"][0].startswith("ncde_fwd_fast<H32,HH32,C40") and gu.relerr(r32["z_out"], ex["z_out"]) <= TIGHT_Z, r32["kernels"]
+    rt = gpu_util.run_case(case, flags=_lib.FLAG_FORCE_TILED, need_grads=False)
+    assert rt["kernels"][0].startswith("ncde_fwd_tiled") and gu.relerr(rt["z_out"], res["z_out"]) <= TIGHT_Z
+
+
 @pytest.mark.parametrize("shape", [(5, 16, 15, 3), (20, 32, 15, 1), (3, 7, 15, 2), (17, 30, 32, 3),      # -> (32, 32, 20)
                                    (4, 47, 32, 3), (3, 64, 15, 2), (2, 40, 64, 1)])                           # -> (64, 64, 4)
 @pytest.mark.parametrize("interp,method,seq", [("linear", "rk4", True), ("cubic", "midpoint", False)])
