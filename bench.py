@@ -21,10 +21,48 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _self_launch():
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start `python -m torch.distributed.run
+    --nproc-per-node N bench.py ...` as a CHILD process -- before this process has imported torch or touched the GPU (never an
+    exec) --, relay rank 0's JSON line and exit with the child's return code."""
+    if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    n = 1
+    for i, a in enumerate(sys.argv[1:], 1):
+        if a == "--gpus" and i + 1 < len(sys.argv):
+            n = int(sys.argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as sk:      # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    child = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in child.stdout.splitlines() if ln.strip()]
+    js = [ln for ln in lines if ln.lstrip().startswith("{") and "\"metric\"" in ln]
+    for ln in lines:
+        if ln not in js:
+            sys.stderr.write(ln + "\n")
+    if js:
+        print(js[-1])
+    sys.exit(child.returncode if child.returncode != 0 or js else 1)
+
+
+if __name__ == "__main__":
+    _self_launch()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
 sys.path.insert(0, ROOT)
 import ncde_amd  # noqa: E402
 from ncde_amd import _lib, distributed as D, solver  # noqa: E402
@@ -253,7 +291,7 @@ class Workload:
 def _pmc_summary(config, B_local):
     """The committed rocprofv3 PMC summary of this config (bench.py cannot run the profiler on itself) -- only if it was taken on
     exactly the kernel sources this library is built from (fingerprint) and on this workload; otherwise None."""
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_%s_summary.json" % (rnd, config))
         try:
             with open(path) as fh:
@@ -329,7 +367,38 @@ def dtype_note(names):
 
 
 N_SIMD = 256 * 4
-CLOCK_HZ = 2.4e9
+CLOCK_HZ = 2.4e9      # (device_clock_hz() replaces it once a device is known: ADVICE round 5)
+
+
+def device_clock_hz():
+    """Peak engine clock of the current device as the runtime reports it (hipDeviceAttributeClockRate, kHz); 2.4 GHz if it does not."""
+    try:
+        khz = torch.cuda.get_device_properties(torch.cuda.current_device()).clock_rate
+        return float(khz) * 1e3 if khz and khz > 1e5 else CLOCK_HZ
+    except Exception:
+        return CLOCK_HZ
+
+
+def rocprof_avg_ms(config, which):
+    """Average duration of the pass's dominant kernel in the committed `rocprofv3 --kernel-trace --stats` summary of this bench command
+    (profiles/r06_bench_<config>_kernel_stats.csv + its .meta.json with the source fingerprint), so the line can be checked against
+    the profile without opening the CSV; None if none of these sources is committed."""
+    import csv
+    for rnd in ("r06",):
+        base = os.path.join(ROOT, "profiles", "%s_bench_%s_kernel_stats" % (rnd, config))
+        try:
+            with open(base + ".meta.json") as fh:
+                if json.load(fh).get("source_fingerprint") != _lib.source_fingerprint():
+                    continue
+            rows = list(csv.DictReader(open(base + ".csv")))
+        except (OSError, ValueError):
+            continue
+        key = {"forward": ("ncde_fwd_",), "backward": ("ncde_adj_", "ncde_dwo_")}[which]
+        hit = [r for r in rows if any(k in r.get("Name", "") for k in key) and "only_faulted" not in r.get("Name", "")]
+        hit = [r for r in hit if float(r.get("AverageNs", 0) or 0) > 2e4]      # (the re-execution launches return at once: not the pass)
+        if hit:
+            return {r["Name"][:120]: round(float(r["AverageNs"]) * 1e-6, 4) for r in sorted(hit, key=lambda r: -float(r["TotalDurationNs"]))[:2]}
+    return None
 _CENSUS_EXPECT = {"cfg2.forward": "ncde_fwd_fast_bf3<H32,HH32,C20,NW4,fp16x2>", "cfg2.backward": "ncde_adj_fast3<",
                   "cfg4.forward": "ncde_fwd_fast_bf3<H64,HH64,C4,NW4,fp16x2>", "cfg4.backward": "ncde_adj_h64<H64,HH64,NS1"}
 
@@ -347,7 +416,7 @@ def isa_census(config, which, name, B_local):
         return ic.census_for([key])[key]
     except Exception as e:      # no llvm-objdump / objects on this box: the committed census, if it is of these sources
         try:
-            with open(os.path.join(ROOT, "profiles", "r05_isa_census.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r06_isa_census.json")) as fh:
                 j = json.load(fh)
             if j.get("_meta", {}).get("source_fingerprint") == _lib.source_fingerprint():
                 return j.get(key)
@@ -367,6 +436,8 @@ def rooflines(model, c, coeffs, config, B_local, T):
 
     tanh_per_step = stages_of(c["solver"]) * c["H"] * c["C"] * 2      # exp + rcp per tanh; the backward recomputes every tanh once
 
+    clock = device_clock_hz()
+
     def roof(ms, flops, nbytes, name, backward):
         tf_s = flops * steps_per_launch / (ms * 1e-3) / 1e12
         pm = pmc_pass(name, config, B_local)
@@ -379,8 +450,8 @@ def rooflines(model, c, coeffs, config, B_local, T):
         ceil = {"hbm": alg / (PEAK_HBM_GBS * 1e9) * 1e3}
         src = {"hbm": "algorithmic bytes / 8 TB/s"}
         if pm is not None and pm.get("mfma_busy_cycles"):
-            ceil["mfma"] = pm["mfma_busy_cycles"] / N_SIMD / CLOCK_HZ * 1e3
-            src["mfma"] = "SQ_VALU_MFMA_BUSY_CYCLES per pass / 1024 SIMDs / 2.4 GHz (%s)" % pm["source"]
+            ceil["mfma"] = pm["mfma_busy_cycles"] / N_SIMD / clock * 1e3
+            src["mfma"] = "SQ_VALU_MFMA_BUSY_CYCLES per pass / 1024 SIMDs / %.2f GHz (%s)" % (clock / 1e9, pm["source"])
         elif cen is not None:
             ceil["mfma"] = cen["mfma_ceiling_ms"]
             src["mfma"] = "static ISA census (tools/isa_census.py): MFMAs in the step loop x their pipe cycles"
@@ -391,7 +462,7 @@ def rooflines(model, c, coeffs, config, B_local, T):
             src["issue"] = "static ISA census: every instruction of the longest wave x its 4-cycle issue slot"
         elif pm is not None and pm.get("insts_valu"):
             # dynamic: VALU instructions (all waves, MFMAs excluded) at 2 cycles + the quarter-rate surcharge of the tanh work
-            ceil["valu"] = (pm["insts_valu"] - (pm.get("insts_mfma") or 0.0)) * 2.0 / N_SIMD / CLOCK_HZ * 1e3 + 0.75 * trans_ms
+            ceil["valu"] = (pm["insts_valu"] - (pm.get("insts_mfma") or 0.0)) * 2.0 / N_SIMD / clock * 1e3 + 0.75 * trans_ms
             src["valu"] = "SQ_INSTS_VALU - SQ_INSTS_MFMA per pass x 2 cycles / 1024 SIMDs + the transcendentals' quarter-rate surcharge"
         # ---- which unit the counters show busiest; `wait` above it = the waves stall more than any unit works ----------------------
         bound, stalled, busy = "unmeasured", None, {}
@@ -401,12 +472,17 @@ def rooflines(model, c, coeffs, config, B_local, T):
             stalled = pm["wait"] is not None and pm["wait"] > busy[bound]
         elif "valu" in ceil and "mfma" in ceil:
             bound = max(("mfma", "valu", "hbm"), key=lambda k: ceil[k])
-        frac = peak = None
-        if bound in ceil:
-            frac = min(ceil[bound] / ms, 1.0)
-            peak = tf_s / frac if frac > 0 else None
-        r = {"bound": bound, "kernel": name, "achieved": round(tf_s, 3), "peak": round(peak, 3) if peak else None, "unit": "TFLOP/s",
-             "frac": round(frac, 4) if frac is not None else None,
+        # PRIMARY: algorithmic fp32 flops per launch / HIP-event time against the fp32
+        # MFMA / vector peak -- `frac` = `frac_fp32_peak` = achieved / 157.3 TFLOP/s, not clamped (above 1 only where the products run as
+        # split-fp16 on the 2.5 PF pipe: `frac_of_issued_pipe` prices those).  The busiest-unit ceiling of the kernel's own instruction
+        # stream is reported beside it, RAW: a model that exceeds the measured time is flagged, not hidden.
+        frac = tf_s / PEAK_FP32_TFLOPS
+        unit_frac = ceil[bound] / ms if bound in ceil else None
+        r = {"bound": bound, "kernel": name, "achieved": round(tf_s, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+             "frac": round(frac, 4), "frac_fp32_peak": round(frac, 4),
+             "frac_of_busiest_unit_ceiling": round(unit_frac, 4) if unit_frac is not None else None,
+             "ceiling_model_exceeds_measured": bool(unit_frac is not None and unit_frac > 1.0),
+             "rocprof_avg_ms": rocprof_avg_ms(config, "backward" if backward else "forward"),
              "traffic": pm["traffic"] if pm else None,
              "traffic_ratio": round(pm["traffic"] / alg, 3) if pm else None,
              "algorithmic_bytes_per_launch": alg, "ms_per_launch": round(ms, 4),
@@ -415,7 +491,7 @@ def rooflines(model, c, coeffs, config, B_local, T):
              "mfma_ceiling_ms": round(ceil["mfma"], 4) if "mfma" in ceil else None,
              "issue_ceiling_ms": round(ceil["issue"], 4) if "issue" in ceil else None,
              "tanh_ceiling_ms": round(trans_ms, 4),
-             "frac_of_issue_ceiling": round(min(ceil["issue"] / ms, 1.0), 4) if "issue" in ceil else None,
+             "frac_of_issue_ceiling": round(ceil["issue"] / ms, 4) if "issue" in ceil else None,
              "ceiling_sources": src,
              "stalled": stalled,
              "busy": {k: round(v, 4) for k, v in busy.items()} if busy else None,
@@ -424,14 +500,16 @@ def rooflines(model, c, coeffs, config, B_local, T):
              "hbm_algorithmic_GBs": round(alg / (ms * 1e-3) / 1e9, 2),
              "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6),
              "x_fp32_peak": round(tf_s / PEAK_FP32_TFLOPS, 4), "fp32_peak": PEAK_FP32_TFLOPS,
-             "issued_pipe": pipe_note, "issued_pipe_peak": round(pipe_peak, 1), "frac_of_issued_pipe": round(min(tf_s / pipe_peak, 1.0), 4),
-             "bound_note": "`bound` = the unit the SQ / TCC counters show busiest (mfma: matrix-pipe busy cycles, valu: VALU + transcendental "
-                           "issue, hbm: counter bytes against 8 TB/s); `frac` = that unit's ceiling for this kernel's own instruction "
-                           "stream / bytes (`ceilings_ms`) over the measured ms_per_launch, never above 1; `peak` = achieved / frac = the "
-                           "algorithmic TFLOP/s the kernel would deliver with that unit saturated; `stalled` = the waves wait "
-                           "(SQ_WAIT_INST_ANY) more than the busiest unit works: latency-, not throughput-bound; `x_fp32_peak` = the same "
-                           "algorithmic fp32 flops as MULTIPLES of the 157.3 TFLOP/s fp32 MFMA / vector peak (SURVEY.md section 8d "
-                           "convention; above 1 where the arithmetic runs as split-fp16 on the 2.5 PF pipe)"}
+             "issued_pipe": pipe_note, "issued_pipe_peak": round(pipe_peak, 1), "frac_of_issued_pipe": round(tf_s / pipe_peak, 4),
+             "clock_hz": clock,
+             "bound_note": "`achieved` = SURVEY.md section 8d algorithmic fp32 flops per sample-step x B (T-1) sample-steps / ms_per_launch (HIP "
+                           "events); `peak` = 157.3 TFLOP/s (fp32 MFMA = fp32 vector peak); `frac` = `frac_fp32_peak` = achieved / peak; "
+                           "`bound` = the unit the SQ / TCC counters show busiest (mfma: matrix-pipe busy cycles, valu: VALU + transcendental "
+                           "issue, hbm: counter bytes against 8 TB/s); `frac_of_busiest_unit_ceiling` = that unit's ceiling for this kernel's "
+                           "own instruction stream / bytes (`ceilings_ms`) over ms_per_launch, unclamped; `stalled` = the waves wait "
+                           "(SQ_WAIT_INST_ANY) more than the busiest unit works: latency-, not throughput-bound; `frac_of_issued_pipe` = the "
+                           "same flops against the pipe the products are issued on (2.5 PF / 3 for split-fp16, / 6 for split-bf16); "
+                           "`rocprof_avg_ms` = the committed rocprofv3 average of the pass's kernels (same sources)"}
         if pm is not None:
             r["traffic_unit"] = "HBM bytes per pass, summed over all launches of all kernels of the pass (rocprofv3 PMC passes on these kernel sources, %s)" % pm["source"]
             r["launches_per_pass"] = pm["launches_per_pass"]
@@ -470,7 +548,8 @@ def main():
     args = ap.parse_args()
 
     rank, local_rank, world = D.env_world()
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    # (a bare `python bench.py --gpus N` never gets here with N > 1: _self_launch() has started the N ranks as a child process)
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d" % (world, args.gpus, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU fallback for the product path"
     # (NCDE_BENCH_BACKEND=gloo: the test-suite's way to run the world > 1 branches on a ONE-GPU box, both ranks on cuda:0 -- RCCL
     # refuses two ranks on one device; the driver's runs use the default, nccl = RCCL, one rank per GPU)

@@ -75,6 +75,9 @@ typedef enum NcdeOutput { NCDE_OUT_INTERVAL = 0, NCDE_OUT_KNOTS = 1, NCDE_OUT_TI
 #define NCDE_FLAG_NO_COOP 0x400u       /* batch-tiled forward and backward: do not use the XCD-cooperative, weight-stationary output phase (round 5, large
                                           hidden sizes: workgroups of one launch exchange activations through L2 and spin on each other --
                                           it needs every workgroup resident, i.e. the GPU's CUs not held by another process's persistent kernel) */
+#define NCDE_FLAG_COOP_FAULT_INJECT 0x800u /* verification (like the dopri5 replay): ONE workgroup of the first cooperative launch withholds its first
+                                          arrival and the spin limit is shortened, so that launch gives up after ~1 ms: exercises the status word
+                                          and the re-execution by the per-workgroup kernels (tests/test_gpu_parity.py); results must not change */
 #define NCDE_FLAG_TILED_NS1 0x1000u    /* batch-tiled forward: force 1 / 2 / 4 sixteen-sample tiles per workgroup     */
 #define NCDE_FLAG_TILED_NS2 0x2000u    /*   (default: the largest that still gives >= 256 workgroups)                 */
 #define NCDE_FLAG_TILED_NS4 0x4000u
@@ -274,6 +277,15 @@ int ncde_num_outputs(const NcdeProblem* p);
 /* scratch bytes needed by ncde_forward[_record] (pass = 0) / ncde_adjoint (pass = 1) / ncde_backward (pass = 2);
  * negative = NcdeStatus */
 int64_t ncde_workspace_bytes(const NcdeProblem* p, int pass);
+
+/* The XCD-cooperative kernels of the batch-tiled family (large hidden sizes) spin on each other and therefore carry a bounded wait: a
+ * launch whose workgroups never all became resident (another process's persistent kernel, a CU mask) GIVES UP, and the per-workgroup
+ * kernels the library always enqueues behind it re-execute the pass -- the caller's outputs are correct either way, only late.  That it
+ * happened is recorded in a STATUS WORD inside the caller's workspace: uint32 at byte offset ncde_coop_status_offset(p, pass), zeroed
+ * by the call, 1 after a cooperative launch of that call gave up.  Read it after the stream has finished the call (it is the caller's
+ * memory; the library never synchronises); a caller that sees 1 should pass NCDE_FLAG_NO_COOP from then on (the Python host does).
+ * Returns NCDE_ERR_UNSUPPORTED (-2) when the problem / pass launches nothing cooperative. */
+int64_t ncde_coop_status_offset(const NcdeProblem* p, int pass);
 
 /* name of the kernel family the call would dispatch to ("generic", "fast_h32_c20", ...); NULL on error */
 const char* ncde_kernel_name(const NcdeProblem* p, int pass);

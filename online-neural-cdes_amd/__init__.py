@@ -7,7 +7,7 @@ the thin Python host mirroring the reference's call surface.  There is no CPU fa
 from . import data  # noqa: F401
 from ._lib import NcdeError, lib  # noqa: F401
 from .interpolation import LinearInterpolation, NaturalCubicSpline  # noqa: F401
-from .solver import FieldSpec, cdeint  # noqa: F401
+from .solver import FieldSpec, cdeint, coop_status  # noqa: F401
 from .vector_fields import GRUGatedVectorField, MinimalGatedVectorField, MLPField, OriginalVectorField  # noqa: F401
 from .ncde import NeuralCDE  # noqa: F401
 from .coefficients import linear_interpolation_coeffs, natural_cubic_coeffs, natural_cubic_spline_coeffs  # noqa: F401

@@ -18,6 +18,7 @@ FLAG_AUTO, FLAG_FORCE_GENERIC, FLAG_FORCE_FAST, FLAG_FP32_MFMA, FLAG_ADJOINT_V1,
 FLAG_ADJOINT_V4 = 32
 FLAG_SPLIT_BF16 = 64        # specialised forward kernels: 3-way split-bf16 GEMMs instead of the default 2-way split-fp16 ones
 FLAG_NO_COOP = 0x400          # batch-tiled forward / backward: per-workgroup kernels instead of the XCD-cooperative output phase (round 5)
+FLAG_COOP_FAULT_INJECT = 0x800   # verification: one workgroup of the first cooperative launch withholds its arrival (see include/ncde_hip.h)
 FLAG_ADJOINT_SPLIT_FP16 = 128   # development builds of the library only (ignored otherwise): see DESIGN.md 5.4c
 
 
@@ -117,6 +118,7 @@ EXPORTS = (
     "ncde_stage_record_bytes", "ncde_forward_record", "ncde_backward",
     "ncde_time_plan_build", "ncde_dopri5_workspace_bytes", "ncde_dopri5_forward", "ncde_dopri5_adjoint",
     "ncde_dopri5_record_bytes", "ncde_dopri5_forward_record", "ncde_dopri5_backward", "ncde_dopri5_kernel_name",
+    "ncde_coop_status_offset",
 )
 
 _LIB = None
@@ -162,6 +164,8 @@ def lib():
     h.ncde_num_outputs.restype = ctypes.c_int
     h.ncde_workspace_bytes.argtypes = [P, ctypes.c_int]
     h.ncde_workspace_bytes.restype = ctypes.c_int64
+    h.ncde_coop_status_offset.argtypes = [P, ctypes.c_int]
+    h.ncde_coop_status_offset.restype = ctypes.c_int64
     h.ncde_kernel_name.argtypes = [P, ctypes.c_int]
     h.ncde_kernel_name.restype = ctypes.c_char_p
     h.ncde_forward.argtypes = [P, vp, vp, sz, vp]

@@ -582,6 +582,30 @@ int64_t ncde_workspace_bytes(const NcdeProblem* p, int pass) {
     return (int64_t)sizeof(float) * (int64_t)y.n_wg * (int64_t)y.theta_size + 256;
 }
 
+int64_t ncde_coop_status_offset(const NcdeProblem* p, int pass) {
+    NcdeProblem q_;
+    int rc = normalize(p, &q_);
+    if (rc != NCDE_OK) return rc;
+    p = &q_;
+    rc = validate(p);
+    if (rc != NCDE_OK) return rc;
+    if (pass < 0 || pass > 2) return fail(NCDE_ERR_INVALID, "pass %d outside {0, 1, 2}", pass);
+    const Layout y = make_layout(p);
+    const int fam = select_family(p, y, pass);
+    if (fam < 0) return fam;
+    int64_t off = -1;
+    if (fam == 2) off = ncde_tiled_status_offset(p, pass);
+    else if (fam == 4) {
+        const PadPlan P = pick_pad_plan(p, pass, true);
+        if (P.inner == 2) {
+            off = ncde_tiled_status_offset(&P.q, pass);
+            if (off >= 0) off += (int64_t)sizeof(float) * pad_head_floats(P, pass);
+        }
+    }
+    if (off < 0) return fail(NCDE_ERR_UNSUPPORTED, "this problem / pass launches no cooperative kernel");
+    return off;
+}
+
 int64_t ncde_stage_record_bytes(const NcdeProblem* p) {
     NcdeProblem q_;
     int rc = normalize(p, &q_);

@@ -80,6 +80,13 @@ struct KArgs {
     unsigned* coop_sync;
     const float* coop_scale;
     int coop_M, coop_G;
+    // round 6: the launch sequence's STATUS word (workspace; zeroed once per C-ABI call, never between its time windows): a cooperative
+    // kernel that gives up (spin time-out) sets it, every later cooperative launch of the call returns at once, and the per-workgroup
+    // kernels enqueued behind them with run_if = this word re-execute the whole pass (they return at once while it is 0)
+    unsigned* coop_status;
+    const unsigned* run_if;
+    unsigned coop_spin;      // polls of a group counter before giving up
+    int coop_inject;         // NCDE_FLAG_COOP_FAULT_INJECT: workgroup 1 skips its first arrival (tests the time-out path)
 };
 
 // ---- time plan (built on the host by ncde_time_plan_build, csrc/ncde_timeplan.hip; layout in 4-byte words) -------------

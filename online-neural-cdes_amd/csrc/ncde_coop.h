@@ -50,7 +50,7 @@
 #define COOP_NRT 5                      // row tiles of Wo per P-role wave (x 4 waves = 20 per workgroup)
 #define COOP_RPM (4 * COOP_NRT)         // row tiles per member
 #define COOP_NCH 4                      // K chunks of 32: last hidden width 128
-#define COOP_SPIN_LIMIT (1 << 22)       // polls of a group counter before giving up (~1-2 s)
+#define COOP_SPIN_LIMIT (1 << 22)       // polls of a group counter before giving up (~1-2 s); the fault-injection flag shortens it
 
 namespace {
 
@@ -109,7 +109,15 @@ __device__ __forceinline__ float coop_pow2_inv(float s) { return __uint_as_float
 struct CoopSync {
     unsigned* words;
     int G;
+    unsigned* status;      // the call's status word (KArgs.coop_status): sticky, survives the per-window reset of `words`
+    unsigned spin;         // polls before giving up
 };
+// giving up: the launch's abort word (every workgroup leaves at its next check) AND the call's status word (the cooperative launches of
+// the later time windows return at once; the per-workgroup kernels enqueued behind them re-execute the pass)
+__device__ __forceinline__ void coop_give_up(const CoopSync& sy) {
+    __hip_atomic_store(sy.words + sy.G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(sy.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __host__ __device__ inline int coop_sync_words(int G, int n_tiles) { return 2 * G + 1 + n_tiles; }
 // Every storing wave has drained (s_waitcnt vmcnt(0)) and the workgroup has barrier-synced before this is called by thread 0.
 __device__ __forceinline__ void coop_arrive(const CoopSync& sy, int g) {
@@ -124,8 +132,8 @@ __device__ __forceinline__ bool coop_wait(const CoopSync& sy, int g, unsigned ta
             const unsigned c = __hip_atomic_load(sy.words + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (c >= target) break;
             if ((spins & 63u) == 63u && __hip_atomic_load(sy.words + sy.G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
-            if (++spins > COOP_SPIN_LIMIT) {
-                __hip_atomic_store(sy.words + sy.G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins > sy.spin) {
+                coop_give_up(sy);
                 ok = 0;
                 break;
             }
@@ -147,15 +155,20 @@ __device__ __forceinline__ int coop_same_xcd(const CoopSync& sy, int g, int memb
     unsigned* ids = sy.words + 2 * sy.G + 1;
     if (tid == 0) {
         const unsigned me = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) + 1u;      // HW_REG_XCC_ID[3:0] + 1
-        __hip_atomic_store(ids + g + sy.G * member, me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(sy.words + sy.G + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int res = 1;
+        // an earlier launch of this call gave up: nothing cooperative runs any more (the per-workgroup kernels behind redo the pass)
+        if (__hip_atomic_load(sy.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) res = -1;
+        if (res >= 0) {
+            __hip_atomic_store(ids + g + sy.G * member, me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(sy.words + sy.G + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         unsigned spins = 0;
-        for (;;) {
+        while (res >= 0) {
             if (__hip_atomic_load(sy.words + sy.G + 1 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)M) break;
-            if (++spins > COOP_SPIN_LIMIT) {
-                __hip_atomic_store(sy.words + sy.G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((spins & 63u) == 63u && __hip_atomic_load(sy.words + sy.G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { res = -1; break; }
+            if (++spins > sy.spin) {
+                coop_give_up(sy);
                 res = -1;
                 break;
             }

@@ -712,6 +712,9 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
     constexpr int NSP = NS * 16, NT = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int fault_s;
+    if constexpr (COOP == 0) {      // re-execution behind a cooperative launch: only when that launch gave up (the word is final by now)
+        if (a.run_if != nullptr && *a.run_if == 0u) return;
+    }
     if constexpr (BF == 1) {
         if (a.only_faulted && a.fault[blockIdx.x] == 0) return;
     }
@@ -755,7 +758,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
     bool c_same = false;
     if constexpr (COOP != 0) {
         cd.H = H; cd.C = a.C; cd.dlast = 128; cd.M = a.coop_M; cd.G = a.coop_G;
-        csy.words = a.coop_sync; csy.G = a.coop_G;
+        csy.words = a.coop_sync; csy.G = a.coop_G; csy.status = a.coop_status; csy.spin = a.coop_spin;
         c_grp = blockIdx.x % a.coop_G;
         c_mem = blockIdx.x / a.coop_G;
         coop_fill_bias(a.bo, a.C, c_mem, CBO, tid);      // (visible after the barriers below)
@@ -953,7 +956,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (tid == 0) coop_arrive(csy, c_grp);
+                if (tid == 0 && !(a.coop_inject != 0 && blockIdx.x == 1 && sc == 0)) coop_arrive(csy, c_grp);      // (fault injection: one arrival withheld)
                 FW_TICK(2)
                 // timeout / another workgroup gave up: the launch is abandoned and this tile's rows of the solution are NaN (never silently wrong)
                 auto poison = [&]() {
@@ -1477,6 +1480,9 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     constexpr int COOP_LDS = 2 * 10 * 2 * 64 * 4 + 2 * 8 * 64 * 4 + 2 * 80 * 16 + 2 * 256 + 2 * 64 + 2 * 4 * 64 + 2 * 16 + 8;      // floats, see CDP .. CFL below
     constexpr int NSP = 16, SCW = W16 ? 16 * (16 * 8 + 4) : ((16 * (16 * PK + 4) > 16 * PK * NSP) ? 16 * (16 * PK + 4) : 16 * PK * NSP);
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if constexpr (COOP == 0) {      // re-execution behind a cooperative launch sequence: only when it gave up (see KArgs.run_if)
+        if (a.run_if != nullptr && *a.run_if == 0u) return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b0 = blockIdx.x * NSP;
@@ -1655,7 +1661,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     float* const CSG = CDP + 3 * 8 * 16;                     // [4][16]     sx, 1/(sx sw), sd, 1/(sd sw) of this tile
     if constexpr (COOP != 0) {
         cd.H = H; cd.C = C; cd.dlast = dlast; cd.M = a.coop_M; cd.G = a.coop_G;
-        csy.words = a.coop_sync; csy.G = a.coop_G;
+        csy.words = a.coop_sync; csy.G = a.coop_G; csy.status = a.coop_status; csy.spin = a.coop_spin;
         c_grp = blockIdx.x % a.coop_G;
         c_mem = blockIdx.x / a.coop_G;
         c_hbw = (c_mem * COOP_RPM + (wave & 3) * COOP_NRT) / (C >> 2);      // P role: the state-unit block every row tile of this wave belongs to
@@ -1951,7 +1957,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
-                    if (tid == 0) coop_arrive(csy, c_grp);
+                    if (tid == 0 && !(a.coop_inject != 0 && blockIdx.x == 1 && sc == 0 && a.resume == 0)) coop_arrive(csy, c_grp);      // (fault injection)
                     TL_TICK(8)
                     coop_load_weights<COOP_PIN, 40>(cw, a.coop_img, c_mem, wave, lane);      // the re-read part: in flight under the records and while the group assembles
                     write_records();      // (needs a, dX/dt, x_L and its split image: all final -- and dead for this stage afterwards)
@@ -2427,6 +2433,7 @@ __global__ __launch_bounds__(256) void ncde_dwo_tiled(KArgs a, int n_sc, int n_s
     // n_sc = stages recorded in this time window; a.resume != 0: add to the partial the earlier windows left in gpartB
     // (the waves' accumulators are summed PKR column tiles at a time: 16 x 256 floats x 4 waves would not fit the 64 KB of static LDS)
     constexpr int PKR = PK > 8 ? 8 : PK;
+    if (a.run_if != nullptr && *a.run_if == 0u) return;      // (re-execution behind a cooperative sequence: see KArgs.run_if)
     __shared__ float patch[4][NRT][16 * 17];
     __shared__ __attribute__((aligned(16))) float red[4][PKR * 256 + 64];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2593,6 +2600,7 @@ __global__ __launch_bounds__(256) void ncde_dwo_pair(KArgs a, int n_sc, int n_st
     static_assert(PK >= 2, "split records need a last hidden width that is a multiple of 32");
     constexpr int NCH = PK / 2;
     constexpr int NH = HEAD == 3 ? 2 : 1;      // HEAD 3 (minimal-gated field): both heads' gradients from ONE recompute of P
+    if (a.run_if != nullptr && *a.run_if == 0u) return;      // (re-execution behind a cooperative sequence: see KArgs.run_if)
     __shared__ float patch[4][NRT][2][NH][16 * 17];
     __shared__ __attribute__((aligned(16))) float red[4][PK * 256 + 64];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2820,6 +2828,25 @@ __global__ __launch_bounds__(256) void ncde_dwo_pair(KArgs a, int n_sc, int n_st
     }
 }
 
+// ncde_reduce_partials (ncde_generic.hip) for the re-execution sequence: runs only when the cooperative sequence gave up
+__global__ __launch_bounds__(256) void ncde_reduce_partials_if(const unsigned* run_if, const float* __restrict__ gpart, int n_part, int theta_size, ReduceSegs segs) {
+    if (*run_if == 0u) return;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= theta_size) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 3 < n_part; p += 4) {      // (the summation order of ncde_reduce_partials)
+        s0 += gpart[(long long)p * theta_size + k];
+        s1 += gpart[(long long)(p + 1) * theta_size + k];
+        s2 += gpart[(long long)(p + 2) * theta_size + k];
+        s3 += gpart[(long long)(p + 3) * theta_size + k];
+    }
+    for (; p < n_part; ++p) s0 += gpart[(long long)p * theta_size + k];
+    const float total = (s0 + s1) + (s2 + s3);
+    for (int i = 0; i < segs.n; ++i)
+        if (k >= segs.off[i] && k < segs.off[i] + segs.len[i]) segs.dst[i][k - segs.off[i]] = total;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -2982,14 +3009,55 @@ size_t tiled_coop_lds(const NcdeProblem* p) {
     for (int l = 0; l < p->n_layers; ++l) D = std::max(D, p->layer_out[l]);
     return sizeof(float) * (size_t)(4 * p->hidden * 16 + (p->n_layers + 2) * D * 16 + p->channels * 16 + kCoopLdsFloats) + (size_t)128 * 16 * 6;
 }
-int tiled_device_cus() {
-    static int cus = -1;
-    if (cus < 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        else cus = 256;      // (no device: the host-only queries of the CPU test-suite)
+int tiled_device_cus() {      // of the CURRENT device (cached per device: ADVICE round 5)
+    static std::mutex mu;
+    static int cus[64];      // 0 = not asked yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;      // (no device: the host-only queries of the CPU test-suite)
+    std::lock_guard<std::mutex> lk(mu);
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
     }
-    return cus;
+    return cus[dev];
+}
+
+// ---- run-time gate of the cooperative launches (round 6) -------------------------------------------------------------
+// The cooperative kernels spin on each other, so every workgroup of a launch must be resident at once.  What is checked here, at
+// launch time, beyond the static plan: (1) the runtime's own occupancy figure for THIS kernel with THIS much LDS says the grid fits
+// the device; (2) no cooperative sequence enqueued on ANOTHER stream of this device is still in flight (two such launches could each
+// hold CUs the other needs: both would spin until they give up).  A call that fails either test simply runs the per-workgroup kernels.
+// What the gate cannot see -- another process's kernels, a CU mask -- ends in the kernels' bounded spin, the call's status word and
+// the re-execution by the per-workgroup kernels enqueued behind (never a hang, never a wrong result).
+struct CoopFlight {
+    hipEvent_t ev;
+    hipStream_t stream;
+    bool valid;
+};
+std::mutex g_coop_mu;
+CoopFlight g_coop_flight[64];
+bool coop_runtime_ok(const void* fn, int threads, size_t lds, int grid, hipStream_t st) {
+    int dev = 0, nb = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds) != hipSuccess || nb < 1) { (void)hipGetLastError(); return false; }
+    if ((long long)nb * tiled_device_cus() < grid) return false;
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    const CoopFlight& f = g_coop_flight[dev];
+    if (f.valid && f.stream != st && hipEventQuery(f.ev) == hipErrorNotReady) return false;
+    (void)hipGetLastError();
+    return true;
+}
+void coop_mark_in_flight(hipStream_t st) {      // after the last cooperative launch of a call
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    CoopFlight& f = g_coop_flight[dev];
+    if (!f.valid) {
+        if (hipEventCreateWithFlags(&f.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+        f.valid = true;
+    }
+    f.stream = st;
+    if (hipEventRecord(f.ev, st) != hipSuccess) (void)hipGetLastError();
 }
 // The sample tiles of the launch split into G groups of M workgroups; each member keeps COOP_RPM = 20 row tiles of Wo (whole
 // state-unit blocks: C/4 in {5, 10, 20}) in registers.  Original field, matmul input, last hidden width 128, H <= 128, and every
@@ -3039,7 +3107,7 @@ FwdCoopPlan tiled_fwd_coop_plan(const NcdeProblem* p) {
     off = (off + 63) & ~63LL;
     f.img = off; off += (long long)c.M * (coop_p_words() + coop_t_words());
     f.x = off; off += d.per_tile_fwd() * n_tiles;
-    f.scale = off; off += 64;
+    f.scale = off; off += 64;      // [0] sw, [1] 1 / sw, [8] max |Wo| bits, [16] the call's status word (KArgs.coop_status)
     f.sync = off; off += 64 + coop_sync_words(c.G, n_tiles);
     f.end = off + 64;
     f.ok = true; f.M = c.M; f.G = c.G;
@@ -3073,7 +3141,7 @@ bool tiled_adj_ok(const NcdeProblem* p) {
 }
 
 struct TiledAdjPlan {
-    int n_st, n_sc, gstride, parts, window, S, nrt;
+    int n_st, n_sc, gstride, parts, parts_pw, window, S, nrt;      // parts_pw: part-groups of the per-workgroup sequence's pass B
     long long recA, recB, recC, recD, gpartA, gpartB, carry, pack, pack_bf, total;   // float offsets into the workspace
     long long theta_o;
     // cooperative output phase: packed weight images, exchange area, {absmax bits, sw, 1/sw}, sync words
@@ -3138,6 +3206,7 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
     if (dlast == 256) t.nrt = 1;      // (one tile's weights, accumulators and two record fragments of 256 columns are the register file)
     t.parts = 1;
     while (t.parts < 64 && (row_tiles / t.nrt) * 4 * t.parts < 4096 && 4 * t.parts * 2 <= t.n_st) t.parts *= 2;
+    t.parts_pw = t.parts;
     t.gpartB = off; off += (long long)t.parts * t.theta_o * (p->field_kind == NCDE_FIELD_MINIMAL ? 2 : 1);
     t.carry = off; off += 2LL * t.n_st * p->hidden * 16;
     t.pack = off; off += tiled_pack_floats(p, false, true);
@@ -3150,7 +3219,7 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
         off = (off + 63) & ~63LL;
         t.coop_img = off; off += (long long)cp.M * (coop_p_words() + coop_t_words());
         t.coop_x = off; off += d.per_tile() * t.n_st;
-        t.coop_scale = off; off += 64;
+        t.coop_scale = off; off += 64;      // [0] sw, [1] 1 / sw, [8] max |Wo| bits, [16] the call's status word (KArgs.coop_status)
         t.coop_state = off; off += (long long)t.n_st * 2 * 8 * 512 * 4;      // the sweep's hidden-dW accumulators while its registers hold Wo: 2 x TL_DWT x NT float4 per workgroup
         t.coop_sync = off; off += 64 + coop_sync_words(cp.G, t.n_st);
     }
@@ -3235,6 +3304,19 @@ int64_t ncde_tiled_workspace_bytes(const NcdeProblem* p, int pass) {
     return (int64_t)sizeof(float) * tiled_adj_plan(p, y).total;
 }
 
+int64_t ncde_tiled_status_offset(const NcdeProblem* p, int pass) {
+    if (!ncde_tiled_supported(p, pass)) return -1;
+    if (pass == 0) {
+        if (p->field_input != NCDE_INPUT_MATMUL) return -1;
+        const FwdCoopPlan fc = tiled_fwd_coop_plan(p);
+        return fc.ok ? (int64_t)sizeof(float) * (fc.scale + 16) : -1;
+    }
+    if (p->field_input != NCDE_INPUT_MATMUL) return -1;
+    const Layout y = make_layout(p);
+    const TiledAdjPlan t = tiled_adj_plan(p, y);
+    return t.coop ? (int64_t)sizeof(float) * (t.coop_scale + 16) : -1;
+}
+
 // forward instantiation with split output tiles: BF = 1 split-bf16, 2 split-fp16; resh = resident hidden fragments (0 / 2 / 4)
 template <int BF>
 static void (*tiled_fwd_split_fn(bool g, bool small, int resh))(KArgs) {
@@ -3293,30 +3375,42 @@ int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws
         else fn = small ? ncde_fwd_tiled<1, TL_NW, 4, 0, 0, 0, 1> : ncde_fwd_tiled<1, TL_NW, 16, 0, 0, 0, 1>;
     }
     const FwdCoopPlan fc = direct ? FwdCoopPlan{} : tiled_fwd_coop_plan(p);
-    size_t lds_launch = lds;
-    if (fc.ok) {      // XCD-cooperative, weight-stationary output phase (ncde_coop.h): the reverse sweep's groups and weight images
-        float* w = (float*)ws;
-        unsigned* amax = reinterpret_cast<unsigned*>(w + fc.scale + 8);
-        if (hipMemsetAsync(amax, 0, sizeof(unsigned), st) != hipSuccess) return NCDE_ERR_HIP;
-        const int n_tiles = (p->batch + 15) / 16;
-        if (hipMemsetAsync(w + fc.sync, 0, sizeof(unsigned) * (size_t)coop_sync_words(fc.G, n_tiles), st) != hipSuccess) return NCDE_ERR_HIP;
-        const long long nw = (long long)p->hidden * p->channels * 128;
-        hipLaunchKernelGGL(ncde_coop_absmax, dim3(512), dim3(256), 0, st, a.Wo, nw, amax);
-        hipLaunchKernelGGL(ncde_coop_pack, dim3(1024), dim3(256), 0, st, a.Wo, (const unsigned*)amax, reinterpret_cast<unsigned*>(w + fc.img), w + fc.scale,
-                           p->channels, 128, fc.M);
-        a.coop_img = reinterpret_cast<const unsigned*>(w + fc.img);
-        a.coop_x = w + fc.x;
-        a.coop_scale = w + fc.scale;
-        a.coop_sync = reinterpret_cast<unsigned*>(w + fc.sync);
-        a.coop_M = fc.M;
-        a.coop_G = fc.G;
-        fn = ncde_fwd_tiled<1, TL_NW, 4, 0, 2, 0, 0, 1>;
-        lds_launch = sizeof(float) * ((size_t)16 * (size_t)(2 * p->hidden + 2 * tiled_dmax(p) + p->channels) + (size_t)kFwdCoopLdsFloats);
-    }
-    if (ncde_lds_optin((const void*)fn, lds_launch) != hipSuccess) return NCDE_ERR_HIP;
     const int nwg = (p->batch + ns * 16 - 1) / (ns * 16);
-    hipLaunchKernelGGL(fn, dim3(nwg), dim3(TL_THREADS), lds_launch, st, a);
-    if (split == 2 && !fc.ok) {      // re-execution of range-faulted sample tiles in split-bf16 (normally none: every workgroup exits at once)
+    if (fc.ok) {      // XCD-cooperative, weight-stationary output phase (ncde_coop.h): the reverse sweep's groups and weight images
+        void (*fc_fn)(KArgs) = ncde_fwd_tiled<1, TL_NW, 4, 0, 2, 0, 0, 1>;
+        const size_t lds_coop = sizeof(float) * ((size_t)16 * (size_t)(2 * p->hidden + 2 * tiled_dmax(p) + p->channels) + (size_t)kFwdCoopLdsFloats);
+        if (ncde_lds_optin((const void*)fc_fn, lds_coop) != hipSuccess) return NCDE_ERR_HIP;
+        if (coop_runtime_ok((const void*)fc_fn, TL_THREADS, lds_coop, nwg, st)) {      // (else: the per-workgroup kernels below, unconditionally)
+            float* w = (float*)ws;
+            unsigned* amax = reinterpret_cast<unsigned*>(w + fc.scale + 8);
+            unsigned* status = reinterpret_cast<unsigned*>(w + fc.scale + 16);
+            if (hipMemsetAsync(amax, 0, sizeof(unsigned), st) != hipSuccess) return NCDE_ERR_HIP;
+            if (hipMemsetAsync(status, 0, sizeof(unsigned), st) != hipSuccess) return NCDE_ERR_HIP;
+            const int n_tiles = (p->batch + 15) / 16;
+            if (hipMemsetAsync(w + fc.sync, 0, sizeof(unsigned) * (size_t)coop_sync_words(fc.G, n_tiles), st) != hipSuccess) return NCDE_ERR_HIP;
+            const long long nw = (long long)p->hidden * p->channels * 128;
+            hipLaunchKernelGGL(ncde_coop_absmax, dim3(512), dim3(256), 0, st, a.Wo, nw, amax);
+            hipLaunchKernelGGL(ncde_coop_pack, dim3(1024), dim3(256), 0, st, a.Wo, (const unsigned*)amax, reinterpret_cast<unsigned*>(w + fc.img), w + fc.scale,
+                               p->channels, 128, fc.M);
+            a.coop_img = reinterpret_cast<const unsigned*>(w + fc.img);
+            a.coop_x = w + fc.x;
+            a.coop_scale = w + fc.scale;
+            a.coop_sync = reinterpret_cast<unsigned*>(w + fc.sync);
+            a.coop_M = fc.M;
+            a.coop_G = fc.G;
+            a.coop_status = status;
+            a.coop_inject = (p->flags & NCDE_FLAG_COOP_FAULT_INJECT) ? 1 : 0;
+            a.coop_spin = a.coop_inject ? (1u << 12) : (unsigned)COOP_SPIN_LIMIT;
+            hipLaunchKernelGGL(fc_fn, dim3(nwg), dim3(TL_THREADS), lds_coop, st, a);
+            coop_mark_in_flight(st);
+            // Behind it, the per-workgroup kernels with run_if = the status word: they return at once unless the cooperative launch gave
+            // up (a workgroup that never became resident: another process's kernels, a CU mask), in which case they redo the solve.
+            a.run_if = status;
+        }
+    }
+    if (ncde_lds_optin((const void*)fn, lds) != hipSuccess) return NCDE_ERR_HIP;
+    hipLaunchKernelGGL(fn, dim3(nwg), dim3(TL_THREADS), lds, st, a);
+    if (split == 2) {      // re-execution of range-faulted sample tiles in split-bf16 (normally none: every workgroup exits at once)
         tiled_pack_launch(p, &a, pack_bf, true, st);
         a.only_faulted = 1;
         if (ncde_lds_optin((const void*)fx, lds) != hipSuccess) return NCDE_ERR_HIP;
@@ -3412,12 +3506,24 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     }
     int nwv_launch = nwv;
     size_t lds_launch = tiled_adj_lds(p);
-    if (t.coop) {      // XCD-cooperative output phase: weights resident in registers, activations exchanged through L2 (ncde_coop.h)
+    void (*const fa_pw)(KArgs) = fa;      // the per-workgroup sweep of this problem (what a cooperative sequence falls back to)
+    const size_t lds_pw = lds_launch;
+    bool coop = false;
+    if (t.coop) {
+        void (*fc_fn)(KArgs) = ncde_adj_tiled<8, 8, 0, 0, 1, 0, 0, 1>;
+        if (ncde_lds_optin((const void*)fc_fn, tiled_coop_lds(p)) != hipSuccess) return NCDE_ERR_HIP;
+        coop = coop_runtime_ok((const void*)fc_fn, 64 * 8, tiled_coop_lds(p), t.n_st, st);      // (see coop_runtime_ok: else the per-workgroup kernels)
+    }
+    if (coop) {      // XCD-cooperative output phase: weights resident in registers, activations exchanged through L2 (ncde_coop.h)
         fa = ncde_adj_tiled<8, 8, 0, 0, 1, 0, 0, 1>;
         nwv_launch = 8;
         lds_launch = tiled_coop_lds(p);
         unsigned* amax = reinterpret_cast<unsigned*>(w + t.coop_scale + 8);
         if (hipMemsetAsync(amax, 0, sizeof(unsigned), st) != hipSuccess) return NCDE_ERR_HIP;
+        a.coop_status = reinterpret_cast<unsigned*>(w + t.coop_scale + 16);      // zeroed ONCE per call: a time-out in one window stops the later ones
+        if (hipMemsetAsync(a.coop_status, 0, sizeof(unsigned), st) != hipSuccess) return NCDE_ERR_HIP;
+        a.coop_inject = (p->flags & NCDE_FLAG_COOP_FAULT_INJECT) ? 1 : 0;
+        a.coop_spin = a.coop_inject ? (1u << 12) : (unsigned)COOP_SPIN_LIMIT;
         // the hidden-layer weight gradients accumulate in the workgroups' global partials from the first stage on
         if (hipMemsetAsync(w + t.gpartA, 0, sizeof(float) * (size_t)t.n_st * t.gstride, st) != hipSuccess) return NCDE_ERR_HIP;
         const long long nw = (long long)p->hidden * p->channels * 128;
@@ -3433,6 +3539,8 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
         a.coop_G = t.coop_G;
     }
     const dim3 gridB(p->hidden * p->channels / 16 / t.nrt, t.parts);
+    void (*const fb_pw)(KArgs, int, int, float*) = fb;      // pass B of the per-workgroup sequence, and its grid
+    const dim3 gridB_pw = gridB;
     const size_t lds = lds_launch;
     if (ncde_lds_optin((const void*)fa, lds) != hipSuccess) return NCDE_ERR_HIP;
     a.carry = w + t.carry;
@@ -3443,13 +3551,14 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     for (int hi = n_rsteps, first = 1; hi >= 1; hi -= t.window, first = 0) {
         const int lo = std::max(0, hi - t.window);
         a.win_hi = hi; a.win_lo = lo; a.resume = first ? 0 : 1;
-        if (t.coop && hipMemsetAsync(a.coop_sync, 0, sizeof(unsigned) * (size_t)coop_sync_words(t.coop_G, t.n_st), st) != hipSuccess) return NCDE_ERR_HIP;
+        if (coop && hipMemsetAsync(a.coop_sync, 0, sizeof(unsigned) * (size_t)coop_sync_words(t.coop_G, t.n_st), st) != hipSuccess) return NCDE_ERR_HIP;
         hipLaunchKernelGGL(fa, dim3(t.n_st), dim3(64 * nwv_launch), lds, st, a);
         const int n_sc = (hi - lo) * t.S;
         hipLaunchKernelGGL(fb, gridB, dim3(256), 0, st, a, n_sc, t.n_st, gB);
         if (fb2) hipLaunchKernelGGL(fb2, gridB, dim3(256), 0, st, a, n_sc, t.n_st, gB2);
         if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
     }
+    if (coop) coop_mark_in_flight(st);
     if (main_kernel_only) return NCDE_OK;
     // deterministic reductions: hidden-layer partials of the sweep, then the part-group partials of pass B
     ReduceSegs segs{};
@@ -3477,6 +3586,25 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
         so.dst[0] = g->grad_Wg;
         so.dst[1] = g->grad_bg;
         hipLaunchKernelGGL(ncde_reduce_partials, dim3(((int)t.theta_o + 255) / 256), dim3(256), 0, st, (const float*)gB2, t.parts, (int)t.theta_o, so);
+    }
+    if (coop) {
+        // Behind the cooperative sequence: the WHOLE pass again on the per-workgroup kernels, every launch with run_if = the status word
+        // -- each returns at once (a few microseconds per window) unless a cooperative launch gave up, and then they overwrite every
+        // output of this call: grad_z0, the hidden-layer partials, the output-layer partials, the reductions.  (cooperative: original
+        // field only, so there is no second head.)
+        a.run_if = a.coop_status;
+        if (ncde_lds_optin((const void*)fa_pw, lds_pw) != hipSuccess) return NCDE_ERR_HIP;
+        for (int hi = n_rsteps, first = 1; hi >= 1; hi -= t.window, first = 0) {
+            const int lo = std::max(0, hi - t.window);
+            a.win_hi = hi; a.win_lo = lo; a.resume = first ? 0 : 1;
+            hipLaunchKernelGGL(fa_pw, dim3(t.n_st), dim3(64 * nwv), lds_pw, st, a);
+            hipLaunchKernelGGL(fb_pw, gridB_pw, dim3(256), 0, st, a, (hi - lo) * t.S, t.n_st, gB);
+            if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
+        }
+        hipLaunchKernelGGL(ncde_reduce_partials_if, dim3((t.gstride + 255) / 256), dim3(256), 0, st, a.run_if, (const float*)a.gpart, t.n_st, t.gstride, segs);
+        so.dst[0] = g->grad_Wo;
+        so.dst[1] = g->grad_bo;
+        hipLaunchKernelGGL(ncde_reduce_partials_if, dim3(((int)t.theta_o + 255) / 256), dim3(256), 0, st, a.run_if, (const float*)gB, t.parts_pw, (int)t.theta_o, so);
     }
     return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
 }

@@ -243,6 +243,64 @@ def _workspace(p, pass_, device):
     return _workspace_bytes(_lib.check(_lib.lib().ncde_workspace_bytes(ctypes.byref(p), pass_), "ncde_workspace_bytes"), device)
 
 
+# ---- the cooperative kernels' status word (include/ncde_hip.h: ncde_coop_status_offset) -------------------------------------------
+# A cooperative launch that gives up (bounded spin: its workgroups never all became resident) is re-executed INSIDE the library by the
+# per-workgroup kernels, so the tensors this module returns are correct either way.  What is left to the host is to notice -- the call
+# took seconds longer -- and to stop asking for the cooperative path: after every call that could launch one, the status word is copied
+# (stream-ordered, asynchronously) into a pinned host slot; the slots of finished calls are looked at -- without synchronising
+# anything -- at the start of the next fused call, and a set word warns once and adds FLAG_NO_COOP to every later call on that device.
+_COOP_SLOTS = {}         # device index -> (pinned int32 ring, next slot)
+_COOP_PENDING = []       # (device index, pinned slot view, event)
+_COOP_DISABLED = {}      # device index -> number of calls whose cooperative launches gave up
+
+
+def _coop_track(p, pass_, ws, dev):
+    off = _lib.lib().ncde_coop_status_offset(ctypes.byref(p), pass_)
+    if off < 0:
+        return
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    ring, nxt = _COOP_SLOTS.get(idx, (None, 0))
+    if ring is None:
+        ring = torch.zeros(256, dtype=torch.int32).pin_memory()
+    if len(_COOP_PENDING) >= 192:      # (a caller that never comes back through cdeint: look now, blocking on the oldest)
+        coop_status(wait=True)
+    slot = ring[nxt:nxt + 1]
+    slot.copy_(ws[int(off):int(off) + 4].view(torch.int32), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    _COOP_PENDING.append((idx, slot, ev))
+    _COOP_SLOTS[idx] = (ring, (nxt + 1) % 256)
+
+
+def coop_status(wait=False):
+    """Look at the status words of the fused calls issued so far (``wait=True``: of all of them, synchronising on their events;
+    default: of those the GPU has finished).  Returns {device index: number of calls in which a cooperative launch gave up and the
+    per-workgroup kernels re-executed the pass}; such a device no longer gets cooperative launches from this process."""
+    keep = []
+    for idx, slot, ev in _COOP_PENDING:
+        if wait:
+            ev.synchronize()
+        if not ev.query():
+            keep.append((idx, slot, ev))
+            continue
+        if int(slot[0]) != 0:
+            if idx not in _COOP_DISABLED:
+                warnings.warn("ncde_amd: a cooperative (XCD-wide) kernel launch on cuda:%d timed out -- its workgroups never all became "
+                              "resident (another process's kernels on the GPU, a CU mask?).  The pass was re-executed on the per-workgroup "
+                              "kernels, so the results are correct; this process now passes FLAG_NO_COOP on that device." % idx, RuntimeWarning)
+            _COOP_DISABLED[idx] = _COOP_DISABLED.get(idx, 0) + 1
+    _COOP_PENDING[:] = keep
+    return dict(_COOP_DISABLED)
+
+
+def _coop_flags(flags, device):
+    """`flags` + FLAG_NO_COOP once a cooperative launch has given up on `device` (looked up without synchronising)."""
+    if _COOP_PENDING:
+        coop_status()
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return flags | _lib.FLAG_NO_COOP if idx in _COOP_DISABLED else flags
+
+
 def _check_tensor(x, name):
     if not (x.is_cuda and x.dtype == torch.float32):
         raise NotImplementedError("cdeint fused path needs fp32 tensors on the GPU; %s is %s on %s" % (name, x.dtype, x.device))
@@ -275,6 +333,8 @@ class _FusedCdeint(torch.autograd.Function):
                                                     ws.numel(), _stream_ptr())
             else:
                 rc = _lib.lib().ncde_forward(ctypes.byref(p), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr())
+            if rc >= 0:
+                _coop_track(p, 0, ws, z0.device)
         _lib.check(rc, "ncde_forward_record" if record else "ncde_forward")
         ctx.cfg = cfg
         ctx.coeffs = coeffs
@@ -320,6 +380,8 @@ class _FusedCdeint(torch.autograd.Function):
                 ws = _workspace(p, 1, dev)
                 rc = _lib.lib().ncde_adjoint(ctypes.byref(p), out.data_ptr(), grad_out.data_ptr(), ctypes.byref(g),
                                              ws.data_ptr(), ws.numel(), _stream_ptr())
+            if rc >= 0:
+                _coop_track(p, 2 if ctx.recorded else 1, ws, dev)
         _lib.check(rc, "ncde_backward" if ctx.recorded else "ncde_adjoint")
         if not ctx.recorded and cfg["func"] is not None and hasattr(cfg["func"], "nfe"):
             cfg["func"].nfe += cfg["nfe_adjoint"]   # the adjoint sweep re-evaluates f (base.py:90); autograd does not
@@ -704,6 +766,7 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
         if len(batch_shape) != 1:
             out = out.reshape(*batch_shape, out.shape[-2], out.shape[-1])
         return out
+    flags = _coop_flags(flags, z0.device)
     output = _time_mode(X, t) if float(step) == 1.0 else None
     stages = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
     plan = None

@@ -49,6 +49,18 @@ def run_case(case, flags=_lib.FLAG_AUTO, device="cuda", need_grads=True, adjoint
     return res
 
 
+def run_case_async(case, flags=_lib.FLAG_AUTO, device="cuda"):
+    """The forward solve of `case` enqueued on the CURRENT stream; returns the device tensor without synchronising."""
+    m = case["meta"]
+    coeffs = torch.from_numpy(case["coeffs"]).to(device)
+    X = (ncde_amd.LinearInterpolation if m["kind"] == "linear" else ncde_amd.NaturalCubicSpline)(coeffs)
+    func = case_field(case, device)
+    z0 = torch.from_numpy(case["z0"]).to(device)
+    with torch.no_grad():
+        return ncde_amd.cdeint(X, func, z0, X.grid_points if m["sequence"] else X.interval, vector_field_type=func.mode,
+                               method=m["method"], options={"step_size": 1}, kernel_flags=flags)
+
+
 def run_adjoint_direct(case, z_out, flags=_lib.FLAG_AUTO, device="cuda", stages=None):
     """Call ncde_adjoint through the C-ABI on a GIVEN forward solution (e.g. the reference's own z_out):
     isolates the adjoint kernel from forward round-off (a last-bit change of z can flip a ReLU mask).
@@ -91,6 +103,25 @@ def run_adjoint_direct(case, z_out, flags=_lib.FLAG_AUTO, device="cuda", stages=
     torch.cuda.synchronize()
     name = (_lib.lib().ncde_kernel_name(ctypes.byref(p), 2 if stages is not None else 1) or b"?").decode()
     return {"dz0": gz0.cpu().numpy(), "kernel": name, "grads": {k: gbuf[id(v)].cpu().numpy() for k, v in func.p.items() if id(v) in gbuf}}
+
+
+def coop_status_word(case, pass_, flags=_lib.FLAG_AUTO, device="cuda"):
+    """The cooperative status word (include/ncde_hip.h: ncde_coop_status_offset) the LAST call of this case / pass / flags left in the
+    workspace arena of the current stream (no other call in between); None if the pass launches nothing cooperative."""
+    import ctypes
+    from ncde_amd import solver
+    m = case["meta"]
+    coeffs = torch.from_numpy(case["coeffs"]).to(device)
+    func = case_field(case, device)
+    z0 = torch.from_numpy(case["z0"]).to(device)
+    p = solver.build_problem(coeffs, m["kind"], z0, func.fused_spec(), m["method"],
+                             _lib.OUT_KNOTS if m["sequence"] else _lib.OUT_INTERVAL, flags)
+    off = _lib.lib().ncde_coop_status_offset(ctypes.byref(p), pass_)
+    if off < 0:
+        return None
+    torch.cuda.synchronize()
+    ws = solver._workspace(p, pass_, device)
+    return int(ws[off:off + 4].view(torch.int32).cpu()[0])
 
 
 def kernel_names(case, flags=_lib.FLAG_AUTO, device="cuda"):

@@ -166,3 +166,23 @@ def test_bench_world_size_two_branches_on_one_gpu(gpu_lib):
     assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["collective_backend"] == "gloo" and rec["ms_allreduce"] > 0
     assert rec["strong"]["global_batch"] == 4096 and rec["strong"]["batch_per_gpu"] == 2048
     assert "cpu_baseline" not in rec      # rank 0 at N = 1 only
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher(gpu_lib):
+    """a bare `python bench.py --gpus 2` (no torch.distributed.run around it, WORLD_SIZE unset) must not
+    die on an assertion -- it starts the two ranks itself as a CHILD process before touching the GPU, relays rank 0's one JSON line and
+    returns the child's code.  On this one-GPU box over gloo, both ranks on cuda:0 (NCDE_BENCH_BACKEND)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(NCDE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras"],
+                         capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["collective_backend"] == "gloo"
+    assert abs(rec["value"] - 2 * 4096 * 398 / (rec["ms_per_step"] * 1e-3)) / rec["value"] < 1e-6

@@ -2230,6 +2230,83 @@ def test_neuralcde_hidden_256_trains_on_the_fused_kernels(adjoint, gpu_lib):
 
 
 @pytest.mark.parametrize("B,L,C,H,HH,nl,interp,method,seq", [
+    (256, 3, 20, 128, 128, 3, "cubic", "midpoint", True),   # two groups of 8: the group of workgroup 1 gives up, the other one runs on until it checks
+    (123, 4, 40, 64, 128, 2, "linear", "rk4", False),       # one group, ragged last tile
+])
+def test_cooperative_timeout_is_reexecuted_not_nan(B, L, C, H, HH, nl, interp, method, seq, gpu_lib):
+    """Round 6: a cooperative launch whose workgroups do not all arrive must neither hang nor
+    return NaN / half-finished gradients.  NCDE_FLAG_COOP_FAULT_INJECT withholds ONE arrival of workgroup 1 in the first cooperative
+    launch (and shortens the spin limit): that launch gives up, sets the call's status word, the cooperative launches of the later time
+    windows return at once, and the per-workgroup kernels enqueued behind them redo the pass -- every output is bit-identical to a
+    NCDE_FLAG_NO_COOP call.  The Python host then sees the word, warns once and stops asking for cooperative launches."""
+    import gpu_util
+    import ncde_amd
+    from ncde_amd import _lib, solver
+    INJ, NOC = _lib.FLAG_COOP_FAULT_INJECT, _lib.FLAG_NO_COOP
+    case = _seeded_case(interp, method, seq, B=B, L=L, C=C, H=H, HH=HH, nl=nl, seed=940 + C)
+    ex = case["expect"]
+    assert all("coop" in k for k in gpu_util.kernel_names(case, flags=INJ))
+    dev = torch.cuda.current_device()
+    solver._COOP_DISABLED.clear()
+    try:
+        # the library alone (C-ABI): forward, continuous adjoint, exact discrete backward, several time windows
+        for win in (0, _lib.FLAG_TILED_WINDOW_STEPS(1)):
+            ref = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=NOC | win)
+            got = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=INJ | win)
+            assert gpu_util.coop_status_word(case, 1, flags=INJ | win) == 1
+            assert np.array_equal(got["dz0"], ref["dz0"]) and np.isfinite(got["dz0"]).all()
+            for k in ref["grads"]:
+                assert np.array_equal(got["grads"][k], ref["grads"][k]), k
+            ok = gpu_util.run_adjoint_direct(case, ex["z_out"], flags=win)      # the same call without the fault: word stays 0
+            assert gpu_util.coop_status_word(case, 1, flags=win) == 0
+            assert gu.relerr(ok["dz0"], ref["dz0"]) <= 2e-5
+        refd = gpu_util.run_adjoint_direct(case, ex["z_out"], stages=case["stage_record"], flags=NOC)
+        gotd = gpu_util.run_adjoint_direct(case, ex["z_out"], stages=case["stage_record"], flags=INJ)
+        assert gpu_util.coop_status_word(case, 2, flags=INJ) == 1
+        assert np.array_equal(gotd["dz0"], refd["dz0"]) and all(np.array_equal(gotd["grads"][k], refd["grads"][k]) for k in refd["grads"])
+        # through cdeint (forward + backward, both with the fault): values, then the host's reaction
+        solver._COOP_DISABLED.clear()
+        solver._COOP_PENDING.clear()
+        reff = gpu_util.run_case(case, flags=NOC)
+        gotf = gpu_util.run_case(case, flags=INJ)
+        assert np.array_equal(gotf["z_out"], reff["z_out"]) and np.array_equal(gotf["dz0"], reff["dz0"])
+        for k in reff["grads"]:
+            assert np.array_equal(gotf["grads"][k], reff["grads"][k]), k
+        with pytest.warns(RuntimeWarning, match="cooperative"):
+            st = ncde_amd.coop_status(wait=True)
+        assert st.get(dev, 0) >= 1
+        assert solver._coop_flags(0, torch.device("cuda", dev)) & NOC
+        again = gpu_util.run_case(case)      # later calls of this process: per-workgroup kernels, no new warning
+        assert np.array_equal(again["z_out"], reff["z_out"])
+    finally:
+        ncde_amd.coop_status(wait=True)
+        solver._COOP_DISABLED.clear()
+    # without the fault nothing is recorded
+    gpu_util.run_case(case)
+    assert ncde_amd.coop_status(wait=True) == {}
+
+
+def test_cooperative_calls_on_two_streams_do_not_wait_for_each_other(gpu_lib):
+    """two cooperative launches on different streams could each hold CUs the other needs.  The library lets only ONE
+    cooperative sequence per device be in flight: a call that finds another stream's sequence unfinished runs the per-workgroup
+    kernels.  Here: two streams, interleaved calls, every result equal (to fp32 round-off) to the single-stream one."""
+    import gpu_util
+    from ncde_amd import _lib
+    case = _seeded_case("linear", "rk4", False, B=512, L=6, C=80, H=128, HH=128, nl=3, seed=951)
+    assert "coop" in gpu_util.kernel_names(case)[0]
+    ref = gpu_util.run_case(case, need_grads=False, flags=_lib.FLAG_NO_COOP)["z_out"]
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for it in range(3):
+        for st in (s1, s2):
+            with torch.cuda.stream(st):
+                outs.append(gpu_util.run_case_async(case))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert gu.relerr(o.cpu().numpy(), ref) <= TIGHT_Z
+
+
+@pytest.mark.parametrize("B,L,C,H,HH,nl,interp,method,seq", [
     (123, 3, 40, 64, 128, 2, "linear", "rk4", False),       # 8 sample tiles = ONE group of 8 members (2 state-unit blocks each), ragged last tile
     (256, 3, 20, 128, 128, 3, "cubic", "midpoint", True),   # 16 tiles = two groups of 8 (4 blocks per member, one wave each), sequence outputs
     (512, 2, 80, 128, 128, 3, "linear", "rk4", True),       # cfg5 dims: 32 tiles = one group of 32 (one block per member)

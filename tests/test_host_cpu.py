@@ -166,6 +166,26 @@ def test_shapes_without_a_backward_kernel_are_known_before_the_forward():
             assert name and "generic" not in name, (C, H, HH, nl, k, name)
 
 
+def test_cooperative_status_word_offset_is_inside_the_workspace():
+    """Round 6: every pass that may launch the XCD-cooperative kernels names a status word inside the
+    caller's workspace; passes that never do say so (NCDE_ERR_UNSUPPORTED), and NCDE_FLAG_NO_COOP removes it."""
+    lib = ncde_amd.lib()
+    big = dict(B=4096, T=799, C=80, H=128, HH=128, nl=3)
+    for ps in (0, 1, 2):
+        p = _problem(**big)
+        off, need = lib.ncde_coop_status_offset(ctypes.byref(p), ps), lib.ncde_workspace_bytes(ctypes.byref(p), ps)
+        assert 0 <= off and off % 4 == 0 and off + 4 <= need, (ps, off, need)
+        q = _problem(flags=_lib.FLAG_NO_COOP, **big)
+        assert lib.ncde_coop_status_offset(ctypes.byref(q), ps) == -2
+        small = _problem()      # cfg2's shape: register-resident kernels, nothing cooperative
+        assert lib.ncde_coop_status_offset(ctypes.byref(small), ps) == -2
+    # a zero-padded problem (hidden width 120 -> 128) on the batch-tiled family: the offset counts the padded-parameter head
+    pp = _problem(B=512, T=9, C=80, H=128, HH=120, nl=3)
+    if b"coop" in (lib.ncde_kernel_name(ctypes.byref(pp), 1) or b""):
+        off, need = lib.ncde_coop_status_offset(ctypes.byref(pp), 1), lib.ncde_workspace_bytes(ctypes.byref(pp), 1)
+        assert 0 < off and off + 4 <= need
+
+
 def test_dopri5_kernel_selection():
     """Round 4: the fused attempt kernels where the shape allows, the per-launch kernels elsewhere and under FORCE_GENERIC."""
     lib = ncde_amd.lib()
