@@ -83,6 +83,10 @@ struct KArgs {
     // round 6: the launch sequence's STATUS word (workspace; zeroed once per C-ABI call, never between its time windows): a cooperative
     // kernel that gives up (spin time-out) sets it, every later cooperative launch of the call returns at once, and the per-workgroup
     // kernels enqueued behind them with run_if = this word re-execute the whole pass (they return at once while it is 0)
+    // round 6: records of the cooperative sweep for ncde_dwo_h2 (2-piece fp16, see ncde_tiled.hip): per (stage, sample tile) scales
+    // {1/(sx sw) per sample [16], u_T, 1/u_T}, and the window's largest weighted cotangent bound / u_T as float bits (atomicMax)
+    float* recS;
+    unsigned* win_max;
     unsigned* coop_status;
     const unsigned* run_if;
     unsigned coop_spin;      // polls of a group counter before giving up

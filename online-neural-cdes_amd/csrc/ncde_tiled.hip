@@ -1937,6 +1937,21 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                         CSG[tid] = sx; CSG[16 + tid] = isx; CSG[32 + tid] = sd; CSG[48 + tid] = isd;
                         coop_st4(crs, a.coop_x, c_same, my_base + cd.off_sc() + tid, sx); coop_st4(crs, a.coop_x, c_same, my_base + cd.off_sc() + 16 + tid, isx);
                         coop_st4(crs, a.coop_x, c_same, my_base + cd.off_sc() + 32 + tid, sd); coop_st4(crs, a.coop_x, c_same, my_base + cd.off_sc() + 48 + tid, isd);
+                        // records for ncde_dwo_h2: the samples of a tile PAIR are the K dimension of its dWo products, so x_L^T carries ONE
+                        // power-of-two scale per tile (u_T, from the tile's largest |x_L|) and dP one per time window -- sigma / u_T, sigma
+                        // from the window's largest (weighted cotangent bound / u_T), gathered here with an atomic max of float bits
+                        float mt = m3[0], bt = fabsf(w) * (m3[1] * m3[2]);
+#pragma unroll
+                        for (int o = 8; o > 0; o >>= 1) { mt = fmaxf(mt, __shfl_xor(mt, o, 64)); bt = fmaxf(bt, __shfl_xor(bt, o, 64)); }
+                        const float uT = coop_pow2_scale(mt), iuT = coop_pow2_inv(uT);
+                        float* rs = a.recS + ((long long)sc * n_st + blockIdx.x) * 32;
+                        rs[tid] = isx;
+                        if (tid == 0) {
+                            CSG[64] = uT;
+                            rs[16] = uT; rs[17] = iuT;
+                            const float bq = bt * iuT;
+                            if (bq > 0.0f && bq < 3.0e38f) atomicMax(a.win_max, __float_as_uint(bq));
+                        }
                     }
                     __syncthreads();
                     // -- OWNER: publish x_L (scaled, split-fp16, B-operand order), a, dX/dt ------------------------------------
@@ -1960,7 +1975,50 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                     if (tid == 0 && !(a.coop_inject != 0 && blockIdx.x == 1 && sc == 0 && a.resume == 0)) coop_arrive(csy, c_grp);      // (fault injection)
                     TL_TICK(8)
                     coop_load_weights<COOP_PIN, 40>(cw, a.coop_img, c_mem, wave, lane);      // the re-read part: in flight under the records and while the group assembles
-                    write_records();      // (needs a, dX/dt, x_L and its split image: all final -- and dead for this stage afterwards)
+                    {   // records for ncde_dwo_h2 (needs a, dX/dt, x_L, the scales: all final -- and dead for this stage afterwards)
+                        const long long tile = (long long)sc * n_st + blockIdx.x;
+                        if (wave < 4) {      // record A: the scaled split-fp16 image of x_L exactly as published to the keepers (8 KB)
+                            const int c = wave, ub = 32 * c + 8 * lk;
+                            const f32x4 v0 = *reinterpret_cast<const f32x4*>(in + (((ub >> 2)) * NSP + li) * 4);
+                            const f32x4 v1 = *reinterpret_cast<const f32x4*>(in + (((ub >> 2) + 1) * NSP + li) * 4);
+                            const float sx = CSG[li];
+                            unsigned h[4], l[4];
+                            coop_split2(v0[0] * sx, v0[1] * sx, h[0], l[0]); coop_split2(v0[2] * sx, v0[3] * sx, h[1], l[1]);
+                            coop_split2(v1[0] * sx, v1[1] * sx, h[2], l[2]); coop_split2(v1[2] * sx, v1[3] * sx, h[3], l[3]);
+                            unsigned* ra = reinterpret_cast<unsigned*>(a.recA) + tile * 2048;
+                            *reinterpret_cast<u32x4*>(ra + ((c * 2 + 0) * 64 + lane) * 4) = (u32x4){h[0], h[1], h[2], h[3]};
+                            *reinterpret_cast<u32x4*>(ra + ((c * 2 + 1) * 64 + lane) * 4) = (u32x4){l[0], l[1], l[2], l[3]};
+                        }
+                        // record B: x_L^T of the tile PAIR (2i, 2i + 1), scaled by this tile's u_T, two fp16 pieces: word
+                        // ((jt * 2 + piece) * 64 + lane) * 4 + 2 half + d = x_L[16 jt + (lane & 15)][samples 4 (lane >> 4) + 2 d, + 1] of tile `half`
+                        {
+                            const float uT = CSG[64];
+                            unsigned* rbp = reinterpret_cast<unsigned*>(a.recB) + ((long long)sc * (n_st >> 1) + (blockIdx.x >> 1)) * 4096;
+                            const int half = blockIdx.x & 1;
+                            for (int e = tid; e < 128 * 4; e += NT) {
+                                const int k = e >> 2, kg = e & 3, ln = (k & 15) + 16 * kg;
+                                float v[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) v[q] = in[((k >> 2) * NSP + 4 * kg + q) * 4 + (k & 3)] * uT;
+                                unsigned h0, l0, h1, l1;
+                                coop_split2(v[0], v[1], h0, l0);
+                                coop_split2(v[2], v[3], h1, l1);
+                                unsigned* dst = rbp + (((k >> 4) * 2) * 64 + ln) * 4 + 2 * half;
+                                *reinterpret_cast<u32x2c*>(dst) = (u32x2c){h0, h1};
+                                *reinterpret_cast<u32x2c*>(dst + 256) = (u32x2c){l0, l1};
+                            }
+                        }
+                        float* rc = a.recC + tile * (H * NSP);      // w a: [h][16 samples]
+                        for (int e = tid; e < H * NSP; e += NT) {
+                            const int hh = e >> 4, s_ = e & 15;
+                            rc[e] = w * AS[((hh >> 2) * NSP + s_) * 4 + (hh & 3)];
+                        }
+                        float* rd = a.recD + tile * (C * NSP);      // dX/dt: [c][16 samples] (the per-workgroup sweep's record is [c/4][16][4])
+                        for (int e = tid; e < C * NSP; e += NT) {
+                            const int cc = e >> 4, s_ = e & 15;
+                            rd[e] = DX[((cc >> 2) * NSP + s_) * 4 + (cc & 3)];
+                        }
+                    }
                     __syncthreads();
                     // the Butcher k-registers wait in LDS arrays that are dead until the reduction (KOY, KOA, G0, G1: 2048 floats each)
 #pragma unroll
@@ -2828,6 +2886,183 @@ __global__ __launch_bounds__(256) void ncde_dwo_pair(KArgs a, int n_sc, int n_st
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// pass B for the records of the COOPERATIVE sweep (round 6): 2-way split-fp16, record stream shared through LDS
+// ------------------------------------------------------------------------------------------------
+// ncde_dwo_pair above re-reads every record once per PAIR of row tiles (320 readers at cfg5: 16 TB/s out of the L2, which is what bounds
+// it), multiplies in 3-way split-bf16 (6 MFMAs per product) and turns every dP tile through an LDS patch.  Here:
+//   * one workgroup = 4 waves (one per SIMD, 512 registers) x 4 row tiles of Wo each = 16 row tiles; the records of a (stage, sample-tile
+//     PAIR) are fetched ONCE per workgroup -- global -> LDS directly (global_load_lds_dwordx4), double-buffered a pair-stage ahead -- and
+//     read from LDS by the four waves: 40 readers of the record stream instead of 320;
+//   * every product is 2-way split-fp16 (3 MFMAs): Wo from the sweep's packed register images (scaled by sw), x_L for P from record A
+//     (the image the owners published: one power-of-two scale per sample), x_L^T for dWo from record B (one scale per tile, u_T), dP
+//     scaled by sigma / u_T with ONE sigma per time window (the samples of a pair are the K dimension of the dWo products: a per-sample
+//     scale would not factor out) -- the accumulators therefore hold sigma x the window's sum and are divided once, exactly, when the
+//     window's partial is folded into the workspace;
+//   * P is formed TRANSPOSED, P^T = x_L^T Wo^T (the operand registers of an MFMA are symmetric in A / B): its D layout -- lane = (row of
+//     the tile, four samples) -- IS the A operand of dWo = dP x_L^T, so dP goes from the tanh epilogue straight into the next MFMA.
+// Exactness of the scaling: powers of two throughout.  An entry far below its window's largest bound keeps an absolute error of 2^-36 of
+// that bound -- below the fp32 rounding of the sum it enters.  Same job, same result layout (gpartB[part][theta_o]) as ncde_dwo_pair.
+#define DW2_NRT 4
+__global__ __launch_bounds__(256) void ncde_dwo_h2(KArgs a, int n_sc, int n_st, float* gpartB) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int dlast = 128, PK = 8, NCH = 4, NRT = DW2_NRT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int C = a.C, H = a.H, ncq = C >> 2;
+    const int n_pair = n_st >> 1, parts = gridDim.y;
+    // LDS: two buffers of { x_L images of the two tiles | x_L^T of the pair | w a of the two tiles | dX/dt of the two tiles | scales }
+    const int nRC = H >> 4, nRD = (C + 15) >> 4;      // 1 KB chunks per tile of the w a / dX/dt records
+    const int oXP = 2 * 2048, oRC = oXP + 4096, oRD = oRC + 2 * nRC * 256, oS = oRD + 2 * nRD * 256, per_buf = oS + 2 * 256;
+    // the four row tiles of this wave: weights (from the sweep's packed images: member, P-role wave, fragment), bias, accumulators
+    int hb[NRT], cq[NRT];
+    u32x4 W[NRT][NCH][2];
+    float bias[NRT];
+    f32x4 gW[NRT][PK];
+    float gb[NRT];
+#pragma unroll
+    for (int q = 0; q < NRT; ++q) {
+        const int rt = (blockIdx.x * 4 + wave) * NRT + q;
+        hb[q] = rt / ncq;
+        cq[q] = rt - hb[q] * ncq;
+        const int mem = rt / COOP_RPM, rw = (rt % COOP_RPM) / COOP_NRT, qq = rt % COOP_NRT;
+        const unsigned* wp = a.coop_img + (long long)mem * (coop_p_words() + coop_t_words()) + rw * (40 * 64 * 4);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) W[q][c][pc] = *reinterpret_cast<const u32x4*>(wp + ((((qq * 4 + c) * 2 + pc) * 64) + lane) * 4);
+        bias[q] = a.bo[(4 * hb[q] + (li >> 2)) * C + 4 * cq[q] + (li & 3)];
+#pragma unroll
+        for (int jt = 0; jt < PK; ++jt) gW[q][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        gb[q] = 0.0f;
+    }
+    const float sigma = coop_pow2_scale(__uint_as_float(*a.win_max)), inv_sigma = coop_pow2_inv(sigma);
+    const int my_n = (int)blockIdx.y < n_pair ? (n_pair - (int)blockIdx.y + parts - 1) / parts : 0;      // pairs blockIdx.y, + parts, ...
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    // chunk ch (1 KB: one wave instruction) of the pair-stage (sc, pr) -> buffer `buf`; the waves take chunks wave, wave + 4, ...
+    const int n_chunk = 2 * 8 + 16 + 2 * nRC + 2 * nRD + 2;
+    auto issue = [&](int sc, int pr, int buf) {
+        const long long ta = (long long)sc * n_st + 2 * pr;
+        float* base = lds + buf * per_buf;
+        for (int ch = wave; ch < n_chunk; ch += 4) {      // (wave-uniform control flow: scalar branches only)
+            const float* src;
+            float* dst;
+            int k = ch;
+            if (k < 16) { src = a.recA + (ta + (k >> 3)) * 2048 + (k & 7) * 256; dst = base + k * 256; }
+            else if ((k -= 16) < 16) { src = a.recB + ((long long)sc * n_pair + pr) * 4096 + k * 256; dst = base + oXP + k * 256; }
+            else if ((k -= 16) < 2 * nRC) { const int t2 = k >= nRC ? 1 : 0, kk = k - t2 * nRC; src = a.recC + (ta + t2) * (H * 16) + kk * 256; dst = base + oRC + k * 256; }
+            else if ((k -= 2 * nRC) < 2 * nRD) { const int t2 = k >= nRD ? 1 : 0, kk = k - t2 * nRD; src = a.recD + (ta + t2) * (C * 16) + kk * 256; dst = base + oRD + k * 256; }
+            else { k -= 2 * nRD; src = a.recS + (ta + k) * 32; dst = base + oS + k * 256; }
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + lane * 4), (lptr_t)dst, 16, 0, 0);
+        }
+    };
+    if (my_n > 0 && n_sc > 0) {
+        const int nq = n_sc * my_n;
+        int sc_n = 0, k_n = 0;      // the pair-stage to request next
+        issue(0, blockIdx.y, 0);
+        if (++k_n == my_n) { k_n = 0; ++sc_n; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int q = 0; q < nq; ++q) {
+            const int buf = q & 1;
+            if (q + 1 < nq) {
+                issue(sc_n, blockIdx.y + parts * k_n, buf ^ 1);
+                if (++k_n == my_n) { k_n = 0; ++sc_n; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float* B_ = lds + buf * per_buf;
+            const unsigned* XS = reinterpret_cast<const unsigned*>(B_);
+            const unsigned* XP = reinterpret_cast<const unsigned*>(B_ + oXP);
+            u32x4 Ap[NRT][2];      // A operand of dWo: lane (row li, k-group lk) = samples 4 lk .. + 3 of tile a (dwords 0, 1), of tile b (2, 3)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const float* S_ = B_ + oS + t2 * 256;
+                const f32x4 isx4 = *reinterpret_cast<const f32x4*>(S_ + 4 * lk);
+                const float fT = sigma * S_[17];      // sigma / u_T
+                f32x4 pm[NRT], px[NRT];
+#pragma unroll
+                for (int i = 0; i < NRT; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pm[i][r] = bias[i] * coop_pow2_inv(isx4[r]);      // sx sw: the bias joins the scaled accumulator exactly
+                    px[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                const unsigned* xs = XS + t2 * 2048;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const u32x4 x0 = *reinterpret_cast<const u32x4*>(xs + ((c * 2 + 0) * 64 + lane) * 4);
+                    const u32x4 x1 = *reinterpret_cast<const u32x4*>(xs + ((c * 2 + 1) * 64 + lane) * 4);
+#pragma unroll
+                    for (int i = 0; i < NRT; ++i) pm[i] = mfma_h(x0, W[i][c][0], pm[i]);
+#pragma unroll
+                    for (int i = 0; i < NRT; ++i) px[i] = mfma_h(x0, W[i][c][1], px[i]);
+#pragma unroll
+                    for (int i = 0; i < NRT; ++i) px[i] = mfma_h(x1, W[i][c][0], px[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < NRT; ++i) {
+                    const f32x4 pc = h2_combine(pm[i], px[i]);
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(B_ + oRC + t2 * nRC * 256 + (4 * hb[i] + (li >> 2)) * 16 + 4 * lk);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(B_ + oRD + t2 * nRD * 256 + (4 * cq[i] + (li & 3)) * 16 + 4 * lk);
+                    float dps[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float th = tanh_dev(pc[r] * isx4[r]);
+                        const float dp = (a4[r] * d4[r]) * (1.0f - th * th);
+                        gb[i] += dp;
+                        dps[r] = dp * fT;
+                    }
+                    unsigned h0, l0, h1, l1;
+                    coop_split2(dps[0], dps[1], h0, l0);
+                    coop_split2(dps[2], dps[3], h1, l1);
+                    Ap[i][0][2 * t2] = h0; Ap[i][0][2 * t2 + 1] = h1;
+                    Ap[i][1][2 * t2] = l0; Ap[i][1][2 * t2 + 1] = l1;
+                }
+            }
+            // dWo += dP x_L^T: the 32 samples of the pair are K; main product into the accumulator, the two cross products through a
+            // temporary that carries 2^11 and is folded at once (the accumulators live for the whole launch)
+#pragma unroll
+            for (int jt = 0; jt < PK; ++jt) {
+                const u32x4 b0 = *reinterpret_cast<const u32x4*>(XP + ((jt * 2 + 0) * 64 + lane) * 4);
+                const u32x4 b1 = *reinterpret_cast<const u32x4*>(XP + ((jt * 2 + 1) * 64 + lane) * 4);
+                f32x4 tx[NRT];
+#pragma unroll
+                for (int i = 0; i < NRT; ++i) gW[i][jt] = mfma_h(Ap[i][0], b0, gW[i][jt]);
+#pragma unroll
+                for (int i = 0; i < NRT; ++i) tx[i] = mfma_h(Ap[i][0], b1, (f32x4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int i = 0; i < NRT; ++i) tx[i] = mfma_h(Ap[i][1], b0, tx[i]);
+#pragma unroll
+                for (int i = 0; i < NRT; ++i) gW[i][jt] = h2_combine(gW[i][jt], tx[i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the next pair-stage's records: requested at the top)
+            __syncthreads();
+        }
+    }
+    // ---- this workgroup's 16 row tiles of the part's partial: sigma divided out exactly, added to what the earlier windows left ------
+    const long long wo_sz = (long long)H * C * dlast, theta_o = wo_sz + (long long)H * C;
+    float* gp = gpartB + (long long)blockIdx.y * theta_o;
+#pragma unroll
+    for (int q = 0; q < NRT; ++q) {
+#pragma unroll
+        for (int jt = 0; jt < PK; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {      // D row 4 lk + r of the tile = (state unit 4 hb + lk, channel 4 cq + r), column 16 jt + li
+                float* dst = gp + ((long long)(4 * hb[q] + lk) * C + 4 * cq[q] + r) * dlast + 16 * jt + li;
+                const float v = gW[q][jt][r] * inv_sigma;
+                *dst = a.resume ? *dst + v : v;
+            }
+        float v = gb[q];      // this lane: row li of the tile, its samples; the other three k-groups hold the rest
+        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        if (lk == 0) {
+            float* dst = gp + wo_sz + (4 * hb[q] + (li >> 2)) * C + 4 * cq[q] + (li & 3);
+            *dst = a.resume ? *dst + v : v;
+        }
+    }
+}
+
 // ncde_reduce_partials (ncde_generic.hip) for the re-execution sequence: runs only when the cooperative sequence gave up
 __global__ __launch_bounds__(256) void ncde_reduce_partials_if(const unsigned* run_if, const float* __restrict__ gpart, int n_part, int theta_size, ReduceSegs segs) {
     if (*run_if == 0u) return;
@@ -3142,6 +3377,7 @@ bool tiled_adj_ok(const NcdeProblem* p) {
 
 struct TiledAdjPlan {
     int n_st, n_sc, gstride, parts, parts_pw, window, S, nrt;      // parts_pw: part-groups of the per-workgroup sequence's pass B
+    long long recS;      // cooperative sweep: per (stage, tile) scales for ncde_dwo_h2
     long long recA, recB, recC, recD, gpartA, gpartB, carry, pack, pack_bf, total;   // float offsets into the workspace
     long long theta_o;
     // cooperative output phase: packed weight images, exchange area, {absmax bits, sw, 1/sw}, sync words
@@ -3207,14 +3443,21 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
     t.parts = 1;
     while (t.parts < 64 && (row_tiles / t.nrt) * 4 * t.parts < 4096 && 4 * t.parts * 2 <= t.n_st) t.parts *= 2;
     t.parts_pw = t.parts;
-    t.gpartB = off; off += (long long)t.parts * t.theta_o * (p->field_kind == NCDE_FIELD_MINIMAL ? 2 : 1);
+    const CoopPlan cp = bf ? tiled_coop_plan(p) : CoopPlan{false, 0, 0};
+    if (cp.ok) {      // ncde_dwo_h2: 16 row tiles per workgroup, the sample-tile pairs of a stage split over `parts` workgroups
+        int pp = 1;
+        while (pp * 2 <= 32 && pp * 2 <= t.n_st / 2) pp *= 2;
+        t.parts = pp;
+    }
+    t.gpartB = off; off += (long long)std::max(t.parts, t.parts_pw) * t.theta_o * (p->field_kind == NCDE_FIELD_MINIMAL ? 2 : 1);
     t.carry = off; off += 2LL * t.n_st * p->hidden * 16;
     t.pack = off; off += tiled_pack_floats(p, false, true);
     t.pack_bf = off; off += (bf && p->field_kind != NCDE_FIELD_MINIMAL) ? tiled_pack_floats(p, true) : 0;
-    const CoopPlan cp = bf ? tiled_coop_plan(p) : CoopPlan{false, 0, 0};
     t.coop = cp.ok;
     if (cp.ok) {
         t.coop_M = cp.M; t.coop_G = cp.G;
+        off = (off + 63) & ~63LL;
+        t.recS = off; off += tiles * 32 + 512;      // (+ the over-read of the last 1 KB chunk ncde_dwo_h2 fetches)
         const CoopDims d{p->hidden, p->channels, 128, cp.M, cp.G};
         off = (off + 63) & ~63LL;
         t.coop_img = off; off += (long long)cp.M * (coop_p_words() + coop_t_words());
@@ -3274,7 +3517,7 @@ const char* ncde_tiled_kernel_name(const NcdeProblem* p, int pass) {
         return pass == 1 ? "ncde_adj_tiled<wide>+ncde_dwo_tiled" : "ncde_adj_tiled<wide,discrete>+ncde_dwo_tiled";
     }
     if (pass >= 1 && tiled_adj_bf(p) && !gated && tiled_coop_plan(p).ok)      // weight-stationary output phase across the workgroups of an XCD
-        return pass == 1 ? "ncde_adj_tiled<coop,fp16x2,bf16 records>+ncde_dwo_pair" : "ncde_adj_tiled<coop,discrete,fp16x2,bf16 records>+ncde_dwo_pair";
+        return pass == 1 ? "ncde_adj_tiled<coop,fp16x2>+ncde_dwo_h2<fp16x2 records>" : "ncde_adj_tiled<coop,discrete,fp16x2>+ncde_dwo_h2<fp16x2 records>";
     if (pass >= 1 && tiled_adj_bf(p)) {      // split-bf16 records: the pair kernel is pass B
         if (pass == 1) return gated ? "ncde_adj_tiled<gated,bf16>+ncde_dwo_pair" : "ncde_adj_tiled<bf16>+ncde_dwo_pair";
         return gated ? "ncde_adj_tiled<gated,discrete,bf16>+ncde_dwo_pair" : "ncde_adj_tiled<discrete,bf16>+ncde_dwo_pair";
@@ -3535,12 +3778,21 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
         a.coop_scale = w + t.coop_scale;
         a.coop_state = w + t.coop_state;
         a.coop_sync = reinterpret_cast<unsigned*>(w + t.coop_sync);
+        a.win_max = a.coop_sync + coop_sync_words(t.coop_G, t.n_st);
         a.coop_M = t.coop_M;
         a.coop_G = t.coop_G;
     }
-    const dim3 gridB(p->hidden * p->channels / 16 / t.nrt, t.parts);
     void (*const fb_pw)(KArgs, int, int, float*) = fb;      // pass B of the per-workgroup sequence, and its grid
-    const dim3 gridB_pw = gridB;
+    const dim3 gridB_pw(p->hidden * p->channels / 16 / t.nrt, t.parts_pw);
+    dim3 gridB = gridB_pw;
+    size_t ldsB = 0;
+    if (coop) {      // the cooperative sweep writes 2-piece fp16 records: ncde_dwo_h2 folds them (16 row tiles per workgroup, records through LDS)
+        fb = ncde_dwo_h2;
+        gridB = dim3(p->hidden * p->channels / 16 / 16, t.parts);
+        ldsB = sizeof(float) * 2 * (size_t)(2 * 2048 + 4096 + 2 * (p->hidden / 16) * 256 + 2 * ((p->channels + 15) / 16) * 256 + 2 * 256);
+        if (ncde_lds_optin((const void*)fb, ldsB) != hipSuccess) return NCDE_ERR_HIP;
+        a.recS = w + t.recS;
+    }
     const size_t lds = lds_launch;
     if (ncde_lds_optin((const void*)fa, lds) != hipSuccess) return NCDE_ERR_HIP;
     a.carry = w + t.carry;
@@ -3551,10 +3803,11 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     for (int hi = n_rsteps, first = 1; hi >= 1; hi -= t.window, first = 0) {
         const int lo = std::max(0, hi - t.window);
         a.win_hi = hi; a.win_lo = lo; a.resume = first ? 0 : 1;
-        if (coop && hipMemsetAsync(a.coop_sync, 0, sizeof(unsigned) * (size_t)coop_sync_words(t.coop_G, t.n_st), st) != hipSuccess) return NCDE_ERR_HIP;
+        // (the sync words of the launch and, behind them, the window's cotangent-bound word: KArgs.win_max)
+        if (coop && hipMemsetAsync(a.coop_sync, 0, sizeof(unsigned) * (size_t)(coop_sync_words(t.coop_G, t.n_st) + 1), st) != hipSuccess) return NCDE_ERR_HIP;
         hipLaunchKernelGGL(fa, dim3(t.n_st), dim3(64 * nwv_launch), lds, st, a);
         const int n_sc = (hi - lo) * t.S;
-        hipLaunchKernelGGL(fb, gridB, dim3(256), 0, st, a, n_sc, t.n_st, gB);
+        hipLaunchKernelGGL(fb, gridB, dim3(256), ldsB, st, a, n_sc, t.n_st, gB);
         if (fb2) hipLaunchKernelGGL(fb2, gridB, dim3(256), 0, st, a, n_sc, t.n_st, gB2);
         if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
     }
