@@ -87,6 +87,7 @@ struct KArgs {
     // {1/(sx sw) per sample [16], u_T, 1/u_T}, and the window's largest weighted cotangent bound / u_T as float bits (atomicMax)
     float* recS;
     unsigned* win_max;
+    int dw2_parts;           // ncde_dwo_h2: part-groups (its grid is 1-D: row groups x parts)
     unsigned* coop_status;
     const unsigned* run_if;
     unsigned coop_spin;      // polls of a group counter before giving up

@@ -204,7 +204,9 @@ __host__ __device__ constexpr int coop_t_words() { return 4 * 40 * 64 * 4; }
 // scratch reload is an in-order vmcnt wait): 292k cycles in those loops, 478k per stage; 30 pinned + 10 re-read: the same nine reloads;
 // all 40 re-read (the shipped setting): clean loops, 168k, but 10 MB per XCD and stage do not fit the 4 MB L2 and come from the
 // Infinity Cache / HBM: +40k cycles waiting for them, 410k per stage (the per-workgroup sweep: 469k).
+#ifndef COOP_PIN
 #define COOP_PIN 0
+#endif
 template <int K0, int K1>
 __device__ __forceinline__ void coop_load_weights(CoopWeights& w, const unsigned* img, int member, int wave, int lane) {
     const unsigned* p = img + (long long)member * (coop_p_words() + coop_t_words()) + wave * (40 * 64 * 4);      // (waves 4..7: behind the P images)
@@ -237,6 +239,7 @@ __device__ __forceinline__ void coop_split2(float x0, float x1, unsigned& hi, un
 
 }  // namespace
 
+#ifndef NCDE_COOP_NO_KERNELS      // (a second translation unit -- ncde_dwo2.hip -- includes this header for the helpers only)
 // ------------------------------------------------------------------------------------------------------------------------------
 // pack kernels (once per call: the parameters change every training step)
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -296,3 +299,4 @@ __global__ __launch_bounds__(256) void ncde_coop_pack(const float* __restrict__ 
         }
     }
 }
+#endif  // NCDE_COOP_NO_KERNELS

@@ -18,6 +18,7 @@
 #include "ncde_host.h"
 #include "ncde_tiled.h"
 #include "ncde_coop.h"
+#include "ncde_dwo2.h"
 
 #define TL_NW 8   // waves per workgroup of the forward family (the backward sweep runs 4, see ncde_adj_tiled)
 #define TL_THREADS (64 * TL_NW)
@@ -2886,183 +2887,6 @@ __global__ __launch_bounds__(256) void ncde_dwo_pair(KArgs a, int n_sc, int n_st
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// pass B for the records of the COOPERATIVE sweep (round 6): 2-way split-fp16, record stream shared through LDS
-// ------------------------------------------------------------------------------------------------
-// ncde_dwo_pair above re-reads every record once per PAIR of row tiles (320 readers at cfg5: 16 TB/s out of the L2, which is what bounds
-// it), multiplies in 3-way split-bf16 (6 MFMAs per product) and turns every dP tile through an LDS patch.  Here:
-//   * one workgroup = 4 waves (one per SIMD, 512 registers) x 4 row tiles of Wo each = 16 row tiles; the records of a (stage, sample-tile
-//     PAIR) are fetched ONCE per workgroup -- global -> LDS directly (global_load_lds_dwordx4), double-buffered a pair-stage ahead -- and
-//     read from LDS by the four waves: 40 readers of the record stream instead of 320;
-//   * every product is 2-way split-fp16 (3 MFMAs): Wo from the sweep's packed register images (scaled by sw), x_L for P from record A
-//     (the image the owners published: one power-of-two scale per sample), x_L^T for dWo from record B (one scale per tile, u_T), dP
-//     scaled by sigma / u_T with ONE sigma per time window (the samples of a pair are the K dimension of the dWo products: a per-sample
-//     scale would not factor out) -- the accumulators therefore hold sigma x the window's sum and are divided once, exactly, when the
-//     window's partial is folded into the workspace;
-//   * P is formed TRANSPOSED, P^T = x_L^T Wo^T (the operand registers of an MFMA are symmetric in A / B): its D layout -- lane = (row of
-//     the tile, four samples) -- IS the A operand of dWo = dP x_L^T, so dP goes from the tanh epilogue straight into the next MFMA.
-// Exactness of the scaling: powers of two throughout.  An entry far below its window's largest bound keeps an absolute error of 2^-36 of
-// that bound -- below the fp32 rounding of the sum it enters.  Same job, same result layout (gpartB[part][theta_o]) as ncde_dwo_pair.
-#define DW2_NRT 4
-__global__ __launch_bounds__(256) void ncde_dwo_h2(KArgs a, int n_sc, int n_st, float* gpartB) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int dlast = 128, PK = 8, NCH = 4, NRT = DW2_NRT;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lk = lane >> 4;
-    const int C = a.C, H = a.H, ncq = C >> 2;
-    const int n_pair = n_st >> 1, parts = gridDim.y;
-    // LDS: two buffers of { x_L images of the two tiles | x_L^T of the pair | w a of the two tiles | dX/dt of the two tiles | scales }
-    const int nRC = H >> 4, nRD = (C + 15) >> 4;      // 1 KB chunks per tile of the w a / dX/dt records
-    const int oXP = 2 * 2048, oRC = oXP + 4096, oRD = oRC + 2 * nRC * 256, oS = oRD + 2 * nRD * 256, per_buf = oS + 2 * 256;
-    // the four row tiles of this wave: weights (from the sweep's packed images: member, P-role wave, fragment), bias, accumulators
-    int hb[NRT], cq[NRT];
-    u32x4 W[NRT][NCH][2];
-    float bias[NRT];
-    f32x4 gW[NRT][PK];
-    float gb[NRT];
-#pragma unroll
-    for (int q = 0; q < NRT; ++q) {
-        const int rt = (blockIdx.x * 4 + wave) * NRT + q;
-        hb[q] = rt / ncq;
-        cq[q] = rt - hb[q] * ncq;
-        const int mem = rt / COOP_RPM, rw = (rt % COOP_RPM) / COOP_NRT, qq = rt % COOP_NRT;
-        const unsigned* wp = a.coop_img + (long long)mem * (coop_p_words() + coop_t_words()) + rw * (40 * 64 * 4);
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int pc = 0; pc < 2; ++pc) W[q][c][pc] = *reinterpret_cast<const u32x4*>(wp + ((((qq * 4 + c) * 2 + pc) * 64) + lane) * 4);
-        bias[q] = a.bo[(4 * hb[q] + (li >> 2)) * C + 4 * cq[q] + (li & 3)];
-#pragma unroll
-        for (int jt = 0; jt < PK; ++jt) gW[q][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        gb[q] = 0.0f;
-    }
-    const float sigma = coop_pow2_scale(__uint_as_float(*a.win_max)), inv_sigma = coop_pow2_inv(sigma);
-    const int my_n = (int)blockIdx.y < n_pair ? (n_pair - (int)blockIdx.y + parts - 1) / parts : 0;      // pairs blockIdx.y, + parts, ...
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    // chunk ch (1 KB: one wave instruction) of the pair-stage (sc, pr) -> buffer `buf`; the waves take chunks wave, wave + 4, ...
-    const int n_chunk = 2 * 8 + 16 + 2 * nRC + 2 * nRD + 2;
-    auto issue = [&](int sc, int pr, int buf) {
-        const long long ta = (long long)sc * n_st + 2 * pr;
-        float* base = lds + buf * per_buf;
-        for (int ch = wave; ch < n_chunk; ch += 4) {      // (wave-uniform control flow: scalar branches only)
-            const float* src;
-            float* dst;
-            int k = ch;
-            if (k < 16) { src = a.recA + (ta + (k >> 3)) * 2048 + (k & 7) * 256; dst = base + k * 256; }
-            else if ((k -= 16) < 16) { src = a.recB + ((long long)sc * n_pair + pr) * 4096 + k * 256; dst = base + oXP + k * 256; }
-            else if ((k -= 16) < 2 * nRC) { const int t2 = k >= nRC ? 1 : 0, kk = k - t2 * nRC; src = a.recC + (ta + t2) * (H * 16) + kk * 256; dst = base + oRC + k * 256; }
-            else if ((k -= 2 * nRC) < 2 * nRD) { const int t2 = k >= nRD ? 1 : 0, kk = k - t2 * nRD; src = a.recD + (ta + t2) * (C * 16) + kk * 256; dst = base + oRD + k * 256; }
-            else { k -= 2 * nRD; src = a.recS + (ta + k) * 32; dst = base + oS + k * 256; }
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + lane * 4), (lptr_t)dst, 16, 0, 0);
-        }
-    };
-    if (my_n > 0 && n_sc > 0) {
-        const int nq = n_sc * my_n;
-        int sc_n = 0, k_n = 0;      // the pair-stage to request next
-        issue(0, blockIdx.y, 0);
-        if (++k_n == my_n) { k_n = 0; ++sc_n; }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int q = 0; q < nq; ++q) {
-            const int buf = q & 1;
-            if (q + 1 < nq) {
-                issue(sc_n, blockIdx.y + parts * k_n, buf ^ 1);
-                if (++k_n == my_n) { k_n = 0; ++sc_n; }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const float* B_ = lds + buf * per_buf;
-            const unsigned* XS = reinterpret_cast<const unsigned*>(B_);
-            const unsigned* XP = reinterpret_cast<const unsigned*>(B_ + oXP);
-            u32x4 Ap[NRT][2];      // A operand of dWo: lane (row li, k-group lk) = samples 4 lk .. + 3 of tile a (dwords 0, 1), of tile b (2, 3)
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) {
-                const float* S_ = B_ + oS + t2 * 256;
-                const f32x4 isx4 = *reinterpret_cast<const f32x4*>(S_ + 4 * lk);
-                const float fT = sigma * S_[17];      // sigma / u_T
-                f32x4 pm[NRT], px[NRT];
-#pragma unroll
-                for (int i = 0; i < NRT; ++i) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pm[i][r] = bias[i] * coop_pow2_inv(isx4[r]);      // sx sw: the bias joins the scaled accumulator exactly
-                    px[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
-                const unsigned* xs = XS + t2 * 2048;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const u32x4 x0 = *reinterpret_cast<const u32x4*>(xs + ((c * 2 + 0) * 64 + lane) * 4);
-                    const u32x4 x1 = *reinterpret_cast<const u32x4*>(xs + ((c * 2 + 1) * 64 + lane) * 4);
-#pragma unroll
-                    for (int i = 0; i < NRT; ++i) pm[i] = mfma_h(x0, W[i][c][0], pm[i]);
-#pragma unroll
-                    for (int i = 0; i < NRT; ++i) px[i] = mfma_h(x0, W[i][c][1], px[i]);
-#pragma unroll
-                    for (int i = 0; i < NRT; ++i) px[i] = mfma_h(x1, W[i][c][0], px[i]);
-                }
-#pragma unroll
-                for (int i = 0; i < NRT; ++i) {
-                    const f32x4 pc = h2_combine(pm[i], px[i]);
-                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(B_ + oRC + t2 * nRC * 256 + (4 * hb[i] + (li >> 2)) * 16 + 4 * lk);
-                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(B_ + oRD + t2 * nRD * 256 + (4 * cq[i] + (li & 3)) * 16 + 4 * lk);
-                    float dps[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float th = tanh_dev(pc[r] * isx4[r]);
-                        const float dp = (a4[r] * d4[r]) * (1.0f - th * th);
-                        gb[i] += dp;
-                        dps[r] = dp * fT;
-                    }
-                    unsigned h0, l0, h1, l1;
-                    coop_split2(dps[0], dps[1], h0, l0);
-                    coop_split2(dps[2], dps[3], h1, l1);
-                    Ap[i][0][2 * t2] = h0; Ap[i][0][2 * t2 + 1] = h1;
-                    Ap[i][1][2 * t2] = l0; Ap[i][1][2 * t2 + 1] = l1;
-                }
-            }
-            // dWo += dP x_L^T: the 32 samples of the pair are K; main product into the accumulator, the two cross products through a
-            // temporary that carries 2^11 and is folded at once (the accumulators live for the whole launch)
-#pragma unroll
-            for (int jt = 0; jt < PK; ++jt) {
-                const u32x4 b0 = *reinterpret_cast<const u32x4*>(XP + ((jt * 2 + 0) * 64 + lane) * 4);
-                const u32x4 b1 = *reinterpret_cast<const u32x4*>(XP + ((jt * 2 + 1) * 64 + lane) * 4);
-                f32x4 tx[NRT];
-#pragma unroll
-                for (int i = 0; i < NRT; ++i) gW[i][jt] = mfma_h(Ap[i][0], b0, gW[i][jt]);
-#pragma unroll
-                for (int i = 0; i < NRT; ++i) tx[i] = mfma_h(Ap[i][0], b1, (f32x4){0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-                for (int i = 0; i < NRT; ++i) tx[i] = mfma_h(Ap[i][1], b0, tx[i]);
-#pragma unroll
-                for (int i = 0; i < NRT; ++i) gW[i][jt] = h2_combine(gW[i][jt], tx[i]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the next pair-stage's records: requested at the top)
-            __syncthreads();
-        }
-    }
-    // ---- this workgroup's 16 row tiles of the part's partial: sigma divided out exactly, added to what the earlier windows left ------
-    const long long wo_sz = (long long)H * C * dlast, theta_o = wo_sz + (long long)H * C;
-    float* gp = gpartB + (long long)blockIdx.y * theta_o;
-#pragma unroll
-    for (int q = 0; q < NRT; ++q) {
-#pragma unroll
-        for (int jt = 0; jt < PK; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {      // D row 4 lk + r of the tile = (state unit 4 hb + lk, channel 4 cq + r), column 16 jt + li
-                float* dst = gp + ((long long)(4 * hb[q] + lk) * C + 4 * cq[q] + r) * dlast + 16 * jt + li;
-                const float v = gW[q][jt][r] * inv_sigma;
-                *dst = a.resume ? *dst + v : v;
-            }
-        float v = gb[q];      // this lane: row li of the tile, its samples; the other three k-groups hold the rest
-        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-        if (lk == 0) {
-            float* dst = gp + wo_sz + (4 * hb[q] + (li >> 2)) * C + 4 * cq[q] + (li & 3);
-            *dst = a.resume ? *dst + v : v;
-        }
-    }
-}
-
 // ncde_reduce_partials (ncde_generic.hip) for the re-execution sequence: runs only when the cooperative sequence gave up
 __global__ __launch_bounds__(256) void ncde_reduce_partials_if(const unsigned* run_if, const float* __restrict__ gpart, int n_part, int theta_size, ReduceSegs segs) {
     if (*run_if == 0u) return;
@@ -3390,10 +3214,12 @@ struct TiledAdjPlan {
 // memory efficient"), so the per-stage records pass B consumes are kept for a WINDOW of steps only: the sweep (pass A) runs W
 // steps, the output-layer gradient pass (pass B) folds those W steps into its accumulators, and the record is reused.  The
 // default budget is sized to stay resident in the 256 MB Infinity Cache between the two passes (NCDE_FLAG_TILED_WINDOW_STEPS(n) overrides).
-long long tiled_window_budget_bytes() {
+// (round 6: the cooperative sweep's pass B, ncde_dwo_h2, reads every record ONCE per XCD -- its workgroups share them through LDS and
+// the L2 --, so its records need not stay cache-resident: 768 MB, windows of 20 steps at cfg5, measured 223 against 231 us per stage)
+long long tiled_window_budget_bytes(bool coop) {
     const char* e = ncde_dev_env("NCDE_TILED_WINDOW_MB");
     if (e && atof(e) > 0.0) return (long long)(atof(e) * (double)(1LL << 20));
-    return 192LL << 20;
+    return coop ? 768LL << 20 : 192LL << 20;
 }
 
 TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
@@ -3422,7 +3248,7 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
     const long long recA_tile = bf ? dlast * 24 : dlast * 16;      // floats per (stage, sample tile) of record A
     const long long per_step = (long long)S * t.n_st * (2 * recA_tile + (p->hidden + p->channels) * 16) * (long long)sizeof(float);
     const int steps = p->output == NCDE_OUT_TIMES ? std::max(p->n_steps_fwd, p->n_steps_adj) : p->n_knots - 1;
-    t.window = (int)std::max<long long>(1, std::min<long long>(steps, tiled_window_budget_bytes() / per_step));
+    t.window = (int)std::max<long long>(1, std::min<long long>(steps, tiled_window_budget_bytes(bf && tiled_coop_plan(p).ok) / per_step));
     const int forced = (int)((p->flags >> 16) & 0xFFu);      // NCDE_FLAG_TILED_WINDOW_STEPS(n)
     if (forced > 0) t.window = (int)std::min<long long>(steps, forced);
     t.n_sc = t.window * S;
@@ -3786,10 +3612,13 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     const dim3 gridB_pw(p->hidden * p->channels / 16 / t.nrt, t.parts_pw);
     dim3 gridB = gridB_pw;
     size_t ldsB = 0;
+    int threadsB = 256;
     if (coop) {      // the cooperative sweep writes 2-piece fp16 records: ncde_dwo_h2 folds them (16 row tiles per workgroup, records through LDS)
         fb = ncde_dwo_h2;
-        gridB = dim3(p->hidden * p->channels / 16 / 16, t.parts);
-        ldsB = sizeof(float) * 2 * (size_t)(2 * 2048 + 4096 + 2 * (p->hidden / 16) * 256 + 2 * ((p->channels + 15) / 16) * 256 + 2 * 256);
+        threadsB = 512;
+        gridB = dim3(p->hidden * p->channels / 16 / 16 * t.parts);
+        a.dw2_parts = t.parts;
+        ldsB = sizeof(float) * 2 * (size_t)(2 * 2048 + 4096 + 2 * (p->hidden / 16) * 256 + 2 * ((p->channels + 15) / 16) * 256 + 2 * 256);      // (ncde_dwo2.hip: two record buffers)
         if (ncde_lds_optin((const void*)fb, ldsB) != hipSuccess) return NCDE_ERR_HIP;
         a.recS = w + t.recS;
     }
@@ -3807,7 +3636,7 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
         if (coop && hipMemsetAsync(a.coop_sync, 0, sizeof(unsigned) * (size_t)(coop_sync_words(t.coop_G, t.n_st) + 1), st) != hipSuccess) return NCDE_ERR_HIP;
         hipLaunchKernelGGL(fa, dim3(t.n_st), dim3(64 * nwv_launch), lds, st, a);
         const int n_sc = (hi - lo) * t.S;
-        hipLaunchKernelGGL(fb, gridB, dim3(256), ldsB, st, a, n_sc, t.n_st, gB);
+        hipLaunchKernelGGL(fb, gridB, dim3(threadsB), ldsB, st, a, n_sc, t.n_st, gB);
         if (fb2) hipLaunchKernelGGL(fb2, gridB, dim3(256), 0, st, a, n_sc, t.n_st, gB2);
         if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
     }
