@@ -159,9 +159,11 @@ PadPlan make_pad_plan(const NcdeProblem* p, int pass, int target = 0) {
     P.inner = target == 0 ? 2 : 1;
     if (p->n_layers < 1 || p->field_input != NCDE_INPUT_MATMUL || p->field_kind == NCDE_FIELD_GRU) return P;
     if (p->hidden > 2048 || p->channels > 4095) return P;
-    // (target 3, round 5: (32, 32, 40) -- a forward-only kernel set: pass 0 on the default time axis)
-    const int tH = target == 2 ? 64 : 32, tHH = tH, tC = target == 1 ? 20 : (target == 2 ? 4 : 40);
+    // (target 3, round 5: (32, 32, 40) -- a forward-only kernel set: pass 0 on the default time axis; targets 4 - 6, round 6: (32, 32, 4 / 8 /
+    // 12) -- few channels, every pass, default time axis)
+    const int tH = target == 2 ? 64 : 32, tHH = tH, tC = target == 1 ? 20 : (target == 2 ? 4 : (target == 3 ? 40 : 4 * (target - 3)));
     if (target == 3 && (pass != 0 || p->output == NCDE_OUT_TIMES)) return P;
+    if (target >= 4 && p->output == NCDE_OUT_TIMES) return P;
     if (target != 0) {
         if (p->field_kind != NCDE_FIELD_ORIGINAL || p->hidden > tH || p->channels > tC) return P;
         // (any batch-tiled knob is a request for that family; the non-default adjoint variants exist for the exact shapes only)
@@ -220,7 +222,7 @@ PadPlan make_pad_plan(const NcdeProblem* p, int pass, int target = 0) {
 }
 // the padded plan a problem takes, if any: a shape-specialised kernel set first, then the batch-tiled family
 PadPlan pick_pad_plan(const NcdeProblem* p, int pass, bool allow_tiled) {
-    for (int target = 1; target <= 3; ++target) {
+    for (int target : {4, 5, 6, 1, 2, 3}) {      // (the smallest channel set that holds the problem first)
         PadPlan P = make_pad_plan(p, pass, target);
         if (P.ok) return P;
     }

@@ -16,6 +16,7 @@
 #include "ncde_fast4.h"
 #include "ncde_fast64.h"
 #include "ncde_fast_nl.h"
+#include "ncde_fast_c.h"
 #include "ncde_fast_fwd3.h"
 #include "ncde_fast_plan.h"
 // HP = 2 (the default adjoint): hidden-layer dW/db of the previous stage behind barrier A (dL/dpre images double-buffered) / all five
@@ -2919,6 +2920,46 @@ static bool use_nl(const NcdeProblem* p, const FastEntry* e, int pass) {
     if (p->flags & (NCDE_FLAG_ADJOINT_V1 | NCDE_FLAG_ADJOINT_V2 | NCDE_FLAG_ADJOINT_V4 | NCDE_FLAG_DEBUG_PROFILE | 0x200u)) return false;
     return ncde_fast_adj3_nl(p->n_layers, p->interp, p->method, nl_hp(p), pass == 2) != nullptr;
 }
+// (H, HH) = (32, 32) with C = 4 / 8 / 12 (round 6, ncde_fast_c.hip): the same kernel templates instantiated for few channels, every
+// layer count 1 .. 4, forward + continuous adjoint + exact discrete backward; default time axis, default / split-bf16 arithmetic
+static int c_set(const NcdeProblem* p) {
+    if (p->hidden != 32 || p->n_layers < 1 || p->n_layers > 4 || p->layer_out[0] != 32 || p->layer_in[0] != 32) return 0;
+    if (p->channels != 4 && p->channels != 8 && p->channels != 12) return 0;
+    if (p->field_kind != NCDE_FIELD_ORIGINAL || p->field_input != NCDE_INPUT_MATMUL || p->output == NCDE_OUT_TIMES) return 0;
+    for (int l = 1; l < p->n_layers; ++l)
+        if (p->layer_out[l] != 32 || p->layer_in[l] != 32 || p->layer_W[l] != p->layer_W[1] || p->layer_b[l] != p->layer_b[1]) return 0;
+    if (p->n_layers > 1 && (p->layer_W[1] == p->layer_W[0] || p->layer_b[1] == p->layer_b[0])) return 0;
+    if (p->flags & (NCDE_FLAG_FP32_MFMA | NCDE_FLAG_ADJOINT_V1 | NCDE_FLAG_ADJOINT_V2 | NCDE_FLAG_ADJOINT_V4 | NCDE_FLAG_ADJOINT_SPLIT_FP16 |
+                    NCDE_FLAG_DEBUG_PROFILE | 0x200u)) return 0;
+    return p->channels;
+}
+static NcdeFastCKernel c_fwd(int C, int interp, int method, int hp) {
+    return C == 4 ? ncde_fast_c4_fwd(interp, method, hp) : (C == 8 ? ncde_fast_c8_fwd(interp, method, hp) : ncde_fast_c12_fwd(interp, method, hp));
+}
+static NcdeFastCKernel c_adj(int C, int nl, int interp, int method, int hp, bool disc) {
+    return C == 4 ? ncde_fast_c4_adj(nl, interp, method, hp, disc) : (C == 8 ? ncde_fast_c8_adj(nl, interp, method, hp, disc) : ncde_fast_c12_adj(nl, interp, method, hp, disc));
+}
+static size_t c_adj_lds(int C, int nl, int interp, int hp) {
+    return C == 4 ? ncde_fast_c4_adj_lds(nl, interp, hp) : (C == 8 ? ncde_fast_c8_adj_lds(nl, interp, hp) : ncde_fast_c12_adj_lds(nl, interp, hp));
+}
+static bool use_c(const NcdeProblem* p, int pass) {
+    const int C = c_set(p);
+    if (!C) return false;
+    if (pass == 0) return c_fwd(C, p->interp, p->method, 1) != nullptr;
+    return c_adj(C, p->n_layers, p->interp, p->method, nl_hp(p), pass == 2) != nullptr && c_adj(C, p->n_layers, p->interp, p->method, 0, pass == 2) != nullptr;
+}
+static const char* c_name(const NcdeProblem* p, int pass) {
+    static char buf[3][5][3][2][96];      // [channel set][layers][pass][split]: filled on first use (idempotent: racing threads write the same bytes)
+    const int C = p->channels, ci = C == 4 ? 0 : (C == 8 ? 1 : 2), bf = (p->flags & NCDE_FLAG_SPLIT_BF16) ? 1 : 0;
+    char* b = buf[ci][p->n_layers][pass][bf];
+    if (!b[0]) {
+        char tmp[96];
+        if (pass == 0) snprintf(tmp, sizeof(tmp), "ncde_fwd_fast_bf3<H32,HH32,C%d,NW4,%s>", C, bf ? "bf16x3" : "fp16x2");
+        else snprintf(tmp, sizeof(tmp), "ncde_adj_fast3<H32,HH32,C%d,NL%d,chain+grad,%s%s>", C, p->n_layers, bf ? "bf16x3" : "fwd-side fp16x2 + bf16x3", pass == 2 ? ",discrete" : "");
+        memcpy(b, tmp, sizeof(tmp));
+    }
+    return b;
+}
 // H = HH = 64, C <= 4: the in-sweep adjoint of ncde_fast64.hip (the entry's own adjoint slots are empty; C < 4 has no entry at all)
 static bool use_h64(const NcdeProblem* p, int pass) { return pass >= 1 && ncde_fast64_supported(p, pass); }
 
@@ -2934,6 +2975,7 @@ static bool planned_ok(const NcdeProblem* p, const FastEntry* e, int pass) {
 
 bool ncde_fast_supported(const NcdeProblem* p, int pass) {
     if (use_h64(p, pass)) return true;
+    if (use_c(p, pass)) return true;
     const FastEntry* e = find_entry(p);
     if (p->output == NCDE_OUT_TIMES) return planned_ok(p, e, pass);
     if (!e) return false;
@@ -2945,6 +2987,7 @@ bool ncde_fast_supported(const NcdeProblem* p, int pass) {
 
 const char* ncde_fast_kernel_name(const NcdeProblem* p, int pass) {
     if (use_h64(p, pass)) return ncde_fast64_kernel_name(p, pass);
+    if (use_c(p, pass)) return c_name(p, pass);
     if (!ncde_fast_supported(p, pass)) return nullptr;
     const FastEntry* e = find_entry(p);
     if (p->output == NCDE_OUT_TIMES) {
@@ -2971,6 +3014,7 @@ static int64_t fault_bytes(const Layout& y) { return ((int64_t)y.n_wg * 4 + 255)
 
 int64_t ncde_fast_workspace_bytes(const NcdeProblem* p, int pass) {
     if (use_h64(p, pass)) return ncde_fast64_workspace_bytes(p, pass);
+    // (the few-channel instances of ncde_fast_c.hip use the generic layout below: partials + fault words)
     if (!ncde_fast_supported(p, pass)) return NCDE_ERR_UNSUPPORTED;
     const Layout y = make_layout(p);
     if (pass == 0) return ((p->flags & NCDE_FLAG_DEBUG_PROFILE) ? 256 + (int64_t)y.n_wg * 8 * 4 * 8 : 256) + fault_bytes(y);
@@ -2981,6 +3025,21 @@ int64_t ncde_fast_workspace_bytes(const NcdeProblem* p, int pass) {
 
 int ncde_fast_forward(const NcdeProblem* p, float* out, float* stages, void* ws, size_t ws_bytes, hipStream_t st) {
     (void)ws_bytes;
+    if (use_c(p, 0)) {      // few channels: ncde_fast_c.hip's instances, the launch protocol of the split-fp16 forward below
+        const Layout y = make_layout(p);
+        KArgs a;
+        fill_kargs(p, y, &a);
+        a.out = out;
+        a.stages = stages;
+        const int hp = (p->flags & NCDE_FLAG_SPLIT_BF16) ? 0 : 1;
+        a.fault = hp ? reinterpret_cast<int*>(static_cast<char*>(ws) + ncde_fast_workspace_bytes(p, 0) - fault_bytes(y)) : nullptr;
+        hipLaunchKernelGGL(c_fwd(p->channels, p->interp, p->method, hp), dim3(y.n_wg), dim3(256), 0, st, a);
+        if (hp) {      // re-execution of range-faulted tiles in split-bf16 (normally none: every workgroup exits at once)
+            a.only_faulted = 1;
+            hipLaunchKernelGGL(c_fwd(p->channels, p->interp, p->method, 0), dim3(y.n_wg), dim3(256), 0, st, a);
+        }
+        return hipGetLastError() == hipSuccess ? NCDE_OK : NCDE_ERR_HIP;
+    }
     const FastEntry* e = find_entry(p);
     if (!e) return NCDE_ERR_UNSUPPORTED;
     FwdFn fn = e->fwd(p->interp, p->method);
@@ -3020,6 +3079,28 @@ int ncde_fast_adjoint(const NcdeProblem* p, const float* z_out, const float* gra
                       size_t ws_bytes, hipStream_t st, bool main_kernel_only, bool discrete) {
     if (use_h64(p, discrete ? 2 : 1)) return ncde_fast64_adjoint(p, z_out, grad_out, g, ws, ws_bytes, st, main_kernel_only, discrete);
     if (!ncde_fast_supported(p, discrete ? 2 : 1)) return NCDE_ERR_UNSUPPORTED;
+    if (use_c(p, discrete ? 2 : 1)) {      // few channels: the same kernel template and launch protocol as the other layer counts below
+        const int hp = nl_hp(p);
+        const Layout y = make_layout(p);
+        KArgs a;
+        fill_kargs(p, y, &a);
+        a.grad_out = grad_out; a.grad_z0 = g->grad_z0;
+        if (discrete) { a.stages = const_cast<float*>(z_out); a.discrete = 1; }
+        else a.z_out = z_out;
+        a.gpart = (float*)ws;
+        a.fault = hp ? reinterpret_cast<int*>(static_cast<char*>(ws) + ncde_fast_workspace_bytes(p, discrete ? 2 : 1) - fault_bytes(y)) : nullptr;
+        for (int pass_hp : {hp, 0}) {      // main launch, then (hp = 2) the split-bf16 instance on range-faulted tiles only
+            NcdeFastCKernel fn = c_adj(p->channels, p->n_layers, p->interp, p->method, pass_hp, discrete);
+            const size_t lds = c_adj_lds(p->channels, p->n_layers, p->interp, pass_hp);
+            if (!fn || ncde_lds_optin((const void*)fn, lds) != hipSuccess) return NCDE_ERR_HIP;
+            hipLaunchKernelGGL(fn, dim3(y.n_wg), dim3(512), lds, st, a);
+            if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
+            if (hp == 0) break;
+            a.only_faulted = 1;
+        }
+        if (main_kernel_only) return NCDE_OK;
+        return launch_reduce_partials(p, y, g, (const float*)ws, y.n_wg, st);
+    }
     const FastEntry* e = find_entry(p);
     if (p->output == NCDE_OUT_TIMES) {      // general time axis: the PLAN = 1 instances of the same kernel template, same launch protocol
         if (discrete || !planned_ok(p, e, 1)) return NCDE_ERR_UNSUPPORTED;

@@ -853,7 +853,8 @@ def test_forward_only_kernel_set_for_up_to_40_channels(shape, interp, method, se
     assert rt["kernels"][0].startswith("ncde_fwd_tiled") and gu.relerr(rt["z_out"], res["z_out"]) <= TIGHT_Z
 
 
-@pytest.mark.parametrize("shape", [(5, 16, 15, 3), (20, 32, 15, 1), (3, 7, 15, 2), (17, 30, 32, 3),      # -> (32, 32, 20)
+@pytest.mark.parametrize("shape", [(5, 16, 15, 3), (20, 32, 15, 1), (3, 7, 15, 2), (17, 30, 32, 3),      # -> (32, 32, 8 | 20 | 4 | 20)
+                                   (4, 32, 15, 3), (8, 32, 32, 4), (12, 20, 15, 1), (9, 32, 32, 3),       # -> (32, 32, 4 | 8 | 12 | 12)
                                    (4, 47, 32, 3), (3, 64, 15, 2), (2, 40, 64, 1)])                           # -> (64, 64, 4)
 @pytest.mark.parametrize("interp,method,seq", [("linear", "rk4", True), ("cubic", "midpoint", False)])
 def test_small_shapes_zero_padded_onto_the_specialised_kernels(shape, interp, method, seq, gpu_lib):
@@ -868,7 +869,10 @@ def test_small_shapes_zero_padded_onto_the_specialised_kernels(shape, interp, me
     ex = case["expect"]
     res = gpu_util.run_case(case)
     big = H > 32 or HH > 32
-    want = ("ncde_fwd_fast_bf3<H64,HH64,C4", "ncde_adj_h64<H64") if big else ("ncde_fwd_fast_bf3<H32,HH32,C20", "ncde_adj_fast3<H32,HH32,C20,NL%d" % nl)
+    cset = 4 if C <= 4 else (8 if C <= 8 else (12 if C <= 12 else 20))      # round 6: few channels have their own instantiations
+    if nl == 4 and interp == "cubic" and not big:      # (the cubic path's LDS plan with four layers: C = 20 does not fit, the smaller sets may)
+        cset = None
+    want = ("ncde_fwd_fast_bf3<H64,HH64,C4", "ncde_adj_h64<H64") if big else ("ncde_fwd_fast_bf3<H32,HH32,C%s" % (cset or ""), "ncde_adj_fast3<H32,HH32,C%s" % ("%d,NL%d" % (cset, nl) if cset else ""))
     assert res["kernels"][0].startswith(want[0]) and res["kernels"][1].startswith(want[1]) and "discrete" in res["kernels"][2], res["kernels"]
     assert gu.relerr(res["z_out"], ex["z_out"]) <= TIGHT_Z
     for k, e in _grad_errors(case, res).items():

@@ -109,11 +109,16 @@ def test_kernel_family_selection():
     p = _problem()                                    # BASELINE cfg2 shape -> specialised kernels
     assert name(p, 0).startswith("ncde_fwd_fast") and name(p, 1).startswith("ncde_adj_fast")
     assert name(_problem(flags=_lib.FLAG_FORCE_GENERIC), 0) == "ncde_fwd_generic"
-    q = _problem(C=5, H=16, HH=24)                    # arbitrary small shape -> zero-padded onto the (32, 32, 20) specialised kernels
-    assert name(q, 0).startswith("ncde_fwd_fast_bf3<H32,HH32,C20") and name(q, 1).startswith("ncde_adj_fast3<H32,HH32,C20") and "discrete" in name(q, 2)
+    q = _problem(C=5, H=16, HH=24)                    # arbitrary small shape -> zero-padded onto the smallest register-resident set that
+    # holds it: (32, 32, 8) of round 6's few-channel sets (C = 4 / 8 / 12), (32, 32, 20) above 12 channels
+    assert name(q, 0).startswith("ncde_fwd_fast_bf3<H32,HH32,C8") and name(q, 1).startswith("ncde_adj_fast3<H32,HH32,C8,NL3") and "discrete" in name(q, 2)
     wq = lib.ncde_workspace_bytes(ctypes.byref(q), 1)
-    q20 = _problem(C=20, H=32, HH=32)                 # the shape it is padded to: same kernels, workspace without the padded copies
-    assert name(q20, 1) == name(q, 1) and 0 < lib.ncde_workspace_bytes(ctypes.byref(q20), 1) < wq
+    q8 = _problem(C=8, H=32, HH=32)                   # the shape it is padded to: same kernels, workspace without the padded copies
+    assert name(q8, 1) == name(q, 1) and 0 < lib.ncde_workspace_bytes(ctypes.byref(q8), 1) < wq
+    for C, cset in ((1, 4), (4, 4), (7, 8), (9, 12), (12, 12), (13, 20), (20, 20)):
+        d = _problem(C=C, H=32, HH=15)                # the reference's default hidden_hidden_dim (src/ncde/ncde.py:47)
+        assert name(d, 0).startswith("ncde_fwd_fast_bf3<H32,HH32,C%d," % cset) and name(d, 1).startswith("ncde_adj_fast3<H32,HH32,C%d," % cset), (C, name(d, 0), name(d, 1))
+        assert "discrete" in name(d, 2) and ("C%d," % cset) in name(d, 2)
     q.flags = _lib.FLAG_FORCE_TILED                   # ... onto the batch-tiled family (C 8, HH 32) when that is asked for, or when the
     assert name(q, 0).startswith("ncde_fwd_tiled") and name(q, 1).startswith("ncde_adj_tiled")      # shape is beyond the specialised ones
     w = _problem(C=21, H=47, HH=93)
