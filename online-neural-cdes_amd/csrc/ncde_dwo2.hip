@@ -95,11 +95,22 @@ __device__ __forceinline__ void dwo_h2_body(const KArgs& a, int n_sc, int n_st, 
         else { k -= 2 * nRD; cst = (a.recS - a.recA) + (long long)k * 32; ssc = n_st * 32; spr = 64; sl = oS + k * 256; }
         s_const[j] = cst; s_sc[j] = ssc; s_pr[j] = spr; s_lds[j] = sl;
     }
-    auto issue = [&](int sc, int pr, int buf) {
+    // (the chunk offsets RUN: pair-stage after pair-stage a slot's offset grows by `parts` pairs, or -- at the last pair of a stage -- by
+    // one stage minus the pairs walked: two scalar adds per chunk instead of two 64-bit multiply-adds)
+    const int my_n_ = by < n_pair ? (n_pair - by + parts - 1) / parts : 0;
+    long long s_off[NSLOT];
+    int s_dpr[NSLOT], s_dsc[NSLOT];
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+        s_off[j] = s_const[j] + (long long)by * s_pr[j];
+        s_dpr[j] = parts * s_pr[j];
+        s_dsc[j] = s_sc[j] - (my_n_ - 1) * parts * s_pr[j];
+    }
+    auto issue = [&](bool wrap, int buf) {      // fetch the pair-stage the running offsets point at, then advance them (wrap: to the next stage)
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) {
-            const float* src = a.recA + (s_const[j] + (long long)sc * s_sc[j] + (long long)pr * s_pr[j]);
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + lane * 4), (lptr_t)(lds + buf * per_buf + s_lds[j]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.recA + s_off[j] + lane * 4), (lptr_t)(lds + buf * per_buf + s_lds[j]), 16, 0, 0);
+            s_off[j] += wrap ? s_dsc[j] : s_dpr[j];
         }
     };
 #ifdef NCDE_DW2_PROF
@@ -122,6 +133,9 @@ __device__ __forceinline__ void dwo_h2_body(const KArgs& a, int n_sc, int n_st, 
         for (int t2 = 0; t2 < 2; ++t2) {
             const float* S_ = B_ + oS + t2 * 256;
             const f32x4 isx4 = *reinterpret_cast<const f32x4*>(S_ + 4 * lk);
+            f32x4 isx2;      // (powers of two times the tanh pre-scale: the same bits as scaling first)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) isx2[r] = isx4[r] * NCDE_TANH_PRESCALE;
             const float fT = sigma * S_[17];      // sigma / u_T
             auto lda = [&](int i) { return *reinterpret_cast<const f32x4*>(B_ + oRC + t2 * nRC * 256 + (4 * hb[i] + (li >> 2)) * 16 + 4 * lk); };
             auto ldd = [&](int i) { return *reinterpret_cast<const f32x4*>(B_ + oRD + t2 * nRD * 256 + (4 * cq[i] + (li & 3)) * 16 + 4 * lk); };
@@ -165,7 +179,7 @@ __device__ __forceinline__ void dwo_h2_body(const KArgs& a, int n_sc, int n_st, 
                 float dps[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float th = tanh_dev(pc[r] * isx4[r]);
+                    const float th = tanh_prescaled(pc[r] * isx2[r]);
                     const float dp = (a4[r] * d4[r]) * (1.0f - th * th);
                     gb[i] += dp;
                     dps[r] = dp * fT;
@@ -225,16 +239,16 @@ __device__ __forceinline__ void dwo_h2_body(const KArgs& a, int n_sc, int n_st, 
     // two waves fill each other's gaps.)
     if (my_n > 0 && n_sc > 0) {
         const int nq = n_sc * my_n;
-        int sc_n = 0, k_n = 0;      // the pair-stage to request next
-        issue(0, by, 0);
-        if (++k_n == my_n) { k_n = 0; ++sc_n; }
+        int k_n = 0;      // index, within its stage, of the pair-stage to request next
+        issue(k_n + 1 == my_n, 0);
+        if (++k_n == my_n) k_n = 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int q = 0; q < nq; ++q) {
             const int buf = q & 1;
             if (q + 1 < nq) {
-                issue(sc_n, by + parts * k_n, buf ^ 1);
-                if (++k_n == my_n) { k_n = 0; ++sc_n; }
+                issue(k_n + 1 == my_n, buf ^ 1);
+                if (++k_n == my_n) k_n = 0;
             }
             __builtin_amdgcn_sched_barrier(0);
             DW2_TICK(0)

@@ -1004,6 +1004,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                         const float* bxs = CBX + (buf * 2 + half_w) * 2048;
                         const float isx = CSC[(buf * 2 + half_w) * 64 + 16 + li];
                         const float sxw = coop_pow2_inv(isx);      // sx sw: the bias joins the scaled accumulator exactly
+                        const float isx2 = isx * NCDE_TANH_PRESCALE;      // (isx is a power of two: folded into the tanh pre-scale, bit for bit)
                         float kk = 0.0f;
                         // (k is a compile-time constant after unrolling: fragments below FWD_KREG are registers, the rest LDS reads)
                         auto wfr = [&](int k) -> u32x4 {
@@ -1040,7 +1041,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                                 const f32x4 pc4 = h2_combine(pm[i], px[i]);
                                 const f32x4 dxv = *reinterpret_cast<const f32x4*>(CDX + (buf * 2 + half_w) * 1280 + ((cq0 + Q0 + i) * NSP + li) * 4);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) kk = fmaf(tanh_dev(pc4[r] * isx), dxv[r], kk);
+                                for (int r = 0; r < 4; ++r) kk = fmaf(tanh_prescaled(pc4[r] * isx2), dxv[r], kk);
                             }
                         };
                         p_batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
@@ -2101,7 +2102,9 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                                 const float isx = CSC[buf * 64 + 16 + li], sd = CSC[buf * 64 + 32 + li];
                                 if (wave == 0 && lane < 16) CIS[buf * 16 + lane] = CSC[buf * 64 + 48 + lane];
                                 const float sxw = coop_pow2_inv(isx);      // sx sw: the bias joins the scaled accumulator exactly
-                                const float aval = CAS[buf * 256 + (hl_w * NSP + li) * 4 + lk];
+                                // (isx and sd are powers of two: folding them into the tanh pre-scale and into the cotangent changes no bit)
+                                const float isx2 = isx * NCDE_TANH_PRESCALE;
+                                const float asd = CAS[buf * 256 + (hl_w * NSP + li) * 4 + lk] * sd;
                                 float kk = 0.0f;
                                 unsigned* dpx = reinterpret_cast<unsigned*>(CDP) + buf * (10 * 2 * 64 * 4);
                                 // P = Wo x_L on the f16 matrix cores, main (h1 h1, starts at the scaled bias) and cross (h1 h2 + h2 h1)
@@ -2138,9 +2141,9 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                                         float dps[4];
 #pragma unroll
                                         for (int r = 0; r < 4; ++r) {
-                                            const float th = tanh_dev(pc4[r] * isx);
+                                            const float th = tanh_prescaled(pc4[r] * isx2);
                                             kk = fmaf(th, dxv[r], kk);
-                                            dps[r] = ((aval * dxv[r]) * (1.0f - th * th)) * sd;
+                                            dps[r] = (asd * dxv[r]) * (1.0f - th * th);
                                         }
                                         // this tile's half of its pair's B operand: the lane's own four values (k = 8 g + 4 (tile & 1) + r)
                                         const int rtl = rw * COOP_NRT + Q0 + i, pr = rtl >> 1, half = rtl & 1;

@@ -4,7 +4,7 @@
 # Writes under gpurun_out/prof_<cfg>/ and the summary gpurun_out/${ROUND}_pmc_<cfg>_summary.json; copy what is to be judged into profiles/.
 set -u
 CFG=${1:-cfg2}; shift || true
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 DEFB=4096; [ "$CFG" = cfg4 ] && DEFB=8192      # (per-GPU batch of the config: bench.py matches the summary on it)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$CFG

@@ -4,7 +4,7 @@ time-step loop of each dispatched instantiation, from `llvm-objdump -d` of the g
 at the issue rates of /opt/skills/guides/MI355X_MICROARCH.md -> the per-launch time the VALU pipe and the matrix pipe need AT LEAST
 for this instruction stream (`valu_ceiling_ms`, `mfma_ceiling_ms` of bench.py's roofline records).
 
-    python tools/isa_census.py            # -> profiles/r05_isa_census.json (+ a table on stdout)
+    python tools/isa_census.py            # -> profiles/r06_isa_census.json (+ a table on stdout)
     python tools/isa_census.py --list ncde_fast      # kernel symbols of one object
 
 How a count becomes a time: natural loops of the kernel's control-flow graph (dominator analysis on the disassembly); every
@@ -314,7 +314,7 @@ def census_for(keys=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--list", default=None, help="object name (e.g. ncde_fast): print its kernel symbols and loop structure")
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_isa_census.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_isa_census.json"))
     a = ap.parse_args()
     if a.list:
         dis = disassemble(os.path.join(ROOT, "online-neural-cdes_amd", "csrc", a.list + ".o"))

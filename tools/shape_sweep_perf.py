@@ -4,7 +4,7 @@ T = 99 (rectilinear, RK4) and compare each shape's time PER ALGORITHMIC FLOP wit
 Round 5: `frac_fwd` / `frac_adj` = the shape's own ALGORITHMIC fp32 flops (forward; 3 x forward for the adjoint)
 per second over the 157.3 TFLOP/s fp32 MFMA / vector peak -- the absolute column beside the self-relative ratios -- and a wider grid
 (H up to 256, C up to 100: the batch-tiled backward of round 5).
-Run on the GPU box:  python tools/shape_sweep_perf.py [--quick] > profiles/r05_shape_sweep_perf.txt"""
+Run on the GPU box:  python tools/shape_sweep_perf.py [--quick] > profiles/r06_shape_sweep_perf.txt"""
 import ctypes, itertools, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
