@@ -579,8 +579,10 @@ _DOPRI5_OPTIONS = ("min_step", "max_step", "first_step", "safety", "ifactor", "d
 
 
 def _run_unfused(reason, X, func, z0, t, adjoint, vector_field_type, method, options, adjoint_params, rtol, atol, adjoint_rtol,
-                 adjoint_atol, adjoint_options):
-    """Outside the fused kernels: the own unfused torch-op solver, same algorithms (unfused.py), on the tensors' device."""
+                 adjoint_atol, adjoint_options, warned=False):
+    """Outside the fused kernels: the own unfused torch-op solver, same algorithms (unfused.py), on the tensors' device.
+    warned: the caller has already been through the fused path's argument checks (a shape without a fused kernel is discovered after
+    them), so the reference's warnings -- unexpected arguments, control buffers requiring gradients -- are not repeated."""
     from . import unfused
     options = dict(options)
     if not z0.is_cuda:
@@ -600,8 +602,9 @@ def _run_unfused(reason, X, func, z0, t, adjoint, vector_field_type, method, opt
         raise NotImplementedError("options['grid_constructor'] is not supported; give options={'step_size': h}")
     options.pop("perturb", None)
     for k in options:
-        warnings.warn("cdeint: Unexpected arguments {}".format({k: options[k]}))
-    if adjoint:
+        if not warned:
+            warnings.warn("cdeint: Unexpected arguments {}".format({k: options[k]}))
+    if adjoint and not warned:
         ids = set(id(q) for q in adjoint_params) if adjoint_params is not None else set()
         for buffer in X.buffers():
             if buffer.requires_grad and id(buffer) not in ids:      # the reference's warning (solver.py:207-221)
@@ -673,9 +676,9 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
 
     z0_in = z0      # (z0 is flattened further down; the unfused solver takes it as given)
 
-    def unfused_(reason):
+    def unfused_(reason, warned=False):
         return _run_unfused(reason, X, func, z0_in, t, adjoint, vector_field_type, method, options_in, adjoint_params, rtol, atol,
-                            adjoint_rtol, adjoint_atol, adjoint_options)
+                            adjoint_rtol, adjoint_atol, adjoint_options, warned)
 
     reason = _unfused_reason(X, func, z0, t, adjoint, adjoint_params, method)
     if reason is not None:
@@ -761,7 +764,7 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
                                                   atol if adjoint_atol is None else adjoint_atol, bopt)}
         why = _no_kernel_reason(build_problem(coeffs, X.interp_name, z0.detach(), spec, "rk4", _lib.OUT_INTERVAL, flags), passes, cfg["adaptive"].ts)
         if why is not None:
-            return unfused_(why)
+            return unfused_(why, warned=True)
         out = (_FusedDopri5 if adjoint else _FusedDopri5Taped).apply(z0, coeffs.detach(), cfg, *uniq)
         if len(batch_shape) != 1:
             out = out.reshape(*batch_shape, out.shape[-2], out.shape[-1])
@@ -780,7 +783,7 @@ def cdeint(X, func, z0, t, adjoint=True, vector_field_type="matmul", **kwargs):
         nfe = nfe_adj = stages * (X.n_knots - 1)
     why = _no_kernel_reason(build_problem(coeffs, X.interp_name, z0.detach(), spec, method, output, flags, plan), passes)
     if why is not None:
-        return unfused_(why)
+        return unfused_(why, warned=True)
     cfg = {"spec": spec, "interp": X.interp_name, "method": method, "output": output, "flags": flags, "plan": plan, "needs_grad": needs_grad,
            "adjoint": bool(adjoint), "func": func, "nfe_per_solve": nfe, "nfe_adjoint": nfe_adj, "adjoint_param_ids": ap}
     out = _FusedCdeint.apply(z0, coeffs.detach(), cfg, *uniq)
