@@ -88,6 +88,8 @@ struct KArgs {
     float* recS;
     unsigned* win_max;
     int dw2_parts;           // ncde_dwo_h2: part-groups (its grid is 1-D: row groups x parts)
+    int dw2_accum;           // ncde_dwo_h2: add to the partial in gpartB (a later time window, or a later batch chunk) instead of overwriting it
+    int Brec;                // batch stride of the stage record when this launch covers a CHUNK of the batch (0: = B)
     unsigned* coop_status;
     const unsigned* run_if;
     unsigned coop_spin;      // polls of a group counter before giving up

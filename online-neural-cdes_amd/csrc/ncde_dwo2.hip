@@ -283,13 +283,13 @@ __device__ __forceinline__ void dwo_h2_body(const KArgs& a, int n_sc, int n_st, 
             for (int r = 0; r < 4; ++r) {      // D row 4 lk + r of the tile = (state unit 4 hb + lk, channel 4 cq + r), column 16 jt + li
                 float* dst = gp + ((long long)(4 * hb[q] + lk) * C + 4 * cq[q] + r) * dlast + 16 * jt + li;
                 const float v = gW[q][jt][r] * inv_sigma;
-                *dst = a.resume ? *dst + v : v;
+                *dst = a.dw2_accum ? *dst + v : v;
             }
         float v = gb[q];      // this lane: row li of the tile, its samples; the other three k-groups hold the rest
         v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
         if (lk == 0) {
             float* dst = gp + wo_sz + (4 * hb[q] + (li >> 2)) * C + 4 * cq[q] + (li & 3);
-            *dst = a.resume ? *dst + v : v;
+            *dst = a.dw2_accum ? *dst + v : v;
         }
     }
 }

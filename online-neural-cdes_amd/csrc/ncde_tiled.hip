@@ -855,7 +855,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
             }
             if (a.stages) {  // record the stage input for the exact discrete backward
                 const int Hr = a.Hr;
-                float* rec = a.stages + ((long long)(n * S + j) * a.B + b0) * Hr;
+                float* rec = a.stages + ((long long)(n * S + j) * (a.Brec ? a.Brec : a.B) + b0) * Hr;      // (Brec: this launch is a chunk of the batch)
                 for (int e = tid; e < NSP * Hr; e += NT) {
                     const int s = e / Hr, u = e - s * Hr;
                     if (b0 + s < a.B) rec[e] = YS[((u >> 2) * NSP + s) * 4 + (u & 3)];
@@ -1518,7 +1518,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
     // plan mode is pinned to the reference
     // (the all-resident variant, RES = 1, is the latency-critical one -- cfg4: +6 % with the plan's extra live state -- and runs
     // the default axis only: the host sends planned problems to RES = 2 / streamed kernels)
-    const bool planned = RES != 1 && COOP == 0 && a.plan != nullptr;      // (the cooperative sweep runs the default axis: the host's choice)
+    const bool planned = RES != 1 && a.plan != nullptr;      // (round 6: the cooperative sweep walks the plan too)
     if (planned && !plan_header_ok(a, S)) return;      // (uniform: before the first barrier)
     const int pw_ = plan_step_words(S);
     const int* pfwd = planned ? a.plan + plan_off_fwd() : nullptr;
@@ -1723,7 +1723,7 @@ __global__ __launch_bounds__(64 * NWV) void ncde_adj_tiled(KArgs a) {
                 dxn[q] = e < NSP * C ? dx_value(e, sdn) : 0.0f;
             }
         }
-        recn = disc ? a.stages + ((long long)((n - 1) * S + (S - 1 - j)) * a.B + b0) * a.Hr : nullptr;
+        recn = disc ? a.stages + ((long long)((n - 1) * S + (S - 1 - j)) * (a.Brec ? a.Brec : a.B) + b0) * a.Hr : nullptr;
         if (disc) {
             const int Hr = a.Hr;
             const float* rec = recn;
@@ -3063,7 +3063,8 @@ bool tiled_adj_bf(const NcdeProblem* p) {
 // ---- XCD-cooperative output phase (ncde_coop.h) --------------------------------------------------------------------------------------
 struct CoopPlan {
     bool ok;
-    int M, G;      // members per group, groups
+    int M, G;      // members per group, groups of ONE launch
+    int chunk;     // sample tiles per launch: all of them, or -- round 6, more tiles than CUs -- the largest multiple of M that is resident at once
 };
 constexpr int kCoopLdsFloats = 2 * 10 * 2 * 64 * 4 + 2 * 8 * 64 * 4 + 2 * 80 * 16 + 2 * 256 + 2 * 64 + 2 * 4 * 64 + 2 * 16 + 8;      // = COOP_LDS of ncde_adj_tiled
 size_t tiled_coop_lds(const NcdeProblem* p) {
@@ -3125,9 +3126,9 @@ void coop_mark_in_flight(hipStream_t st) {      // after the last cooperative la
 // state-unit blocks: C/4 in {5, 10, 20}) in registers.  Original field, matmul input, last hidden width 128, H <= 128, and every
 // workgroup resident at once (one per CU).
 CoopPlan tiled_coop_plan(const NcdeProblem* p) {
-    CoopPlan c{false, 0, 0};
+    CoopPlan c{false, 0, 0, 0};
     if (p->flags & (NCDE_FLAG_NO_COOP | NCDE_FLAG_FP32_MFMA | NCDE_FLAG_DEBUG_PROFILE)) return c;
-    if (p->field_kind != NCDE_FIELD_ORIGINAL || p->field_input != NCDE_INPUT_MATMUL || p->n_layers < 1 || p->output == NCDE_OUT_TIMES) return c;
+    if (p->field_kind != NCDE_FIELD_ORIGINAL || p->field_input != NCDE_INPUT_MATMUL || p->n_layers < 1) return c;      // (any time axis: round 6)
     if (p->layer_out[p->n_layers - 1] != 128 || p->hidden > 128 || p->hidden % 16 || p->channels % 4) return c;
     const int ncq = p->channels / 4;
     if (ncq != 5 && ncq != 10 && ncq != 20) return c;
@@ -3135,11 +3136,14 @@ CoopPlan tiled_coop_plan(const NcdeProblem* p) {
     if (row_tiles % COOP_RPM) return c;
     c.M = row_tiles / COOP_RPM;
     const int n_tiles = (p->batch + 15) / 16;
-    if (c.M < 4 || c.M % 4 || n_tiles % c.M || n_tiles > tiled_device_cus()) return c;
-    c.G = n_tiles / c.M;
+    if (c.M < 4 || c.M % 4 || n_tiles % c.M || c.M > tiled_device_cus()) return c;
+    // every workgroup of a launch must be resident at once (one per CU): a batch of more tiles runs as several launches over CHUNKS of the
+    // batch, one after the other on the stream (samples are independent; the parameter-gradient partials add up)
+    c.chunk = std::min(n_tiles, tiled_device_cus() / c.M * c.M);
+    c.G = c.chunk / c.M;
     if (tiled_coop_lds(p) > (size_t)kLdsLimit) return c;
     CoopDims d{p->hidden, p->channels, 128, c.M, c.G};
-    if (d.per_tile() * n_tiles * 4 > 0x7ff00000LL) return c;      // the exchange area is addressed with 32-bit byte offsets
+    if (d.per_tile() * c.chunk * 4 > 0x7ff00000LL) return c;      // the exchange area is addressed with 32-bit byte offsets
     c.ok = true;
     return c;
 }
@@ -3152,7 +3156,7 @@ size_t tiled_adj_lds(const NcdeProblem* p) {
 // the partials.  Workspace regions (float offsets) behind the split-fp16 forward's own [h2 copy | bf16 copy | fault words].
 struct FwdCoopPlan {
     bool ok;
-    int M, G;
+    int M, G, chunk;
     long long img, x, scale, sync, end;
 };
 constexpr int kFwdCoopLdsFloats = 2 * 2 * 2048 + 2 * 2 * 1280 + 2 * 2 * 64 + 2 * 8 * 64 + 8 * 16 + 64 + 320 + 4 * 4 * 256 + 8;      // = CBX .. CFL of ncde_fwd_tiled
@@ -3168,11 +3172,12 @@ FwdCoopPlan tiled_fwd_coop_plan(const NcdeProblem* p) {
     long long off = 64 + tiled_pack_floats(p, false) + tiled_pack_floats(p, true) + tiled_fault_floats(p);
     off = (off + 63) & ~63LL;
     f.img = off; off += (long long)c.M * (coop_p_words() + coop_t_words());
-    f.x = off; off += d.per_tile_fwd() * n_tiles;
+    f.x = off; off += d.per_tile_fwd() * c.chunk;
     f.scale = off; off += 64;      // [0] sw, [1] 1 / sw, [8] max |Wo| bits, [16] the call's status word (KArgs.coop_status)
-    f.sync = off; off += 64 + coop_sync_words(c.G, n_tiles);
+    f.sync = off; off += 64 + coop_sync_words(c.G, c.chunk);
     f.end = off + 64;
-    f.ok = true; f.M = c.M; f.G = c.G;
+    f.ok = true; f.M = c.M; f.G = c.G; f.chunk = c.chunk;
+    (void)n_tiles;
     return f;
 }
 
@@ -3209,7 +3214,7 @@ struct TiledAdjPlan {
     long long theta_o;
     // cooperative output phase: packed weight images, exchange area, {absmax bits, sw, 1/sw}, sync words
     bool coop;
-    int coop_M, coop_G;
+    int coop_M, coop_G, coop_chunk;
     long long coop_img, coop_x, coop_scale, coop_sync, coop_state;
 };
 
@@ -3272,10 +3277,10 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
     t.parts = 1;
     while (t.parts < 64 && (row_tiles / t.nrt) * 4 * t.parts < 4096 && 4 * t.parts * 2 <= t.n_st) t.parts *= 2;
     t.parts_pw = t.parts;
-    const CoopPlan cp = bf ? tiled_coop_plan(p) : CoopPlan{false, 0, 0};
+    const CoopPlan cp = bf ? tiled_coop_plan(p) : CoopPlan{false, 0, 0, 0};
     if (cp.ok) {      // ncde_dwo_h2: 16 row tiles per workgroup, the sample-tile pairs of a stage split over `parts` workgroups
         int pp = 1;
-        while (pp * 2 <= 32 && pp * 2 <= t.n_st / 2) pp *= 2;
+        while (pp * 2 <= 32 && pp * 2 <= cp.chunk / 2) pp *= 2;
         t.parts = pp;
     }
     t.gpartB = off; off += (long long)std::max(t.parts, t.parts_pw) * t.theta_o * (p->field_kind == NCDE_FIELD_MINIMAL ? 2 : 1);
@@ -3284,16 +3289,16 @@ TiledAdjPlan tiled_adj_plan(const NcdeProblem* p, const Layout& y) {
     t.pack_bf = off; off += (bf && p->field_kind != NCDE_FIELD_MINIMAL) ? tiled_pack_floats(p, true) : 0;
     t.coop = cp.ok;
     if (cp.ok) {
-        t.coop_M = cp.M; t.coop_G = cp.G;
+        t.coop_M = cp.M; t.coop_G = cp.G; t.coop_chunk = cp.chunk;
         off = (off + 63) & ~63LL;
         t.recS = off; off += tiles * 32 + 512;      // (+ the over-read of the last 1 KB chunk ncde_dwo_h2 fetches)
         const CoopDims d{p->hidden, p->channels, 128, cp.M, cp.G};
         off = (off + 63) & ~63LL;
         t.coop_img = off; off += (long long)cp.M * (coop_p_words() + coop_t_words());
-        t.coop_x = off; off += d.per_tile() * t.n_st;
+        t.coop_x = off; off += d.per_tile() * cp.chunk;
         t.coop_scale = off; off += 64;      // [0] sw, [1] 1 / sw, [8] max |Wo| bits, [16] the call's status word (KArgs.coop_status)
         t.coop_state = off; off += (long long)t.n_st * 2 * 8 * 512 * 4;      // the sweep's hidden-dW accumulators while its registers hold Wo: 2 x TL_DWT x NT float4 per workgroup
-        t.coop_sync = off; off += 64 + coop_sync_words(cp.G, t.n_st);
+        t.coop_sync = off; off += 64 + coop_sync_words(cp.G, cp.chunk);
     }
     t.total = off + 64;
     return t;
@@ -3452,14 +3457,13 @@ int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws
         void (*fc_fn)(KArgs) = ncde_fwd_tiled<1, TL_NW, 4, 0, 2, 0, 0, 1>;
         const size_t lds_coop = sizeof(float) * ((size_t)16 * (size_t)(2 * p->hidden + 2 * tiled_dmax(p) + p->channels) + (size_t)kFwdCoopLdsFloats);
         if (ncde_lds_optin((const void*)fc_fn, lds_coop) != hipSuccess) return NCDE_ERR_HIP;
-        if (coop_runtime_ok((const void*)fc_fn, TL_THREADS, lds_coop, nwg, st)) {      // (else: the per-workgroup kernels below, unconditionally)
+        if (coop_runtime_ok((const void*)fc_fn, TL_THREADS, lds_coop, fc.chunk, st)) {      // (else: the per-workgroup kernels below, unconditionally)
             float* w = (float*)ws;
             unsigned* amax = reinterpret_cast<unsigned*>(w + fc.scale + 8);
             unsigned* status = reinterpret_cast<unsigned*>(w + fc.scale + 16);
             if (hipMemsetAsync(amax, 0, sizeof(unsigned), st) != hipSuccess) return NCDE_ERR_HIP;
             if (hipMemsetAsync(status, 0, sizeof(unsigned), st) != hipSuccess) return NCDE_ERR_HIP;
             const int n_tiles = (p->batch + 15) / 16;
-            if (hipMemsetAsync(w + fc.sync, 0, sizeof(unsigned) * (size_t)coop_sync_words(fc.G, n_tiles), st) != hipSuccess) return NCDE_ERR_HIP;
             const long long nw = (long long)p->hidden * p->channels * 128;
             hipLaunchKernelGGL(ncde_coop_absmax, dim3(512), dim3(256), 0, st, a.Wo, nw, amax);
             hipLaunchKernelGGL(ncde_coop_pack, dim3(1024), dim3(256), 0, st, a.Wo, (const unsigned*)amax, reinterpret_cast<unsigned*>(w + fc.img), w + fc.scale,
@@ -3473,7 +3477,20 @@ int ncde_tiled_forward(const NcdeProblem* p, float* out, float* stages, void* ws
             a.coop_status = status;
             a.coop_inject = (p->flags & NCDE_FLAG_COOP_FAULT_INJECT) ? 1 : 0;
             a.coop_spin = a.coop_inject ? (1u << 12) : (unsigned)COOP_SPIN_LIMIT;
-            hipLaunchKernelGGL(fc_fn, dim3(nwg), dim3(TL_THREADS), lds_coop, st, a);
+            // one launch per CHUNK of the batch (all of it unless the batch has more sample tiles than the device has CUs)
+            for (int t0 = 0; t0 < n_tiles; t0 += fc.chunk) {
+                const int tiles_c = std::min(fc.chunk, n_tiles - t0);
+                KArgs ac = a;
+                ac.B = std::min(p->batch - 16 * t0, 16 * tiles_c);
+                ac.coeffs = a.coeffs + (long long)16 * t0 * a.cs_b;
+                ac.z0 = a.z0 + (long long)16 * t0 * a.Hr;
+                ac.out = a.out + (long long)16 * t0 * a.n_out * a.Hr;
+                if (a.stages) { ac.stages = a.stages + (long long)16 * t0 * a.Hr; ac.Brec = p->batch; }
+                if (a.fault) ac.fault = a.fault + t0;
+                ac.coop_G = tiles_c / fc.M;
+                if (hipMemsetAsync(w + fc.sync, 0, sizeof(unsigned) * (size_t)coop_sync_words(ac.coop_G, tiles_c), st) != hipSuccess) return NCDE_ERR_HIP;
+                hipLaunchKernelGGL(fc_fn, dim3(tiles_c), dim3(TL_THREADS), lds_coop, st, ac);
+            }
             coop_mark_in_flight(st);
             // Behind it, the per-workgroup kernels with run_if = the status word: they return at once unless the cooperative launch gave
             // up (a workgroup that never became resident: another process's kernels, a CU mask), in which case they redo the solve.
@@ -3584,7 +3601,7 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     if (t.coop) {
         void (*fc_fn)(KArgs) = ncde_adj_tiled<8, 8, 0, 0, 1, 0, 0, 1>;
         if (ncde_lds_optin((const void*)fc_fn, tiled_coop_lds(p)) != hipSuccess) return NCDE_ERR_HIP;
-        coop = coop_runtime_ok((const void*)fc_fn, 64 * 8, tiled_coop_lds(p), t.n_st, st);      // (see coop_runtime_ok: else the per-workgroup kernels)
+        coop = coop_runtime_ok((const void*)fc_fn, 64 * 8, tiled_coop_lds(p), t.coop_chunk, st);      // (see coop_runtime_ok: else the per-workgroup kernels)
     }
     if (coop) {      // XCD-cooperative output phase: weights resident in registers, activations exchanged through L2 (ncde_coop.h)
         fa = ncde_adj_tiled<8, 8, 0, 0, 1, 0, 0, 1>;
@@ -3607,7 +3624,7 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
         a.coop_scale = w + t.coop_scale;
         a.coop_state = w + t.coop_state;
         a.coop_sync = reinterpret_cast<unsigned*>(w + t.coop_sync);
-        a.win_max = a.coop_sync + coop_sync_words(t.coop_G, t.n_st);
+        a.win_max = a.coop_sync + coop_sync_words(t.coop_G, t.coop_chunk);      // (behind the sync words of a FULL chunk; a smaller last chunk uses fewer)
         a.coop_M = t.coop_M;
         a.coop_G = t.coop_G;
     }
@@ -3632,18 +3649,43 @@ int ncde_tiled_adjoint(const NcdeProblem* p, const float* src, const float* grad
     float* gB2 = gB + (long long)t.parts * t.theta_o;
     // time windows, newest first: sweep W steps (pass A), fold their records into the output-layer gradient (pass B)
     const int n_rsteps = p->output == NCDE_OUT_TIMES ? (discrete ? p->n_steps_fwd : p->n_steps_adj) : p->n_knots - 1;
+    if (coop) {
+        // cooperative sequence: one CHUNK of the batch at a time (all of it unless there are more sample tiles than CUs), each chunk through
+        // all its time windows; the hidden-layer partials are per workgroup (rows t0 .. of gpartA), ncde_dwo_h2 keeps adding to gB
+        for (int t0 = 0, firstc = 1; t0 < t.n_st; t0 += t.coop_chunk, firstc = 0) {
+            const int tiles_c = std::min(t.coop_chunk, t.n_st - t0);
+            KArgs ac = a;
+            ac.B = std::min(p->batch - 16 * t0, 16 * tiles_c);
+            ac.coeffs = a.coeffs + (long long)16 * t0 * a.cs_b;
+            ac.grad_out = a.grad_out + (long long)16 * t0 * a.n_out * a.Hr;
+            ac.grad_z0 = a.grad_z0 + (long long)16 * t0 * a.Hr;
+            if (discrete) { ac.stages = a.stages + (long long)16 * t0 * a.Hr; ac.Brec = p->batch; }
+            else ac.z_out = a.z_out + (long long)16 * t0 * a.n_out * a.Hr;
+            ac.gpart = a.gpart + (long long)t0 * a.gstride;
+            ac.coop_G = tiles_c / t.coop_M;
+            ac.win_max = a.coop_sync + coop_sync_words(ac.coop_G, tiles_c);
+            for (int hi = n_rsteps, first = 1; hi >= 1; hi -= t.window, first = 0) {
+                const int lo = std::max(0, hi - t.window);
+                ac.win_hi = hi; ac.win_lo = lo; ac.resume = first ? 0 : 1;
+                ac.dw2_accum = (first && firstc) ? 0 : 1;
+                // (the sync words of the launch and, behind them, the window's cotangent-bound word: KArgs.win_max)
+                if (hipMemsetAsync(a.coop_sync, 0, sizeof(unsigned) * (size_t)(coop_sync_words(ac.coop_G, tiles_c) + 1), st) != hipSuccess) return NCDE_ERR_HIP;
+                hipLaunchKernelGGL(fa, dim3(tiles_c), dim3(64 * nwv_launch), lds, st, ac);
+                hipLaunchKernelGGL(fb, gridB, dim3(threadsB), ldsB, st, ac, (hi - lo) * t.S, tiles_c, gB);
+                if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
+            }
+        }
+        coop_mark_in_flight(st);
+    } else
     for (int hi = n_rsteps, first = 1; hi >= 1; hi -= t.window, first = 0) {
         const int lo = std::max(0, hi - t.window);
         a.win_hi = hi; a.win_lo = lo; a.resume = first ? 0 : 1;
-        // (the sync words of the launch and, behind them, the window's cotangent-bound word: KArgs.win_max)
-        if (coop && hipMemsetAsync(a.coop_sync, 0, sizeof(unsigned) * (size_t)(coop_sync_words(t.coop_G, t.n_st) + 1), st) != hipSuccess) return NCDE_ERR_HIP;
         hipLaunchKernelGGL(fa, dim3(t.n_st), dim3(64 * nwv_launch), lds, st, a);
         const int n_sc = (hi - lo) * t.S;
         hipLaunchKernelGGL(fb, gridB, dim3(threadsB), ldsB, st, a, n_sc, t.n_st, gB);
         if (fb2) hipLaunchKernelGGL(fb2, gridB, dim3(256), 0, st, a, n_sc, t.n_st, gB2);
         if (hipGetLastError() != hipSuccess) return NCDE_ERR_HIP;
     }
-    if (coop) coop_mark_in_flight(st);
     if (main_kernel_only) return NCDE_OK;
     // deterministic reductions: hidden-layer partials of the sweep, then the part-group partials of pass B
     ReduceSegs segs{};
