@@ -141,13 +141,13 @@ __device__ __forceinline__ void dwo_h2_body(const KArgs& a, int n_sc, int n_st, 
             auto ldd = [&](int i) { return *reinterpret_cast<const f32x4*>(B_ + oRD + t2 * nRD * 256 + (4 * cq[i] + (li & 3)) * 16 + 4 * lk); };
             f32x4 na4, nd4;
             if constexpr (AHEAD) { na4 = lda(0); nd4 = ldd(0); }
-            // (three accumulators per tile -- main, and one per cross product -- so that no MFMA waits for the one issued just before it)
-            f32x4 pm[NRT], px[NRT], py[NRT];
+            // (main and cross accumulator per tile; the order below keeps the two cross products of a tile 2 NRT MFMAs apart)
+            f32x4 pm[NRT], px[NRT];
 #pragma unroll
             for (int i = 0; i < NRT; ++i) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pm[i][r] = bias[i] * coop_pow2_inv(isx4[r]);      // sx sw: the bias joins the scaled accumulator exactly
-                px[i] = py[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                px[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
@@ -158,16 +158,12 @@ __device__ __forceinline__ void dwo_h2_body(const KArgs& a, int n_sc, int n_st, 
                     else if (t2 == 0) { nx0 = ldx(1, 0, 0); nx1 = ldx(1, 0, 1); }
                 } else { x0 = ldx(t2, c, 0); x1 = ldx(t2, c, 1); }
 #pragma unroll
-                for (int i = 0; i < NRT; ++i) pm[i] = mfma_h(x0, W[i][c][0], pm[i]);
-#pragma unroll
                 for (int i = 0; i < NRT; ++i) px[i] = mfma_h(x0, W[i][c][1], px[i]);
 #pragma unroll
-                for (int i = 0; i < NRT; ++i) py[i] = mfma_h(x1, W[i][c][0], py[i]);
+                for (int i = 0; i < NRT; ++i) pm[i] = mfma_h(x0, W[i][c][0], pm[i]);
+#pragma unroll
+                for (int i = 0; i < NRT; ++i) px[i] = mfma_h(x1, W[i][c][0], px[i]);
             }
-#pragma unroll
-            for (int i = 0; i < NRT; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) px[i][r] += py[i][r];
 #pragma unroll
             for (int i = 0; i < NRT; ++i) {
                 const f32x4 pc = h2_combine(pm[i], px[i]);
@@ -200,7 +196,7 @@ __device__ __forceinline__ void dwo_h2_body(const KArgs& a, int n_sc, int n_st, 
         auto ldb = [&](int jt, int pc) { return *reinterpret_cast<const u32x4*>(XP + ((jt * 2 + pc) * 64 + lane) * 4); };
         u32x4 nb0, nb1;
         if constexpr (AHEAD) { nb0 = ldb(0, 0); nb1 = ldb(0, 1); }
-        f32x4 ptx[NRT], pty[NRT];
+        f32x4 ptx[NRT];
 #pragma unroll
         for (int jt = 0; jt < PK; ++jt) {
             u32x4 b0, b1;
@@ -208,30 +204,22 @@ __device__ __forceinline__ void dwo_h2_body(const KArgs& a, int n_sc, int n_st, 
                 b0 = nb0; b1 = nb1;
                 if (jt + 1 < PK) { nb0 = ldb(jt + 1, 0); nb1 = ldb(jt + 1, 1); }
             } else { b0 = ldb(jt, 0); b1 = ldb(jt, 1); }
-            f32x4 tx[NRT], ty[NRT];      // (independent temporaries: no MFMA of a column tile waits for another one)
+            f32x4 tx[NRT];      // (the two cross products of a tile are 2 NRT MFMAs apart: neither waits for the other)
 #pragma unroll
             for (int i = 0; i < NRT; ++i) tx[i] = mfma_h(Ap[i][0], b1, (f32x4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-            for (int i = 0; i < NRT; ++i) ty[i] = mfma_h(Ap[i][1], b0, (f32x4){0.f, 0.f, 0.f, 0.f});
-#pragma unroll
             for (int i = 0; i < NRT; ++i) gW[i][jt] = mfma_h(Ap[i][0], b0, gW[i][jt]);
+#pragma unroll
+            for (int i = 0; i < NRT; ++i) tx[i] = mfma_h(Ap[i][1], b0, tx[i]);
             if (jt > 0) {      // fold the previous column tile's cross products while this one's MFMAs run
 #pragma unroll
-                for (int i = 0; i < NRT; ++i) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ptx[i][r] += pty[i][r];
-                    gW[i][jt - 1] = h2_combine(gW[i][jt - 1], ptx[i]);
-                }
+                for (int i = 0; i < NRT; ++i) gW[i][jt - 1] = h2_combine(gW[i][jt - 1], ptx[i]);
             }
 #pragma unroll
-            for (int i = 0; i < NRT; ++i) { ptx[i] = tx[i]; pty[i] = ty[i]; }
+            for (int i = 0; i < NRT; ++i) ptx[i] = tx[i];
         }
 #pragma unroll
-        for (int i = 0; i < NRT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ptx[i][r] += pty[i][r];
-            gW[i][PK - 1] = h2_combine(gW[i][PK - 1], ptx[i]);
-        }
+        for (int i = 0; i < NRT; ++i) gW[i][PK - 1] = h2_combine(gW[i][PK - 1], ptx[i]);
     };
     // (Two waves share each SIMD at NRT = 2.  Running the upper half of the waves one pair-stage late -- so that one wave of a SIMD
     // multiplies while the other does its tanh / split work -- was built and measured SLOWER, 8.6k against 7.4k cycles per pair-stage:
