@@ -1044,8 +1044,15 @@ __global__ __launch_bounds__(64 * NWV) void ncde_fwd_tiled(KArgs a) {
                                 for (int r = 0; r < 4; ++r) kk = fmaf(tanh_prescaled(pc4[r] * isx2), dxv[r], kk);
                             }
                         };
-                        p_batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
-                        p_batch(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+                        // neighbouring SIMDs take their two batches in opposite order (round 6: forward -5 %; keyed on the SIMD pair instead --
+                        // (w, w + 4) share one -- it is -1.4 %, keyed on both it is slower than either)
+                        if ((wave & 1) == 0) {
+                            p_batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+                            p_batch(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+                        } else {
+                            p_batch(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+                            p_batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+                        }
                         CKX[(buf * 8 + wave) * 64 + lane] = kk;
                     }
                     if (it >= 1 && tid < 2 * 64 * jh) {      // f.dX of this member's state units for the two tiles of iteration it - 1

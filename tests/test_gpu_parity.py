@@ -1382,12 +1382,18 @@ def test_general_time_axis_on_the_cooperative_kernels_vs_oracle(C, H, HH, nl, B,
         res = gpu_util.run_times_case(g, meta, adjoint=True, kind="original", mode="matmul", params=p, flags=wflags)
         resd = gpu_util.run_times_case(g, meta, adjoint=False, kind="original", mode="matmul", params=p, flags=wflags)
         assert gu.relerr(res["z_out"], z) <= TIGHT_Z, gu.relerr(res["z_out"], z)
-        assert gu.relerr(res["dz0"], dz0) <= E2E_G, gu.relerr(res["dz0"], dz0)
+        # dz0 per SAMPLE row: a pre-activation within rounding of zero may get the other ReLU mask than the oracle's and move that one
+        # sample's row (the knife-edge below); every other row at the end-to-end bar, and the parameter gradients -- sums over all
+        # samples -- at the bar as a whole
+        bars_ = []
+        for got_, ref_ in ((res["dz0"], dz0.numpy()), (resd["dz0"], bdz0.numpy())):
+            rows_ = np.abs(got_ - ref_).max(axis=1) / np.abs(ref_).max()
+            assert int((rows_ > E2E_G).sum()) <= 1 and float(rows_.max()) <= 50 * E2E_G, (int((rows_ > E2E_G).sum()), float(rows_.max()))
+            bars_.append(E2E_G if float(rows_.max()) <= E2E_G else 2 * E2E_G)      # (that sample's share of a parameter gradient)
         for n_, g_ in zip(names, gp):
-            assert gu.relerr(res["grads"][n_], g_) <= E2E_G, (n_, gu.relerr(res["grads"][n_], g_))
-        assert gu.relerr(resd["dz0"], bdz0) <= E2E_G
+            assert gu.relerr(res["grads"][n_], g_) <= bars_[0], (n_, gu.relerr(res["grads"][n_], g_))
         for n_, g_ in zip(names, bgp):
-            assert gu.relerr(resd["grads"][n_], g_) <= E2E_G, ("discrete", n_, gu.relerr(resd["grads"][n_], g_))
+            assert gu.relerr(resd["grads"][n_], g_) <= bars_[1], ("discrete", n_, gu.relerr(resd["grads"][n_], g_))
     # against the per-workgroup kernels: two fp32 implementations of the same sweep -- a pre-activation within rounding of zero may flip
     # a ReLU mask in one of them and move THAT sample's row (the knife-edge of DESIGN.md / HISTORY.md 5.5d): all but at most two rows
     old = gpu_util.run_times_case(g, meta, adjoint=True, kind="original", mode="matmul", params=p, flags=_lib.FLAG_NO_COOP)
