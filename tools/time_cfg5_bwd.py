@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
 import ncde_amd, bench
 from ncde_amd import _lib, solver
+if os.environ.get("NCDE_LIB"): _lib.LIB_PATH = os.path.join(ROOT, os.environ["NCDE_LIB"])      # (a variant build, e.g. variants/x.so)
 c = dict(bench.CONFIGS["cfg5"]); c["L"] = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 flag_sets = [int(f, 0) for f in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
