@@ -447,8 +447,16 @@ def rooflines(model, c, coeffs, config, B_local, T):
         trans_ms = tanh_per_step * steps_per_launch / TRANS_PER_S * 1e3
         # ---- ceilings: the least time each unit needs for THIS kernel's instruction stream / bytes (floors on ms_per_launch) -------
         # matrix pipe: busy cycles the SQ counted (dynamic: skipped branches are not in it) / 1024 SIMDs, else the static census
-        ceil = {"hbm": alg / (PEAK_HBM_GBS * 1e9) * 1e3}
-        src = {"hbm": "algorithmic bytes / 8 TB/s"}
+        # HBM: the bytes the TCC counters saw for this pass (the kernel's OWN traffic, as the other units are priced on its own
+        # instruction stream), else the algorithmic bytes; the algorithmic floor is always listed beside it
+        ceil = {"hbm_algorithmic": alg / (PEAK_HBM_GBS * 1e9) * 1e3}
+        src = {"hbm_algorithmic": "algorithmic bytes / 8 TB/s"}
+        if pm is not None and pm.get("traffic"):
+            ceil["hbm"] = pm["traffic"] / (PEAK_HBM_GBS * 1e9) * 1e3
+            src["hbm"] = "FETCH_SIZE + WRITE_SIZE of the pass (gfx950 corrections) / 8 TB/s (%s)" % pm["source"]
+        else:
+            ceil["hbm"] = ceil["hbm_algorithmic"]
+            src["hbm"] = src["hbm_algorithmic"]
         if pm is not None and pm.get("mfma_busy_cycles"):
             ceil["mfma"] = pm["mfma_busy_cycles"] / N_SIMD / clock * 1e3
             src["mfma"] = "SQ_VALU_MFMA_BUSY_CYCLES per pass / 1024 SIMDs / %.2f GHz (%s)" % (clock / 1e9, pm["source"])
