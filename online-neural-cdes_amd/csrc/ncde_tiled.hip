@@ -123,10 +123,7 @@ __device__ __forceinline__ void tl_dense_relu_pk(const float* __restrict__ W, co
     for (int q = 0; q < nq; ++q) {
         const int ti = q / npan, pan = q - ti * npan, t = wave + NWV * ti;
         const Panel<PK> P = Pn;
-        {
-            const int qn = q + 1 < nq ? q + 1 : q;
-            Pn = tl_load_panel<PK>(wrow_of(qn), (qn % npan) * PK);
-        }
+        if (q + 1 < nq) Pn = tl_load_panel<PK>(wrow_of(q + 1), ((q + 1) % npan) * PK);      // (nothing behind the last pair)
         if (pan == 0) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 16 * t + 4 * lk);
 #pragma unroll
