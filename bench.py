@@ -472,6 +472,21 @@ def rooflines(model, c, coeffs, config, B_local, T):
             # dynamic: VALU instructions (all waves, MFMAs excluded) at 2 cycles + the quarter-rate surcharge of the tanh work
             ceil["valu"] = (pm["insts_valu"] - (pm.get("insts_mfma") or 0.0)) * 2.0 / N_SIMD / clock * 1e3 + 0.75 * trans_ms
             src["valu"] = "SQ_INSTS_VALU - SQ_INSTS_MFMA per pass x 2 cycles / 1024 SIMDs + the transcendentals' quarter-rate surcharge"
+        # ---- serial-issue model (round 6; measured: tools/mfma_valu_overlap.hip, profiles/r06_mfma_valu_overlap.txt): the matrix pipe
+        # and the VALU of a SIMD do not work side by side -- next to a saturated MFMA stream the SIMD's other wave gets one VALU
+        # instruction per 12.8 cycles, mixed streams of two waves finish one after the other --, so a mixed stream needs about the SUM
+        # over the SIMD's waves of VALU 4.1 / packed 6.5 / transcendental 10 / MFMA 17.1 (16x16x32), 32.1 (32x32x16, fp32 16x16x4) cycles
+        serial_ms, serial_src = None, None
+        if cen is not None and cen.get("serial_issue_ceiling_ms"):
+            serial_ms = cen["serial_issue_ceiling_ms"]
+            serial_src = "static ISA census priced at the measured serial issue costs (tools/isa_census.py, profiles/r06_mfma_valu_overlap.txt)"
+        elif pm is not None and pm.get("insts_valu") and pm.get("mfma_busy_cycles"):
+            n_trans = tanh_per_step * steps_per_launch / 64.0      # wave instructions
+            serial_ms = ((pm["insts_valu"] - (pm.get("insts_mfma") or 0.0)) * 4.1 + n_trans * (10.0 - 4.1) + pm["mfma_busy_cycles"] * (17.1 / 16.0)) / N_SIMD / clock * 1e3
+            serial_src = "SQ_INSTS_VALU - SQ_INSTS_MFMA at 4.1 cycles + the transcendentals' surcharge + matrix-pipe busy cycles x 17.1 / 16, per SIMD (%s)" % pm["source"]
+        if serial_ms is not None:
+            ceil["serial_issue"] = serial_ms
+            src["serial_issue"] = serial_src
         # ---- which unit the counters show busiest; `wait` above it = the waves stall more than any unit works ----------------------
         bound, stalled, busy = "unmeasured", None, {}
         if pm is not None and pm["mfma_busy"] is not None and pm["valu_active"] is not None:
@@ -500,6 +515,8 @@ def rooflines(model, c, coeffs, config, B_local, T):
              "issue_ceiling_ms": round(ceil["issue"], 4) if "issue" in ceil else None,
              "tanh_ceiling_ms": round(trans_ms, 4),
              "frac_of_issue_ceiling": round(ceil["issue"] / ms, 4) if "issue" in ceil else None,
+             "serial_issue_model_ms": round(serial_ms, 4) if serial_ms is not None else None,
+             "frac_of_serial_issue_model": round(serial_ms / ms, 4) if serial_ms is not None else None,
              "ceiling_sources": src,
              "stalled": stalled,
              "busy": {k: round(v, 4) for k, v in busy.items()} if busy else None,
@@ -526,8 +543,11 @@ def rooflines(model, c, coeffs, config, B_local, T):
     return (roof(ms_fwd, f_fwd, by_fwd, names[0], False), roof(ms_adj, f_adj, by_fwd, names[1], True)), names
 
 
-def other_config(name, dev, steps=3, warmup=1):
-    """One BASELINE shape besides the headline, single GPU: `steps` training steps (forward + adjoint + Adam) and the kernel rooflines."""
+def other_config(name, dev, steps=None, warmup=None):
+    """One BASELINE shape besides the headline, single GPU: `steps` training steps (forward + adjoint + Adam) and the kernel rooflines.
+    (cfg5's step takes 0.85 s: three of them; the millisecond configs get ten, so that one hiccup does not double their mean)"""
+    steps = steps if steps is not None else (3 if name == "cfg5" else 10)
+    warmup = warmup if warmup is not None else (1 if name == "cfg5" else 2)
     c = dict(CONFIGS[name])
     w = Workload(c, c["B"], c["B"], 0, dev)
     dt, loss = w.timed(steps, warmup, 1, dev)

@@ -79,13 +79,19 @@ __device__ __forceinline__ void dwo_h2_body(const KArgs& a, int n_sc, int n_st, 
     // LDS offset), so that issuing a pair-stage's loads is straight-line scalar arithmetic -- a decision tree per chunk inside the
     // pair-stage loop cost 330 cycles per load instruction (measured: 2.6k of 9k cycles per pair-stage).
     const int n_chunk = 2 * 8 + 16 + 2 * nRC + 2 * nRD + 2;
-    constexpr int NSLOT = (60 + NWV - 1) / NWV;      // (H <= 128, C <= 80: at most 60 chunks)
+#ifndef DW2_NIW
+#define DW2_NIW 4
+#endif
+    // (only the first NIW waves fetch: with two waves per SIMD the older wave of each pair has the priority and ends every pair-stage
+    // waiting at the barrier for the younger one -- the fetch instructions ride in that slack)
+    constexpr int NIW = DW2_NIW < NWV ? DW2_NIW : NWV;
+    constexpr int NSLOT = (60 + NIW - 1) / NIW;      // (H <= 128, C <= 80: at most 60 chunks)
     long long s_const[NSLOT];
     int s_sc[NSLOT], s_pr[NSLOT], s_lds[NSLOT];
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
-        int k = wave + NWV * j;
-        if (k >= n_chunk) k = wave;      // (a slot past the end fetches this wave's first chunk again: harmless)
+        int k = wave + NIW * j;
+        if (k >= n_chunk) k = wave < NIW ? wave : 0;      // (a slot past the end fetches this wave's first chunk again: harmless)
         long long cst;
         int ssc, spr, sl;
         if (k < 16) { cst = (long long)(k >> 3) * 2048 + (k & 7) * 256; ssc = n_st * 2048; spr = 2 * 2048; sl = k * 256; }
@@ -107,6 +113,7 @@ __device__ __forceinline__ void dwo_h2_body(const KArgs& a, int n_sc, int n_st, 
         s_dsc[j] = s_sc[j] - (my_n_ - 1) * parts * s_pr[j];
     }
     auto issue = [&](bool wrap, int buf) {      // fetch the pair-stage the running offsets point at, then advance them (wrap: to the next stage)
+        if (wave >= NIW) return;
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) {
             __builtin_amdgcn_global_load_lds((gptr_t)(a.recA + s_off[j] + lane * 4), (lptr_t)(lds + buf * per_buf + s_lds[j]), 16, 0, 0);

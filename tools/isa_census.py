@@ -15,6 +15,12 @@ v_mfma_*_16x16x32_{f16,bf16} 16, 32x32x16 32, f32-input 16x16x4 32, 32x32x2 64 (
 `waves_per_simd` waves of the workgroup, each issuing the same stream, and the chip runs ceil(workgroups / (256 CUs x wgs per CU))
 rounds: ceiling = rounds x waves_per_simd x cycles / 2.4 GHz.  It is a floor on the kernel time for THIS instruction stream (no stall,
 perfect dual issue of the two pipes), which is what makes achieved / ceiling a roofline fraction <= 1.
+`serial_issue_ceiling_ms` (round 6): measured on MI355X (tools/mfma_valu_overlap.hip, profiles/r06_mfma_valu_overlap.txt), the matrix
+pipe and the VALU of a SIMD do NOT work side by side: next to a saturated MFMA stream the other wave of the SIMD issues one VALU
+instruction per 12.8 cycles (4.3 alone), two mixed streams on one SIMD finish one AFTER the other (the older wave has priority), and
+inside one wave an independent FMA next to every MFMA costs 4.1 cycles on top of the MFMA's 17.  So the floor of a mixed stream is the
+SUM over the waves of a SIMD of: VALU 4.1, packed fp32 6.5, transcendental 10.0, MFMA 16x16x32 17.1, 32x32x16 / 16x16x4-f32 32.1
+cycles per instruction -- not the maximum of the two pipes.
 `issue_ceiling_ms`: a wave issues at most one instruction per 4-cycle slot (MI355X_MICROARCH.md: "32 cyc/SIMD ~ 8 issue slots of ~4
 cyc"), so its own stream -- every class, waits and nops included -- takes instructions x 4 cycles at least; for kernels whose waves
 play different roles the longest role counts.  With ONE wave per SIMD (the register-resident kernels) this, not a pipe, is the floor.
@@ -34,6 +40,9 @@ sys.path.insert(0, ROOT)
 LLVM = "/opt/rocm/lib/llvm/bin"
 CLOCK_HZ = 2.4e9
 N_CU = 256
+
+# measured serial issue cost per wave64 instruction when MFMA and VALU work share a SIMD (tools/mfma_valu_overlap.hip)
+SERIAL = {"valu": 4.1, "valu_pk": 6.5, "trans": 10.0, "mfma": {16: 17.1, 32: 32.1, 64: 64.0}}
 
 TRANS = ("v_exp_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_log_", "v_sin_", "v_cos_")
 
@@ -236,8 +245,10 @@ def census(ins, trips):
         counts[cls] += w
         if cls == "mfma":
             cycles["mfma"] += w * cyc
+            cycles["serial"] += w * SERIAL["mfma"][cyc]
         elif cyc:
             cycles["valu"] += w * cyc
+            cycles["serial"] += w * SERIAL[cls]
     return counts, cycles, used
 
 
@@ -302,7 +313,8 @@ def run(entry):
            "waves_sharing_a_simd": share, "rounds": rounds, "instructions_issued_by_the_longest_wave": round(issue_ins, 1),
            "valu_ceiling_ms": round(rounds * share * cycles["valu"] / CLOCK_HZ * 1e3, 4),
            "mfma_ceiling_ms": round(rounds * share * cycles["mfma"] / CLOCK_HZ * 1e3, 4),
-           "issue_ceiling_ms": round(rounds * issue_ins * 4 / CLOCK_HZ * 1e3, 4)}
+           "issue_ceiling_ms": round(rounds * issue_ins * 4 / CLOCK_HZ * 1e3, 4),
+           "serial_issue_ceiling_ms": round(rounds * share * cycles["serial"] / CLOCK_HZ * 1e3, 4)}
     return res
 
 
@@ -329,12 +341,14 @@ def main():
     out = {"_meta": {"source_fingerprint": _lib.source_fingerprint(), "clock_hz": CLOCK_HZ,
                      "issue_cycles": {"valu": 2, "valu_pk_f32": 4, "transcendental": 8, "mfma_16x16x32_16bit": 16, "mfma_32x32x16_16bit": 32,
                                       "mfma_16x16x4_f32": 32, "mfma_32x32x2_f32": 64},
+                     "serial_issue_cycles": {"valu": 4.1, "valu_pk_f32": 6.5, "transcendental": 10.0, "mfma_16x16x32_16bit": 17.1, "mfma_32x32x16_16bit": 32.1,
+                                             "mfma_16x16x4_f32": 32.1, "source": "profiles/r06_mfma_valu_overlap.txt (tools/mfma_valu_overlap.hip)"},
                      "note": "static census by tools/isa_census.py; ceilings are floors on the kernel time for the instruction stream as compiled"}}
     for name, entry in table().items():
         out[name] = run(entry)
         r = out[name]
-        print("%-14s valu %.3f ms  mfma %.3f ms  issue %.3f ms  (weighted per launch: valu %d trans %d pk %d mfma %d)" % (
-            name, r["valu_ceiling_ms"], r["mfma_ceiling_ms"], r["issue_ceiling_ms"], r["per_launch_weighted"].get("valu", 0),
+        print("%-14s valu %.3f ms  mfma %.3f ms  issue %.3f ms  serial issue (MFMA + VALU of a SIMD add up) %.3f ms  (weighted per launch: valu %d trans %d pk %d mfma %d)" % (
+            name, r["valu_ceiling_ms"], r["mfma_ceiling_ms"], r["issue_ceiling_ms"], r["serial_issue_ceiling_ms"], r["per_launch_weighted"].get("valu", 0),
             r["per_launch_weighted"].get("trans", 0), r["per_launch_weighted"].get("valu_pk", 0), r["per_launch_weighted"].get("mfma", 0)))
     json.dump(out, open(a.out, "w"), indent=1)
 
